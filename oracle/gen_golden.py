@@ -1,0 +1,373 @@
+#!/usr/bin/env python3
+"""Golden-vector generator (TEST INFRASTRUCTURE, runs only in the build container).
+
+Imports the read-only reference at /root/reference under the stand-in `gym`
+package in oracle/refshim/, drives `MiniGridEnv.step` / `gen_obs` /
+`FullyObsWrapper.observation` (reference: gym_minigrid/minigrid.py:1227-1381,
+gym_minigrid/wrappers.py:311-338) and records inputs + expected outputs as small
+.npz fixtures under tests/golden/.  Nothing of the reference's source travels:
+the fixtures are data (states, actions, observations).
+
+    MPLBACKEND=Agg PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+
+Every trace stores the *explicit* initial state (encoded grid + aux plane +
+agent pose), so step/observation parity never depends on how a level was
+generated; the seed is stored as well so that level generation itself can be
+checked (tests/test_levelgen.py).
+
+File format (one .npz per case), all arrays stacked over traces (leading dim K):
+  meta            json: env_id, W, H, max_steps, see_through, lava_v1, full_obs
+  seed      (K,)  int64   seed used for `env.seed(s); env.reset()` (-1: hand-built state)
+  init_grid (K,W,H,3) u8  Grid.encode() of the initial grid, index [x][y][c]
+  init_aux  (K,W,H)   u8  bit0 = Goal.overlap (terminal goal, toggletimes<=0)
+  init_agent(K,3)     i32 x, y, dir
+  init_obs  (K,7,7,3) u8  obs['image'] returned by reset()
+  actions   (K,T)     u8
+  obs       (K,T,7,7,3) u8 ; direction (K,T) u8 ; reward (K,T) f64 ; done (K,T) u8
+  agent     (K,T,3)   i32 ; carry (K,T,3) u8 ((1,0,0) = nothing) ; steps (K,T) i32
+  grid      (K,T,W,H,3) u8  post-step Grid.encode()
+  full      (K,T,W,H,3) u8  FullyObsWrapper image (only when meta.full_obs)
+  init_full (K,W,H,3)       FullyObsWrapper image at reset (only when meta.full_obs)
+  Episode boundaries (caller-side reset on done, run_tests.py:64-66 convention,
+  re-seeding with the SAME seed = ReseedWrapper(seeds=[s]), wrappers.py:24-28):
+  reset_k (R,) trace index, reset_t (R,) step index after which reset happened,
+  reset_grid (R,W,H,3), reset_aux (R,W,H), reset_agent (R,3), reset_obs (R,7,7,3)
+"""
+import json
+import os
+import sys
+from collections import deque
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.dont_write_bytecode = True
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, os.path.join(HERE, "refshim"))
+
+import numpy as np  # noqa: E402
+import gym  # noqa: E402
+import gym_minigrid  # noqa: E402,F401
+from gym_minigrid import minigrid as M  # noqa: E402
+from gym_minigrid.wrappers import FullyObsWrapper  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+# --------------------------------------------------------------------------- helpers
+def aux_plane(env):
+    W, H = env.grid.width, env.grid.height
+    a = np.zeros((W, H), np.uint8)
+    for x in range(W):
+        for y in range(H):
+            o = env.grid.get(x, y)
+            if o is not None and o.type == "goal" and o.overlap:
+                a[x, y] = 1
+    return a
+
+
+def carry_triple(env):
+    return env.carrying.encode() if env.carrying is not None else (1, 0, 0)
+
+
+def full_image(env):
+    return FullyObsWrapper.observation(_FakeWrap(env), {"mission": ""})["image"]
+
+
+class _FakeWrap:
+    """Lets us call FullyObsWrapper.observation on a bare env without re-wrapping."""
+
+    def __init__(self, env):
+        self.unwrapped = env
+
+
+class SoupEnv(M.MiniGridEnv):
+    """Our own level: walled room filled at random with every object kind the
+    hot path distinguishes (reference classes, reference step/gen_obs)."""
+
+    def __init__(self, width, height, see_through, max_steps, density, v1=False):
+        self._density = density
+        super().__init__(width=width, height=height, max_steps=max_steps,
+                         see_through_walls=see_through)
+
+    def _gen_grid(self, width, height):
+        rs = self.np_random
+        self.grid = M.Grid(width, height)
+        self.grid.wall_rect(0, 0, width, height)
+        colors = list(M.COLOR_TO_IDX.keys())
+        for x in range(1, width - 1):
+            for y in range(1, height - 1):
+                if rs.uniform(0, 1) >= self._density:
+                    continue
+                k = rs.randint(0, 12)
+                c = colors[rs.randint(0, len(colors))]
+                if k == 0:
+                    o = M.Wall(c)
+                elif k == 1:
+                    o = M.Floor(c)
+                elif k in (2, 3, 4):
+                    st = rs.randint(0, 3)
+                    o = M.Door(c, is_open=(st == 0), is_locked=(st == 2))
+                elif k in (5, 6):
+                    o = M.Key(c)
+                elif k == 7:
+                    o = M.Ball(c)
+                elif k == 8:
+                    o = M.Box(c)
+                elif k == 9:
+                    o = M.Goal()
+                elif k == 10:
+                    o = M.Goal(toggletimes=0)
+                else:
+                    o = M.Lava()
+                self.grid.set(x, y, o)
+        # agent on a free interior cell
+        while True:
+            x, y = rs.randint(1, width - 1), rs.randint(1, height - 1)
+            o = self.grid.get(x, y)
+            if o is None or o.can_overlap():
+                break
+        self.agent_pos = np.array((x, y))
+        self.agent_dir = rs.randint(0, 4)
+        self.mission = "soup"
+
+
+class SoupEnvv1(SoupEnv):
+    """Class name contains 'v1' -> lava gives reward -1 and no done (minigrid.py:1262-1268)."""
+
+
+class PlantedGoalEnv(M.MiniGridEnv):
+    """Empty 8x8 with a terminal goal Goal(toggletimes=0) at (3,1): general goal/reward branch."""
+
+    def __init__(self):
+        super().__init__(grid_size=8, max_steps=256, see_through_walls=True)
+
+    def _gen_grid(self, width, height):
+        self.grid = M.Grid(width, height)
+        self.grid.wall_rect(0, 0, width, height)
+        self.put_obj(M.Goal(), width - 2, height - 2)
+        self.put_obj(M.Goal(toggletimes=0), 3, 1)
+        self.agent_pos = np.array((1, 1))
+        self.agent_dir = 0
+        self.mission = "planted"
+
+
+# --------------------------------------------------------------------------- planner (own code)
+DIRS = [(1, 0), (0, 1), (-1, 0), (0, -1)]
+
+
+def plan_face(env, target, passable_extra=()):
+    """Actions that bring the agent adjacent to `target`, facing it (BFS over (x,y,dir))."""
+    W, H = env.grid.width, env.grid.height
+
+    def free(x, y):
+        if not (0 <= x < W and 0 <= y < H):
+            return False
+        if (x, y) in passable_extra:
+            return True
+        o = env.grid.get(x, y)
+        return o is None or (o.can_overlap() and o.type != "lava")
+
+    start = (int(env.agent_pos[0]), int(env.agent_pos[1]), int(env.agent_dir))
+    prev = {start: None}
+    q = deque([start])
+    goal_state = None
+    while q:
+        s = q.popleft()
+        x, y, d = s
+        if (x + DIRS[d][0], y + DIRS[d][1]) == tuple(target):
+            goal_state = s
+            break
+        nxt = [((x, y, (d + 3) % 4), 0), ((x, y, (d + 1) % 4), 1)]
+        fx, fy = x + DIRS[d][0], y + DIRS[d][1]
+        if free(fx, fy):
+            nxt.append(((fx, fy, d), 2))
+        for n, a in nxt:
+            if n not in prev:
+                prev[n] = (s, a)
+                q.append(n)
+    if goal_state is None:
+        return None
+    acts = []
+    s = goal_state
+    while prev[s] is not None:
+        s, a = prev[s]
+        acts.append(a)
+    return acts[::-1]
+
+
+def find(env, typ):
+    for x in range(env.grid.width):
+        for y in range(env.grid.height):
+            o = env.grid.get(x, y)
+            if o is not None and o.type == typ:
+                return (x, y)
+    return None
+
+
+def doorkey_script(env):
+    """pickup key, try to drop onto the wall (no-op), unlock+open door, close, open,
+    walk through the doorway (agent stands in the open door carrying the key),
+    step on the goal (reward 0, not done in this fork), toggle the goal away."""
+    acts = []
+
+    def run(seq):
+        for a in seq:
+            env.step(a)
+            acts.append(a)
+
+    key = find(env, "key")
+    run(plan_face(env, key))
+    run([2, 3, 3, 4, 4, 3])          # bump key, pickup, pickup again, drop, drop(no-op: occupied), pickup
+    door = find(env, "door")
+    run(plan_face(env, door))
+    run([4, 5, 5, 5, 2, 2])          # drop on door (no-op), unlock/open, close, open, into doorway, beyond
+    goal = find(env, "goal")
+    p = plan_face(env, goal)
+    run(p)
+    run([2, 6, 0, 0, 2, 0, 0, 5])    # onto goal, done-action, turn round, step off, turn back, toggle goal away
+    run([4, 1, 1])                   # drop key where the goal was, look around
+    return acts
+
+
+# --------------------------------------------------------------------------- recorder
+def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False):
+    K = len(seeds)
+    env0 = make_env()
+    W, H = env0.width, env0.height
+    meta = dict(env_id=name, W=W, H=H, max_steps=int(env0.max_steps),
+                see_through=bool(env0.see_through_walls), lava_v1=bool(v1), full_obs=bool(full_obs))
+    z = dict(
+        seed=np.zeros(K, np.int64), init_grid=np.zeros((K, W, H, 3), np.uint8),
+        init_aux=np.zeros((K, W, H), np.uint8), init_agent=np.zeros((K, 3), np.int32),
+        init_obs=np.zeros((K, 7, 7, 3), np.uint8), actions=np.zeros((K, T), np.uint8),
+        obs=np.zeros((K, T, 7, 7, 3), np.uint8), direction=np.zeros((K, T), np.uint8),
+        reward=np.zeros((K, T), np.float64), done=np.zeros((K, T), np.uint8),
+        agent=np.zeros((K, T, 3), np.int32), carry=np.zeros((K, T, 3), np.uint8),
+        steps=np.zeros((K, T), np.int32), grid=np.zeros((K, T, W, H, 3), np.uint8))
+    if full_obs:
+        z["full"] = np.zeros((K, T, W, H, 3), np.uint8)
+        z["init_full"] = np.zeros((K, W, H, 3), np.uint8)
+    rk, rt, rg, ra, rag, ro = [], [], [], [], [], []
+    for k, s in enumerate(seeds):
+        env = make_env()
+        env.seed(int(s))
+        o = env.reset()
+        z["seed"][k] = s
+        z["init_grid"][k] = env.grid.encode()
+        z["init_aux"][k] = aux_plane(env)
+        z["init_agent"][k] = (env.agent_pos[0], env.agent_pos[1], env.agent_dir)
+        z["init_obs"][k] = o["image"]
+        if full_obs:
+            z["init_full"][k] = full_image(env)
+        # action stream: optional scripted prefix (computed on a scratch copy), then random
+        acts = []
+        if scripts is not None and scripts[k] is not None:
+            scratch = make_env()
+            scratch.seed(int(s))
+            scratch.reset()
+            acts = scripts[k](scratch)
+        rnd = np.random.RandomState(1000 + k).randint(0, 7, size=T)
+        stream = (list(acts) + list(rnd))[:T]
+        for t, a in enumerate(stream):
+            o, r, d, info = env.step(int(a))
+            assert info == {}
+            z["actions"][k, t] = a
+            z["obs"][k, t] = o["image"]
+            z["direction"][k, t] = o["direction"]
+            z["reward"][k, t] = r
+            z["done"][k, t] = d
+            z["agent"][k, t] = (env.agent_pos[0], env.agent_pos[1], env.agent_dir)
+            z["carry"][k, t] = carry_triple(env)
+            z["steps"][k, t] = env.step_count
+            z["grid"][k, t] = env.grid.encode()
+            if full_obs:
+                z["full"][k, t] = full_image(env)
+            if d:
+                env.seed(int(s))
+                o2 = env.reset()
+                rk.append(k)
+                rt.append(t)
+                rg.append(env.grid.encode())
+                ra.append(aux_plane(env))
+                rag.append((env.agent_pos[0], env.agent_pos[1], env.agent_dir))
+                ro.append(o2["image"])
+    R = len(rk)
+    z["reset_k"] = np.asarray(rk, np.int32)
+    z["reset_t"] = np.asarray(rt, np.int32)
+    z["reset_grid"] = np.asarray(rg, np.uint8).reshape(R, W, H, 3)
+    z["reset_aux"] = np.asarray(ra, np.uint8).reshape(R, W, H)
+    z["reset_agent"] = np.asarray(rag, np.int32).reshape(R, 3)
+    z["reset_obs"] = np.asarray(ro, np.uint8).reshape(R, 7, 7, 3)
+    z["meta"] = np.frombuffer(json.dumps(meta).encode(), np.uint8)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **z)
+    print("%-34s K=%d T=%d resets=%d dones=%d nonzero-reward=%d  %6.1f KB" % (
+        name, K, T, R, int(z["done"].sum()), int((z["reward"] != 0).sum()), os.path.getsize(path) / 1024))
+
+
+def record_levels():
+    """Seeded level generation known answers: seed -> initial grid/agent."""
+    out = {}
+    for env_id, seeds in [("MiniGrid-Empty-8x8-v0", range(4)), ("MiniGrid-Empty-16x16-v0", range(2)),
+                          ("MiniGrid-Empty-5x5-v0", range(2)), ("MiniGrid-Empty-6x6-v0", range(2)),
+                          ("MiniGrid-DoorKey-5x5-v0", range(64)), ("MiniGrid-DoorKey-6x6-v0", range(64)),
+                          ("MiniGrid-DoorKey-8x8-v0", range(256)), ("MiniGrid-DoorKey-16x16-v0", range(32)),
+                          ("MiniGrid-LavaCrossingS9N1-v0", range(256)), ("MiniGrid-LavaCrossingS9N2-v0", range(64)),
+                          ("MiniGrid-LavaCrossingS9N3-v0", range(64)), ("MiniGrid-LavaCrossingS11N5-v0", range(64)),
+                          ("MiniGrid-SimpleCrossingS9N1-v0", range(64)), ("MiniGrid-SimpleCrossingS9N2-v0", range(64)),
+                          ("MiniGrid-SimpleCrossingS9N3-v0", range(64)), ("MiniGrid-SimpleCrossingS11N5-v0", range(64))]:
+        env = gym.make(env_id)
+        grids, agents = [], []
+        big = [1337, 2 ** 32 - 1, 2 ** 32, 2 ** 40 + 12345, 2 ** 64 - 1]
+        ss = list(seeds) + big
+        for s in ss:
+            env.seed(int(s))
+            env.reset()
+            grids.append(env.grid.encode())
+            agents.append((env.agent_pos[0], env.agent_pos[1], env.agent_dir))
+        key = env_id.replace("MiniGrid-", "").replace("-v0", "")
+        out[key + ":seeds"] = np.asarray(ss, np.uint64)
+        out[key + ":grid"] = np.asarray(grids, np.uint8)
+        out[key + ":agent"] = np.asarray(agents, np.int32)
+        out[key + ":max_steps"] = np.asarray([env.max_steps, int(env.see_through_walls)], np.int32)
+    path = os.path.join(OUT, "levels.npz")
+    np.savez_compressed(path, **out)
+    print("levels.npz %6.1f KB" % (os.path.getsize(path) / 1024))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    mk = lambda i: (lambda: gym.make(i))  # noqa: E731
+    record_case("Empty-8x8", mk("MiniGrid-Empty-8x8-v0"), [0, 1, 2, 3], 300)
+    record_case("Empty-5x5", mk("MiniGrid-Empty-5x5-v0"), [0, 1], 120)
+    record_case("Empty-Random-6x6", mk("MiniGrid-Empty-Random-6x6-v0"), [0, 1, 2, 3], 160)
+    record_case("Empty-16x16-full", mk("MiniGrid-Empty-16x16-v0"), [0, 1], 1100, full_obs=True)
+    record_case("DoorKey-8x8", mk("MiniGrid-DoorKey-8x8-v0"), list(range(8)), 700,
+                scripts=[doorkey_script] * 4 + [None] * 4)
+    record_case("DoorKey-8x8-full", mk("MiniGrid-DoorKey-8x8-v0"), [11, 12], 200,
+                scripts=[doorkey_script, None], full_obs=True)
+    record_case("DoorKey-5x5", mk("MiniGrid-DoorKey-5x5-v0"), [0, 1, 2, 3], 260, scripts=[doorkey_script] * 4)
+    record_case("DoorKey-16x16", mk("MiniGrid-DoorKey-16x16-v0"), [0, 1], 200, scripts=[doorkey_script] * 2)
+    record_case("LavaCrossingS9N1", mk("MiniGrid-LavaCrossingS9N1-v0"), list(range(8)), 400)
+    record_case("LavaCrossingS9N3", mk("MiniGrid-LavaCrossingS9N3-v0"), [0, 1, 2, 3], 200)
+    record_case("LavaCrossingS11N5", mk("MiniGrid-LavaCrossingS11N5-v0"), [0, 1], 200)
+    record_case("SimpleCrossingS9N2", mk("MiniGrid-SimpleCrossingS9N2-v0"), [0, 1, 2, 3], 340)
+    record_case("LavaGapS7-v1", mk("MiniGrid-LavaGapS7-v1"), [0, 1, 2, 3], 220, v1=True)
+    record_case("LavaGapS6", mk("MiniGrid-LavaGapS6-v0"), [0, 1], 160)
+    record_case("MultiRoom-N2-S4", mk("MiniGrid-MultiRoom-N2-S4-v0"), [0, 1, 2, 3], 120)
+    record_case("MultiRoom-N6", mk("MiniGrid-MultiRoom-N6-v0"), [0, 1], 150)
+    record_case("PlantedGoal-8x8", PlantedGoalEnv, [0, 1], 40,
+                scripts=[lambda e: [2, 2, 5, 2, 2], lambda e: [6, 2, 0, 1, 2, 2]])
+    record_case("Soup-8x8", lambda: SoupEnv(8, 8, False, 96, 0.45), list(range(12)), 200)
+    record_case("Soup-8x8-see", lambda: SoupEnv(8, 8, True, 64, 0.45), list(range(4)), 130)
+    record_case("Soup-9x9", lambda: SoupEnv(9, 9, False, 100, 0.35), list(range(8)), 200)
+    record_case("Soup-7x11", lambda: SoupEnv(7, 11, False, 80, 0.3), list(range(8)), 170)
+    record_case("Soup-13x6-full", lambda: SoupEnv(13, 6, False, 80, 0.3), list(range(6)), 170, full_obs=True)
+    record_case("Soup-9x9-v1", lambda: SoupEnvv1(9, 9, False, 100, 0.35), list(range(6)), 200, v1=True)
+    record_case("Soup-19x19", lambda: SoupEnv(19, 19, False, 150, 0.25), list(range(3)), 300)
+    record_levels()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,305 @@
+/*
+ * minigrid_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C restatement of the reference's hot path, written to follow the
+ * reference's *sequential* algorithm step by step (slice -> rotate_left x (dir+1)
+ * -> process_vis two-sweep flood -> agent-cell overwrite -> encode), so that it is
+ * an independent check of the closed-form / bit-mask formulation used by the HIP
+ * kernels.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+ * may load this library.  Parity is PINNED: tests/test_oracle_golden.py replays
+ * every fixture in tests/golden/ (recorded from the reference itself by
+ * oracle/gen_golden.py) through these functions and demands byte equality.
+ *
+ * Reference (paths relative to /root/reference/gym_minigrid/):
+ *   minigrid.py:27-61     OBJECT/COLOR/STATE codebooks
+ *   minigrid.py:93-107    WorldObj.can_overlap / can_pickup / see_behind defaults
+ *   minigrid.py:156-181   Goal (overlap = toggletimes<=0; toggle removes a default goal)
+ *   minigrid.py:184-237   Floor / Lava / Wall predicates
+ *   minigrid.py:239-275   Door predicates, toggle, encode
+ *   minigrid.py:301-364   Key / Ball / Box (pickup; default Box toggle -> contents = None)
+ *   minigrid.py:411-419   Grid.get/set  (row-major j*W+i, bounds asserts)
+ *   minigrid.py:439-473   Grid.rotate_left / Grid.slice
+ *   minigrid.py:571-594   Grid.encode(vis_mask)
+ *   minigrid.py:617-648   Grid.process_vis (default_vis branch)
+ *   minigrid.py:933-937   _reward
+ *   minigrid.py:1112-1133 front_pos / left_pos / right_pos
+ *   minigrid.py:1162-1189 get_view_exts
+ *   minigrid.py:1227-1325 MiniGridEnv.step
+ *   minigrid.py:1327-1381 gen_obs_grid / gen_obs
+ *   wrappers.py:311-338   FullyObsWrapper.observation
+ *
+ * State representation used here = the reference's own encoding:
+ *   grid  u8[W][H][3]   Grid.encode() layout, index [x][y][channel]; (1,0,0) = None
+ *   aux   u8[W][H]      bit0 = Goal.overlap (a goal built with toggletimes<=0)
+ *   agent i32[3]        x, y, dir
+ *   carry u8[3]         encode() of the carried object, (1,0,0) = nothing; carry_aux u8
+ *   steps i32           step_count
+ */
+#include <stdint.h>
+#include <string.h>
+
+#define V 7 /* agent_view_size (minigrid.py:776) */
+
+enum { T_UNSEEN = 0, T_EMPTY = 1, T_WALL = 2, T_FLOOR = 3, T_DOOR = 4, T_KEY = 5,
+       T_BALL = 6, T_BOX = 7, T_GOAL = 8, T_LAVA = 9, T_AGENT = 10 };
+enum { ST_OPEN = 0, ST_CLOSED = 1, ST_LOCKED = 2 };
+enum { A_LEFT = 0, A_RIGHT = 1, A_FORWARD = 2, A_PICKUP = 3, A_DROP = 4, A_TOGGLE = 5, A_DONE = 6 };
+
+#define MGO_OK 0
+#define MGO_ERR_ACTION (-1) /* reference: assert False, "unknown action"  (minigrid.py:1318) */
+#define MGO_ERR_OOB (-2)    /* reference: Grid.get bounds assert         (minigrid.py:417-418) */
+
+typedef struct { uint8_t t, c, s, a; } cell_t; /* t == T_EMPTY  <=>  Python None */
+
+typedef struct {
+    int W, H, max_steps, see_through, lava_v1;
+} mgo_cfg;
+
+static const int DIR_TO_VEC[4][2] = { {1, 0}, {0, 1}, {-1, 0}, {0, -1} }; /* minigrid.py:64-73 */
+
+static cell_t NONE(void) { cell_t c = { T_EMPTY, 0, 0, 0 }; return c; }
+static int is_none(cell_t c) { return c.t == T_EMPTY; }
+
+static cell_t grid_get(const mgo_cfg *cf, const uint8_t *g, const uint8_t *aux, int i, int j)
+{
+    cell_t c;
+    const uint8_t *p = g + ((size_t)i * cf->H + j) * 3;
+    c.t = p[0]; c.c = p[1]; c.s = p[2]; c.a = aux ? aux[(size_t)i * cf->H + j] : 0;
+    return c;
+}
+
+static void grid_set(const mgo_cfg *cf, uint8_t *g, uint8_t *aux, int i, int j, cell_t c)
+{
+    uint8_t *p = g + ((size_t)i * cf->H + j) * 3;
+    p[0] = c.t; p[1] = c.c; p[2] = c.s;
+    if (aux) aux[(size_t)i * cf->H + j] = c.a;
+}
+
+/* can_overlap: None handled by callers.  Goal/Floor/Lava True, Door iff open,
+ * Box iff color == triage_color (triage_color is None for every in-scope box -> False). */
+static int can_overlap(cell_t c)
+{
+    switch (c.t) {
+    case T_GOAL: case T_FLOOR: case T_LAVA: return 1;
+    case T_DOOR: return c.s == ST_OPEN;
+    default: return 0;
+    }
+}
+static int can_pickup(cell_t c) { return c.t == T_KEY || c.t == T_BALL || c.t == T_BOX; }
+static int see_behind(cell_t c)
+{
+    if (c.t == T_WALL) return 0;
+    if (c.t == T_DOOR) return c.s == ST_OPEN;
+    return 1;
+}
+
+/* gen_obs_grid + gen_obs (minigrid.py:1327-1381): literal slice/rotate/process_vis/encode */
+static void gen_obs(const mgo_cfg *cf, const uint8_t *g, const uint8_t *aux, const int32_t *agent,
+                    const uint8_t *carry, uint8_t *image /* [V][V][3] */)
+{
+    int ax = agent[0], ay = agent[1], dir = agent[2];
+    int topX, topY, i, j, r;
+    cell_t a[V][V], b[V][V]; /* [i][j] = Grid.get(i, j) of the view grid */
+    int mask[V][V];
+
+    /* get_view_exts (minigrid.py:1162-1189) */
+    if (dir == 0)      { topX = ax;             topY = ay - V / 2; }
+    else if (dir == 1) { topX = ax - V / 2;     topY = ay; }
+    else if (dir == 2) { topX = ax - V + 1;     topY = ay - V / 2; }
+    else               { topX = ax - V / 2;     topY = ay - V + 1; }
+
+    /* Grid.slice (minigrid.py:453-473): out of bounds -> Wall() (grey) */
+    for (j = 0; j < V; j++)
+        for (i = 0; i < V; i++) {
+            int x = topX + i, y = topY + j;
+            if (x >= 0 && x < cf->W && y >= 0 && y < cf->H) a[i][j] = grid_get(cf, g, aux, x, y);
+            else { cell_t w = { T_WALL, 5, 0, 0 }; a[i][j] = w; }
+        }
+
+    /* rotate_left (minigrid.py:439-451), dir+1 times (minigrid.py:1338-1339) */
+    for (r = 0; r < dir + 1; r++) {
+        for (i = 0; i < V; i++)
+            for (j = 0; j < V; j++)
+                b[j][V - 1 - i] = a[i][j];
+        memcpy(a, b, sizeof a);
+    }
+
+    /* process_vis, default_vis branch (minigrid.py:617-648) */
+    if (!cf->see_through) {
+        memset(mask, 0, sizeof mask);
+        mask[V / 2][V - 1] = 1;
+        for (j = V - 1; j >= 0; j--) {
+            for (i = 0; i < V - 1; i++) {
+                if (!mask[i][j]) continue;
+                if (!is_none(a[i][j]) && !see_behind(a[i][j])) continue;
+                mask[i + 1][j] = 1;
+                if (j > 0) { mask[i + 1][j - 1] = 1; mask[i][j - 1] = 1; }
+            }
+            for (i = V - 1; i >= 1; i--) {
+                if (!mask[i][j]) continue;
+                if (!is_none(a[i][j]) && !see_behind(a[i][j])) continue;
+                mask[i - 1][j] = 1;
+                if (j > 0) { mask[i - 1][j - 1] = 1; mask[i][j - 1] = 1; }
+            }
+        }
+    } else {
+        for (i = 0; i < V; i++) for (j = 0; j < V; j++) mask[i][j] = 1;
+    }
+
+    /* agent sees what it carries, at its own view cell (minigrid.py:1349-1356) */
+    {
+        cell_t c = { carry[0], carry[1], carry[2], 0 };
+        a[V / 2][V - 1] = c; /* (1,0,0) == None */
+    }
+
+    /* Grid.encode(vis_mask) (minigrid.py:571-594) */
+    for (i = 0; i < V; i++)
+        for (j = 0; j < V; j++) {
+            uint8_t *p = image + (i * V + j) * 3;
+            if (mask[i][j]) { p[0] = a[i][j].t; p[1] = a[i][j].c; p[2] = a[i][j].s; }
+            else { p[0] = p[1] = p[2] = 0; }
+        }
+}
+
+/* FullyObsWrapper.observation (wrappers.py:326-338) */
+static void full_obs(const mgo_cfg *cf, const uint8_t *g, const int32_t *agent, uint8_t *image)
+{
+    memcpy(image, g, (size_t)cf->W * cf->H * 3);
+    uint8_t *p = image + ((size_t)agent[0] * cf->H + agent[1]) * 3;
+    p[0] = T_AGENT; p[1] = 0 /* red */; p[2] = (uint8_t)agent[2];
+}
+
+/* MiniGridEnv.step (minigrid.py:1227-1325) without the trailing gen_obs */
+static int step_state(const mgo_cfg *cf, uint8_t *g, uint8_t *aux, int32_t *agent, uint8_t *carry,
+                      uint8_t *carry_aux, int32_t *steps, int action, double *reward, uint8_t *done)
+{
+    int dir = agent[2];
+    int fx, fy, lx, ly, rx, ry;
+    cell_t fwd;
+    *steps += 1;
+    *reward = 0.0;
+    *done = 0;
+
+    fx = agent[0] + DIR_TO_VEC[dir][0];           fy = agent[1] + DIR_TO_VEC[dir][1];
+    lx = agent[0] + DIR_TO_VEC[(dir + 3) % 4][0]; ly = agent[1] + DIR_TO_VEC[(dir + 3) % 4][1];
+    rx = agent[0] + DIR_TO_VEC[(dir + 1) % 4][0]; ry = agent[1] + DIR_TO_VEC[(dir + 1) % 4][1];
+    /* grid.get(fwd/left/right) all assert bounds (minigrid.py:1239-1243) */
+    if (fx < 0 || fx >= cf->W || fy < 0 || fy >= cf->H || lx < 0 || lx >= cf->W || ly < 0 || ly >= cf->H ||
+        rx < 0 || rx >= cf->W || ry < 0 || ry >= cf->H) {
+        if (*steps >= cf->max_steps) *done = 1;
+        return MGO_ERR_OOB;
+    }
+    if (action < 0 || action > A_DONE) {
+        /* extended (strafe) actions are out of scope; the reference asserts here */
+        if (*steps >= cf->max_steps) *done = 1;
+        return MGO_ERR_ACTION;
+    }
+    fwd = grid_get(cf, g, aux, fx, fy);
+
+    if (action == A_LEFT) {
+        agent[2] -= 1;
+        if (agent[2] < 0) agent[2] += 4;
+    } else if (action == A_RIGHT) {
+        agent[2] = (agent[2] + 1) % 4;
+    } else if (action == A_FORWARD) {
+        if (is_none(fwd) || can_overlap(fwd)) { agent[0] = fx; agent[1] = fy; }
+        if (!is_none(fwd) && fwd.t == T_GOAL && (fwd.a & 1)) {
+            *done = 1;
+            *reward = 1.0 * (1 - 0.9 * ((double)*steps / (double)cf->max_steps));
+        }
+        if (!is_none(fwd) && fwd.t == T_LAVA) {
+            if (cf->lava_v1) { *done = 0; *reward = -1; }
+            else *done = 1;
+        }
+    } else if (action == A_PICKUP) {
+        if (!is_none(fwd) && can_pickup(fwd)) {
+            if (carry[0] == T_EMPTY) {
+                carry[0] = fwd.t; carry[1] = fwd.c; carry[2] = fwd.s; *carry_aux = fwd.a;
+                grid_set(cf, g, aux, fx, fy, NONE());
+            }
+        }
+    } else if (action == A_DROP) {
+        if (is_none(fwd) && carry[0] != T_EMPTY) {
+            cell_t c = { carry[0], carry[1], carry[2], *carry_aux };
+            grid_set(cf, g, aux, fx, fy, c);
+            carry[0] = T_EMPTY; carry[1] = 0; carry[2] = 0; *carry_aux = 0;
+        }
+    } else if (action == A_TOGGLE) {
+        if (!is_none(fwd)) {
+            if (fwd.t == T_DOOR) { /* Door.toggle minigrid.py:252-262 */
+                if (fwd.s == ST_LOCKED) {
+                    if (carry[0] == T_KEY && carry[1] == fwd.c) { fwd.s = ST_OPEN; grid_set(cf, g, aux, fx, fy, fwd); }
+                } else {
+                    fwd.s = (fwd.s == ST_OPEN) ? ST_CLOSED : ST_OPEN;
+                    grid_set(cf, g, aux, fx, fy, fwd);
+                }
+            } else if (fwd.t == T_GOAL) { /* Goal.toggle minigrid.py:171-181; default toggletimes=1 */
+                if (!(fwd.a & 1)) grid_set(cf, g, aux, fx, fy, NONE());
+            } else if (fwd.t == T_BOX) { /* Box.toggle minigrid.py:355-364; contains=None */
+                grid_set(cf, g, aux, fx, fy, NONE());
+            }
+        }
+    } /* A_DONE: pass */
+
+    if (*steps >= cf->max_steps) *done = 1;
+    return MGO_OK;
+}
+
+/* ------------------------------------------------------------------ exported, batched */
+
+/* One reference `env.step(a)` per env, in place.  obs may be NULL.  full may be NULL.
+ * Returns 0, or the first per-env error code (processing continues for the rest);
+ * err (optional, i32[n]) receives the per-env code. */
+int mgo_step_batch(const mgo_cfg *cf, int64_t n, uint8_t *grid, uint8_t *aux, int32_t *agent,
+                   uint8_t *carry, uint8_t *carry_aux, int32_t *steps, const uint8_t *actions,
+                   uint8_t *obs, uint8_t *full, double *reward, uint8_t *done, int32_t *err)
+{
+    const size_t cells = (size_t)cf->W * cf->H;
+    int first = 0;
+    for (int64_t e = 0; e < n; e++) {
+        uint8_t *g = grid + e * cells * 3, *ax = aux + e * cells;
+        int rc = step_state(cf, g, ax, agent + e * 3, carry + e * 3, carry_aux + e, steps + e,
+                            actions[e], reward + e, done + e);
+        if (err) err[e] = rc;
+        if (rc && !first) first = rc;
+        if (obs) gen_obs(cf, g, ax, agent + e * 3, carry + e * 3, obs + e * (V * V * 3));
+        if (full) full_obs(cf, g, agent + e * 3, full + e * cells * 3);
+    }
+    return first;
+}
+
+/* reset()-time observation of the current state (minigrid.py:857) */
+void mgo_obs_batch(const mgo_cfg *cf, int64_t n, const uint8_t *grid, const uint8_t *aux,
+                   const int32_t *agent, const uint8_t *carry, uint8_t *obs, uint8_t *full)
+{
+    const size_t cells = (size_t)cf->W * cf->H;
+    for (int64_t e = 0; e < n; e++) {
+        if (obs) gen_obs(cf, grid + e * cells * 3, aux + e * cells, agent + e * 3, carry + e * 3, obs + e * (V * V * 3));
+        if (full) full_obs(cf, grid + e * cells * 3, agent + e * 3, full + e * cells * 3);
+    }
+}
+
+/* CPU-baseline helper for bench.py: T steps over n envs with "restore the episode's
+ * initial state on done" (= ReseedWrapper(seeds=[s]) + caller-side reset, wrappers.py:24-28,
+ * run_tests.py:64-66).  actions u8[T][n].  Returns the number of env-steps executed. */
+int64_t mgo_rollout(const mgo_cfg *cf, int64_t n, int64_t T, uint8_t *grid, uint8_t *aux, int32_t *agent,
+                    uint8_t *carry, uint8_t *carry_aux, int32_t *steps, const uint8_t *grid0,
+                    const uint8_t *aux0, const int32_t *agent0, const uint8_t *actions, uint8_t *obs,
+                    uint8_t *full, double *reward, uint8_t *done)
+{
+    const size_t cells = (size_t)cf->W * cf->H;
+    for (int64_t t = 0; t < T; t++) {
+        mgo_step_batch(cf, n, grid, aux, agent, carry, carry_aux, steps, actions + t * n, obs, full, reward, done, 0);
+        for (int64_t e = 0; e < n; e++) {
+            if (!done[e]) continue;
+            memcpy(grid + e * cells * 3, grid0 + e * cells * 3, cells * 3);
+            memcpy(aux + e * cells, aux0 + e * cells, cells);
+            memcpy(agent + e * 3, agent0 + e * 3, 3 * sizeof(int32_t));
+            carry[e * 3] = T_EMPTY; carry[e * 3 + 1] = 0; carry[e * 3 + 2] = 0; carry_aux[e] = 0;
+            steps[e] = 0;
+            if (obs) gen_obs(cf, grid + e * cells * 3, aux + e * cells, agent + e * 3, carry + e * 3, obs + e * (V * V * 3));
+            if (full) full_obs(cf, grid + e * cells * 3, agent + e * 3, full + e * cells * 3);
+        }
+    }
+    return n * T;
+}

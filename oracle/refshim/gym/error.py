@@ -1,0 +1,4 @@
+class Error(Exception):
+    pass
+class UnregisteredEnv(Error):
+    pass

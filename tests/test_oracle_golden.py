@@ -1,0 +1,50 @@
+"""Pins the CPU oracle (oracle/minigrid_oracle.c) to the reference: every golden
+trace recorded from the reference (oracle/gen_golden.py) is replayed through the
+oracle and every output byte, reward, done flag and post-step state must match."""
+import numpy as np
+import pytest
+
+from conftest import golden_cases, load_case
+from oracle.minigrid_oracle import OracleEnvs
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_oracle_replays_reference_trace(name):
+    meta, z = load_case(name)
+    K, T = z["actions"].shape
+    full = meta["full_obs"]
+    env = OracleEnvs(meta["W"], meta["H"], meta["max_steps"], meta["see_through"], meta["lava_v1"])
+    env.set_state(z["init_grid"], z["init_agent"], aux=z["init_aux"])
+    if full:
+        o, f = env.observe(full=True)
+        assert np.array_equal(f, z["init_full"])
+    else:
+        o = env.observe()
+    assert np.array_equal(o, z["init_obs"])
+    resets = {}
+    for r, (k, t) in enumerate(zip(z["reset_k"], z["reset_t"])):
+        resets.setdefault(int(t), []).append((int(k), r))
+    for t in range(T):
+        out = env.step(z["actions"][:, t], full=full)
+        if full:
+            obs, fo, rew, done = out
+            assert np.array_equal(fo, z["full"][:, t]), (name, t)
+        else:
+            obs, rew, done = out
+        assert (env.err == 0).all()
+        assert np.array_equal(obs, z["obs"][:, t]), (name, t)
+        assert np.array_equal(rew, z["reward"][:, t]), (name, t)       # float64, exact
+        assert np.array_equal(done, z["done"][:, t]), (name, t)
+        assert np.array_equal(env.agent, z["agent"][:, t]), (name, t)
+        assert np.array_equal(env.agent[:, 2], z["direction"][:, t]), (name, t)
+        assert np.array_equal(env.carry, z["carry"][:, t]), (name, t)
+        assert np.array_equal(env.steps, z["steps"][:, t]), (name, t)
+        assert np.array_equal(env.grid, z["grid"][:, t]), (name, t)
+        # caller-side reset on done, same seed -> the recorded reset state is the episode start
+        assert sorted(k for k, _ in resets.get(t, [])) == sorted(np.flatnonzero(done).tolist())
+        for k, r in resets.get(t, []):
+            assert np.array_equal(z["reset_grid"][r], z["init_grid"][k])
+            assert np.array_equal(z["reset_aux"][r], z["init_aux"][k])
+            assert np.array_equal(z["reset_agent"][r], z["init_agent"][k])
+            assert np.array_equal(z["reset_obs"][r], z["init_obs"][k])
+        env.reset_where(done)
