@@ -1,0 +1,394 @@
+// levelgen.cpp -- host-side seeded level generation for the built-in env families.
+//
+// Reproduces `env.seed(s); env.reset()` of the reference for the families named in
+// BASELINE.json's configs (plus their siblings), in the reference's own encoding:
+//   EmptyEnv._gen_grid     /root/reference/gym_minigrid/envs/empty.py:30-57
+//   DoorKeyEnv._gen_grid   /root/reference/gym_minigrid/envs/doorkey.py:15-44
+//   CrossingEnv._gen_grid  /root/reference/gym_minigrid/envs/crossing.py:24-92
+//   LavaGapEnv._gen_grid   /root/reference/gym_minigrid/envs/lavagap.py:21-59
+//   place_obj/place_agent  /root/reference/gym_minigrid/minigrid.py:1003-1090
+//   seed()                 /root/reference/gym_minigrid/minigrid.py:860-863 -> gym.utils.seeding.np_random
+//
+// The random stream is third-party (gym < 0.22 + numpy RandomState, neither vendored by the
+// reference; setup.py:9-12 pins only lower bounds).  Restated here from their published
+// algorithms:
+//   gym legacy seeding : seed mod 2^64 -> SHA-512(str(seed)) -> first 8 bytes as little-endian
+//                        uint32 words (trailing zero words dropped, 0 -> [0]) ->
+//   numpy RandomState  : MT19937 init_by_array(words); randint/choice/shuffle all reduce to
+//                        "raw 32-bit output & mask, redraw while > max" (mask = next 2^k-1 >= max;
+//                        max == 0 consumes nothing); randint(lo,hi) = lo + bounded(hi-lo-1);
+//                        shuffle(list) draws bounded(i) for i = n-1 .. 1; choice(seq) = randint(0,len).
+// Pinned by tests/test_levelgen.py against tests/golden/levels.npz (recorded from the reference
+// running on this image's NumPy under the oracle's gym stand-in).
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mgx.h"
+#include "mgx_internal.h"
+
+namespace {
+
+// ----------------------------------------------------------------------------- SHA-512 (FIPS 180-4)
+const uint64_t K512[80] = {
+    0x428a2f98d728ae22ULL, 0x7137449123ef65cdULL, 0xb5c0fbcfec4d3b2fULL, 0xe9b5dba58189dbbcULL, 0x3956c25bf348b538ULL,
+    0x59f111f1b605d019ULL, 0x923f82a4af194f9bULL, 0xab1c5ed5da6d8118ULL, 0xd807aa98a3030242ULL, 0x12835b0145706fbeULL,
+    0x243185be4ee4b28cULL, 0x550c7dc3d5ffb4e2ULL, 0x72be5d74f27b896fULL, 0x80deb1fe3b1696b1ULL, 0x9bdc06a725c71235ULL,
+    0xc19bf174cf692694ULL, 0xe49b69c19ef14ad2ULL, 0xefbe4786384f25e3ULL, 0x0fc19dc68b8cd5b5ULL, 0x240ca1cc77ac9c65ULL,
+    0x2de92c6f592b0275ULL, 0x4a7484aa6ea6e483ULL, 0x5cb0a9dcbd41fbd4ULL, 0x76f988da831153b5ULL, 0x983e5152ee66dfabULL,
+    0xa831c66d2db43210ULL, 0xb00327c898fb213fULL, 0xbf597fc7beef0ee4ULL, 0xc6e00bf33da88fc2ULL, 0xd5a79147930aa725ULL,
+    0x06ca6351e003826fULL, 0x142929670a0e6e70ULL, 0x27b70a8546d22ffcULL, 0x2e1b21385c26c926ULL, 0x4d2c6dfc5ac42aedULL,
+    0x53380d139d95b3dfULL, 0x650a73548baf63deULL, 0x766a0abb3c77b2a8ULL, 0x81c2c92e47edaee6ULL, 0x92722c851482353bULL,
+    0xa2bfe8a14cf10364ULL, 0xa81a664bbc423001ULL, 0xc24b8b70d0f89791ULL, 0xc76c51a30654be30ULL, 0xd192e819d6ef5218ULL,
+    0xd69906245565a910ULL, 0xf40e35855771202aULL, 0x106aa07032bbd1b8ULL, 0x19a4c116b8d2d0c8ULL, 0x1e376c085141ab53ULL,
+    0x2748774cdf8eeb99ULL, 0x34b0bcb5e19b48a8ULL, 0x391c0cb3c5c95a63ULL, 0x4ed8aa4ae3418acbULL, 0x5b9cca4f7763e373ULL,
+    0x682e6ff3d6b2b8a3ULL, 0x748f82ee5defb2fcULL, 0x78a5636f43172f60ULL, 0x84c87814a1f0ab72ULL, 0x8cc702081a6439ecULL,
+    0x90befffa23631e28ULL, 0xa4506cebde82bde9ULL, 0xbef9a3f7b2c67915ULL, 0xc67178f2e372532bULL, 0xca273eceea26619cULL,
+    0xd186b8c721c0c207ULL, 0xeada7dd6cde0eb1eULL, 0xf57d4f7fee6ed178ULL, 0x06f067aa72176fbaULL, 0x0a637dc5a2c898a6ULL,
+    0x113f9804bef90daeULL, 0x1b710b35131c471bULL, 0x28db77f523047d84ULL, 0x32caab7b40c72493ULL, 0x3c9ebe0a15c9bebcULL,
+    0x431d67c49c100d4cULL, 0x4cc5d4becb3e42b6ULL, 0x597f299cfc657e2aULL, 0x5fcb6fab3ad6faecULL, 0x6c44198c4a475817ULL};
+
+inline uint64_t rotr(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
+
+// digest of a message shorter than 112 bytes (one block) -- all we need for str(seed)
+void sha512_short(const uint8_t *msg, size_t len, uint8_t out[64])
+{
+    uint8_t blk[128];
+    memset(blk, 0, sizeof blk);
+    memcpy(blk, msg, len);
+    blk[len] = 0x80;
+    uint64_t bits = (uint64_t)len * 8;
+    for (int i = 0; i < 8; i++) blk[127 - i] = (uint8_t)(bits >> (8 * i));
+    uint64_t w[80];
+    for (int t = 0; t < 16; t++) {
+        uint64_t v = 0;
+        for (int i = 0; i < 8; i++) v = (v << 8) | blk[t * 8 + i];
+        w[t] = v;
+    }
+    for (int t = 16; t < 80; t++) {
+        uint64_t s0 = rotr(w[t - 15], 1) ^ rotr(w[t - 15], 8) ^ (w[t - 15] >> 7);
+        uint64_t s1 = rotr(w[t - 2], 19) ^ rotr(w[t - 2], 61) ^ (w[t - 2] >> 6);
+        w[t] = w[t - 16] + s0 + w[t - 7] + s1;
+    }
+    uint64_t h[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
+                     0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
+    uint64_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    for (int t = 0; t < 80; t++) {
+        uint64_t S1 = rotr(e, 14) ^ rotr(e, 18) ^ rotr(e, 41);
+        uint64_t ch = (e & f) ^ (~e & g);
+        uint64_t t1 = hh + S1 + ch + K512[t] + w[t];
+        uint64_t S0 = rotr(a, 28) ^ rotr(a, 34) ^ rotr(a, 39);
+        uint64_t mj = (a & b) ^ (a & c) ^ (b & c);
+        uint64_t t2 = S0 + mj;
+        hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+    for (int i = 0; i < 8; i++)
+        for (int j = 0; j < 8; j++) out[i * 8 + j] = (uint8_t)(h[i] >> (56 - 8 * j));
+}
+
+// ----------------------------------------------------------------------------- MT19937 + numpy legacy draws
+struct Rng {
+    uint32_t mt[624];
+    int idx;
+
+    void init_genrand(uint32_t s)
+    {
+        mt[0] = s;
+        for (int i = 1; i < 624; i++) mt[i] = 1812433253U * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+        idx = 624;
+    }
+    void init_by_array(const uint32_t *key, int klen)
+    {
+        init_genrand(19650218U);
+        int i = 1, j = 0;
+        int k = 624 > klen ? 624 : klen;
+        for (; k; k--) {
+            mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525U)) + key[j] + (uint32_t)j;
+            i++; j++;
+            if (i >= 624) { mt[0] = mt[623]; i = 1; }
+            if (j >= klen) j = 0;
+        }
+        for (k = 623; k; k--) {
+            mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941U)) - (uint32_t)i;
+            i++;
+            if (i >= 624) { mt[0] = mt[623]; i = 1; }
+        }
+        mt[0] = 0x80000000U;
+        idx = 624;
+    }
+    uint32_t next32()
+    {
+        if (idx >= 624) {
+            int kk;
+            for (kk = 0; kk < 624 - 397; kk++) {
+                uint32_t y = (mt[kk] & 0x80000000U) | (mt[kk + 1] & 0x7fffffffU);
+                mt[kk] = mt[kk + 397] ^ (y >> 1) ^ ((y & 1U) ? 0x9908b0dfU : 0U);
+            }
+            for (; kk < 623; kk++) {
+                uint32_t y = (mt[kk] & 0x80000000U) | (mt[kk + 1] & 0x7fffffffU);
+                mt[kk] = mt[kk + (397 - 624)] ^ (y >> 1) ^ ((y & 1U) ? 0x9908b0dfU : 0U);
+            }
+            uint32_t y = (mt[623] & 0x80000000U) | (mt[0] & 0x7fffffffU);
+            mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1U) ? 0x9908b0dfU : 0U);
+            idx = 0;
+        }
+        uint32_t y = mt[idx++];
+        y ^= (y >> 11);
+        y ^= (y << 7) & 0x9d2c5680U;
+        y ^= (y << 15) & 0xefc60000U;
+        y ^= (y >> 18);
+        return y;
+    }
+    // uniform integer in [0, max] by masked rejection
+    uint32_t bounded(uint32_t max)
+    {
+        if (max == 0) return 0;
+        uint32_t mask = max;
+        mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+        uint32_t v;
+        do { v = next32() & mask; } while (v > max);
+        return v;
+    }
+    int randint(int lo, int hi) { return lo + (int)bounded((uint32_t)(hi - lo - 1)); }
+
+    // gym.utils.seeding.np_random(seed)
+    void seed_gym(uint64_t seed)
+    {
+        char txt[32];
+        int n = snprintf(txt, sizeof txt, "%llu", (unsigned long long)seed);
+        uint8_t dg[64];
+        sha512_short((const uint8_t *)txt, (size_t)n, dg);
+        uint32_t key[2];
+        key[0] = (uint32_t)dg[0] | ((uint32_t)dg[1] << 8) | ((uint32_t)dg[2] << 16) | ((uint32_t)dg[3] << 24);
+        key[1] = (uint32_t)dg[4] | ((uint32_t)dg[5] << 8) | ((uint32_t)dg[6] << 16) | ((uint32_t)dg[7] << 24);
+        int klen = key[1] ? 2 : 1; // _int_list_from_bigint drops a zero high word; 0 -> [0]
+        init_by_array(key, klen);
+    }
+};
+
+// ----------------------------------------------------------------------------- tiny grid helper
+struct Level {
+    int W, H;
+    uint8_t *g; // [W][H][3]
+    int ax = -1, ay = -1, adir = 0;
+
+    uint8_t *at(int x, int y) { return g + ((size_t)x * H + y) * 3; }
+    void set(int x, int y, int t, int c, int s) { uint8_t *p = at(x, y); p[0] = (uint8_t)t; p[1] = (uint8_t)c; p[2] = (uint8_t)s; }
+    bool empty(int x, int y) { return at(x, y)[0] == 1; }
+    void clear()
+    {
+        for (int i = 0; i < W * H; i++) { g[i * 3] = 1; g[i * 3 + 1] = 0; g[i * 3 + 2] = 0; }
+    }
+    void wall_rect()
+    { // Grid.wall_rect(0,0,W,H), minigrid.py:433-437
+        for (int x = 0; x < W; x++) { set(x, 0, 2, 5, 0); set(x, H - 1, 2, 5, 0); }
+        for (int y = 0; y < H; y++) { set(0, y, 2, 5, 0); set(W - 1, y, 2, 5, 0); }
+    }
+    // place_obj(obj=None, top=(0,0), size=(sw,sh)) rejection sampling, minigrid.py:1028-1053
+    void sample_free(Rng &r, int sw, int sh, bool reject_agent, int *ox, int *oy)
+    {
+        for (;;) {
+            int x = r.randint(0, std::min(sw, W));
+            int y = r.randint(0, std::min(sh, H));
+            if (!empty(x, y)) continue;
+            if (reject_agent && x == ax && y == ay) continue;
+            *ox = x; *oy = y;
+            return;
+        }
+    }
+};
+
+void gen_empty(const mgx_config &c, Rng &r, Level &L)
+{
+    L.clear();
+    L.wall_rect();
+    L.set(L.W - 2, L.H - 2, 8, 1, 0); // Goal() green
+    if (c.level_arg0 == 0) { L.ax = 1; L.ay = 1; L.adir = 0; }
+    else { // agent_start_pos=None -> place_agent(size=sizetop)
+        int sw = c.level_arg1 > 0 ? c.level_arg1 : L.W, sh = c.level_arg1 > 0 ? c.level_arg1 : L.H;
+        L.sample_free(r, sw, sh, false, &L.ax, &L.ay);
+        L.adir = r.randint(0, 4);
+    }
+}
+
+void gen_doorkey(const mgx_config &, Rng &r, Level &L)
+{
+    L.clear();
+    L.wall_rect();
+    L.set(L.W - 2, L.H - 2, 8, 1, 0);
+    int split = r.randint(2, L.W - 2);
+    for (int y = 0; y < L.H; y++) L.set(split, y, 2, 5, 0); // vert_wall(split, 0)
+    L.sample_free(r, split, L.H, false, &L.ax, &L.ay);      // place_agent(size=(split, H))
+    L.adir = r.randint(0, 4);
+    int door = r.randint(1, L.W - 2);
+    L.set(split, door, 4, 4, 2);                            // Door('yellow', is_locked=True)
+    int kx, ky;
+    L.sample_free(r, split, L.H, true, &kx, &ky);           // Key('yellow'), rejects the agent cell
+    L.set(kx, ky, 5, 4, 0);
+}
+
+void gen_crossing(const mgx_config &c, Rng &r, Level &L)
+{
+    const int W = L.W, H = L.H, ncross = c.level_arg0;
+    const int ot = c.level_arg1 == 2 ? 2 : 9, oc = c.level_arg1 == 2 ? 5 : 0;
+    L.clear();
+    L.wall_rect();
+    L.ax = 1; L.ay = 1; L.adir = 0;
+    L.set(W - 2, H - 2, 8, 1, 0);
+    struct River { int vertical; int pos; };
+    std::vector<River> rivers;
+    for (int i = 2; i < H - 2; i += 2) rivers.push_back({1, i}); // (v, i)
+    for (int j = 2; j < W - 2; j += 2) rivers.push_back({0, j}); // (h, j)
+    for (int i = (int)rivers.size() - 1; i >= 1; i--) {          // np_random.shuffle(list)
+        int j = (int)r.bounded((uint32_t)i);
+        std::swap(rivers[i], rivers[j]);
+    }
+    if ((int)rivers.size() > ncross) rivers.resize(ncross);
+    std::vector<int> rv, rh;
+    for (auto &x : rivers) (x.vertical ? rv : rh).push_back(x.pos);
+    std::sort(rv.begin(), rv.end());
+    std::sort(rh.begin(), rh.end());
+    for (int j : rh) for (int i = 1; i < W - 1; i++) L.set(i, j, ot, oc, 0); // product(range(1,W-1), rivers_h)
+    for (int i : rv) for (int j = 1; j < H - 1; j++) L.set(i, j, ot, oc, 0); // product(rivers_v, range(1,H-1))
+    std::vector<int> path; // 1 = h step (crosses a vertical river), 0 = v step
+    for (size_t i = 0; i < rv.size(); i++) path.push_back(1);
+    for (size_t i = 0; i < rh.size(); i++) path.push_back(0);
+    for (int i = (int)path.size() - 1; i >= 1; i--) {
+        int j = (int)r.bounded((uint32_t)i);
+        std::swap(path[i], path[j]);
+    }
+    std::vector<int> lim_v, lim_h;
+    lim_v.push_back(0); for (int v : rv) lim_v.push_back(v); lim_v.push_back(H - 1);
+    lim_h.push_back(0); for (int h : rh) lim_h.push_back(h); lim_h.push_back(W - 1);
+    int room_i = 0, room_j = 0;
+    for (int d : path) {
+        int i, j;
+        if (d == 1) {
+            i = lim_v[room_i + 1];
+            int lo = lim_h[room_j] + 1, hi = lim_h[room_j + 1];
+            j = lo + r.randint(0, hi - lo); // choice(range(lo, hi))
+            room_i++;
+        } else {
+            int lo = lim_v[room_i] + 1, hi = lim_v[room_i + 1];
+            i = lo + r.randint(0, hi - lo);
+            j = lim_h[room_j + 1];
+            room_j++;
+        }
+        L.set(i, j, 1, 0, 0);
+    }
+}
+
+void gen_lavagap(const mgx_config &c, Rng &r, Level &L)
+{
+    const int W = L.W, H = L.H;
+    const int ot = c.level_arg1 == 2 ? 2 : 9, oc = c.level_arg1 == 2 ? 5 : 0;
+    L.clear();
+    L.wall_rect();
+    L.ax = 1; L.ay = 1; L.adir = 0;
+    L.set(W - 2, H - 2, 8, 1, 0);
+    int gx, gy;
+    if (!c.level_arg0) { gx = r.randint(2, W - 2); gy = r.randint(1, H - 1); }
+    else { gx = W / 2; gy = r.randint(1, H - 1); }
+    for (int j = 0; j < H - 2; j++) L.set(gx, 1 + j, ot, oc, 0); // vert_wall(gx, 1, H-2, obstacle)
+    L.set(gx, gy, 1, 0, 0);
+}
+
+struct EnvId { const char *id; mgx_config cfg; };
+
+mgx_config mk(int w, int h, int max_steps, int see, int v1, int kind, int a0, int a1)
+{
+    mgx_config c;
+    memset(&c, 0, sizeof c);
+    c.width = w; c.height = h; c.max_steps = max_steps; c.see_through_walls = see; c.lava_v1 = v1;
+    c.level_kind = kind; c.level_arg0 = a0; c.level_arg1 = a1;
+    return c;
+}
+
+const std::vector<EnvId> &registry()
+{
+    static const std::vector<EnvId> R = {
+        // EmptyEnv: max_steps = 4*size^2, see_through_walls=True (envs/empty.py:23-28)
+        {"MiniGrid-Empty-5x5-v0", mk(5, 5, 100, 1, 0, MGX_LEVEL_EMPTY, 0, 0)},
+        {"MiniGrid-Empty-6x6-v0", mk(6, 6, 144, 1, 0, MGX_LEVEL_EMPTY, 0, 0)},
+        {"MiniGrid-Empty-8x8-v0", mk(8, 8, 256, 1, 0, MGX_LEVEL_EMPTY, 0, 0)},
+        {"MiniGrid-Empty-16x16-v0", mk(16, 16, 1024, 1, 0, MGX_LEVEL_EMPTY, 0, 0)},
+        {"MiniGrid-Empty-Random-5x5-v0", mk(5, 5, 100, 1, 0, MGX_LEVEL_EMPTY, 1, 0)},
+        {"MiniGrid-Empty-Random-6x6-v0", mk(6, 6, 144, 1, 0, MGX_LEVEL_EMPTY, 1, 0)},
+        {"MiniGrid-Empty-Random-8x8-v0", mk(8, 8, 256, 1, 0, MGX_LEVEL_EMPTY, 1, 0)},
+        {"MiniGrid-Empty-Random-10x10-v0", mk(10, 10, 400, 1, 0, MGX_LEVEL_EMPTY, 1, 4)},
+        // DoorKeyEnv: max_steps = 10*size^2 (envs/doorkey.py:9-13)
+        {"MiniGrid-DoorKey-5x5-v0", mk(5, 5, 250, 0, 0, MGX_LEVEL_DOORKEY, 0, 0)},
+        {"MiniGrid-DoorKey-6x6-v0", mk(6, 6, 360, 0, 0, MGX_LEVEL_DOORKEY, 0, 0)},
+        {"MiniGrid-DoorKey-8x8-v0", mk(8, 8, 640, 0, 0, MGX_LEVEL_DOORKEY, 0, 0)},
+        {"MiniGrid-DoorKey-16x16-v0", mk(16, 16, 2560, 0, 0, MGX_LEVEL_DOORKEY, 0, 0)},
+        // CrossingEnv: max_steps = 4*size^2 (envs/crossing.py:12-22,94-172)
+        {"MiniGrid-LavaCrossingS9N1-v0", mk(9, 9, 324, 0, 0, MGX_LEVEL_CROSSING, 1, 9)},
+        {"MiniGrid-LavaCrossingS9N2-v0", mk(9, 9, 324, 0, 0, MGX_LEVEL_CROSSING, 2, 9)},
+        {"MiniGrid-LavaCrossingS9N3-v0", mk(9, 9, 324, 0, 0, MGX_LEVEL_CROSSING, 3, 9)},
+        {"MiniGrid-LavaCrossingS11N5-v0", mk(11, 11, 484, 0, 0, MGX_LEVEL_CROSSING, 5, 9)},
+        {"MiniGrid-SimpleCrossingS9N1-v0", mk(9, 9, 324, 0, 0, MGX_LEVEL_CROSSING, 1, 2)},
+        {"MiniGrid-SimpleCrossingS9N2-v0", mk(9, 9, 324, 0, 0, MGX_LEVEL_CROSSING, 2, 2)},
+        {"MiniGrid-SimpleCrossingS9N3-v0", mk(9, 9, 324, 0, 0, MGX_LEVEL_CROSSING, 3, 2)},
+        {"MiniGrid-SimpleCrossingS11N5-v0", mk(11, 11, 484, 0, 0, MGX_LEVEL_CROSSING, 5, 2)},
+        // LavaGapEnv: max_steps = 4*size^2; 'v1' classes are const-gap AND change lava semantics
+        // (envs/lavagap.py:10-19,62-85; minigrid.py:1263)
+        {"MiniGrid-LavaGapS5-v0", mk(5, 5, 100, 0, 0, MGX_LEVEL_LAVAGAP, 0, 9)},
+        {"MiniGrid-LavaGapS6-v0", mk(6, 6, 144, 0, 0, MGX_LEVEL_LAVAGAP, 0, 9)},
+        {"MiniGrid-LavaGapS7-v0", mk(7, 7, 196, 0, 0, MGX_LEVEL_LAVAGAP, 0, 9)},
+        {"MiniGrid-NormalGapS6-v0", mk(6, 6, 144, 0, 0, MGX_LEVEL_LAVAGAP, 0, 2)},
+        {"MiniGrid-LavaGapS6-v1", mk(6, 6, 144, 0, 1, MGX_LEVEL_LAVAGAP, 1, 9)},
+        {"MiniGrid-LavaGapS7-v1", mk(7, 7, 196, 0, 1, MGX_LEVEL_LAVAGAP, 1, 9)},
+    };
+    return R;
+}
+
+} // namespace
+
+extern "C" int mgx_env_config(const char *env_id, mgx_config *cfg)
+{
+    if (!env_id || !cfg) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_env_config: null argument");
+    for (auto &e : registry())
+        if (!strcmp(e.id, env_id)) { *cfg = e.cfg; return MGX_OK; }
+    return mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_env_config: unknown env id '%s'", env_id);
+}
+
+extern "C" const char *mgx_env_id(int i)
+{
+    auto &R = registry();
+    return (i >= 0 && i < (int)R.size()) ? R[i].id : nullptr;
+}
+
+extern "C" int mgx_generate_levels(const mgx_config *cfg, int64_t n, const uint64_t *seeds, uint8_t *grid, int32_t *agent)
+{
+    if (!cfg || !seeds || !grid || !agent || n < 0) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_generate_levels: null argument");
+    const int W = cfg->width, H = cfg->height;
+    if (W < 3 || H < 3) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_generate_levels: grid %dx%d too small", W, H);
+    switch (cfg->level_kind) {
+    case MGX_LEVEL_EMPTY: case MGX_LEVEL_DOORKEY: case MGX_LEVEL_LAVAGAP: break;
+    case MGX_LEVEL_CROSSING:
+        if (W % 2 == 0 || H % 2 == 0) return mgx_fail(MGX_ERR_INVALID_ARG, "crossing levels need odd sizes (envs/crossing.py:25)");
+        break;
+    default: return mgx_fail(MGX_ERR_NO_LEVELGEN, "level_kind %d has no built-in generator", cfg->level_kind);
+    }
+    Rng rng;
+    const size_t cells = (size_t)W * H;
+    for (int64_t e = 0; e < n; e++) {
+        Level L;
+        L.W = W; L.H = H; L.g = grid + e * cells * 3;
+        // Empty with a fixed start consumes no randomness: skip the 624-word seeding
+        if (!(cfg->level_kind == MGX_LEVEL_EMPTY && cfg->level_arg0 == 0)) rng.seed_gym(seeds[e]);
+        switch (cfg->level_kind) {
+        case MGX_LEVEL_EMPTY: gen_empty(*cfg, rng, L); break;
+        case MGX_LEVEL_DOORKEY: gen_doorkey(*cfg, rng, L); break;
+        case MGX_LEVEL_CROSSING: gen_crossing(*cfg, rng, L); break;
+        default: gen_lavagap(*cfg, rng, L); break;
+        }
+        agent[e * 3] = L.ax; agent[e * 3 + 1] = L.ay; agent[e * 3 + 2] = L.adir;
+    }
+    return MGX_OK;
+}

@@ -1,0 +1,496 @@
+// mgx_api.cpp -- host side of libmgx.so: the C ABI declared in include/mgx.h.
+//
+// Owns the per-GPU handle (SoA state in HBM, episode-start snapshot, counters, staging buffers for
+// host-pointer callers, HIP stream/events) and enqueues the kernels of mgx_kernels.hip.  There is NO CPU
+// fallback for any compute entry point: without a usable HIP device mgx_create fails loudly.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "mgx.h"
+#include "mgx_internal.h"
+#include "mgx_kernels.h"
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+
+int mgx_fail(int status, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return status;
+}
+
+extern "C" const char *mgx_last_error(void) { return g_err; }
+extern "C" const char *mgx_version(void) { return "mgx 0.1 (gfx950)"; }
+
+#define HIP_TRY(expr)                                                                                         \
+    do {                                                                                                      \
+        hipError_t e_ = (expr);                                                                               \
+        if (e_ != hipSuccess) return mgx_fail(MGX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------ handle
+struct Staging { // grow-only device scratch + pinned host mirror for host-pointer callers
+    void *dev = nullptr;
+    size_t cap = 0;
+};
+
+struct mgx_env_s {
+    mgx_config cfg;
+    int64_t n = 0, n_pad = 0;
+    int device = 0;
+    int W = 0, H = 0, cells = 0, S = 0, LS = 0, wave_lds = 0, wpb = 4;
+    int64_t obs_bytes = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    uint8_t *cells_d = nullptr, *cells0_d = nullptr;
+    uint2 *agent_d = nullptr, *agent0_d = nullptr;
+    MgxCounters *ctr_d = nullptr;
+    Staging st_in[6], st_out[4];
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool profiling = false;
+    int64_t prof_launches = 0, steps_total = 0;
+    bool faults_cleared_base_set = false;
+    unsigned long long base_bad_act = 0, base_oob = 0;
+};
+
+namespace {
+
+int ensure(Staging &s, size_t bytes)
+{
+    if (bytes <= s.cap) return MGX_OK;
+    if (s.dev) (void)hipFree(s.dev);
+    s.dev = nullptr; s.cap = 0;
+    HIP_TRY(hipMalloc(&s.dev, bytes));
+    s.cap = bytes;
+    return MGX_OK;
+}
+
+// Is `p` device memory we can hand to a kernel directly?
+bool is_device_ptr(const void *p)
+{
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof a);
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; } // plain host memory
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+// Input argument: returns a device pointer holding `bytes` of *src (staged if src is host memory).
+int dev_in(mgx_handle h, int slot, const void *src, size_t bytes, const void **out)
+{
+    if (!src) { *out = nullptr; return MGX_OK; }
+    if (is_device_ptr(src)) {
+        if ((uintptr_t)src & 15) return mgx_fail(MGX_ERR_INVALID_ARG, "device pointer %p is not 16-byte aligned", src);
+        *out = src;
+        return MGX_OK;
+    }
+    int rc = ensure(h->st_in[slot], bytes);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(h->st_in[slot].dev, src, bytes, hipMemcpyHostToDevice, h->stream));
+    *out = h->st_in[slot].dev;
+    return MGX_OK;
+}
+
+struct OutArg { void *user = nullptr; void *dev = nullptr; size_t bytes = 0; bool staged = false; };
+
+int dev_out(mgx_handle h, int slot, void *dst, size_t bytes, OutArg *o)
+{
+    o->user = dst; o->bytes = bytes; o->staged = false; o->dev = nullptr;
+    if (!dst) return MGX_OK;
+    if (is_device_ptr(dst)) {
+        if ((uintptr_t)dst & 15) return mgx_fail(MGX_ERR_INVALID_ARG, "device pointer %p is not 16-byte aligned", dst);
+        o->dev = dst;
+        return MGX_OK;
+    }
+    int rc = ensure(h->st_out[slot], bytes);
+    if (rc) return rc;
+    o->dev = h->st_out[slot].dev;
+    o->staged = true;
+    return MGX_OK;
+}
+
+// copies staged outputs back; synchronises only if something was staged
+int finish_out(mgx_handle h, OutArg *outs, int n_outs)
+{
+    bool any = false;
+    for (int i = 0; i < n_outs; i++)
+        if (outs[i].staged) {
+            HIP_TRY(hipMemcpyAsync(outs[i].user, outs[i].dev, outs[i].bytes, hipMemcpyDeviceToHost, h->stream));
+            any = true;
+        }
+    if (any) HIP_TRY(hipStreamSynchronize(h->stream));
+    return MGX_OK;
+}
+
+StepParams base_params(mgx_handle h)
+{
+    StepParams p;
+    memset(&p, 0, sizeof p);
+    p.cells = h->cells_d; p.agent = h->agent_d; p.cells0 = h->cells0_d; p.agent0 = h->agent0_d;
+    p.ctr = h->ctr_d;
+    p.n = h->n; p.n_tiles = (int)(h->n_pad / 64);
+    p.W = h->W; p.H = h->H; p.S = h->S; p.LS = h->LS; p.wave_lds = h->wave_lds;
+    p.max_steps = h->cfg.max_steps; p.see_through = h->cfg.see_through_walls; p.lava_v1 = h->cfg.lava_v1;
+    p.auto_reset = h->cfg.auto_reset;
+    return p;
+}
+
+int check_handle(mgx_handle h, const char *fn)
+{
+    if (!h) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: null handle", fn);
+    hipError_t e = hipSetDevice(h->device);
+    if (e != hipSuccess) return mgx_fail(MGX_ERR_HIP, "%s: hipSetDevice(%d): %s", fn, h->device, hipGetErrorString(e));
+    return MGX_OK;
+}
+
+int read_counters(mgx_handle h, MgxCounters *c)
+{
+    HIP_TRY(hipMemcpyAsync(c, h->ctr_d, sizeof *c, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return MGX_OK;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------ lifecycle
+extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx_handle *out)
+{
+    if (!cfg || !out) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: null argument");
+    *out = nullptr;
+    if (n_envs <= 0) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: n_envs must be positive");
+    if (cfg->width < 3 || cfg->height < 3 || cfg->width > 255 || cfg->height > 255)
+        return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: grid %dx%d outside 3..255 (Grid.__init__ asserts >= 3)", cfg->width, cfg->height);
+    if (cfg->max_steps <= 0) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: max_steps must be positive");
+    if (cfg->obs_mode != MGX_OBS_PARTIAL && cfg->obs_mode != MGX_OBS_FULL)
+        return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: bad obs_mode %d", cfg->obs_mode);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return mgx_fail(MGX_ERR_HIP, "mgx_create: no HIP device (%s); libmgx has no CPU fallback", e == hipSuccess ? "count=0" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: device %d of %d", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+
+    mgx_env_s *h = new (std::nothrow) mgx_env_s();
+    if (!h) return mgx_fail(MGX_ERR_HIP, "mgx_create: out of host memory");
+    h->cfg = *cfg;
+    h->n = n_envs;
+    h->n_pad = (n_envs + 63) / 64 * 64;
+    h->device = device;
+    h->W = cfg->width; h->H = cfg->height;
+    h->cells = h->W * h->H;
+    h->S = (h->cells + 3) & ~3;
+    h->LS = h->S + (((h->S >> 2) & 1) ? 0 : 4); // odd dword stride per env in LDS
+    const int obs_img = cfg->obs_mode == MGX_OBS_PARTIAL ? 64 * MGX_OBS_PARTIAL_BYTES : 0;
+    int need = 64 * h->LS;
+    if (obs_img > need) need = obs_img;
+    h->wave_lds = (need + 15) & ~15;
+    h->obs_bytes = cfg->obs_mode == MGX_OBS_PARTIAL ? MGX_OBS_PARTIAL_BYTES : (int64_t)h->cells * 3;
+    const int LDS_DEFAULT = 64 * 1024, LDS_MAX = 160 * 1024;
+    if (h->wave_lds > LDS_MAX) {
+        int rc = mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_create: a %dx%d tile (64 envs) needs %d B of LDS > %d", h->W, h->H, h->wave_lds, LDS_MAX);
+        delete h;
+        return rc;
+    }
+    h->wpb = LDS_DEFAULT / h->wave_lds;
+    if (h->wpb > 4) h->wpb = 4;
+    if (h->wpb < 1) {
+        h->wpb = 1;
+        hipError_t e2 = mgx_raise_lds_limit(h->W, h->H, cfg->obs_mode, h->wave_lds);
+        if (e2 != hipSuccess) {
+            int rc = mgx_fail(MGX_ERR_HIP, "mgx_create: cannot raise dynamic LDS to %d B: %s", h->wave_lds, hipGetErrorString(e2));
+            delete h;
+            return rc;
+        }
+    }
+#define CREATE_TRY(expr)                                                                     \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            int rc_ = mgx_fail(MGX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+            mgx_destroy(h);                                                                  \
+            return rc_;                                                                      \
+        }                                                                                    \
+    } while (0)
+    CREATE_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
+    const size_t cb = (size_t)h->n_pad * h->S, ab = (size_t)h->n_pad * sizeof(uint2);
+    CREATE_TRY(hipMalloc((void **)&h->cells_d, cb));
+    CREATE_TRY(hipMalloc((void **)&h->cells0_d, cb));
+    CREATE_TRY(hipMalloc((void **)&h->agent_d, ab));
+    CREATE_TRY(hipMalloc((void **)&h->agent0_d, ab));
+    CREATE_TRY(hipMalloc((void **)&h->ctr_d, sizeof(MgxCounters)));
+    CREATE_TRY(hipMemsetAsync(h->cells_d, 0, cb, h->stream));
+    CREATE_TRY(hipMemsetAsync(h->cells0_d, 0, cb, h->stream));
+    CREATE_TRY(hipMemsetAsync(h->agent_d, 0, ab, h->stream));
+    CREATE_TRY(hipMemsetAsync(h->agent0_d, 0, ab, h->stream));
+    CREATE_TRY(hipMemsetAsync(h->ctr_d, 0, sizeof(MgxCounters), h->stream));
+    CREATE_TRY(hipEventCreate(&h->ev0));
+    CREATE_TRY(hipEventCreate(&h->ev1));
+    CREATE_TRY(hipStreamSynchronize(h->stream));
+#undef CREATE_TRY
+    *out = h;
+    return MGX_OK;
+}
+
+extern "C" int mgx_destroy(mgx_handle h)
+{
+    if (!h) return MGX_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(h->cells_d); (void)hipFree(h->cells0_d); (void)hipFree(h->agent_d); (void)hipFree(h->agent0_d);
+    (void)hipFree(h->ctr_d);
+    for (auto &s : h->st_in) if (s.dev) (void)hipFree(s.dev);
+    for (auto &s : h->st_out) if (s.dev) (void)hipFree(s.dev);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return MGX_OK;
+}
+
+extern "C" int mgx_set_stream(mgx_handle h, void *hip_stream)
+{
+    int rc = check_handle(h, "mgx_set_stream");
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream)); // hand-over point: everything enqueued so far is complete
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return MGX_OK;
+}
+
+extern "C" int mgx_obs_bytes(mgx_handle h, int64_t *per_env)
+{
+    if (!h || !per_env) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_obs_bytes: null argument");
+    *per_env = h->obs_bytes;
+    return MGX_OK;
+}
+
+extern "C" int mgx_sync(mgx_handle h)
+{
+    int rc = check_handle(h, "mgx_sync");
+    if (rc) return rc;
+    MgxCounters c;
+    rc = read_counters(h, &c);
+    if (rc) return rc;
+    if (c.invalid_actions > h->base_bad_act)
+        return mgx_fail(MGX_ERR_INVALID_ACTION, "%llu env-steps were given an action >= %d (reference: AssertionError 'unknown action')",
+                        c.invalid_actions - h->base_bad_act, MGX_NUM_ACTIONS);
+    if (c.out_of_bounds > h->base_oob)
+        return mgx_fail(MGX_ERR_OUT_OF_BOUNDS, "%llu env-steps had a front/left/right cell outside the grid (reference: Grid.get assert)",
+                        c.out_of_bounds - h->base_oob);
+    return MGX_OK;
+}
+
+extern "C" int mgx_clear_faults(mgx_handle h)
+{
+    int rc = check_handle(h, "mgx_clear_faults");
+    if (rc) return rc;
+    MgxCounters c;
+    rc = read_counters(h, &c);
+    if (rc) return rc;
+    h->base_bad_act = c.invalid_actions;
+    h->base_oob = c.out_of_bounds;
+    return MGX_OK;
+}
+
+extern "C" int mgx_get_stats(mgx_handle h, mgx_stats *out)
+{
+    int rc = check_handle(h, "mgx_get_stats");
+    if (rc) return rc;
+    if (!out) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_get_stats: null argument");
+    MgxCounters c;
+    rc = read_counters(h, &c);
+    if (rc) return rc;
+    out->steps = h->steps_total;
+    out->episodes = (int64_t)c.episodes;
+    out->reward_sum = c.reward_sum;
+    out->invalid_actions = (int64_t)c.invalid_actions;
+    out->out_of_bounds = (int64_t)c.out_of_bounds;
+    return MGX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ state I/O
+static int set_state_impl(mgx_handle h, const uint8_t *grid, const uint8_t *aux, const int32_t *agent,
+                          const uint8_t *carry, const int32_t *steps, const uint8_t *mask_host)
+{
+    if (!grid || !agent) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_set_state: grid and agent are required");
+    const size_t n = (size_t)h->n, cells = (size_t)h->cells;
+    PackParams p;
+    memset(&p, 0, sizeof p);
+    const void *d;
+    int rc;
+    if ((rc = dev_in(h, 0, grid, n * cells * 3, &d))) return rc;
+    p.grid = (const uint8_t *)d;
+    if ((rc = dev_in(h, 1, aux, n * cells, &d))) return rc;
+    p.aux = (const uint8_t *)d;
+    if ((rc = dev_in(h, 2, agent, n * 3 * sizeof(int32_t), &d))) return rc;
+    p.agent = (const int32_t *)d;
+    if ((rc = dev_in(h, 3, carry, n * 3, &d))) return rc;
+    p.carry = (const uint8_t *)d;
+    if ((rc = dev_in(h, 4, steps, n * sizeof(int32_t), &d))) return rc;
+    p.steps = (const int32_t *)d;
+    if ((rc = dev_in(h, 5, mask_host, n, &d))) return rc;
+    p.mask = (const uint8_t *)d;
+    p.cells = h->cells_d; p.cells0 = h->cells0_d; p.rec = h->agent_d; p.rec0 = h->agent0_d;
+    p.ctr = h->ctr_d;
+    p.n = h->n; p.W = h->W; p.H = h->H; p.S = h->S;
+    MgxCounters before, after;
+    if ((rc = read_counters(h, &before))) return rc;
+    HIP_TRY(mgx_launch_pack(p, h->stream));
+    if ((rc = read_counters(h, &after))) return rc;
+    if (after.invalid_state != before.invalid_state)
+        return mgx_fail(MGX_ERR_INVALID_STATE, "mgx_set_state: input holds a cell/agent/carry value the reference cannot produce "
+                                               "(type 1..9, color 0..6, state 0 or door 0..2, agent inside the grid, dir 0..3, carry key/ball/box)");
+    return MGX_OK;
+}
+
+extern "C" int mgx_set_state(mgx_handle h, const uint8_t *grid, const uint8_t *aux, const int32_t *agent,
+                             const uint8_t *carry, const int32_t *steps)
+{
+    int rc = check_handle(h, "mgx_set_state");
+    if (rc) return rc;
+    return set_state_impl(h, grid, aux, agent, carry, steps, nullptr);
+}
+
+extern "C" int mgx_get_state(mgx_handle h, uint8_t *grid, uint8_t *aux, int32_t *agent, uint8_t *carry, int32_t *steps)
+{
+    int rc = check_handle(h, "mgx_get_state");
+    if (rc) return rc;
+    const size_t n = (size_t)h->n, cells = (size_t)h->cells;
+    // get_state is a debugging / checkpoint path: stage everything through fresh device buffers
+    struct Tmp { void *dev = nullptr; void *user = nullptr; size_t bytes = 0; bool direct = false; } t[5];
+    void *users[5] = {grid, aux, agent, carry, steps};
+    size_t sizes[5] = {n * cells * 3, n * cells, n * 3 * sizeof(int32_t), n * 3, n * sizeof(int32_t)};
+    for (int i = 0; i < 5; i++) {
+        t[i].user = users[i]; t[i].bytes = sizes[i];
+        if (!users[i]) continue;
+        if (is_device_ptr(users[i])) { t[i].dev = users[i]; t[i].direct = true; }
+        else {
+            hipError_t e = hipMalloc(&t[i].dev, sizes[i]);
+            if (e != hipSuccess) {
+                for (int j = 0; j < i; j++) if (t[j].dev && !t[j].direct) (void)hipFree(t[j].dev);
+                return mgx_fail(MGX_ERR_HIP, "mgx_get_state: hipMalloc(%zu): %s", sizes[i], hipGetErrorString(e));
+            }
+        }
+    }
+    PackParams p;
+    memset(&p, 0, sizeof p);
+    p.cells = h->cells_d; p.rec = h->agent_d;
+    p.grid_out = (uint8_t *)t[0].dev; p.aux_out = (uint8_t *)t[1].dev; p.agent_out = (int32_t *)t[2].dev;
+    p.carry_out = (uint8_t *)t[3].dev; p.steps_out = (int32_t *)t[4].dev;
+    p.n = h->n; p.W = h->W; p.H = h->H; p.S = h->S;
+    hipError_t e = mgx_launch_unpack(p, h->stream);
+    for (int i = 0; i < 5 && e == hipSuccess; i++)
+        if (t[i].dev && !t[i].direct) e = hipMemcpyAsync(t[i].user, t[i].dev, t[i].bytes, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    for (int i = 0; i < 5; i++) if (t[i].dev && !t[i].direct) (void)hipFree(t[i].dev);
+    if (e != hipSuccess) return mgx_fail(MGX_ERR_HIP, "mgx_get_state: %s", hipGetErrorString(e));
+    return MGX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ step / observe
+static int run_step(mgx_handle h, bool do_step, const uint8_t *actions, uint8_t *obs, float *reward, uint8_t *done)
+{
+    StepParams p = base_params(h);
+    p.do_step = do_step ? 1 : 0;
+    const void *d = nullptr;
+    int rc;
+    if (do_step) {
+        if (!actions) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_step: actions is required");
+        if ((rc = dev_in(h, 0, actions, (size_t)h->n, &d))) return rc;
+        p.actions = (const uint8_t *)d;
+    }
+    OutArg o[3];
+    if ((rc = dev_out(h, 0, obs, (size_t)h->n * h->obs_bytes, &o[0]))) return rc;
+    if ((rc = dev_out(h, 1, reward, (size_t)h->n * sizeof(float), &o[1]))) return rc;
+    if ((rc = dev_out(h, 2, done, (size_t)h->n, &o[2]))) return rc;
+    p.obs = (uint8_t *)o[0].dev; p.reward = (float *)o[1].dev; p.done = (uint8_t *)o[2].dev;
+    HIP_TRY(mgx_launch_step(p, h->cfg.obs_mode, h->wpb, h->stream));
+    if (do_step) {
+        h->steps_total += h->n;
+        if (h->profiling) h->prof_launches++;
+    }
+    return finish_out(h, o, 3);
+}
+
+extern "C" int mgx_step(mgx_handle h, const uint8_t *actions, uint8_t *obs, float *reward, uint8_t *done)
+{
+    int rc = check_handle(h, "mgx_step");
+    if (rc) return rc;
+    return run_step(h, true, actions, obs, reward, done);
+}
+
+extern "C" int mgx_observe(mgx_handle h, uint8_t *obs)
+{
+    int rc = check_handle(h, "mgx_observe");
+    if (rc) return rc;
+    if (!obs) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_observe: obs is required");
+    return run_step(h, false, nullptr, obs, nullptr, nullptr);
+}
+
+extern "C" int mgx_reset(mgx_handle h, const uint64_t *seeds, const uint8_t *mask, uint8_t *obs)
+{
+    int rc = check_handle(h, "mgx_reset");
+    if (rc) return rc;
+    if (h->cfg.level_kind == MGX_LEVEL_NONE)
+        return mgx_fail(MGX_ERR_NO_LEVELGEN, "mgx_reset: this handle has no built-in level generator; use mgx_set_state");
+    if (!seeds) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_reset: seeds is required");
+    const size_t n = (size_t)h->n, cells = (size_t)h->cells;
+    std::vector<uint8_t> grid(n * cells * 3);
+    std::vector<int32_t> agent(n * 3);
+    // (generation for unmasked envs is wasted work but keeps the code simple; k_pack_state ignores them)
+    rc = mgx_generate_levels(&h->cfg, h->n, seeds, grid.data(), agent.data());
+    if (rc) return rc;
+    rc = set_state_impl(h, grid.data(), nullptr, agent.data(), nullptr, nullptr, mask);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream)); // the host vectors above are about to go away
+    if (obs) return run_step(h, false, nullptr, obs, nullptr, nullptr);
+    return MGX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ bench helpers
+extern "C" int mgx_fill_actions(mgx_handle h, uint64_t seed, int64_t env0, int64_t t0, int64_t T, uint8_t *actions)
+{
+    int rc = check_handle(h, "mgx_fill_actions");
+    if (rc) return rc;
+    if (!actions || T < 0) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_fill_actions: bad argument");
+    if (is_device_ptr(actions)) {
+        HIP_TRY(mgx_launch_fill_actions(actions, seed, env0, t0, h->n, T, h->stream));
+        return MGX_OK;
+    }
+    for (int64_t t = 0; t < T; t++)
+        for (int64_t e = 0; e < h->n; e++)
+            actions[t * h->n + e] = (uint8_t)mgx_action_of(seed, (uint64_t)(env0 + e), (uint64_t)(t0 + t));
+    return MGX_OK;
+}
+
+extern "C" int mgx_profile_begin(mgx_handle h)
+{
+    int rc = check_handle(h, "mgx_profile_begin");
+    if (rc) return rc;
+    h->profiling = true;
+    h->prof_launches = 0;
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    return MGX_OK;
+}
+
+extern "C" int mgx_profile_end(mgx_handle h, int64_t *launches, double *total_ms)
+{
+    int rc = check_handle(h, "mgx_profile_end");
+    if (rc) return rc;
+    if (!h->profiling) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_profile_end without mgx_profile_begin");
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->profiling = false;
+    if (launches) *launches = h->prof_launches;
+    if (total_ms) *total_ms = (double)ms;
+    return MGX_OK;
+}

@@ -1,0 +1,52 @@
+// mgx_kernels.h -- launch interface between mgx_api.cpp (host) and mgx_kernels.hip (device).
+#ifndef MGX_KERNELS_H
+#define MGX_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MGX_NUM_ACTIONS_K 7u
+
+struct MgxCounters {
+    unsigned long long episodes;
+    double reward_sum;
+    unsigned long long invalid_actions, out_of_bounds, invalid_state;
+};
+
+struct StepParams {
+    uint8_t *cells;        // u8[n_pad][S]   internal cell codes, x-major
+    uint2 *agent;          // [n_pad]        x | y<<8 | dir<<16 | carry<<24 ; step_count
+    const uint8_t *cells0; // episode-start snapshot (auto-reset)
+    const uint2 *agent0;
+    const uint8_t *actions; // u8[n]
+    uint8_t *obs;           // u8[n][147] or u8[n][W*H*3]; may be null
+    float *reward;          // may be null
+    uint8_t *done;          // may be null
+    MgxCounters *ctr;
+    int64_t n;
+    int n_tiles;
+    int W, H, S, LS, wave_lds;
+    int max_steps, see_through, lava_v1, auto_reset, do_step;
+};
+
+struct PackParams {
+    // inputs (reference encoding)
+    const uint8_t *grid; const uint8_t *aux; const int32_t *agent; const uint8_t *carry; const int32_t *steps;
+    const uint8_t *mask;
+    // internal state
+    uint8_t *cells; uint8_t *cells0; uint2 *rec; uint2 *rec0;
+    // outputs (unpack)
+    uint8_t *grid_out; uint8_t *aux_out; int32_t *agent_out; uint8_t *carry_out; int32_t *steps_out;
+    MgxCounters *ctr;
+    int64_t n;
+    int W, H, S;
+};
+
+hipError_t mgx_launch_step(const StepParams &p, int mode, int waves_per_block, hipStream_t st);
+hipError_t mgx_raise_lds_limit(int W, int H, int mode, int bytes);
+hipError_t mgx_launch_pack(const PackParams &p, hipStream_t st);
+hipError_t mgx_launch_unpack(const PackParams &p, hipStream_t st);
+hipError_t mgx_launch_fill_actions(uint8_t *out, uint64_t seed, int64_t env0, int64_t t0, int64_t n, int64_t T, hipStream_t st);
+uint32_t mgx_action_of(uint64_t seed, uint64_t env, uint64_t t);
+
+#endif

@@ -1,0 +1,567 @@
+// mgx_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of libmgx.so.
+//
+// One launch = one lockstep `env.step(a)` (or `gen_obs()`) for every env of the handle:
+//   MiniGridEnv.step       /root/reference/gym_minigrid/minigrid.py:1227-1325
+//   gen_obs_grid / gen_obs minigrid.py:1327-1381  (slice :453, rotate_left :439, process_vis :617, encode :571)
+//   FullyObsWrapper        /root/reference/gym_minigrid/wrappers.py:326-338
+//
+// Mapping (wave64, no MFMA -- this is integer gather/scan work, bounded by HBM):
+//   * one wavefront owns a TILE of 64 consecutive envs; lane e simulates env e of the tile.
+//   * state in HBM is SoA: cells u8[N][S] (1-byte cell codes, x-major like Grid.encode, S = W*H rounded
+//     up to 4) and one 8-byte agent record per env.  A tile's cells are one contiguous 64*S-byte run, so the
+//     wave streams it with 16-B/lane loads and parks it in LDS with an ODD dword stride per env, which makes
+//     the per-lane dynamic gathers (forward cell, 7x7 view) conflict-free up to the agents' own offsets.
+//   * the transition touches the forward cell only (one LDS byte read, at most one byte written back).
+//   * view: closed form  world = pos + f*(6-vy) + r*(vx-3)  (spec O1) -> 49 LDS byte reads.
+//   * occlusion (process_vis) is BIT-SLICED ACROSS THE WAVE: transparency of view cell (vx,vy) for all 64
+//     envs is one 64-bit ballot; the reference's two-sweep row flood becomes s_and/s_or on SGPR pairs
+//     (scalar unit, off the VALU), and the result is applied with v_cndmask on the inverse ballot.
+//   * the 147-byte observation is not dword aligned per env: each lane packs its 49 triples into 37 dwords,
+//     funnel-shifts them by its byte phase (3*lane mod 4), merges the boundary dword with its neighbour by
+//     DPP row_shr:1 and stores to the wave's LDS image of the tile's 9408 contiguous output bytes, which then
+//     leaves as 16-B/lane coalesced global stores.
+//   * done / fault flags reduce with wave ballots: one atomic per wave and only when something happened.
+//   * auto-reset restores the episode-start snapshot for the (rare) done lanes inside the same launch.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mgx_internal.h"
+#include "mgx_kernels.h"
+
+namespace {
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ void wave_sync()
+{
+    // all LDS traffic of a wave is issued in program order and returns in order, so lanes of ONE wave may hand
+    // data to each other through LDS without s_barrier; this only pins the compiler's ordering.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ bool lane_bit(u64 m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
+// cell code -> (type | color<<8 | state<<16), the reference's WorldObj.encode()/Door.encode() (minigrid.py:113-115,264-275)
+__device__ __forceinline__ uint32_t decode_triple(uint32_t c)
+{
+    const uint32_t k = c & 15u, col = (c >> 4) & 7u;
+    const bool shut = k > MGX_K_AGENT; // 11 closed, 12 locked
+    const uint32_t type = shut ? 4u : k;
+    const uint32_t st = shut ? k - 10u : 0u;
+    return type | (col << 8) | (st << 16);
+}
+
+// full-obs variant: kind 10 is the agent marker (10, 0, dir) with dir kept in the colour bits
+__device__ __forceinline__ uint32_t decode_triple_full(uint32_t c)
+{
+    const uint32_t k = c & 15u, col = (c >> 4) & 7u;
+    if (k == MGX_K_AGENT) return 10u | (col << 16);
+    return decode_triple(c);
+}
+
+// Wall, or Door that is not open: see_behind() False (minigrid.py:105,233,249)
+__device__ __forceinline__ bool is_opaque(uint32_t c)
+{
+    const uint32_t k = c & 15u;
+    return k == MGX_K_WALL || k > MGX_K_AGENT;
+}
+
+// ------------------------------------------------------------------------------------------------
+// global -> LDS: the tile's 64*S contiguous bytes, re-strided to LS bytes per env (LS/4 odd).
+template <int CS>
+__device__ __forceinline__ void stage_tile(const uint8_t *__restrict__ cells, int64_t env0, int S_rt, int LS,
+                                           uint8_t *lds, int lane)
+{
+    const int S = CS ? CS : S_rt;
+    const int SD = S >> 2, LSD = LS >> 2;
+    const uint4 *src = reinterpret_cast<const uint4 *>(cells + env0 * S);
+    uint32_t *l32 = reinterpret_cast<uint32_t *>(lds);
+    const int n_chunks = 4 * S; // 64*S/16
+#pragma unroll 4
+    for (int c = lane; c < n_chunks; c += 64) {
+        const uint4 v = src[c];
+        const int d = c * 4;
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int dd = d + j;
+            const int e = dd / SD;
+            l32[e * LSD + (dd - e * SD)] = w[j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct Lane {
+    int ax, ay, dir;
+    uint32_t carry; // cell code, MGX_CODE_EMPTY = nothing
+    int steps;
+};
+
+__device__ __forceinline__ Lane unpack_rec(uint2 r)
+{
+    Lane L;
+    L.ax = r.x & 255u; L.ay = (r.x >> 8) & 255u; L.dir = (r.x >> 16) & 3u; L.carry = r.x >> 24; L.steps = (int)r.y;
+    return L;
+}
+__device__ __forceinline__ uint2 pack_rec(const Lane &L)
+{
+    return make_uint2((uint32_t)L.ax | ((uint32_t)L.ay << 8) | ((uint32_t)L.dir << 16) | (L.carry << 24), (uint32_t)L.steps);
+}
+
+// MiniGridEnv.step without the observation (spec S1-S8).  `g` = this lane's env in LDS.
+template <int CW, int CH>
+__device__ __forceinline__ void transition(const StepParams &p, Lane &L, uint32_t act, bool valid, uint8_t *g,
+                                           float &reward, bool &done, bool &bad_act, bool &oob, int &wr_idx, uint32_t &wr_code)
+{
+    const int W = CW ? CW : p.W, H = CH ? CH : p.H;
+    L.steps += 1;
+    reward = 0.f;
+    done = false;
+    wr_idx = -1;
+    wr_code = 0;
+    const int dir = L.dir;
+    const int dx = (dir == 0) - (dir == 2), dy = (dir == 1) - (dir == 3); // DIR_TO_VEC (minigrid.py:64-73)
+    const int fx = L.ax + dx, fy = L.ay + dy;
+    // front/left/right are all read by the reference (minigrid.py:1239-1243): any of them outside -> assert
+    const uint32_t okm = (uint32_t)(L.ax + 1 < W) | ((uint32_t)(L.ay + 1 < H) << 1) | ((uint32_t)(L.ax >= 1) << 2) |
+                         ((uint32_t)(L.ay >= 1) << 3);
+    const uint32_t need = 0xFu & ~(1u << ((dir + 2) & 3));
+    oob = valid && ((okm & need) != need);
+    bad_act = valid && act >= MGX_NUM_ACTIONS_K;
+    if (valid && !oob && !bad_act) {
+        const int fidx = fx * H + fy;
+        const uint32_t fc = g[fidx];
+        const uint32_t k = fc & 15u;
+        uint32_t nc = fc; // new forward-cell code
+        if (act == 0) L.dir = (dir + 3) & 3;
+        else if (act == 1) L.dir = (dir + 1) & 3;
+        else if (act == 2) {
+            // None, Floor, open Door, Goal, Lava can be walked onto (minigrid.py:93,164-166,192,211,245-247)
+            const uint32_t OVERLAP = (1u << MGX_K_EMPTY) | (1u << MGX_K_FLOOR) | (1u << MGX_K_DOOR_OPEN) | (1u << MGX_K_GOAL) | (1u << MGX_K_LAVA);
+            if ((OVERLAP >> k) & 1u) { L.ax = fx; L.ay = fy; }
+            if (k == MGX_K_GOAL && (fc & 0x80u)) { // goal.overlap (minigrid.py:1259-1261)
+                done = true;
+                // _reward(): 1 - 0.9*(step_count/max_steps) in Python doubles (minigrid.py:933-937), then f32
+                reward = (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps));
+            }
+            if (k == MGX_K_LAVA) { // minigrid.py:1262-1268
+                if (p.lava_v1) { done = false; reward = -1.f; }
+                else done = true;
+            }
+        } else if (act == 3) {
+            const uint32_t PICK = (1u << MGX_K_KEY) | (1u << MGX_K_BALL) | (1u << MGX_K_BOX);
+            if (((PICK >> k) & 1u) && L.carry == MGX_CODE_EMPTY) { L.carry = fc; nc = MGX_CODE_EMPTY; }
+        } else if (act == 4) {
+            if (k == MGX_K_EMPTY && L.carry != MGX_CODE_EMPTY) { nc = L.carry; L.carry = MGX_CODE_EMPTY; }
+        } else if (act == 5) {
+            if (k == MGX_K_DOOR_LOCKED) { // Door.toggle (minigrid.py:252-262)
+                if ((L.carry & 15u) == MGX_K_KEY && ((L.carry >> 4) & 7u) == ((fc >> 4) & 7u)) nc = (fc & 0xF0u) | MGX_K_DOOR_OPEN;
+            } else if (k == MGX_K_DOOR_OPEN) nc = (fc & 0xF0u) | MGX_K_DOOR_CLOSED;
+            else if (k == MGX_K_DOOR_CLOSED) nc = (fc & 0xF0u) | MGX_K_DOOR_OPEN;
+            else if (k == MGX_K_GOAL) { if (!(fc & 0x80u)) nc = MGX_CODE_EMPTY; } // Goal.toggle, toggletimes=1 (minigrid.py:171-181)
+            else if (k == MGX_K_BOX) nc = MGX_CODE_EMPTY;                         // Box.toggle, contains=None (minigrid.py:355-364)
+        } // act == 6 ("done"): pass (minigrid.py:1291-1293)
+        if (nc != fc) {
+            g[fidx] = (uint8_t)nc;
+            wr_idx = fidx; // written back to HBM by the caller once `done` is known
+            wr_code = nc;
+        }
+    }
+    if (valid && L.steps >= p.max_steps) done = true; // minigrid.py:1320-1321
+}
+
+// Restore the episode-start snapshot of every lane in `mask` (wave-cooperative copy), LDS + HBM.
+template <int CS>
+__device__ __forceinline__ void restore_envs(const StepParams &p, u64 mask, int64_t env0, uint8_t *lds, int LS, int lane)
+{
+    const int S = CS ? CS : p.S;
+    const int SD = S >> 2, LSD = LS >> 2;
+    uint32_t *l32 = reinterpret_cast<uint32_t *>(lds);
+    while (mask) {
+        const int j = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const uint32_t *s = reinterpret_cast<const uint32_t *>(p.cells0 + (env0 + j) * S);
+        uint32_t *d = reinterpret_cast<uint32_t *>(p.cells + (env0 + j) * S);
+        for (int i = lane; i < SD; i += 64) {
+            const uint32_t v = s[i];
+            l32[j * LSD + i] = v;
+            d[i] = v;
+        }
+    }
+}
+
+__device__ __forceinline__ void wave_stats(const StepParams &p, bool valid, bool done, float reward, bool bad_act, bool oob, int lane)
+{
+    const u64 md = __ballot(valid && done), mr = __ballot(valid && reward != 0.f);
+    const u64 ma = __ballot(bad_act), mo = __ballot(oob);
+    if (md && lane == 0) atomicAdd(&p.ctr->episodes, (u64)__popcll(md));
+    if (ma && lane == 0) atomicAdd(&p.ctr->invalid_actions, (u64)__popcll(ma));
+    if (mo && lane == 0) atomicAdd(&p.ctr->out_of_bounds, (u64)__popcll(mo));
+    if (mr) { // rare: wave-reduce the rewards in f64, one atomic
+        double r = valid ? (double)reward : 0.0;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) r += __shfl_xor(r, o, 64);
+        if (lane == 0) atomicAdd(&p.ctr->reward_sum, r);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Partial (7x7x3) observation of lane's env -> wave's LDS image of the tile's output -> HBM.
+template <int CW, int CH>
+__device__ __forceinline__ void emit_partial_obs(const StepParams &p, const Lane &L, uint8_t *lds, const uint8_t *g,
+                                                 int64_t env0, int lane)
+{
+    constexpr int V = 7;
+    const int W = CW ? CW : p.W, H = CH ? CH : p.H;
+    const int dir = L.dir;
+    const int dx = (dir == 0) - (dir == 2), dy = (dir == 1) - (dir == 3);
+    const int rx = -dy, ry = dx; // right_vec (minigrid.py:1102-1109)
+    const int base = L.ax * H + L.ay;
+    const int sf = dx * H + dy, sr = rx * H + ry;
+
+    // in-bounds is separable: the forward coordinate depends on d = 6-vy only, the lateral one on l = vx-3 only
+    bool vf[V], vl[V];
+#pragma unroll
+    for (int d = 0; d < V; d++) vf[d] = (unsigned)(L.ax + dx * d) < (unsigned)W && (unsigned)(L.ay + dy * d) < (unsigned)H;
+#pragma unroll
+    for (int k = 0; k < V; k++) vl[k] = (unsigned)(L.ax + rx * (k - 3)) < (unsigned)W && (unsigned)(L.ay + ry * (k - 3)) < (unsigned)H;
+
+    // gather: code[vx][vy]; outside the grid -> grey wall (Grid.slice, minigrid.py:465-469)
+    uint32_t code[V][V];
+#pragma unroll
+    for (int vy = V - 1; vy >= 0; vy--) {
+        const int rowbase = base + (V - 1 - vy) * sf;
+#pragma unroll
+        for (int vx = 0; vx < V; vx++) {
+            const bool inb = vf[V - 1 - vy] && vl[vx];
+            const int idx = inb ? rowbase + (vx - 3) * sr : base;
+            const uint32_t c = g[idx];
+            code[vx][vy] = inb ? c : (uint32_t)MGX_CODE_WALL_GREY;
+        }
+    }
+
+    // occlusion, bit-sliced over the wave (process_vis default branch, minigrid.py:617-648; spec O4)
+    if (!p.see_through) {
+        u64 vis[V];
+#pragma unroll
+        for (int i = 0; i < V; i++) vis[i] = (i == V / 2) ? ~0ull : 0ull;
+#pragma unroll
+        for (int vy = V - 1; vy >= 0; vy--) {
+            u64 T[V];
+#pragma unroll
+            for (int i = 0; i < V; i++) T[i] = __ballot(!is_opaque(code[i][vy]));
+#pragma unroll
+            for (int i = 0; i < V - 1; i++) vis[i + 1] |= vis[i] & T[i]; // left-to-right sweep (:624-635)
+#pragma unroll
+            for (int i = V - 1; i >= 1; i--) vis[i - 1] |= vis[i] & T[i]; // right-to-left sweep (:637-648)
+#pragma unroll
+            for (int i = 0; i < V; i++) code[i][vy] = lane_bit(vis[i]) ? code[i][vy] : 0u; // unseen -> (0,0,0)
+            if (vy > 0) {
+                u64 s[V], nx[V];
+#pragma unroll
+                for (int i = 0; i < V; i++) s[i] = vis[i] & T[i]; // visible and transparent: lights the row above
+#pragma unroll
+                for (int i = 0; i < V; i++) nx[i] = s[i] | (i > 0 ? s[i - 1] : 0ull) | (i < V - 1 ? s[i + 1] : 0ull);
+#pragma unroll
+                for (int i = 0; i < V; i++) vis[i] = nx[i];
+            }
+        }
+    }
+    // the agent's own cell shows what it carries, after occlusion; always visible (minigrid.py:1349-1356)
+    code[V / 2][V - 1] = L.carry;
+
+    // pack 49 triples (image[vx][vy][c], vx-major) into 37 dwords; v_perm_b32 picks 4 of the 8 bytes {S0,S1}
+    uint32_t D[37];
+#pragma unroll
+    for (int q = 0; q < 12; q++) {
+        const uint32_t c0 = decode_triple(code[(4 * q) / V][(4 * q) % V]);
+        const uint32_t c1 = decode_triple(code[(4 * q + 1) / V][(4 * q + 1) % V]);
+        const uint32_t c2 = decode_triple(code[(4 * q + 2) / V][(4 * q + 2) % V]);
+        const uint32_t c3 = decode_triple(code[(4 * q + 3) / V][(4 * q + 3) % V]);
+        D[3 * q + 0] = __builtin_amdgcn_perm(c1, c0, 0x04020100u); // c0.b0 c0.b1 c0.b2 c1.b0
+        D[3 * q + 1] = __builtin_amdgcn_perm(c2, c1, 0x05040201u); // c1.b1 c1.b2 c2.b0 c2.b1
+        D[3 * q + 2] = __builtin_amdgcn_perm(c3, c2, 0x06050402u); // c2.b2 c3.b0 c3.b1 c3.b2
+    }
+    D[36] = decode_triple(code[6][6]); // 3 bytes
+
+    // byte phase of this env inside the tile's contiguous output: 147*lane = 4*P + s.  Q = D delayed by s bytes:
+    // Q[k] = bytes (4-s)..(7-s) of {D[k], D[k-1]}  -> one v_perm_b32 with a per-lane selector
+    const uint32_t s = (3u * (uint32_t)lane) & 3u;
+    const uint32_t sel = 0x07060504u - s * 0x01010101u;
+    uint32_t Q[38];
+    Q[0] = __builtin_amdgcn_perm(D[0], 0u, sel);
+#pragma unroll
+    for (int k = 1; k < 37; k++) Q[k] = __builtin_amdgcn_perm(D[k], D[k - 1], sel);
+    Q[37] = __builtin_amdgcn_perm(0u, D[36], sel);
+    // the last, partial dword belongs to the next lane's first dword
+    const uint32_t tail = (s == 0u) ? Q[36] : Q[37];
+    const uint32_t prev_tail = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tail, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
+    if (s != 0u) Q[0] |= prev_tail;
+
+    wave_sync(); // every lane is done reading the grid image that the output image overlays
+    uint32_t *o32 = reinterpret_cast<uint32_t *>(lds) + ((147u * (uint32_t)lane) >> 2);
+#pragma unroll
+    for (int k = 0; k < 36; k++) o32[k] = Q[k];
+    if (s != 0u) o32[36] = Q[36];
+    wave_sync();
+
+    // LDS image -> HBM, 16 B per lane, contiguous
+    const int64_t nv = p.n - env0; // valid envs in this tile (>= 1)
+    uint8_t *dst = p.obs + env0 * 147;
+    const uint4 *l128 = reinterpret_cast<const uint4 *>(lds);
+    if (nv >= 64) {
+#pragma unroll
+        for (int c = lane; c < 588; c += 64) reinterpret_cast<uint4 *>(dst)[c] = l128[c];
+    } else {
+        const int lim = (int)nv * 147;
+        for (int c = lane; c < 588; c += 64) {
+            if (16 * c + 16 <= lim) reinterpret_cast<uint4 *>(dst)[c] = l128[c];
+            else
+                for (int b = 16 * c; b < lim; b++) dst[b] = lds[b];
+        }
+    }
+}
+
+// Full-grid observation: Grid.encode() + agent marker (wrappers.py:326-338).  The wave decodes its tile's
+// 64*W*H cells cooperatively: lane handles output dwords lane, lane+64, ... (coalesced 4-B stores).
+template <int CW, int CH>
+__device__ __forceinline__ void emit_full_obs(const StepParams &p, const Lane &L, bool valid, uint8_t *lds, uint8_t *g,
+                                              int LS, int64_t env0, int lane)
+{
+    const int W = CW ? CW : p.W, H = CH ? CH : p.H;
+    const int cells = W * H;
+    if (valid) g[L.ax * H + L.ay] = (uint8_t)(MGX_K_AGENT | (L.dir << 4)); // LDS copy only
+    wave_sync();
+    const int64_t nv = p.n - env0;
+    const int n_env = nv >= 64 ? 64 : (int)nv;
+    const int n_dw = n_env * cells * 3 / 4;      // whole dwords
+    const int n_bytes = n_env * cells * 3;
+    uint8_t *dst = p.obs + env0 * cells * 3;
+    for (int j = lane; j < n_dw; j += 64) {
+        const int b = 4 * j;
+        const int q = b / 3, r = b - 3 * q; // first cell of the tile's cell stream touched by this dword, byte phase
+        const int e0 = q / cells, c0 = q - e0 * cells;
+        int e1 = e0, c1 = c0 + 1;
+        if (c1 == cells) { c1 = 0; e1 = e0 + 1; }
+        const uint32_t t0 = decode_triple_full(lds[e0 * LS + c0]);
+        const uint32_t t1 = (e1 < 64) ? decode_triple_full(lds[e1 * LS + c1]) : 0u;
+        const u64 both = (u64)t0 | ((u64)t1 << 24);
+        reinterpret_cast<uint32_t *>(dst)[j] = (uint32_t)(both >> (8 * r));
+    }
+    // (n_env*cells*3 is a multiple of 4 unless the tail tile has an odd cell count: finish by bytes)
+    for (int b = 4 * n_dw + lane; b < n_bytes; b += 64) {
+        const int q = b / 3, r = b - 3 * q;
+        const int e0 = q / cells, c0 = q - e0 * cells;
+        dst[b] = (uint8_t)(decode_triple_full(lds[e0 * LS + c0]) >> (8 * r));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int CW, int CH, int MODE>
+__global__ __launch_bounds__(256) void k_step(const StepParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int tile = blockIdx.x * (blockDim.x >> 6) + wv;
+    if (tile >= p.n_tiles) return; // wave-uniform
+    constexpr int CS = (CW && CH) ? ((CW * CH + 3) & ~3) : 0;
+    const int S = CS ? CS : p.S;
+    const int LS = p.LS;
+    uint8_t *lds = smem + (size_t)wv * p.wave_lds;
+    const int64_t env0 = (int64_t)tile * 64;
+    const int64_t env = env0 + lane;
+    const bool valid = env < p.n;
+
+    const uint2 rec = p.agent[env]; // agent/cells arrays are padded to whole tiles
+    uint32_t act = 6;
+    if (p.do_step && valid) act = p.actions[env];
+    stage_tile<CS>(p.cells, env0, S, LS, lds, lane);
+    wave_sync();
+
+    Lane L = unpack_rec(rec);
+    uint8_t *g = lds + lane * LS;
+    float reward = 0.f;
+    bool done = false, bad_act = false, oob = false;
+    if (p.do_step) {
+        int wr_idx;
+        uint32_t wr_code;
+        transition<CW, CH>(p, L, act, valid, g, reward, done, bad_act, oob, wr_idx, wr_code);
+        // the one cell a transition can change; skipped when the env is about to be restored anyway
+        if (wr_idx >= 0 && !(p.auto_reset && done)) p.cells[env * S + wr_idx] = (uint8_t)wr_code;
+        if (p.reward && valid) p.reward[env] = reward;
+        if (p.done && valid) p.done[env] = done ? 1 : 0;
+        wave_stats(p, valid, done, reward, bad_act, oob, lane);
+        if (p.auto_reset) {
+            const u64 md = __ballot(valid && done);
+            if (md) { // wave-uniform, rare
+                wave_sync();
+                restore_envs<CS>(p, md, env0, lds, LS, lane);
+                wave_sync();
+                if (done) L = unpack_rec(p.agent0[env]);
+            }
+        }
+        if (valid) p.agent[env] = pack_rec(L);
+    }
+    if (p.obs) {
+        if (MODE == 0) emit_partial_obs<CW, CH>(p, L, lds, g, env0, lane);
+        else emit_full_obs<CW, CH>(p, L, valid, lds, g, LS, env0, lane);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// reference encoding <-> internal codes
+__global__ __launch_bounds__(256) void k_pack_state(const PackParams p)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int cells = p.W * p.H;
+    const int64_t total = p.n * (int64_t)p.S;
+    bool bad = false;
+    if (t < total) {
+        const int64_t e = t / p.S;
+        const int c = (int)(t - e * p.S);
+        if (!p.mask || p.mask[e]) {
+            uint32_t code = 0;
+            if (c < cells) {
+                const uint8_t *tr = p.grid + (e * cells + c) * 3;
+                const uint32_t ty = tr[0], co = tr[1], st = tr[2];
+                const uint32_t ax = p.aux ? p.aux[e * cells + c] : 0u;
+                uint32_t k = ty;
+                if (ty < 1 || ty > 9 || co > 6 || ax > 1) bad = true;
+                if (ty == 4) { if (st > 2) bad = true; k = st == 0 ? MGX_K_DOOR_OPEN : (st == 1 ? MGX_K_DOOR_CLOSED : MGX_K_DOOR_LOCKED); }
+                else if (st != 0) bad = true;
+                if (ty == 1 && (co != 0 || ax != 0)) bad = true; // None encodes as exactly (1,0,0)
+                code = (k & 15u) | ((co & 7u) << 4) | ((ax & 1u) << 7);
+            }
+            p.cells[t] = (uint8_t)code;
+            p.cells0[t] = (uint8_t)code;
+        }
+    }
+    if (t < p.n && (!p.mask || p.mask[t])) {
+        const int32_t x = p.agent[t * 3], y = p.agent[t * 3 + 1], d = p.agent[t * 3 + 2];
+        if (x < 0 || x >= p.W || y < 0 || y >= p.H || d < 0 || d > 3) bad = true;
+        uint32_t cc = MGX_CODE_EMPTY;
+        if (p.carry) {
+            const uint32_t ty = p.carry[t * 3], co = p.carry[t * 3 + 1], st = p.carry[t * 3 + 2];
+            if (ty == 1) { if (co || st) bad = true; }
+            else if ((ty != 5 && ty != 6 && ty != 7) || co > 6 || st != 0) bad = true; // only can_pickup() objects
+            cc = (ty & 15u) | ((co & 7u) << 4);
+        }
+        const int32_t sc = p.steps ? p.steps[t] : 0;
+        if (sc < 0) bad = true;
+        const uint2 rec = make_uint2((uint32_t)(x & 255) | ((uint32_t)(y & 255) << 8) | ((uint32_t)(d & 3) << 16) | (cc << 24), (uint32_t)sc);
+        p.rec[t] = rec;
+        // the episode start always has nothing carried and step_count 0 (reset(), minigrid.py:851-854)
+        p.rec0[t] = make_uint2((rec.x & 0x00FFFFFFu) | ((uint32_t)MGX_CODE_EMPTY << 24), 0u);
+    }
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicAdd(&p.ctr->invalid_state, 1ull);
+}
+
+__global__ __launch_bounds__(256) void k_unpack_state(const PackParams p)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int cells = p.W * p.H;
+    const int64_t total = p.n * (int64_t)cells;
+    if (t < total && (p.grid_out || p.aux_out)) {
+        const int64_t e = t / cells;
+        const int c = (int)(t - e * cells);
+        const uint32_t code = p.cells[e * p.S + c];
+        const uint32_t tr = decode_triple(code);
+        if (p.grid_out) {
+            uint8_t *o = p.grid_out + t * 3;
+            o[0] = (uint8_t)tr; o[1] = (uint8_t)(tr >> 8); o[2] = (uint8_t)(tr >> 16);
+        }
+        if (p.aux_out) p.aux_out[t] = (uint8_t)(code >> 7);
+    }
+    if (t < p.n) {
+        const Lane L = unpack_rec(p.rec[t]);
+        if (p.agent_out) { p.agent_out[t * 3] = L.ax; p.agent_out[t * 3 + 1] = L.ay; p.agent_out[t * 3 + 2] = L.dir; }
+        if (p.carry_out) {
+            const uint32_t tr = decode_triple(L.carry);
+            p.carry_out[t * 3] = (uint8_t)tr; p.carry_out[t * 3 + 1] = (uint8_t)(tr >> 8); p.carry_out[t * 3 + 2] = (uint8_t)(tr >> 16);
+        }
+        if (p.steps_out) p.steps_out[t] = L.steps;
+    }
+}
+
+// counter-based action stream shared with the tests (tests/actions.py): mix(seed, env, t) -> 0..6
+__device__ __host__ inline uint32_t action_of(uint64_t seed, uint64_t env, uint64_t t)
+{
+    uint64_t z = seed + env * 0x9E3779B97F4A7C15ull + t * 0xD1B54A32D192ED03ull;
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(((z >> 32) * 7ull) >> 32);
+}
+
+__global__ __launch_bounds__(256) void k_fill_actions(uint8_t *out, uint64_t seed, int64_t env0, int64_t t0, int64_t n, int64_t T)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * T) return;
+    const int64_t t = i / n, e = i - t * n;
+    out[i] = (uint8_t)action_of(seed, (uint64_t)(env0 + e), (uint64_t)(t0 + t));
+}
+
+template <int CW, int CH>
+hipError_t launch_sized(const StepParams &p, int mode, dim3 grid, dim3 block, size_t shmem, hipStream_t st)
+{
+    if (mode == 0) hipLaunchKernelGGL((k_step<CW, CH, 0>), grid, block, shmem, st, p);
+    else hipLaunchKernelGGL((k_step<CW, CH, 1>), grid, block, shmem, st, p);
+    return hipGetLastError();
+}
+
+template <int CW, int CH>
+hipError_t raise_lds_limit(int mode, int bytes)
+{
+    if (mode == 0) return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<CW, CH, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<CW, CH, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+} // namespace
+
+#define MGX_SIZED(X) X(5, 5) X(6, 6) X(7, 7) X(8, 8) X(9, 9) X(11, 11) X(16, 16)
+
+hipError_t mgx_launch_step(const StepParams &p, int mode, int waves_per_block, hipStream_t st)
+{
+    const dim3 block(64 * waves_per_block);
+    const dim3 grid((p.n_tiles + waves_per_block - 1) / waves_per_block);
+    const size_t shmem = (size_t)waves_per_block * p.wave_lds;
+#define CASE(w, h) if (p.W == w && p.H == h) return launch_sized<w, h>(p, mode, grid, block, shmem, st);
+    MGX_SIZED(CASE)
+#undef CASE
+    return launch_sized<0, 0>(p, mode, grid, block, shmem, st);
+}
+
+hipError_t mgx_raise_lds_limit(int W, int H, int mode, int bytes)
+{
+#define CASE(w, h) if (W == w && H == h) return raise_lds_limit<w, h>(mode, bytes);
+    MGX_SIZED(CASE)
+#undef CASE
+    return raise_lds_limit<0, 0>(mode, bytes);
+}
+
+hipError_t mgx_launch_pack(const PackParams &p, hipStream_t st)
+{
+    const int64_t total = p.n * (int64_t)p.S;
+    hipLaunchKernelGGL(k_pack_state, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+hipError_t mgx_launch_unpack(const PackParams &p, hipStream_t st)
+{
+    const int64_t total = p.n * (int64_t)p.W * p.H;
+    hipLaunchKernelGGL(k_unpack_state, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+hipError_t mgx_launch_fill_actions(uint8_t *out, uint64_t seed, int64_t env0, int64_t t0, int64_t n, int64_t T, hipStream_t st)
+{
+    const int64_t total = n * T;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_fill_actions, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, out, seed, env0, t0, n, T);
+    return hipGetLastError();
+}
+
+uint32_t mgx_action_of(uint64_t seed, uint64_t env, uint64_t t) { return action_of(seed, env, t); }

@@ -1,0 +1,233 @@
+"""VecMiniGrid -- the batched, MI355X-resident counterpart of the reference's gym.Env surface.
+
+Mirrors, for N lockstep env instances, the methods and attributes callers use on
+`gym_minigrid.minigrid.MiniGridEnv` (/root/reference/gym_minigrid/minigrid.py):
+    reset() -> obs                      :831-858   (+ ReseedWrapper: seed(s_i) then reset(), wrappers.py:24-28)
+    seed(seed)                          :860-863
+    step(actions) -> obs, reward, done, info   :1227-1325
+    action_space = Discrete(7)          :792
+    observation_space['image']          :799-807   (FullyObsWrapper: (W, H, 3), wrappers.py:316-324)
+    max_steps, width, height, mission
+with observations as the `image` array only (ImgObsWrapper semantics, wrappers.py:156-166), batched to
+uint8 (N,7,7,3) / (N,W,H,3).  All simulation runs in libmgx.so's HIP kernels; this file is plumbing.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .spaces import Box, Dict, Discrete
+
+MISSIONS = {1: "get to the green goal square",
+            2: "use the key to open the door and then get to the goal",
+            3: {9: "avoid the lava and get to the green goal square",
+                2: "find the opening and get to the green goal square"},
+            4: {9: "avoid the lava and get to the green goal square",
+                2: "find the opening and get to the green goal square"}}
+
+
+def _ptr(a):
+    """numpy array / torch tensor / None -> c_void_p"""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"]
+        return ctypes.c_void_p(a.ctypes.data)
+    assert a.is_contiguous()
+    return ctypes.c_void_p(a.data_ptr())
+
+
+class VecMiniGrid:
+    """N independent MiniGrid envs of one registered id (or an explicit config), stepped on one GPU.
+
+    backend='torch': outputs are torch tensors on cuda:<device> (zero-copy device pointers, asynchronous on
+                     torch's current stream).  backend='numpy': host arrays (staged copies, synchronous).
+    auto_reset=True: an env that reports done is restored to its episode start inside the same step and `obs`
+                     is the first observation of the new episode (VecEnv convention; ReseedWrapper(seeds=[s_i])
+                     layout semantics).  auto_reset=False: exact reference semantics, the caller resets.
+    seeds: int (env i gets seed+i+env_offset) or an array of N uint64 seeds.
+    """
+
+    def __init__(self, env_id=None, num_envs=1, device=0, seeds=0, obs_mode="partial", auto_reset=True,
+                 config=None, backend="torch", env_offset=0, check_actions=False):
+        L = _lib.lib()
+        if config is None:
+            if env_id is None:
+                raise ValueError("give env_id or config")
+            config = _lib.env_config(env_id)
+        self.env_id = env_id
+        cfg = _lib.Config()
+        ctypes.memmove(ctypes.byref(cfg), ctypes.byref(config), ctypes.sizeof(cfg))
+        cfg.obs_mode = {"partial": _lib.OBS_PARTIAL, "full": _lib.OBS_FULL}[obs_mode]
+        cfg.auto_reset = int(bool(auto_reset))
+        self.cfg = cfg
+        self.num_envs = int(num_envs)
+        self.device = int(device)
+        self.backend = backend
+        self.env_offset = int(env_offset)
+        self.check_actions = bool(check_actions)
+        self.width, self.height, self.max_steps = cfg.width, cfg.height, cfg.max_steps
+        self.obs_mode = obs_mode
+        self.obs_shape = (7, 7, 3) if obs_mode == "partial" else (cfg.width, cfg.height, 3)
+        self.action_space = Discrete(7)
+        self.observation_space = Dict({"image": Box(0, 255, self.obs_shape, "uint8")})
+        self.reward_range = (0, 1)
+        m = MISSIONS.get(cfg.level_kind, "")
+        self.mission = m.get(cfg.level_arg1, "") if isinstance(m, dict) else m
+        self._h = ctypes.c_void_p()
+        _lib.check(L.mgx_create(ctypes.byref(cfg), self.num_envs, self.device, ctypes.byref(self._h)))
+        self._torch = None
+        if backend == "torch":
+            import torch
+            self._torch = torch
+            self._dev = torch.device("cuda", self.device)
+            self._bind_stream()
+        elif backend != "numpy":
+            raise ValueError("backend must be 'torch' or 'numpy'")
+        self._obs = self._new((self.num_envs,) + self.obs_shape, "uint8")
+        self._reward = self._new((self.num_envs,), "float32")
+        self._done = self._new((self.num_envs,), "uint8")
+        self.seed(seeds)
+
+    # ------------------------------------------------------------------ plumbing
+    def _new(self, shape, dtype):
+        if self._torch is not None:
+            return self._torch.empty(shape, dtype=getattr(self._torch, dtype), device=self._dev)
+        return np.empty(shape, dtype=dtype)
+
+    def _bind_stream(self):
+        s = self._torch.cuda.current_stream(self._dev).cuda_stream
+        if getattr(self, "_stream", None) != s:
+            _lib.check(_lib.lib().mgx_set_stream(self._h, ctypes.c_void_p(s)))
+            self._stream = s
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.lib().mgx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _actions(self, actions):
+        if self._torch is not None:
+            t = self._torch
+            if not isinstance(actions, t.Tensor):
+                actions = t.as_tensor(np.asarray(actions), device=self._dev)
+            if self.check_actions and bool((actions >= 7).any() | (actions < 0).any()):
+                raise AssertionError("unknown action")  # minigrid.py:1318
+            if actions.dtype != t.uint8 or actions.device != self._dev:
+                actions = actions.to(device=self._dev, dtype=t.uint8)
+            actions = actions.contiguous()
+        else:
+            actions = np.asarray(actions)
+            if self.check_actions and ((actions >= 7).any() or (actions < 0).any()):
+                raise AssertionError("unknown action")
+            actions = np.ascontiguousarray(actions, dtype=np.uint8)
+        if tuple(actions.shape) != (self.num_envs,):
+            raise ValueError("actions must have shape (%d,)" % self.num_envs)
+        return actions
+
+    # ------------------------------------------------------------------ gym.Env surface
+    def seed(self, seed=1337):
+        """env i will be reset with seed_i: an int gives seed + env_offset + i, an array gives seeds[i]."""
+        if np.ndim(seed) == 0:
+            s = (np.uint64(int(seed) % (1 << 64)) + np.arange(self.env_offset, self.env_offset + self.num_envs, dtype=np.uint64))
+        else:
+            s = np.ascontiguousarray(seed, dtype=np.uint64)
+            if s.shape != (self.num_envs,):
+                raise ValueError("seeds must have shape (%d,)" % self.num_envs)
+        self.seeds = s
+        return [seed]
+
+    def reset(self, mask=None):
+        """seed(seed_i); reset() for every env (or those with mask[i] != 0).  Returns obs of ALL envs."""
+        if self._torch is not None:
+            self._bind_stream()
+        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        _lib.check(_lib.lib().mgx_reset(self._h, _ptr(self.seeds), _ptr(m), _ptr(self._obs)))
+        return self._obs
+
+    def step(self, actions):
+        if self._torch is not None:
+            self._bind_stream()
+        a = self._actions(actions)
+        _lib.check(_lib.lib().mgx_step(self._h, _ptr(a), _ptr(self._obs), _ptr(self._reward), _ptr(self._done)))
+        self._last_actions = a  # keep alive until the async kernel has consumed it
+        return self._obs, self._reward, self._done, {}
+
+    def observe(self):
+        if self._torch is not None:
+            self._bind_stream()
+        _lib.check(_lib.lib().mgx_observe(self._h, _ptr(self._obs)))
+        return self._obs
+
+    # ------------------------------------------------------------------ state injection / inspection
+    def set_state(self, grid, agent, aux=None, carry=None, steps=None):
+        """Reference-encoded state (host numpy arrays): grid (N,W,H,3) u8, agent (N,3) i32, aux (N,W,H) u8,
+        carry (N,3) u8, steps (N,) i32.  Also becomes the episode start used by auto-reset."""
+        n, W, H = self.num_envs, self.width, self.height
+        g = np.ascontiguousarray(grid, np.uint8)
+        assert g.shape == (n, W, H, 3), g.shape
+        ag = np.ascontiguousarray(agent, np.int32)
+        assert ag.shape == (n, 3)
+        ax = None if aux is None else np.ascontiguousarray(aux, np.uint8)
+        ca = None if carry is None else np.ascontiguousarray(carry, np.uint8)
+        st = None if steps is None else np.ascontiguousarray(steps, np.int32)
+        if self._torch is not None:
+            self._bind_stream()
+        _lib.check(_lib.lib().mgx_set_state(self._h, _ptr(g), _ptr(ax), _ptr(ag), _ptr(ca), _ptr(st)))
+
+    def get_state(self):
+        n, W, H = self.num_envs, self.width, self.height
+        out = dict(grid=np.empty((n, W, H, 3), np.uint8), aux=np.empty((n, W, H), np.uint8),
+                   agent=np.empty((n, 3), np.int32), carry=np.empty((n, 3), np.uint8), steps=np.empty(n, np.int32))
+        if self._torch is not None:
+            self._bind_stream()
+        _lib.check(_lib.lib().mgx_get_state(self._h, _ptr(out["grid"]), _ptr(out["aux"]), _ptr(out["agent"]),
+                                            _ptr(out["carry"]), _ptr(out["steps"])))
+        return out
+
+    def sync(self):
+        """Wait for all enqueued work; raises AssertionError subclasses for recorded faults (like the reference)."""
+        _lib.check(_lib.lib().mgx_sync(self._h))
+
+    def clear_faults(self):
+        _lib.check(_lib.lib().mgx_clear_faults(self._h))
+
+    def stats(self):
+        s = _lib.Stats()
+        _lib.check(_lib.lib().mgx_get_stats(self._h, ctypes.byref(s)))
+        return dict(steps=s.steps, episodes=s.episodes, reward_sum=s.reward_sum,
+                    invalid_actions=s.invalid_actions, out_of_bounds=s.out_of_bounds)
+
+    def fill_actions(self, seed, t0, T, out=None):
+        """actions[T][N] of the synthetic counter-based stream (actions.action_stream), generated on the GPU."""
+        if out is None:
+            out = self._new((T, self.num_envs), "uint8")
+        if self._torch is not None:
+            self._bind_stream()
+        _lib.check(_lib.lib().mgx_fill_actions(self._h, ctypes.c_uint64(seed), self.env_offset, int(t0), int(T), _ptr(out)))
+        return out
+
+    def profile_begin(self):
+        _lib.check(_lib.lib().mgx_profile_begin(self._h))
+
+    def profile_end(self):
+        n, ms = ctypes.c_int64(), ctypes.c_double()
+        _lib.check(_lib.lib().mgx_profile_end(self._h, ctypes.byref(n), ctypes.byref(ms)))
+        return n.value, ms.value
+
+
+def generate_levels(env_id_or_cfg, seeds):
+    """Host-side `env.seed(s); env.reset()` of a built-in family -> (grid (n,W,H,3) u8, agent (n,3) i32)."""
+    cfg = _lib.env_config(env_id_or_cfg) if isinstance(env_id_or_cfg, str) else env_id_or_cfg
+    s = np.ascontiguousarray(seeds, dtype=np.uint64)
+    n = s.shape[0]
+    grid = np.empty((n, cfg.width, cfg.height, 3), np.uint8)
+    agent = np.empty((n, 3), np.int32)
+    _lib.check(_lib.lib().mgx_generate_levels(ctypes.byref(cfg), n, _ptr(s), _ptr(grid), _ptr(agent)))
+    return grid, agent

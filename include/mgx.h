@@ -1,0 +1,159 @@
+/*
+ * mgx.h -- C ABI of libmgx.so: batched MiniGrid `step -> gen_obs -> encode` on MI355X (gfx950).
+ *
+ * The reference (rohitrango/gym-minigrid) has no FFI / plugin layer: its only
+ * interface for this path is the legacy gym.Env Python API.  Each entry point below
+ * therefore cites the reference *method* it replaces (paths relative to
+ * /root/reference/gym_minigrid/), batched over N independent env instances:
+ *
+ *   mgx_create / mgx_destroy   MiniGridEnv.__init__ kwargs        minigrid.py:767-829
+ *   mgx_env_config             per-id constructor arguments       envs/empty.py:10-28, envs/doorkey.py:9-13,
+ *                                                                 envs/crossing.py:12-22, envs/lavagap.py:10-19
+ *   mgx_reset                  seed(s); reset()                   minigrid.py:831-863, wrappers.py:24-28
+ *   mgx_set_state/get_state    env.grid / agent_pos / agent_dir / carrying / step_count attributes
+ *                                                                 minigrid.py:816-823,851-854, Grid.encode :571-594
+ *   mgx_observe                gen_obs()                          minigrid.py:1359-1381
+ *   mgx_step                   step(action)                       minigrid.py:1227-1325
+ *                              (+ FullyObsWrapper.observation     wrappers.py:326-338 when obs_mode = MGX_OBS_FULL)
+ *   mgx_generate_levels        _gen_grid of the built-in families envs/empty.py:30-57, envs/doorkey.py:15-44,
+ *                                                                 envs/crossing.py:24-92, envs/lavagap.py:21-59
+ *
+ * Conventions
+ *   - every function returns 0 (MGX_OK) or a negative mgx_status; mgx_last_error()
+ *     returns a thread-local message for the last failure.  No C++ exception crosses.
+ *   - buffers are CALLER-OWNED.  Every data pointer may be a device pointer on the
+ *     handle's GPU (zero-copy; must be 16-byte aligned) or a host pointer (staged
+ *     through an internal buffer).  The library detects which.
+ *   - calls on one handle are NOT thread-safe; work is enqueued asynchronously on the
+ *     handle's HIP stream (mgx_set_stream adopts a caller stream, e.g. torch's).
+ *     Host-pointer outputs are complete when the call returns; device-pointer outputs
+ *     are complete after mgx_sync() or any later work on the same stream.
+ *   - one handle per GPU; envs shard across GPUs by contiguous index blocks with no
+ *     data-path collective.
+ *
+ * Encodings (identical to the reference's):
+ *   grid   uint8 [N][W][H][3]  Grid.encode(): index [x][y][channel] = (type, color, state); (1,0,0) = empty
+ *   aux    uint8 [N][W][H]     bit0 = Goal.overlap, i.e. a goal built with toggletimes<=0 (terminal goal,
+ *                              minigrid.py:156-162,1259-1261).  NULL = all zeros (the default objects).
+ *   agent  int32 [N][3]        x, y, dir (0 right, 1 down, 2 left, 3 up; minigrid.py:64-73)
+ *   carry  uint8 [N][3]        encode() of the carried object, (1,0,0) = nothing
+ *   steps  int32 [N]           step_count
+ *   obs    uint8 [N][7][7][3]  obs['image'] (MGX_OBS_PARTIAL) or uint8 [N][W][H][3] (MGX_OBS_FULL)
+ *   reward float [N]           the reference's Python double narrowed to f32
+ *   done   uint8 [N]           0/1
+ */
+#ifndef MGX_H
+#define MGX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGX_VIEW 7              /* agent_view_size (minigrid.py:776) */
+#define MGX_OBS_PARTIAL_BYTES (MGX_VIEW * MGX_VIEW * 3)
+#define MGX_NUM_ACTIONS 7       /* MiniGridEnv.Actions (minigrid.py:731-745) */
+
+typedef enum {
+    MGX_OK = 0,
+    MGX_ERR_INVALID_ARG = -1,
+    MGX_ERR_INVALID_STATE = -2,  /* set_state: a cell / agent / carry value the reference cannot produce */
+    MGX_ERR_INVALID_ACTION = -3, /* an action >= 7 was stepped (reference: AssertionError, minigrid.py:1318) */
+    MGX_ERR_OUT_OF_BOUNDS = -4,  /* agent neighbour outside the grid (reference: Grid.get assert, :417-418) */
+    MGX_ERR_UNSUPPORTED = -5,    /* grid too large for one wavefront's LDS tile, unknown env id, ... */
+    MGX_ERR_HIP = -6,            /* HIP runtime failure (message has hipGetErrorString) */
+    MGX_ERR_NO_LEVELGEN = -7     /* mgx_reset on a handle whose family has no built-in generator */
+} mgx_status;
+
+typedef enum { MGX_OBS_PARTIAL = 0, MGX_OBS_FULL = 1 } mgx_obs_mode;
+
+/* level families with a built-in seeded generator */
+typedef enum {
+    MGX_LEVEL_NONE = 0,     /* state is injected with mgx_set_state only */
+    MGX_LEVEL_EMPTY = 1,    /* EmptyEnv: level_arg0 = 1 -> random agent start (Empty-Random-*), arg1 = sizetop (0 = none) */
+    MGX_LEVEL_DOORKEY = 2,  /* DoorKeyEnv */
+    MGX_LEVEL_CROSSING = 3, /* CrossingEnv: level_arg0 = num_crossings, level_arg1 = obstacle type (9 lava, 2 wall) */
+    MGX_LEVEL_LAVAGAP = 4   /* LavaGapEnv:  level_arg0 = const gap column (0/1), level_arg1 = obstacle type */
+} mgx_level_kind;
+
+typedef struct {
+    int32_t width, height;      /* grid size, >= 3 */
+    int32_t max_steps;
+    int32_t see_through_walls;  /* 1 = skip process_vis (minigrid.py:1344-1347) */
+    int32_t lava_v1;            /* 1 = class name contains 'v1': lava gives reward -1, no done (minigrid.py:1262-1268) */
+    int32_t obs_mode;           /* mgx_obs_mode */
+    int32_t auto_reset;         /* 0 = reference semantics (caller resets, run_tests.py:64-66).
+                                   1 = on done the env is restored to its episode-start state (the state last given
+                                       by mgx_reset / mgx_set_state: ReseedWrapper(seeds=[s]) semantics) inside the same
+                                       step, and obs is the first observation of the new episode (VecEnv convention);
+                                       reward/done still describe the terminal transition. */
+    int32_t level_kind;         /* mgx_level_kind */
+    int32_t level_arg0, level_arg1;
+    int32_t reserved[6];
+} mgx_config;
+
+typedef struct mgx_env_s *mgx_handle;
+
+const char *mgx_last_error(void);
+const char *mgx_version(void);
+
+/* Fill *cfg for a registered reference id ("MiniGrid-Empty-8x8-v0", ...).  obs_mode and
+ * auto_reset are left 0.  Unknown id -> MGX_ERR_UNSUPPORTED. */
+int mgx_env_config(const char *env_id, mgx_config *cfg);
+/* i-th supported env id, or NULL past the end. */
+const char *mgx_env_id(int i);
+
+int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx_handle *out);
+int mgx_destroy(mgx_handle h);
+int mgx_set_stream(mgx_handle h, void *hip_stream); /* NULL = back to the handle's own stream */
+int mgx_sync(mgx_handle h); /* waits for the stream; returns MGX_ERR_INVALID_ACTION / MGX_ERR_OUT_OF_BOUNDS
+                               if a fault was recorded since the last mgx_clear_faults */
+int mgx_clear_faults(mgx_handle h);
+int mgx_obs_bytes(mgx_handle h, int64_t *per_env);
+
+/* Host-side level generation (pure CPU, no handle, no GPU): seeds -> initial states in the
+ * reference's encoding.  Reproduces `env.seed(s); env.reset()` of the family. */
+int mgx_generate_levels(const mgx_config *cfg, int64_t n, const uint64_t *seeds,
+                        uint8_t *grid, int32_t *agent);
+
+/* env.seed(seeds[i]); env.reset() for every env with mask[i] != 0 (mask NULL = all).
+ * seeds/mask are HOST pointers.  obs (optional) receives the reset observation of ALL envs. */
+int mgx_reset(mgx_handle h, const uint64_t *seeds, const uint8_t *mask, uint8_t *obs);
+
+/* Inject / read back the full simulator state.  set_state also records the state as the
+ * episode start used by auto_reset.  aux, carry, steps may be NULL (zeros / nothing / 0).
+ * get_state: any pointer may be NULL. */
+int mgx_set_state(mgx_handle h, const uint8_t *grid, const uint8_t *aux, const int32_t *agent,
+                  const uint8_t *carry, const int32_t *steps);
+int mgx_get_state(mgx_handle h, uint8_t *grid, uint8_t *aux, int32_t *agent, uint8_t *carry, int32_t *steps);
+
+/* gen_obs() of the current state, no transition. */
+int mgx_observe(mgx_handle h, uint8_t *obs);
+
+/* One lockstep env.step(actions[i]) for all N envs.  reward / done may be NULL. */
+int mgx_step(mgx_handle h, const uint8_t *actions, uint8_t *obs, float *reward, uint8_t *done);
+
+/* Counters accumulated on the device since creation (for logging): env-steps executed,
+ * episodes finished (done=1 transitions), sum of rewards, faults.  Synchronises the stream. */
+typedef struct {
+    int64_t steps, episodes;
+    double reward_sum;
+    int64_t invalid_actions, out_of_bounds;
+} mgx_stats;
+int mgx_get_stats(mgx_handle h, mgx_stats *out);
+
+/* Bench helper: fill actions[T][N] (device or host pointer) with the counter-based stream
+ * a = mix(seed, env0 + i, t0 + t) % 7  (same function as oracle-side tests use). */
+int mgx_fill_actions(mgx_handle h, uint64_t seed, int64_t env0, int64_t t0, int64_t T, uint8_t *actions);
+
+/* Timing of the step kernel alone, measured with HIP events on the handle's stream:
+ * mgx_profile_begin() starts bracketing every subsequent step kernel launch;
+ * mgx_profile_end() synchronises and returns launches and their summed duration. */
+int mgx_profile_begin(mgx_handle h);
+int mgx_profile_end(mgx_handle h, int64_t *launches, double *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGX_H */

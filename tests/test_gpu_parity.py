@@ -1,0 +1,222 @@
+"""GPU parity: the HIP path (libmgx.so, through the C ABI) against (1) the golden traces recorded from the
+reference and (2) the CPU oracle on seeded random batches.  Bit-exact for every byte; rewards are compared as
+float32(oracle double) == returned float32 (tolerance 0)."""
+import numpy as np
+import pytest
+
+import gym_minigrid_amd as mg
+from conftest import golden_cases, load_case
+from helpers import make_oracle, random_states, to_np
+
+pytestmark = pytest.mark.gpu
+
+
+def cfg_from(W, H, max_steps, see_through, lava_v1=False):
+    c = mg.Config()
+    c.width, c.height, c.max_steps = W, H, max_steps
+    c.see_through_walls, c.lava_v1 = int(see_through), int(lava_v1)
+    return c
+
+
+def check_state(env, grid, agent, carry, steps, aux=None, where=""):
+    st = env.get_state()
+    assert np.array_equal(st["agent"], agent), where
+    assert np.array_equal(st["carry"], carry), where
+    assert np.array_equal(st["steps"], steps), where
+    assert np.array_equal(st["grid"], grid), where
+    if aux is not None:
+        assert np.array_equal(st["aux"], aux), where
+
+
+@pytest.mark.parametrize("backend", ["numpy", "torch"])
+@pytest.mark.parametrize("name", golden_cases())
+def test_golden_trace_no_autoreset(name, backend):
+    """Reference semantics (caller resets on done).  N = 197 envs = 3 full tiles + a 5-env tail tile, env i
+    replays trace i % K, so both the full-tile and the tail-tile code paths see every golden byte."""
+    meta, z = load_case(name)
+    K, T = z["actions"].shape
+    N = 197 if backend == "numpy" else K
+    sel = np.arange(N) % K
+    mode = "full" if meta["full_obs"] else "partial"
+    env = mg.VecMiniGrid(config=cfg_from(meta["W"], meta["H"], meta["max_steps"], meta["see_through"], meta["lava_v1"]),
+                         num_envs=N, obs_mode=mode, auto_reset=False, backend=backend)
+    env.set_state(z["init_grid"][sel], z["init_agent"][sel], aux=z["init_aux"][sel])
+    want0 = z["init_full"] if meta["full_obs"] else z["init_obs"]
+    assert np.array_equal(to_np(env.observe()), want0[sel])
+    want_obs = z["full"] if meta["full_obs"] else z["obs"]
+    every = 1 if T <= 400 else 7
+    for t in range(T):
+        obs, rew, done, info = env.step(z["actions"][sel, t])
+        obs, rew, done = to_np(obs), to_np(rew), to_np(done)
+        assert info == {}
+        assert np.array_equal(obs, want_obs[sel, t]), (name, t)
+        assert np.array_equal(rew, z["reward"][sel, t].astype(np.float32)), (name, t)
+        assert np.array_equal(done, z["done"][sel, t]), (name, t)
+        if t % every == 0 or done.any():
+            check_state(env, z["grid"][sel, t], z["agent"][sel, t], z["carry"][sel, t], z["steps"][sel, t], where=(name, t))
+        if done.any():  # caller-side reset with the same seed == the recorded episode start
+            st = env.get_state()
+            d = done.astype(bool)
+            st["grid"][d] = z["init_grid"][sel][d]
+            st["aux"][d] = z["init_aux"][sel][d]
+            st["agent"][d] = z["init_agent"][sel][d]
+            st["carry"][d] = (1, 0, 0)
+            st["steps"][d] = 0
+            env.set_state(st["grid"], st["agent"], aux=st["aux"], carry=st["carry"], steps=st["steps"])
+    env.sync()
+    env.close()
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_golden_trace_autoreset(name):
+    """auto_reset=True: terminal reward/done are reported, obs is the first observation of the next episode
+    (the reference's recorded `reset()` observation), state is the episode start."""
+    meta, z = load_case(name)
+    if meta["full_obs"]:
+        pytest.skip("reset observations are recorded for the partial view")
+    K, T = z["actions"].shape
+    N = 64 + K
+    sel = np.arange(N) % K
+    env = mg.VecMiniGrid(config=cfg_from(meta["W"], meta["H"], meta["max_steps"], meta["see_through"], meta["lava_v1"]),
+                         num_envs=N, auto_reset=True, backend="numpy")
+    env.set_state(z["init_grid"][sel], z["init_agent"][sel], aux=z["init_aux"][sel])
+    dones = 0
+    for t in range(T):
+        obs, rew, done, _ = env.step(z["actions"][sel, t])
+        want = z["obs"][sel, t].copy()
+        d = z["done"][sel, t].astype(bool)
+        want[d] = z["init_obs"][sel][d]
+        assert np.array_equal(obs, want), (name, t)
+        assert np.array_equal(rew, z["reward"][sel, t].astype(np.float32))
+        assert np.array_equal(done, z["done"][sel, t])
+        dones += int(d.sum())
+        if d.any():
+            st = env.get_state()
+            assert np.array_equal(st["grid"][d], z["init_grid"][sel][d])
+            assert np.array_equal(st["agent"][d], z["init_agent"][sel][d])
+            assert (st["steps"][d] == 0).all() and (st["carry"][d] == (1, 0, 0)).all()
+    s = env.stats()
+    assert s["episodes"] == dones and s["steps"] == N * T
+    assert abs(s["reward_sum"] - float(z["reward"][sel].astype(np.float32).astype(np.float64).sum())) < 1e-9
+    env.close()
+
+
+SHAPES = [(8, 8), (9, 9), (16, 16), (5, 5), (6, 6), (7, 7), (11, 11), (7, 11), (13, 6), (19, 19), (25, 25), (3, 3), (40, 33)]
+
+
+@pytest.mark.parametrize("mode", ["partial", "full"])
+@pytest.mark.parametrize("auto_reset", [False, True])
+@pytest.mark.parametrize("W,H", SHAPES)
+def test_random_batch_vs_oracle(W, H, auto_reset, mode):
+    """Seeded random states + uniform random actions, HIP vs CPU oracle, every step, every byte."""
+    N = 64 * 9 + 17 if W * H <= 400 else 64 * 2 + 3
+    T = 48
+    max_steps = 23  # several time-outs inside T
+    see = (W * 7 + H) % 3 == 0
+    v1 = (W + H) % 5 == 0
+    if W >= 5 and H >= 5:
+        grid, aux, agent, carry, steps = random_states(N, W, H, seed=W * 100 + H)
+    else:  # 3x3: one interior cell
+        grid, aux, agent, carry, steps = random_states(N, W, H, seed=1, density=0.0)
+    orc = make_oracle(W, H, max_steps, see, v1, grid, aux, agent, carry, steps)
+    env = mg.VecMiniGrid(config=cfg_from(W, H, max_steps, see, v1), num_envs=N, obs_mode=mode,
+                         auto_reset=auto_reset, backend="torch")
+    env.set_state(grid, agent, aux=aux, carry=carry, steps=steps)
+    o0 = orc.observe(full=True)
+    assert np.array_equal(to_np(env.observe()), o0[1] if mode == "full" else o0[0])
+    rs = np.random.RandomState(7)
+    for t in range(T):
+        a = rs.randint(0, 7, size=N).astype(np.uint8)
+        obs, rew, done, _ = env.step(a)
+        oo, of, orew, odone = orc.step(a, full=True)
+        want = of if mode == "full" else oo
+        if auto_reset:
+            orc.reset_where(odone)
+            ro = orc.observe(full=True)
+            d = odone.astype(bool)
+            want = want.copy()
+            want[d] = (ro[1] if mode == "full" else ro[0])[d]
+        assert np.array_equal(to_np(done), odone), t
+        assert np.array_equal(to_np(rew), orew.astype(np.float32)), t
+        assert np.array_equal(to_np(obs), want), t
+        if t % 8 == 7:
+            check_state(env, orc.grid, orc.agent, orc.carry, orc.steps, aux=orc.aux, where=t)
+    env.sync()
+    env.close()
+
+
+@pytest.mark.parametrize("env_id", ["MiniGrid-Empty-8x8-v0", "MiniGrid-DoorKey-8x8-v0", "MiniGrid-LavaCrossingS9N1-v0",
+                                    "MiniGrid-Empty-Random-6x6-v0", "MiniGrid-LavaGapS7-v1", "MiniGrid-SimpleCrossingS11N5-v0"])
+def test_seeded_reset_on_device(env_id):
+    N = 300
+    env = mg.VecMiniGrid(env_id, num_envs=N, seeds=5, auto_reset=True, backend="torch")
+    obs = to_np(env.reset())
+    grid, agent = mg.generate_levels(env_id, 5 + np.arange(N, dtype=np.uint64))
+    cfg = mg.env_config(env_id)
+    orc = make_oracle(cfg.width, cfg.height, cfg.max_steps, cfg.see_through_walls, cfg.lava_v1, grid,
+                      np.zeros(grid.shape[:3], np.uint8), agent)
+    assert np.array_equal(obs, orc.observe())
+    st = env.get_state()
+    assert np.array_equal(st["grid"], grid) and np.array_equal(st["agent"], agent)
+    acts = to_np(env.fill_actions(3, 0, 40))
+    assert np.array_equal(acts, mg.action_stream(3, np.arange(N)[None, :], np.arange(40)[:, None]))
+    for t in range(40):
+        obs, rew, done, _ = env.step(acts[t])
+        oo, orew, odone = orc.step(acts[t])
+        orc.reset_where(odone)
+        want = np.where(odone.astype(bool)[:, None, None, None], orc.observe(), oo)
+        assert np.array_equal(to_np(obs), want) and np.array_equal(to_np(done), odone)
+    # masked re-seed: only the masked envs change
+    mask = (np.arange(N) % 3 == 0).astype(np.uint8)
+    env.seed(1000)
+    env.reset(mask=mask)
+    g2, a2 = mg.generate_levels(env_id, 1000 + np.arange(N, dtype=np.uint64))
+    st = env.get_state()
+    m = mask.astype(bool)
+    assert np.array_equal(st["grid"][m], g2[m]) and np.array_equal(st["agent"][m], a2[m])
+    assert np.array_equal(st["grid"][~m], orc.grid[~m]) and np.array_equal(st["agent"][~m], orc.agent[~m])
+    env.close()
+
+
+def test_faults_and_errors():
+    N = 70
+    grid, aux, agent, carry, steps = random_states(N, 8, 8, seed=3)
+    env = mg.VecMiniGrid(config=cfg_from(8, 8, 50, False), num_envs=N, auto_reset=False, backend="numpy")
+    env.set_state(grid, agent, aux=aux)
+    a = np.full(N, 6, np.uint8)
+    a[5] = 7
+    a[69] = 200
+    before = env.get_state()
+    env.step(a)
+    with pytest.raises(AssertionError):   # reference: assert False, "unknown action"
+        env.sync()
+    st = env.stats()
+    assert st["invalid_actions"] == 2
+    after = env.get_state()
+    assert np.array_equal(after["grid"], before["grid"]) and np.array_equal(after["agent"], before["agent"])
+    env.clear_faults()
+    env.sync()
+    # a state the reference cannot produce
+    bad = grid.copy()
+    bad[3, 2, 2] = (12, 0, 0)
+    with pytest.raises(mg.MgxError):
+        env.set_state(bad, agent)
+    bad_agent = agent.copy()
+    bad_agent[0, 0] = 8
+    with pytest.raises(mg.MgxError):
+        env.set_state(grid, bad_agent)
+    # agent on the border facing out: the reference's Grid.get asserts
+    g2 = grid.copy()
+    ag2 = agent.copy()
+    ag2[1] = (0, 3, 2)
+    g2[1, 0, 3] = (1, 0, 0)
+    env.set_state(g2, ag2, aux=aux)
+    env.step(np.full(N, 2, np.uint8))
+    with pytest.raises(AssertionError):
+        env.sync()
+    assert env.stats()["out_of_bounds"] == 1
+    env.close()
+    with pytest.raises(mg.MgxError):
+        mg.VecMiniGrid(config=cfg_from(2, 8, 10, False), num_envs=4, backend="numpy")
+    with pytest.raises(mg.MgxError):
+        mg.VecMiniGrid(config=cfg_from(8, 8, 10, False), num_envs=0, backend="numpy")

@@ -1,0 +1,30 @@
+"""Host-side seeded level generation (csrc/levelgen.cpp: SHA-512 + MT19937 + numpy-legacy draws) against
+layouts recorded from the reference (`env.seed(s); env.reset()`, tests/golden/levels.npz)."""
+import numpy as np
+import pytest
+
+import gym_minigrid_amd as mg
+
+IDS = ["Empty-8x8", "Empty-16x16", "Empty-5x5", "Empty-6x6", "DoorKey-5x5", "DoorKey-6x6", "DoorKey-8x8",
+       "DoorKey-16x16", "LavaCrossingS9N1", "LavaCrossingS9N2", "LavaCrossingS9N3", "LavaCrossingS11N5",
+       "SimpleCrossingS9N1", "SimpleCrossingS9N2", "SimpleCrossingS9N3", "SimpleCrossingS11N5"]
+
+
+@pytest.mark.parametrize("key", IDS)
+def test_levels_match_reference(levels, key):
+    env_id = "MiniGrid-%s-v0" % key
+    seeds = levels[key + ":seeds"]
+    grid, agent = mg.generate_levels(env_id, seeds)
+    assert np.array_equal(grid, levels[key + ":grid"])
+    assert np.array_equal(agent, levels[key + ":agent"])
+    cfg = mg.env_config(env_id)
+    assert (cfg.max_steps, cfg.see_through_walls) == tuple(levels[key + ":max_steps"])
+
+
+def test_registry_and_errors():
+    ids = mg.env_ids()
+    assert "MiniGrid-Empty-8x8-v0" in ids and "MiniGrid-LavaCrossingS9N1-v0" in ids
+    with pytest.raises(mg.MgxError):
+        mg.env_config("MiniGrid-DoesNotExist-v0")
+    cfg = mg.env_config("MiniGrid-LavaGapS7-v1")
+    assert cfg.lava_v1 == 1 and cfg.width == 7
