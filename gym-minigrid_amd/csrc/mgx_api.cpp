@@ -83,11 +83,11 @@ bool is_device_ptr(const void *p)
 }
 
 // Input argument: returns a device pointer holding `bytes` of *src (staged if src is host memory).
-int dev_in(mgx_handle h, int slot, const void *src, size_t bytes, const void **out)
+int dev_in(mgx_handle h, int slot, const void *src, size_t bytes, const void **out, unsigned align = 1)
 {
     if (!src) { *out = nullptr; return MGX_OK; }
     if (is_device_ptr(src)) {
-        if ((uintptr_t)src & 15) return mgx_fail(MGX_ERR_INVALID_ARG, "device pointer %p is not 16-byte aligned", src);
+        if ((uintptr_t)src & (align - 1)) return mgx_fail(MGX_ERR_INVALID_ARG, "device pointer %p is not %u-byte aligned", src, align);
         *out = src;
         return MGX_OK;
     }
@@ -100,12 +100,12 @@ int dev_in(mgx_handle h, int slot, const void *src, size_t bytes, const void **o
 
 struct OutArg { void *user = nullptr; void *dev = nullptr; size_t bytes = 0; bool staged = false; };
 
-int dev_out(mgx_handle h, int slot, void *dst, size_t bytes, OutArg *o)
+int dev_out(mgx_handle h, int slot, void *dst, size_t bytes, OutArg *o, unsigned align = 1)
 {
     o->user = dst; o->bytes = bytes; o->staged = false; o->dev = nullptr;
     if (!dst) return MGX_OK;
     if (is_device_ptr(dst)) {
-        if ((uintptr_t)dst & 15) return mgx_fail(MGX_ERR_INVALID_ARG, "device pointer %p is not 16-byte aligned", dst);
+        if ((uintptr_t)dst & (align - 1)) return mgx_fail(MGX_ERR_INVALID_ARG, "device pointer %p is not %u-byte aligned", dst, align);
         o->dev = dst;
         return MGX_OK;
     }
@@ -260,7 +260,16 @@ extern "C" int mgx_set_stream(mgx_handle h, void *hip_stream)
     int rc = check_handle(h, "mgx_set_stream");
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream)); // hand-over point: everything enqueued so far is complete
-    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    h->stream = (hipStream_t)hip_stream; // NULL is a real stream: the device's default (null) stream
+    return MGX_OK;
+}
+
+extern "C" int mgx_use_own_stream(mgx_handle h)
+{
+    int rc = check_handle(h, "mgx_use_own_stream");
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->stream = h->own_stream;
     return MGX_OK;
 }
 
@@ -329,11 +338,11 @@ static int set_state_impl(mgx_handle h, const uint8_t *grid, const uint8_t *aux,
     p.grid = (const uint8_t *)d;
     if ((rc = dev_in(h, 1, aux, n * cells, &d))) return rc;
     p.aux = (const uint8_t *)d;
-    if ((rc = dev_in(h, 2, agent, n * 3 * sizeof(int32_t), &d))) return rc;
+    if ((rc = dev_in(h, 2, agent, n * 3 * sizeof(int32_t), &d, 4))) return rc;
     p.agent = (const int32_t *)d;
     if ((rc = dev_in(h, 3, carry, n * 3, &d))) return rc;
     p.carry = (const uint8_t *)d;
-    if ((rc = dev_in(h, 4, steps, n * sizeof(int32_t), &d))) return rc;
+    if ((rc = dev_in(h, 4, steps, n * sizeof(int32_t), &d, 4))) return rc;
     p.steps = (const int32_t *)d;
     if ((rc = dev_in(h, 5, mask_host, n, &d))) return rc;
     p.mask = (const uint8_t *)d;
@@ -407,8 +416,8 @@ static int run_step(mgx_handle h, bool do_step, const uint8_t *actions, uint8_t 
         p.actions = (const uint8_t *)d;
     }
     OutArg o[3];
-    if ((rc = dev_out(h, 0, obs, (size_t)h->n * h->obs_bytes, &o[0]))) return rc;
-    if ((rc = dev_out(h, 1, reward, (size_t)h->n * sizeof(float), &o[1]))) return rc;
+    if ((rc = dev_out(h, 0, obs, (size_t)h->n * h->obs_bytes, &o[0], 16))) return rc;
+    if ((rc = dev_out(h, 1, reward, (size_t)h->n * sizeof(float), &o[1], 4))) return rc;
     if ((rc = dev_out(h, 2, done, (size_t)h->n, &o[2]))) return rc;
     p.obs = (uint8_t *)o[0].dev; p.reward = (float *)o[1].dev; p.done = (uint8_t *)o[2].dev;
     HIP_TRY(mgx_launch_step(p, h->cfg.obs_mode, h->wpb, h->stream));

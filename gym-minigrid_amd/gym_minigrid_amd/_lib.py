@@ -48,6 +48,7 @@ SIGNATURES = {
     "mgx_create": (_int, [ctypes.POINTER(Config), _i64, _int, ctypes.POINTER(_vp)]),
     "mgx_destroy": (_int, [_vp]),
     "mgx_set_stream": (_int, [_vp, _vp]),
+    "mgx_use_own_stream": (_int, [_vp]),
     "mgx_sync": (_int, [_vp]),
     "mgx_clear_faults": (_int, [_vp]),
     "mgx_obs_bytes": (_int, [_vp, ctypes.POINTER(_i64)]),
@@ -74,6 +75,14 @@ def lib():
             raise ImportError("libmgx.so is missing (%s). Build it with `make -C %s` or "
                               "`python -c 'import __graft_entry__ as g; g.build()'`; there is no CPU fallback."
                               % (SO_PATH, CSRC))
+        # One HIP runtime per process: the PyTorch-ROCm wheel bundles its own libamdhip64.so.7 / libhsa-runtime64.
+        # Importing torch first makes libmgx.so's NEEDED libamdhip64.so.7 resolve (by SONAME) to that already
+        # loaded copy, so torch tensors and libmgx share one runtime, one context and one address space.  Loading
+        # in the other order puts two runtimes in the process and torch then finds "No HIP GPUs".
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(SO_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

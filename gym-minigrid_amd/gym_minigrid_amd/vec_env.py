@@ -97,7 +97,7 @@ class VecMiniGrid:
 
     def _bind_stream(self):
         s = self._torch.cuda.current_stream(self._dev).cuda_stream
-        if getattr(self, "_stream", None) != s:
+        if getattr(self, "_stream", -1) != s:
             _lib.check(_lib.lib().mgx_set_stream(self._h, ctypes.c_void_p(s)))
             self._stream = s
 

@@ -22,7 +22,7 @@
  *   - every function returns 0 (MGX_OK) or a negative mgx_status; mgx_last_error()
  *     returns a thread-local message for the last failure.  No C++ exception crosses.
  *   - buffers are CALLER-OWNED.  Every data pointer may be a device pointer on the
- *     handle's GPU (zero-copy; must be 16-byte aligned) or a host pointer (staged
+ *     handle's GPU (zero-copy; obs must be 16-byte aligned, int32/float arrays 4-byte) or a host pointer (staged
  *     through an internal buffer).  The library detects which.
  *   - calls on one handle are NOT thread-safe; work is enqueued asynchronously on the
  *     handle's HIP stream (mgx_set_stream adopts a caller stream, e.g. torch's).
@@ -106,7 +106,8 @@ const char *mgx_env_id(int i);
 
 int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx_handle *out);
 int mgx_destroy(mgx_handle h);
-int mgx_set_stream(mgx_handle h, void *hip_stream); /* NULL = back to the handle's own stream */
+int mgx_set_stream(mgx_handle h, void *hip_stream); /* adopt a caller stream (hipStream_t); NULL = the null stream */
+int mgx_use_own_stream(mgx_handle h);               /* back to the handle's own non-blocking stream (the default) */
 int mgx_sync(mgx_handle h); /* waits for the stream; returns MGX_ERR_INVALID_ACTION / MGX_ERR_OUT_OF_BOUNDS
                                if a fault was recorded since the last mgx_clear_faults */
 int mgx_clear_faults(mgx_handle h);
