@@ -190,6 +190,7 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     const int obs_img = cfg->obs_mode == MGX_OBS_PARTIAL ? 64 * MGX_OBS_PARTIAL_BYTES : 0;
     int need = 64 * h->LS;
     if (obs_img > need) need = obs_img;
+    if (cfg->obs_mode == MGX_OBS_FULL) need = ((need + 15) & ~15) + 3072; // + transpose scratch of emit_full_obs
     h->wave_lds = (need + 15) & ~15;
     h->obs_bytes = cfg->obs_mode == MGX_OBS_PARTIAL ? MGX_OBS_PARTIAL_BYTES : (int64_t)h->cells * 3;
     const int LDS_DEFAULT = 64 * 1024, LDS_MAX = 160 * 1024;
@@ -317,10 +318,25 @@ extern "C" int mgx_get_stats(mgx_handle h, mgx_stats *out)
     rc = read_counters(h, &c);
     if (rc) return rc;
     out->steps = h->steps_total;
-    out->episodes = (int64_t)c.episodes;
-    out->reward_sum = c.reward_sum;
+    unsigned long long ep = 0;
+    double rs = 0.0;
+    for (int i = 0; i < MGX_CTR_SHARDS; i++) { ep += c.shard[i].episodes; rs += c.shard[i].reward_sum; }
+    out->episodes = (int64_t)ep;
+    out->reward_sum = rs;
     out->invalid_actions = (int64_t)c.invalid_actions;
     out->out_of_bounds = (int64_t)c.out_of_bounds;
+    return MGX_OK;
+}
+
+// Enqueue (no host sync) a copy of the running totals into caller DEVICE memory, e.g. two elements of a torch
+// tensor that is then all-reduced over RCCL for logging: out[0] = episodes finished, out[1] = reward sum.
+extern "C" int mgx_read_stats_async(mgx_handle h, double *out2_dev)
+{
+    int rc = check_handle(h, "mgx_read_stats_async");
+    if (rc) return rc;
+    if (!out2_dev || !is_device_ptr(out2_dev) || ((uintptr_t)out2_dev & 7))
+        return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_read_stats_async: need an 8-byte aligned device pointer");
+    HIP_TRY(mgx_launch_read_stats(h->ctr_d, out2_dev, h->stream));
     return MGX_OK;
 }
 

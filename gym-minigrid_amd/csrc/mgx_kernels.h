@@ -7,9 +7,17 @@
 
 #define MGX_NUM_ACTIONS_K 7u
 
-struct MgxCounters {
+// Running totals.  The per-step counters are SHARDED over 256 cache lines (shard = tile & 255): with one word,
+// LavaCrossing (40% of the waves see a done every step) spent >half of the step serialising ~3,300 same-address
+// atomics in L2.  Readers sum the shards.
+#define MGX_CTR_SHARDS 256
+struct MgxCounterShard {
     unsigned long long episodes;
     double reward_sum;
+    unsigned long long pad[6]; // one 64-byte line per shard
+};
+struct MgxCounters {
+    MgxCounterShard shard[MGX_CTR_SHARDS];
     unsigned long long invalid_actions, out_of_bounds, invalid_state;
 };
 
@@ -47,6 +55,7 @@ hipError_t mgx_raise_lds_limit(int W, int H, int mode, int bytes);
 hipError_t mgx_launch_pack(const PackParams &p, hipStream_t st);
 hipError_t mgx_launch_unpack(const PackParams &p, hipStream_t st);
 hipError_t mgx_launch_fill_actions(uint8_t *out, uint64_t seed, int64_t env0, int64_t t0, int64_t n, int64_t T, hipStream_t st);
+hipError_t mgx_launch_read_stats(const MgxCounters *ctr, double *out2, hipStream_t st);
 uint32_t mgx_action_of(uint64_t seed, uint64_t env, uint64_t t);
 
 #endif

@@ -173,38 +173,50 @@ __device__ __forceinline__ void transition(const StepParams &p, Lane &L, uint32_
     if (valid && L.steps >= p.max_steps) done = true; // minigrid.py:1320-1321
 }
 
-// Restore the episode-start snapshot of every lane in `mask` (wave-cooperative copy), LDS + HBM.
+// Restore this lane's env to its episode-start snapshot (LDS image + HBM).  Each done lane copies its own
+// S bytes with all loads issued back to back, so a wave pays ONE memory latency however many of its envs
+// finished (a wave-cooperative loop over done envs would pay one per env: measured 2x slower end to end on
+// LavaCrossing, where 40% of the waves see a reset every step).
 template <int CS>
-__device__ __forceinline__ void restore_envs(const StepParams &p, u64 mask, int64_t env0, uint8_t *lds, int LS, int lane)
+__device__ __forceinline__ void restore_own(const StepParams &p, int64_t env, uint8_t *g)
 {
     const int S = CS ? CS : p.S;
-    const int SD = S >> 2, LSD = LS >> 2;
-    uint32_t *l32 = reinterpret_cast<uint32_t *>(lds);
-    while (mask) {
-        const int j = __builtin_ctzll(mask);
-        mask &= mask - 1;
-        const uint32_t *s = reinterpret_cast<const uint32_t *>(p.cells0 + (env0 + j) * S);
-        uint32_t *d = reinterpret_cast<uint32_t *>(p.cells + (env0 + j) * S);
-        for (int i = lane; i < SD; i += 64) {
+    uint32_t *l32 = reinterpret_cast<uint32_t *>(g);
+    if constexpr (CS != 0 && (CS % 16) == 0) {
+        const uint4 *s = reinterpret_cast<const uint4 *>(p.cells0 + env * S);
+        uint4 *d = reinterpret_cast<uint4 *>(p.cells + env * S);
+#pragma unroll 8
+        for (int i = 0; i < CS / 16; i++) {
+            const uint4 v = s[i];
+            l32[4 * i + 0] = v.x; l32[4 * i + 1] = v.y; l32[4 * i + 2] = v.z; l32[4 * i + 3] = v.w;
+            d[i] = v;
+        }
+    } else {
+        const uint32_t *s = reinterpret_cast<const uint32_t *>(p.cells0 + env * S);
+        uint32_t *d = reinterpret_cast<uint32_t *>(p.cells + env * S);
+        const int SD = S >> 2;
+#pragma unroll 8
+        for (int i = 0; i < SD; i++) {
             const uint32_t v = s[i];
-            l32[j * LSD + i] = v;
+            l32[i] = v;
             d[i] = v;
         }
     }
 }
 
-__device__ __forceinline__ void wave_stats(const StepParams &p, bool valid, bool done, float reward, bool bad_act, bool oob, int lane)
+__device__ __forceinline__ void wave_stats(const StepParams &p, bool valid, bool done, float reward, bool bad_act, bool oob, int lane, int tile)
 {
+    MgxCounterShard *sh = &p.ctr->shard[tile & (MGX_CTR_SHARDS - 1)];
     const u64 md = __ballot(valid && done), mr = __ballot(valid && reward != 0.f);
     const u64 ma = __ballot(bad_act), mo = __ballot(oob);
-    if (md && lane == 0) atomicAdd(&p.ctr->episodes, (u64)__popcll(md));
+    if (md && lane == 0) atomicAdd(&sh->episodes, (u64)__popcll(md));
     if (ma && lane == 0) atomicAdd(&p.ctr->invalid_actions, (u64)__popcll(ma));
     if (mo && lane == 0) atomicAdd(&p.ctr->out_of_bounds, (u64)__popcll(mo));
     if (mr) { // rare: wave-reduce the rewards in f64, one atomic
         double r = valid ? (double)reward : 0.0;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) r += __shfl_xor(r, o, 64);
-        if (lane == 0) atomicAdd(&p.ctr->reward_sum, r);
+        if (lane == 0) atomicAdd(&sh->reward_sum, r);
     }
 }
 
@@ -337,9 +349,55 @@ __device__ __forceinline__ void emit_full_obs(const StepParams &p, const Lane &L
     wave_sync();
     const int64_t nv = p.n - env0;
     const int n_env = nv >= 64 ? 64 : (int)nv;
+    uint8_t *dst = p.obs + env0 * cells * 3;
+    if constexpr (CW != 0 && ((CW * CH) % 16) == 0) {
+        // fast path: a lane decodes 16 consecutive cells of one env (4 LDS dwords) into 48 output bytes = 3 x 16-B stores
+        constexpr int UPE = (CW * CH) / 16; // units per env
+        const int n_units = n_env * UPE;
+        const uint32_t *l32 = reinterpret_cast<const uint32_t *>(lds);
+        uint8_t *xpose = lds + 64 * LS; // 3 KiB scratch behind the grid image (sized by the host: wave_lds)
+        for (int u0 = 0; u0 < n_units; u0 += 64) { // wave-uniform trip count
+            const int u = u0 + lane;
+            const int uc = u < n_units ? u : n_units - 1;
+            const int e = uc / UPE, o = uc - e * UPE;
+            const uint32_t *src = l32 + e * (LS >> 2) + o * 4;
+            uint32_t t[16];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t w = src[i];
+#pragma unroll
+                for (int j = 0; j < 4; j++) t[4 * i + j] = decode_triple_full((w >> (8 * j)) & 255u);
+            }
+            uint32_t D[12];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                D[3 * q + 0] = __builtin_amdgcn_perm(t[4 * q + 1], t[4 * q + 0], 0x04020100u);
+                D[3 * q + 1] = __builtin_amdgcn_perm(t[4 * q + 2], t[4 * q + 1], 0x05040201u);
+                D[3 * q + 2] = __builtin_amdgcn_perm(t[4 * q + 3], t[4 * q + 2], 0x06050402u);
+            }
+            if (u0 + 64 <= n_units) {
+                // 64 lanes x 48 B = 3 KiB contiguous: transpose through LDS so each store instruction is 1 KiB contiguous
+                uint4 *x4 = reinterpret_cast<uint4 *>(xpose);
+                x4[3 * lane + 0] = make_uint4(D[0], D[1], D[2], D[3]);
+                x4[3 * lane + 1] = make_uint4(D[4], D[5], D[6], D[7]);
+                x4[3 * lane + 2] = make_uint4(D[8], D[9], D[10], D[11]);
+                wave_sync();
+                uint4 *o4 = reinterpret_cast<uint4 *>(dst + (size_t)u0 * 48);
+                const uint4 a = x4[lane], b = x4[64 + lane], c = x4[128 + lane];
+                o4[lane] = a; o4[64 + lane] = b; o4[128 + lane] = c;
+                wave_sync();
+            } else if (u < n_units) {
+                uint4 *o4 = reinterpret_cast<uint4 *>(dst + (size_t)u * 48);
+                o4[0] = make_uint4(D[0], D[1], D[2], D[3]);
+                o4[1] = make_uint4(D[4], D[5], D[6], D[7]);
+                o4[2] = make_uint4(D[8], D[9], D[10], D[11]);
+            }
+        }
+        return;
+    }
+
     const int n_dw = n_env * cells * 3 / 4;      // whole dwords
     const int n_bytes = n_env * cells * 3;
-    uint8_t *dst = p.obs + env0 * cells * 3;
     for (int j = lane; j < n_dw; j += 64) {
         const int b = 4 * j;
         const int q = b / 3, r = b - 3 * q; // first cell of the tile's cell stream touched by this dword, byte phase
@@ -393,15 +451,10 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
         if (wr_idx >= 0 && !(p.auto_reset && done)) p.cells[env * S + wr_idx] = (uint8_t)wr_code;
         if (p.reward && valid) p.reward[env] = reward;
         if (p.done && valid) p.done[env] = done ? 1 : 0;
-        wave_stats(p, valid, done, reward, bad_act, oob, lane);
-        if (p.auto_reset) {
-            const u64 md = __ballot(valid && done);
-            if (md) { // wave-uniform, rare
-                wave_sync();
-                restore_envs<CS>(p, md, env0, lds, LS, lane);
-                wave_sync();
-                if (done) L = unpack_rec(p.agent0[env]);
-            }
+        wave_stats(p, valid, done, reward, bad_act, oob, lane, tile);
+        if (p.auto_reset && valid && done) {
+            restore_own<CS>(p, env, g);
+            L = unpack_rec(p.agent0[env]);
         }
         if (valid) p.agent[env] = pack_rec(L);
     }
@@ -504,6 +557,15 @@ __global__ __launch_bounds__(256) void k_fill_actions(uint8_t *out, uint64_t see
     out[i] = (uint8_t)action_of(seed, (uint64_t)(env0 + e), (uint64_t)(t0 + t));
 }
 
+__global__ __launch_bounds__(64) void k_read_stats(const MgxCounters *ctr, double *out2)
+{
+    double ep = 0.0, rs = 0.0;
+    for (int i = threadIdx.x; i < MGX_CTR_SHARDS; i += 64) { ep += (double)ctr->shard[i].episodes; rs += ctr->shard[i].reward_sum; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { ep += __shfl_xor(ep, o, 64); rs += __shfl_xor(rs, o, 64); }
+    if (threadIdx.x == 0) { out2[0] = ep; out2[1] = rs; }
+}
+
 template <int CW, int CH>
 hipError_t launch_sized(const StepParams &p, int mode, dim3 grid, dim3 block, size_t shmem, hipStream_t st)
 {
@@ -561,6 +623,12 @@ hipError_t mgx_launch_fill_actions(uint8_t *out, uint64_t seed, int64_t env0, in
     const int64_t total = n * T;
     if (total == 0) return hipSuccess;
     hipLaunchKernelGGL(k_fill_actions, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, out, seed, env0, t0, n, T);
+    return hipGetLastError();
+}
+
+hipError_t mgx_launch_read_stats(const MgxCounters *ctr, double *out2, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_read_stats, dim3(1), dim3(64), 0, st, ctr, out2);
     return hipGetLastError();
 }
 

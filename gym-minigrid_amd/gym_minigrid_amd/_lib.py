@@ -59,6 +59,7 @@ SIGNATURES = {
     "mgx_observe": (_int, [_vp, _vp]),
     "mgx_step": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "mgx_get_stats": (_int, [_vp, ctypes.POINTER(Stats)]),
+    "mgx_read_stats_async": (_int, [_vp, _vp]),
     "mgx_fill_actions": (_int, [_vp, ctypes.c_uint64, _i64, _i64, _i64, _vp]),
     "mgx_profile_begin": (_int, [_vp]),
     "mgx_profile_end": (_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double)]),

@@ -204,6 +204,12 @@ class VecMiniGrid:
         return dict(steps=s.steps, episodes=s.episodes, reward_sum=s.reward_sum,
                     invalid_actions=s.invalid_actions, out_of_bounds=s.out_of_bounds)
 
+    def read_stats_async(self, out2):
+        """Enqueue (episodes, reward_sum) -> out2 (float64 cuda tensor of 2 elements); no host sync."""
+        self._bind_stream()
+        _lib.check(_lib.lib().mgx_read_stats_async(self._h, _ptr(out2)))
+        return out2
+
     def fill_actions(self, seed, t0, T, out=None):
         """actions[T][N] of the synthetic counter-based stream (actions.action_stream), generated on the GPU."""
         if out is None:

@@ -144,6 +144,10 @@ typedef struct {
 } mgx_stats;
 int mgx_get_stats(mgx_handle h, mgx_stats *out);
 
+/* Asynchronous variant for multi-GPU logging: enqueues a copy of (episodes, reward_sum) as two doubles into
+ * caller DEVICE memory (e.g. a torch tensor that is then all-reduced over RCCL).  No host synchronisation. */
+int mgx_read_stats_async(mgx_handle h, double *out2_dev);
+
 /* Bench helper: fill actions[T][N] (device or host pointer) with the counter-based stream
  * a = mix(seed, env0 + i, t0 + t) % 7  (same function as oracle-side tests use). */
 int mgx_fill_actions(mgx_handle h, uint64_t seed, int64_t env0, int64_t t0, int64_t T, uint8_t *actions);
