@@ -495,6 +495,8 @@ extern "C" int mgx_fill_actions(mgx_handle h, uint64_t seed, int64_t env0, int64
     return MGX_OK;
 }
 
+extern "C" uint32_t mgx_action_at(uint64_t seed, int64_t env, int64_t t) { return mgx_action_of(seed, (uint64_t)env, (uint64_t)t); }
+
 extern "C" int mgx_profile_begin(mgx_handle h)
 {
     int rc = check_handle(h, "mgx_profile_begin");

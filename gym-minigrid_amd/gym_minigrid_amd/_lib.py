@@ -61,6 +61,7 @@ SIGNATURES = {
     "mgx_get_stats": (_int, [_vp, ctypes.POINTER(Stats)]),
     "mgx_read_stats_async": (_int, [_vp, _vp]),
     "mgx_fill_actions": (_int, [_vp, ctypes.c_uint64, _i64, _i64, _i64, _vp]),
+    "mgx_action_at": (ctypes.c_uint32, [ctypes.c_uint64, _i64, _i64]),
     "mgx_profile_begin": (_int, [_vp]),
     "mgx_profile_end": (_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double)]),
 }

@@ -152,6 +152,9 @@ int mgx_read_stats_async(mgx_handle h, double *out2_dev);
  * a = mix(seed, env0 + i, t0 + t) % 7  (same function as oracle-side tests use). */
 int mgx_fill_actions(mgx_handle h, uint64_t seed, int64_t env0, int64_t t0, int64_t T, uint8_t *actions);
 
+/* The same stream as a plain function (no handle, no GPU): action of global env `env` at step `t`. */
+uint32_t mgx_action_at(uint64_t seed, int64_t env, int64_t t);
+
 /* Timing of the step kernel alone, measured with HIP events on the handle's stream:
  * mgx_profile_begin() starts bracketing every subsequent step kernel launch;
  * mgx_profile_end() synchronises and returns launches and their summed duration. */
