@@ -47,6 +47,7 @@ struct mgx_env_s {
     int64_t n = 0, n_pad = 0;
     int device = 0;
     int W = 0, H = 0, cells = 0, S = 0, LS = 0, wave_lds = 0, wpb = 4;
+    int kernel_mode = 0; // 0 partial view, 1 full obs via the LDS tile image, 2 full obs direct (W*H % 4 == 0)
     int64_t obs_bytes = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     uint8_t *cells_d = nullptr, *cells0_d = nullptr;
@@ -193,6 +194,7 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     if (cfg->obs_mode == MGX_OBS_FULL) need = ((need + 15) & ~15) + 3072; // + transpose scratch of emit_full_obs
     h->wave_lds = (need + 15) & ~15;
     h->obs_bytes = cfg->obs_mode == MGX_OBS_PARTIAL ? MGX_OBS_PARTIAL_BYTES : (int64_t)h->cells * 3;
+    h->kernel_mode = cfg->obs_mode == MGX_OBS_PARTIAL ? 0 : ((h->cells % 4 == 0 && h->cells <= 65535) ? 2 : 1);
     const int LDS_DEFAULT = 64 * 1024, LDS_MAX = 160 * 1024;
     if (h->wave_lds > LDS_MAX) {
         int rc = mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_create: a %dx%d tile (64 envs) needs %d B of LDS > %d", h->W, h->H, h->wave_lds, LDS_MAX);
@@ -203,7 +205,7 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     if (h->wpb > 4) h->wpb = 4;
     if (h->wpb < 1) {
         h->wpb = 1;
-        hipError_t e2 = mgx_raise_lds_limit(h->W, h->H, cfg->obs_mode, h->wave_lds);
+        hipError_t e2 = mgx_raise_lds_limit(h->W, h->H, h->kernel_mode == 0 ? 0 : 1, h->wave_lds);
         if (e2 != hipSuccess) {
             int rc = mgx_fail(MGX_ERR_HIP, "mgx_create: cannot raise dynamic LDS to %d B: %s", h->wave_lds, hipGetErrorString(e2));
             delete h;
@@ -436,7 +438,7 @@ static int run_step(mgx_handle h, bool do_step, const uint8_t *actions, uint8_t 
     if ((rc = dev_out(h, 1, reward, (size_t)h->n * sizeof(float), &o[1], 4))) return rc;
     if ((rc = dev_out(h, 2, done, (size_t)h->n, &o[2]))) return rc;
     p.obs = (uint8_t *)o[0].dev; p.reward = (float *)o[1].dev; p.done = (uint8_t *)o[2].dev;
-    HIP_TRY(mgx_launch_step(p, h->cfg.obs_mode, h->wpb, h->stream));
+    HIP_TRY(mgx_launch_step(p, h->kernel_mode, h->wpb, h->stream));
     if (do_step) {
         h->steps_total += h->n;
         if (h->profiling) h->prof_launches++;

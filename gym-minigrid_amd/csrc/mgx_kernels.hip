@@ -111,66 +111,62 @@ __device__ __forceinline__ uint2 pack_rec(const Lane &L)
     return make_uint2((uint32_t)L.ax | ((uint32_t)L.ay << 8) | ((uint32_t)L.dir << 16) | (L.carry << 24), (uint32_t)L.steps);
 }
 
-// MiniGridEnv.step without the observation (spec S1-S8).  `g` = this lane's env in LDS.
+// MiniGridEnv.step without the observation (spec S1-S8), in two halves so that the forward cell can come from
+// the LDS tile image (partial-view kernel) or straight from HBM (full-obs kernel).
+// Half 1: step_count += 1, fault checks, index of the forward cell (-1: nothing to read, no transition).
 template <int CW, int CH>
-__device__ __forceinline__ void transition(const StepParams &p, Lane &L, uint32_t act, bool valid, uint8_t *g,
-                                           float &reward, bool &done, bool &bad_act, bool &oob, int &wr_idx, uint32_t &wr_code)
+__device__ __forceinline__ int transition_begin(const StepParams &p, Lane &L, uint32_t act, bool valid, bool &bad_act, bool &oob)
 {
     const int W = CW ? CW : p.W, H = CH ? CH : p.H;
     L.steps += 1;
-    reward = 0.f;
-    done = false;
-    wr_idx = -1;
-    wr_code = 0;
     const int dir = L.dir;
     const int dx = (dir == 0) - (dir == 2), dy = (dir == 1) - (dir == 3); // DIR_TO_VEC (minigrid.py:64-73)
-    const int fx = L.ax + dx, fy = L.ay + dy;
     // front/left/right are all read by the reference (minigrid.py:1239-1243): any of them outside -> assert
     const uint32_t okm = (uint32_t)(L.ax + 1 < W) | ((uint32_t)(L.ay + 1 < H) << 1) | ((uint32_t)(L.ax >= 1) << 2) |
                          ((uint32_t)(L.ay >= 1) << 3);
     const uint32_t need = 0xFu & ~(1u << ((dir + 2) & 3));
     oob = valid && ((okm & need) != need);
     bad_act = valid && act >= MGX_NUM_ACTIONS_K;
-    if (valid && !oob && !bad_act) {
-        const int fidx = fx * H + fy;
-        const uint32_t fc = g[fidx];
-        const uint32_t k = fc & 15u;
-        uint32_t nc = fc; // new forward-cell code
-        if (act == 0) L.dir = (dir + 3) & 3;
-        else if (act == 1) L.dir = (dir + 1) & 3;
-        else if (act == 2) {
-            // None, Floor, open Door, Goal, Lava can be walked onto (minigrid.py:93,164-166,192,211,245-247)
-            const uint32_t OVERLAP = (1u << MGX_K_EMPTY) | (1u << MGX_K_FLOOR) | (1u << MGX_K_DOOR_OPEN) | (1u << MGX_K_GOAL) | (1u << MGX_K_LAVA);
-            if ((OVERLAP >> k) & 1u) { L.ax = fx; L.ay = fy; }
-            if (k == MGX_K_GOAL && (fc & 0x80u)) { // goal.overlap (minigrid.py:1259-1261)
-                done = true;
-                // _reward(): 1 - 0.9*(step_count/max_steps) in Python doubles (minigrid.py:933-937), then f32
-                reward = (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps));
-            }
-            if (k == MGX_K_LAVA) { // minigrid.py:1262-1268
-                if (p.lava_v1) { done = false; reward = -1.f; }
-                else done = true;
-            }
-        } else if (act == 3) {
-            const uint32_t PICK = (1u << MGX_K_KEY) | (1u << MGX_K_BALL) | (1u << MGX_K_BOX);
-            if (((PICK >> k) & 1u) && L.carry == MGX_CODE_EMPTY) { L.carry = fc; nc = MGX_CODE_EMPTY; }
-        } else if (act == 4) {
-            if (k == MGX_K_EMPTY && L.carry != MGX_CODE_EMPTY) { nc = L.carry; L.carry = MGX_CODE_EMPTY; }
-        } else if (act == 5) {
-            if (k == MGX_K_DOOR_LOCKED) { // Door.toggle (minigrid.py:252-262)
-                if ((L.carry & 15u) == MGX_K_KEY && ((L.carry >> 4) & 7u) == ((fc >> 4) & 7u)) nc = (fc & 0xF0u) | MGX_K_DOOR_OPEN;
-            } else if (k == MGX_K_DOOR_OPEN) nc = (fc & 0xF0u) | MGX_K_DOOR_CLOSED;
-            else if (k == MGX_K_DOOR_CLOSED) nc = (fc & 0xF0u) | MGX_K_DOOR_OPEN;
-            else if (k == MGX_K_GOAL) { if (!(fc & 0x80u)) nc = MGX_CODE_EMPTY; } // Goal.toggle, toggletimes=1 (minigrid.py:171-181)
-            else if (k == MGX_K_BOX) nc = MGX_CODE_EMPTY;                         // Box.toggle, contains=None (minigrid.py:355-364)
-        } // act == 6 ("done"): pass (minigrid.py:1291-1293)
-        if (nc != fc) {
-            g[fidx] = (uint8_t)nc;
-            wr_idx = fidx; // written back to HBM by the caller once `done` is known
-            wr_code = nc;
+    if (!valid || oob || bad_act) return -1;
+    return (L.ax + dx) * H + (L.ay + dy);
+}
+
+// Half 2: the action switch on the forward cell code `fc`; returns the cell's new code (== fc: unchanged).
+__device__ __forceinline__ uint32_t transition_apply(const StepParams &p, Lane &L, uint32_t act, uint32_t fc, float &reward, bool &done)
+{
+    const int dir = L.dir;
+    const int dx = (dir == 0) - (dir == 2), dy = (dir == 1) - (dir == 3);
+    const uint32_t k = fc & 15u;
+    uint32_t nc = fc;
+    if (act == 0) L.dir = (dir + 3) & 3;
+    else if (act == 1) L.dir = (dir + 1) & 3;
+    else if (act == 2) {
+        // None, Floor, open Door, Goal, Lava can be walked onto (minigrid.py:93,164-166,192,211,245-247)
+        const uint32_t OVERLAP = (1u << MGX_K_EMPTY) | (1u << MGX_K_FLOOR) | (1u << MGX_K_DOOR_OPEN) | (1u << MGX_K_GOAL) | (1u << MGX_K_LAVA);
+        if ((OVERLAP >> k) & 1u) { L.ax += dx; L.ay += dy; }
+        if (k == MGX_K_GOAL && (fc & 0x80u)) { // goal.overlap (minigrid.py:1259-1261)
+            done = true;
+            // _reward(): 1 - 0.9*(step_count/max_steps) in Python doubles (minigrid.py:933-937), then f32
+            reward = (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps));
         }
-    }
-    if (valid && L.steps >= p.max_steps) done = true; // minigrid.py:1320-1321
+        if (k == MGX_K_LAVA) { // minigrid.py:1262-1268
+            if (p.lava_v1) { done = false; reward = -1.f; }
+            else done = true;
+        }
+    } else if (act == 3) {
+        const uint32_t PICK = (1u << MGX_K_KEY) | (1u << MGX_K_BALL) | (1u << MGX_K_BOX);
+        if (((PICK >> k) & 1u) && L.carry == MGX_CODE_EMPTY) { L.carry = fc; nc = MGX_CODE_EMPTY; }
+    } else if (act == 4) {
+        if (k == MGX_K_EMPTY && L.carry != MGX_CODE_EMPTY) { nc = L.carry; L.carry = MGX_CODE_EMPTY; }
+    } else if (act == 5) {
+        if (k == MGX_K_DOOR_LOCKED) { // Door.toggle (minigrid.py:252-262)
+            if ((L.carry & 15u) == MGX_K_KEY && ((L.carry >> 4) & 7u) == ((fc >> 4) & 7u)) nc = (fc & 0xF0u) | MGX_K_DOOR_OPEN;
+        } else if (k == MGX_K_DOOR_OPEN) nc = (fc & 0xF0u) | MGX_K_DOOR_CLOSED;
+        else if (k == MGX_K_DOOR_CLOSED) nc = (fc & 0xF0u) | MGX_K_DOOR_OPEN;
+        else if (k == MGX_K_GOAL) { if (!(fc & 0x80u)) nc = MGX_CODE_EMPTY; } // Goal.toggle, toggletimes=1 (minigrid.py:171-181)
+        else if (k == MGX_K_BOX) nc = MGX_CODE_EMPTY;                         // Box.toggle, contains=None (minigrid.py:355-364)
+    } // act == 6 ("done"): pass (minigrid.py:1291-1293)
+    return nc;
 }
 
 // Restore this lane's env to its episode-start snapshot (LDS image + HBM).  Each done lane copies its own
@@ -185,7 +181,7 @@ __device__ __forceinline__ void restore_own(const StepParams &p, int64_t env, ui
     if constexpr (CS != 0 && (CS % 16) == 0) {
         const uint4 *s = reinterpret_cast<const uint4 *>(p.cells0 + env * S);
         uint4 *d = reinterpret_cast<uint4 *>(p.cells + env * S);
-#pragma unroll 8
+#pragma unroll
         for (int i = 0; i < CS / 16; i++) {
             const uint4 v = s[i];
             l32[4 * i + 0] = v.x; l32[4 * i + 1] = v.y; l32[4 * i + 2] = v.z; l32[4 * i + 3] = v.w;
@@ -194,12 +190,20 @@ __device__ __forceinline__ void restore_own(const StepParams &p, int64_t env, ui
     } else {
         const uint32_t *s = reinterpret_cast<const uint32_t *>(p.cells0 + env * S);
         uint32_t *d = reinterpret_cast<uint32_t *>(p.cells + env * S);
-        const int SD = S >> 2;
+        if constexpr (CS != 0) { // e.g. 9x9: 21 dword loads, all in flight before the first use
+            uint32_t v[CS / 4];
+#pragma unroll
+            for (int i = 0; i < CS / 4; i++) v[i] = s[i];
+#pragma unroll
+            for (int i = 0; i < CS / 4; i++) { l32[i] = v[i]; d[i] = v[i]; }
+        } else {
+            const int SD = S >> 2;
 #pragma unroll 8
-        for (int i = 0; i < SD; i++) {
-            const uint32_t v = s[i];
-            l32[i] = v;
-            d[i] = v;
+            for (int i = 0; i < SD; i++) {
+                const uint32_t v = s[i];
+                l32[i] = v;
+                d[i] = v;
+            }
         }
     }
 }
@@ -444,11 +448,15 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
     float reward = 0.f;
     bool done = false, bad_act = false, oob = false;
     if (p.do_step) {
-        int wr_idx;
-        uint32_t wr_code;
-        transition<CW, CH>(p, L, act, valid, g, reward, done, bad_act, oob, wr_idx, wr_code);
-        // the one cell a transition can change; skipped when the env is about to be restored anyway
-        if (wr_idx >= 0 && !(p.auto_reset && done)) p.cells[env * S + wr_idx] = (uint8_t)wr_code;
+        const int fidx = transition_begin<CW, CH>(p, L, act, valid, bad_act, oob);
+        if (fidx >= 0) {
+            const uint32_t fc = g[fidx];
+            const uint32_t nc = transition_apply(p, L, act, fc, reward, done);
+            if (nc != fc) g[fidx] = (uint8_t)nc;
+            if (valid && L.steps >= p.max_steps) done = true; // minigrid.py:1320-1321
+            // the one cell a transition can change; skipped when the env is about to be restored anyway
+            if (nc != fc && !(p.auto_reset && done)) p.cells[env * S + fidx] = (uint8_t)nc;
+        } else if (valid && L.steps >= p.max_steps) done = true;
         if (p.reward && valid) p.reward[env] = reward;
         if (p.done && valid) p.done[env] = done ? 1 : 0;
         wave_stats(p, valid, done, reward, bad_act, oob, lane, tile);
@@ -461,6 +469,113 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
     if (p.obs) {
         if (MODE == 0) emit_partial_obs<CW, CH>(p, L, lds, g, env0, lane);
         else emit_full_obs<CW, CH>(p, L, valid, lds, g, LS, env0, lane);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// FullyObs, direct form (W*H a multiple of 4): no tile image in LDS, and a tile of 64 envs belongs to a whole
+// 256-thread BLOCK so that the cooperative decode has 4x the waves (a wave walking a 16x16 tile alone needs 16
+// dependent load->decode->store rounds and the kernel becomes latency-bound: measured 48 us wave lifetime).
+//   prefetch : every thread issues the coalesced loads of the cell units it will decode, before anything else;
+//   phase A  : wave 0, lane-per-env: transition with the forward cell gathered straight from HBM (its line is part
+//              of the prefetch, so no extra HBM bytes), results handed over through LDS;
+//   phase B  : all 4 waves: unit = 4 consecutive cells (one dword) -> 12 output bytes, stored with ONE
+//              global_store_dwordx3 per lane: consecutive lanes write consecutive 12-byte records, so every store
+//              instruction covers 768 contiguous, line-aligned bytes (16-cell units + 3 dwordx4 stores at a 48-byte
+//              lane stride measured ~20% slower: each lane's 16 bytes was its own L1 transaction).
+//              Envs that finished re-read the episode-start snapshot and write it back (a coalesced restore); the
+//              one cell phase A changed and the agent marker are patched in registers, so phase B never depends
+//              on phase A's global stores being visible.
+template <int CW, int CH>
+__global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
+{
+    __shared__ uint32_t s_info[64]; // per env: agent idx | dir<<16 | reset<<18 | (1<<19 if a cell changed)
+    __shared__ uint32_t s_wr[64];   // changed cell: idx | code<<16
+    __shared__ uint32_t s_lut[256]; // cell code -> (type | color<<8 | state<<16)
+    constexpr int CS = CW * CH;
+    constexpr int KPF = CS ? (CS / 4 * 64 + 255) / 256 : 0; // prefetched units per thread (compile-time sizes only)
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x;
+    const int H = CH ? CH : p.H;
+    const int S = CS ? CS : p.S;
+    const int UPE = S >> 2; // 4-cell units per env
+    const int64_t env0 = (int64_t)tile * 64;
+    const int64_t nv = p.n - env0;
+    const int n_units = (nv >= 64 ? 64 : (int)nv) * UPE;
+    const uint32_t *cells32 = reinterpret_cast<const uint32_t *>(p.cells + env0 * S);
+
+    uint32_t pf[KPF ? KPF : 1];
+#pragma unroll
+    for (int k = 0; k < KPF; k++) {
+        const int u = tid + 256 * k;
+        pf[k] = cells32[u < n_units ? u : 0];
+    }
+    s_lut[tid] = decode_triple_full(tid);
+
+    if (tid < 64) { // phase A: wave 0
+        const int lane = tid;
+        const int64_t env = env0 + lane;
+        const bool valid = env < p.n;
+        Lane L = unpack_rec(p.agent[env]);
+        uint32_t act = 6;
+        if (p.do_step && valid) act = p.actions[env];
+        float reward = 0.f;
+        bool done = false, bad_act = false, oob = false, reset = false;
+        uint32_t wr = 0, changed = 0;
+        if (p.do_step) {
+            const int fidx = transition_begin<CW, CH>(p, L, act, valid, bad_act, oob);
+            if (fidx >= 0) {
+                const uint32_t fc = p.cells[env * S + fidx];
+                const uint32_t nc = transition_apply(p, L, act, fc, reward, done);
+                if (valid && L.steps >= p.max_steps) done = true;
+                if (nc != fc && !(p.auto_reset && done)) {
+                    p.cells[env * S + fidx] = (uint8_t)nc;
+                    wr = (uint32_t)fidx | (nc << 16);
+                    changed = 1;
+                }
+            } else if (valid && L.steps >= p.max_steps) done = true;
+            if (p.reward && valid) p.reward[env] = reward;
+            if (p.done && valid) p.done[env] = done ? 1 : 0;
+            wave_stats(p, valid, done, reward, bad_act, oob, lane, tile);
+            if (p.auto_reset && valid && done) { L = unpack_rec(p.agent0[env]); reset = true; }
+            if (valid) p.agent[env] = pack_rec(L);
+        }
+        s_info[lane] = (uint32_t)(L.ax * H + L.ay) | ((uint32_t)L.dir << 16) | ((uint32_t)reset << 18) | (changed << 19);
+        s_wr[lane] = wr;
+    }
+    __syncthreads();
+
+    struct __attribute__((packed, aligned(4))) Out12 { uint32_t a, b, c; };
+    Out12 *dst = p.obs ? reinterpret_cast<Out12 *>(p.obs + env0 * (int64_t)S * 3) : nullptr;
+    constexpr int NIT = KPF ? KPF : 1;
+    const int n_iter = KPF ? KPF : (n_units + 255) / 256;
+#pragma unroll
+    for (int kk = 0; kk < NIT; kk++)
+    for (int k = kk; k < (KPF ? kk + 1 : n_iter); k++) { // compile-time sizes: fully unrolled (pf[] stays in registers)
+        const int u = tid + 256 * k;
+        if (u >= n_units) break;
+        const int e = u / UPE, o = u - e * UPE;
+        const uint32_t info = s_info[e];
+        const bool rst = (info >> 18) & 1u;
+        uint32_t w;
+        if (KPF != 0 && !rst) w = pf[kk];
+        else w = reinterpret_cast<const uint32_t *>(rst ? p.cells0 + env0 * S : p.cells + env0 * S)[u];
+        if (rst) reinterpret_cast<uint32_t *>(p.cells + env0 * S)[u] = w; // restore, coalesced
+        if (!dst) continue;
+        if ((info >> 19) & 1u) { // the cell the transition changed (whether or not the load already saw it)
+            const uint32_t x = s_wr[e], idx = x & 0xFFFFu, code = x >> 16, sh = 8u * (idx & 3u);
+            if ((int)(idx >> 2) == o) w = (w & ~(0xFFu << sh)) | (code << sh);
+        }
+        { // agent marker (10, 0, dir): wrappers.py:329-333
+            const uint32_t idx = info & 0xFFFFu, code = MGX_K_AGENT | (((info >> 16) & 3u) << 4), sh = 8u * (idx & 3u);
+            if ((int)(idx >> 2) == o) w = (w & ~(0xFFu << sh)) | (code << sh);
+        }
+        const uint32_t t0 = s_lut[w & 255u], t1 = s_lut[(w >> 8) & 255u], t2 = s_lut[(w >> 16) & 255u], t3 = s_lut[w >> 24];
+        Out12 r;
+        r.a = __builtin_amdgcn_perm(t1, t0, 0x04020100u);
+        r.b = __builtin_amdgcn_perm(t2, t1, 0x05040201u);
+        r.c = __builtin_amdgcn_perm(t3, t2, 0x06050402u);
+        dst[u] = r;
     }
 }
 
@@ -570,7 +685,8 @@ template <int CW, int CH>
 hipError_t launch_sized(const StepParams &p, int mode, dim3 grid, dim3 block, size_t shmem, hipStream_t st)
 {
     if (mode == 0) hipLaunchKernelGGL((k_step<CW, CH, 0>), grid, block, shmem, st, p);
-    else hipLaunchKernelGGL((k_step<CW, CH, 1>), grid, block, shmem, st, p);
+    else if (mode == 1) hipLaunchKernelGGL((k_step<CW, CH, 1>), grid, block, shmem, st, p);
+    else hipLaunchKernelGGL((k_step_fulldirect<CW, CH>), dim3(p.n_tiles), dim3(256), 0, st, p);
     return hipGetLastError();
 }
 
