@@ -188,7 +188,7 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     h->cells = h->W * h->H;
     h->S = (h->cells + 3) & ~3;
     h->LS = h->S + (((h->S >> 2) & 1) ? 0 : 4); // odd dword stride per env in LDS
-    const int obs_img = cfg->obs_mode == MGX_OBS_PARTIAL ? 64 * MGX_OBS_PARTIAL_BYTES : 0;
+    const int obs_img = cfg->obs_mode == MGX_OBS_PARTIAL ? 32 * MGX_OBS_PARTIAL_BYTES : 0; // half-tile output image
     int need = 64 * h->LS;
     if (obs_img > need) need = obs_img;
     if (cfg->obs_mode == MGX_OBS_FULL) need = ((need + 15) & ~15) + 3072; // + transpose scratch of emit_full_obs

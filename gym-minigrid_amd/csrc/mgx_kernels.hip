@@ -317,26 +317,35 @@ __device__ __forceinline__ void emit_partial_obs(const StepParams &p, const Lane
     const uint32_t prev_tail = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tail, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
     if (s != 0u) Q[0] |= prev_tail;
 
-    wave_sync(); // every lane is done reading the grid image that the output image overlays
-    uint32_t *o32 = reinterpret_cast<uint32_t *>(lds) + ((147u * (uint32_t)lane) >> 2);
-#pragma unroll
-    for (int k = 0; k < 36; k++) o32[k] = Q[k];
-    if (s != 0u) o32[36] = Q[36];
-    wave_sync();
-
-    // LDS image -> HBM, 16 B per lane, contiguous
+    // The tile's 9408 output bytes go through LDS in two halves of 32 envs (4704 B = 294 x 16 B each): the LDS image is
+    // then no larger than the grid image it overlays, which doubles the resident waves per CU (LDS was the limiter).
     const int64_t nv = p.n - env0; // valid envs in this tile (>= 1)
-    uint8_t *dst = p.obs + env0 * 147;
+    const int lim_all = nv >= 64 ? 9408 : (int)nv * 147;
+    uint32_t *o32 = reinterpret_cast<uint32_t *>(lds) + ((147u * (uint32_t)(lane & 31)) >> 2);
     const uint4 *l128 = reinterpret_cast<const uint4 *>(lds);
-    if (nv >= 64) {
 #pragma unroll
-        for (int c = lane; c < 588; c += 64) reinterpret_cast<uint4 *>(dst)[c] = l128[c];
-    } else {
-        const int lim = (int)nv * 147;
-        for (int c = lane; c < 588; c += 64) {
-            if (16 * c + 16 <= lim) reinterpret_cast<uint4 *>(dst)[c] = l128[c];
-            else
-                for (int b = 16 * c; b < lim; b++) dst[b] = lds[b];
+    for (int h = 0; h < 2; h++) {
+        wave_sync(); // every lane is done reading what this image overlays (grid image / previous half)
+        if ((lane >> 5) == h) {
+#pragma unroll
+            for (int k = 0; k < 36; k++) o32[k] = Q[k];
+            if (s != 0u) o32[36] = Q[36];
+        }
+        wave_sync();
+        uint8_t *dst = p.obs + env0 * 147 + h * 4704;
+        const int lim = lim_all - h * 4704; // valid bytes of this half (may be <= 0 in a tail tile)
+        if (lim >= 4704) {
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+                const int c = lane + 64 * i;
+                if (c < 294) reinterpret_cast<uint4 *>(dst)[c] = l128[c];
+            }
+        } else if (lim > 0) {
+            for (int c = lane; c < 294; c += 64) {
+                if (16 * c + 16 <= lim) reinterpret_cast<uint4 *>(dst)[c] = l128[c];
+                else
+                    for (int b = 16 * c; b < lim; b++) dst[b] = lds[b];
+            }
         }
     }
 }
