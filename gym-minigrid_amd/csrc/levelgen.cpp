@@ -28,8 +28,11 @@
 #include <string>
 #include <vector>
 
+#include <thread>
+
 #include "mgx.h"
 #include "mgx_internal.h"
+#include "levelgen_core.h"
 
 namespace {
 
@@ -171,131 +174,39 @@ struct Rng {
     }
 };
 
-// ----------------------------------------------------------------------------- tiny grid helper
-struct Level {
-    int W, H;
-    uint8_t *g; // [W][H][3]
-    int ax = -1, ay = -1, adir = 0;
-
-    uint8_t *at(int x, int y) { return g + ((size_t)x * H + y) * 3; }
-    void set(int x, int y, int t, int c, int s) { uint8_t *p = at(x, y); p[0] = (uint8_t)t; p[1] = (uint8_t)c; p[2] = (uint8_t)s; }
-    bool empty(int x, int y) { return at(x, y)[0] == 1; }
-    void clear()
-    {
-        for (int i = 0; i < W * H; i++) { g[i * 3] = 1; g[i * 3 + 1] = 0; g[i * 3 + 2] = 0; }
-    }
-    void wall_rect()
-    { // Grid.wall_rect(0,0,W,H), minigrid.py:433-437
-        for (int x = 0; x < W; x++) { set(x, 0, 2, 5, 0); set(x, H - 1, 2, 5, 0); }
-        for (int y = 0; y < H; y++) { set(0, y, 2, 5, 0); set(W - 1, y, 2, 5, 0); }
-    }
-    // place_obj(obj=None, top=(0,0), size=(sw,sh)) rejection sampling, minigrid.py:1028-1053
-    void sample_free(Rng &r, int sw, int sh, bool reject_agent, int *ox, int *oy)
-    {
-        for (;;) {
-            int x = r.randint(0, std::min(sw, W));
-            int y = r.randint(0, std::min(sh, H));
-            if (!empty(x, y)) continue;
-            if (reject_agent && x == ax && y == ay) continue;
-            *ox = x; *oy = y;
-            return;
-        }
-    }
-};
-
-void gen_empty(const mgx_config &c, Rng &r, Level &L)
+// ----------------------------------------------------------------------------- glue to levelgen_core.h
+// codes -> the reference's (type, color, state) triples
+void codes_to_triples(const uint8_t *codes, int cells, uint8_t *out)
 {
-    L.clear();
-    L.wall_rect();
-    L.set(L.W - 2, L.H - 2, 8, 1, 0); // Goal() green
-    if (c.level_arg0 == 0) { L.ax = 1; L.ay = 1; L.adir = 0; }
-    else { // agent_start_pos=None -> place_agent(size=sizetop)
-        int sw = c.level_arg1 > 0 ? c.level_arg1 : L.W, sh = c.level_arg1 > 0 ? c.level_arg1 : L.H;
-        L.sample_free(r, sw, sh, false, &L.ax, &L.ay);
-        L.adir = r.randint(0, 4);
+    for (int i = 0; i < cells; i++) {
+        const uint32_t c = codes[i], k = c & 15u, col = (c >> 4) & 7u;
+        const bool shut = k > MGX_K_AGENT;
+        out[3 * i] = (uint8_t)(shut ? 4u : k);
+        out[3 * i + 1] = (uint8_t)col;
+        out[3 * i + 2] = (uint8_t)(shut ? k - 10u : 0u);
     }
 }
 
-void gen_doorkey(const mgx_config &, Rng &r, Level &L)
+int check_levelgen_cfg(const mgx_config *cfg, const char *fn)
 {
-    L.clear();
-    L.wall_rect();
-    L.set(L.W - 2, L.H - 2, 8, 1, 0);
-    int split = r.randint(2, L.W - 2);
-    for (int y = 0; y < L.H; y++) L.set(split, y, 2, 5, 0); // vert_wall(split, 0)
-    L.sample_free(r, split, L.H, false, &L.ax, &L.ay);      // place_agent(size=(split, H))
-    L.adir = r.randint(0, 4);
-    int door = r.randint(1, L.W - 2);
-    L.set(split, door, 4, 4, 2);                            // Door('yellow', is_locked=True)
-    int kx, ky;
-    L.sample_free(r, split, L.H, true, &kx, &ky);           // Key('yellow'), rejects the agent cell
-    L.set(kx, ky, 5, 4, 0);
-}
-
-void gen_crossing(const mgx_config &c, Rng &r, Level &L)
-{
-    const int W = L.W, H = L.H, ncross = c.level_arg0;
-    const int ot = c.level_arg1 == 2 ? 2 : 9, oc = c.level_arg1 == 2 ? 5 : 0;
-    L.clear();
-    L.wall_rect();
-    L.ax = 1; L.ay = 1; L.adir = 0;
-    L.set(W - 2, H - 2, 8, 1, 0);
-    struct River { int vertical; int pos; };
-    std::vector<River> rivers;
-    for (int i = 2; i < H - 2; i += 2) rivers.push_back({1, i}); // (v, i)
-    for (int j = 2; j < W - 2; j += 2) rivers.push_back({0, j}); // (h, j)
-    for (int i = (int)rivers.size() - 1; i >= 1; i--) {          // np_random.shuffle(list)
-        int j = (int)r.bounded((uint32_t)i);
-        std::swap(rivers[i], rivers[j]);
+    const int W = cfg->width, H = cfg->height;
+    if (W < 3 || H < 3 || W > 255 || H > 255) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: grid %dx%d outside 3..255", fn, W, H);
+    switch (cfg->level_kind) {
+    case MGX_LEVEL_EMPTY: break;
+    case MGX_LEVEL_DOORKEY:
+        if (W < 5 || H < 5) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: DoorKey needs at least 5x5", fn);
+        break;
+    case MGX_LEVEL_LAVAGAP:
+        if (W < 5 || H < 5) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: LavaGap needs at least 5x5 (envs/lavagap.py:22)", fn);
+        break;
+    case MGX_LEVEL_CROSSING:
+        if (W % 2 == 0 || H % 2 == 0) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: crossing levels need odd sizes (envs/crossing.py:25)", fn);
+        if ((W - 3) / 2 > MGX_LG_MAX_RIVERS || (H - 3) / 2 > MGX_LG_MAX_RIVERS)
+            return mgx_fail(MGX_ERR_UNSUPPORTED, "%s: crossing grid %dx%d has more than %d candidate rivers per axis", fn, W, H, MGX_LG_MAX_RIVERS);
+        break;
+    default: return mgx_fail(MGX_ERR_NO_LEVELGEN, "%s: level_kind %d has no built-in generator", fn, cfg->level_kind);
     }
-    if ((int)rivers.size() > ncross) rivers.resize(ncross);
-    std::vector<int> rv, rh;
-    for (auto &x : rivers) (x.vertical ? rv : rh).push_back(x.pos);
-    std::sort(rv.begin(), rv.end());
-    std::sort(rh.begin(), rh.end());
-    for (int j : rh) for (int i = 1; i < W - 1; i++) L.set(i, j, ot, oc, 0); // product(range(1,W-1), rivers_h)
-    for (int i : rv) for (int j = 1; j < H - 1; j++) L.set(i, j, ot, oc, 0); // product(rivers_v, range(1,H-1))
-    std::vector<int> path; // 1 = h step (crosses a vertical river), 0 = v step
-    for (size_t i = 0; i < rv.size(); i++) path.push_back(1);
-    for (size_t i = 0; i < rh.size(); i++) path.push_back(0);
-    for (int i = (int)path.size() - 1; i >= 1; i--) {
-        int j = (int)r.bounded((uint32_t)i);
-        std::swap(path[i], path[j]);
-    }
-    std::vector<int> lim_v, lim_h;
-    lim_v.push_back(0); for (int v : rv) lim_v.push_back(v); lim_v.push_back(H - 1);
-    lim_h.push_back(0); for (int h : rh) lim_h.push_back(h); lim_h.push_back(W - 1);
-    int room_i = 0, room_j = 0;
-    for (int d : path) {
-        int i, j;
-        if (d == 1) {
-            i = lim_v[room_i + 1];
-            int lo = lim_h[room_j] + 1, hi = lim_h[room_j + 1];
-            j = lo + r.randint(0, hi - lo); // choice(range(lo, hi))
-            room_i++;
-        } else {
-            int lo = lim_v[room_i] + 1, hi = lim_v[room_i + 1];
-            i = lo + r.randint(0, hi - lo);
-            j = lim_h[room_j + 1];
-            room_j++;
-        }
-        L.set(i, j, 1, 0, 0);
-    }
-}
-
-void gen_lavagap(const mgx_config &c, Rng &r, Level &L)
-{
-    const int W = L.W, H = L.H;
-    const int ot = c.level_arg1 == 2 ? 2 : 9, oc = c.level_arg1 == 2 ? 5 : 0;
-    L.clear();
-    L.wall_rect();
-    L.ax = 1; L.ay = 1; L.adir = 0;
-    L.set(W - 2, H - 2, 8, 1, 0);
-    int gx, gy;
-    if (!c.level_arg0) { gx = r.randint(2, W - 2); gy = r.randint(1, H - 1); }
-    else { gx = W / 2; gy = r.randint(1, H - 1); }
-    for (int j = 0; j < H - 2; j++) L.set(gx, 1 + j, ot, oc, 0); // vert_wall(gx, 1, H-2, obstacle)
-    L.set(gx, gy, 1, 0, 0);
+    return MGX_OK;
 }
 
 struct EnvId { const char *id; mgx_config cfg; };
@@ -366,29 +277,61 @@ extern "C" const char *mgx_env_id(int i)
 extern "C" int mgx_generate_levels(const mgx_config *cfg, int64_t n, const uint64_t *seeds, uint8_t *grid, int32_t *agent)
 {
     if (!cfg || !seeds || !grid || !agent || n < 0) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_generate_levels: null argument");
-    const int W = cfg->width, H = cfg->height;
-    if (W < 3 || H < 3) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_generate_levels: grid %dx%d too small", W, H);
-    switch (cfg->level_kind) {
-    case MGX_LEVEL_EMPTY: case MGX_LEVEL_DOORKEY: case MGX_LEVEL_LAVAGAP: break;
-    case MGX_LEVEL_CROSSING:
-        if (W % 2 == 0 || H % 2 == 0) return mgx_fail(MGX_ERR_INVALID_ARG, "crossing levels need odd sizes (envs/crossing.py:25)");
-        break;
-    default: return mgx_fail(MGX_ERR_NO_LEVELGEN, "level_kind %d has no built-in generator", cfg->level_kind);
-    }
+    int rc = check_levelgen_cfg(cfg, "mgx_generate_levels");
+    if (rc) return rc;
+    const int cells = cfg->width * cfg->height;
+    std::vector<uint8_t> codes((size_t)cells);
     Rng rng;
-    const size_t cells = (size_t)W * H;
     for (int64_t e = 0; e < n; e++) {
-        Level L;
-        L.W = W; L.H = H; L.g = grid + e * cells * 3;
-        // Empty with a fixed start consumes no randomness: skip the 624-word seeding
-        if (!(cfg->level_kind == MGX_LEVEL_EMPTY && cfg->level_arg0 == 0)) rng.seed_gym(seeds[e]);
-        switch (cfg->level_kind) {
-        case MGX_LEVEL_EMPTY: gen_empty(*cfg, rng, L); break;
-        case MGX_LEVEL_DOORKEY: gen_doorkey(*cfg, rng, L); break;
-        case MGX_LEVEL_CROSSING: gen_crossing(*cfg, rng, L); break;
-        default: gen_lavagap(*cfg, rng, L); break;
-        }
+        LgLevel L;
+        L.g = codes.data(); L.W = cfg->width; L.H = cfg->height; L.ax = L.ay = -1; L.adir = 0;
+        if (lg_uses_rng(*cfg)) rng.seed_gym(seeds[e]); // Empty with a fixed start consumes no randomness: skip the seeding
+        lg_generate(*cfg, rng, L);
+        codes_to_triples(codes.data(), cells, grid + (size_t)e * cells * 3);
         agent[e * 3] = L.ax; agent[e * 3 + 1] = L.ay; agent[e * 3 + 2] = L.adir;
     }
+    return MGX_OK;
+}
+
+// `env.seed(seed)` once, then K consecutive `env.reset()`s: the env's RNG stream continues across episodes
+// (plain reference behaviour without ReseedWrapper, minigrid.py:836-839).  grid u8[K][W][H][3], agent i32[K][3].
+extern "C" int mgx_generate_level_stream(const mgx_config *cfg, uint64_t seed, int64_t K, uint8_t *grid, int32_t *agent)
+{
+    if (!cfg || !grid || !agent || K < 0) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_generate_level_stream: null argument");
+    int rc = check_levelgen_cfg(cfg, "mgx_generate_level_stream");
+    if (rc) return rc;
+    const int cells = cfg->width * cfg->height;
+    std::vector<uint8_t> codes((size_t)cells);
+    Rng rng;
+    rng.seed_gym(seed);
+    for (int64_t k = 0; k < K; k++) {
+        LgLevel L;
+        L.g = codes.data(); L.W = cfg->width; L.H = cfg->height; L.ax = L.ay = -1; L.adir = 0;
+        lg_generate(*cfg, rng, L);
+        codes_to_triples(codes.data(), cells, grid + (size_t)k * cells * 3);
+        agent[k * 3] = L.ax; agent[k * 3 + 1] = L.ay; agent[k * 3 + 2] = L.adir;
+    }
+    return MGX_OK;
+}
+
+// MT19937 states right after `env.seed(seeds[i])`: mt u32[n][624] (the index is 624: nothing drawn yet).
+// Used by mgx_reset in stream mode to initialise the per-env generators kept in HBM.
+int mgx_seed_states(int64_t n, const uint64_t *seeds, const uint8_t *mask, uint32_t *mt)
+{
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt == 0) nt = 1;
+    if (nt > 16) nt = 16;
+    if ((int64_t)nt > n) nt = (unsigned)(n > 0 ? n : 1);
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++)
+        th.emplace_back([=]() {
+            Rng rng;
+            for (int64_t e = t; e < n; e += nt) {
+                if (mask && !mask[e]) continue;
+                rng.seed_gym(seeds[e]);
+                memcpy(mt + (size_t)e * 624, rng.mt, 624 * sizeof(uint32_t));
+            }
+        });
+    for (auto &x : th) x.join();
     return MGX_OK;
 }

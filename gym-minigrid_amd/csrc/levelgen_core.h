@@ -1,0 +1,201 @@
+// levelgen_core.h -- the seeded level generators, written once for host (levelgen.cpp) and device (k_levelgen in
+// mgx_kernels.hip).  Everything here is `__host__ __device__`, allocation-free and works on 1-byte cell codes
+// (mgx_internal.h), x-major like Grid.encode().
+//
+// Reference: EmptyEnv._gen_grid     /root/reference/gym_minigrid/envs/empty.py:30-57
+//            DoorKeyEnv._gen_grid   /root/reference/gym_minigrid/envs/doorkey.py:15-44
+//            CrossingEnv._gen_grid  /root/reference/gym_minigrid/envs/crossing.py:24-92
+//            LavaGapEnv._gen_grid   /root/reference/gym_minigrid/envs/lavagap.py:21-59
+//            place_obj/place_agent  /root/reference/gym_minigrid/minigrid.py:1003-1090
+// Random draws follow numpy's legacy RandomState on top of MT19937 (see levelgen.cpp's header): every draw is
+// "raw 32-bit output & mask, redraw while > max".  `R` is any type with `uint32_t next32()`.
+#ifndef MGX_LEVELGEN_CORE_H
+#define MGX_LEVELGEN_CORE_H
+
+#include <stdint.h>
+
+#include "mgx.h"
+#include "mgx_internal.h"
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define LG_FN __host__ __device__ inline
+#else
+#define LG_FN inline
+#endif
+
+#define MGX_CODE_GOAL_GREEN (MGX_K_GOAL | (1 << 4))        /* Goal(): green            */
+#define MGX_CODE_LAVA (MGX_K_LAVA)                         /* Lava(): red = 0          */
+#define MGX_CODE_DOOR_YELLOW_LOCKED (MGX_K_DOOR_LOCKED | (4 << 4))
+#define MGX_CODE_KEY_YELLOW (MGX_K_KEY | (4 << 4))
+#define MGX_LG_MAX_RIVERS 32
+
+struct LgLevel {
+    uint8_t *g; // W*H cell codes, idx = x*H + y
+    int W, H;
+    int ax, ay, adir;
+};
+
+LG_FN void lg_set(LgLevel &L, int x, int y, uint32_t code) { L.g[x * L.H + y] = (uint8_t)code; }
+LG_FN bool lg_empty(const LgLevel &L, int x, int y) { return L.g[x * L.H + y] == MGX_CODE_EMPTY; }
+
+// uniform integer in [0, max] by masked rejection (numpy legacy bounded_uint32)
+template <class R>
+LG_FN uint32_t lg_bounded(R &r, uint32_t max)
+{
+    if (max == 0) return 0;
+    uint32_t mask = max;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    uint32_t v;
+    do { v = r.next32() & mask; } while (v > max);
+    return v;
+}
+template <class R>
+LG_FN int lg_randint(R &r, int lo, int hi) { return lo + (int)lg_bounded(r, (uint32_t)(hi - lo - 1)); }
+
+// empty room inside a grey wall rectangle, green goal in the bottom-right corner
+LG_FN void lg_room(LgLevel &L)
+{
+    for (int i = 0; i < L.W * L.H; i++) L.g[i] = MGX_CODE_EMPTY;
+    for (int x = 0; x < L.W; x++) { lg_set(L, x, 0, MGX_CODE_WALL_GREY); lg_set(L, x, L.H - 1, MGX_CODE_WALL_GREY); }
+    for (int y = 0; y < L.H; y++) { lg_set(L, 0, y, MGX_CODE_WALL_GREY); lg_set(L, L.W - 1, y, MGX_CODE_WALL_GREY); }
+    lg_set(L, L.W - 2, L.H - 2, MGX_CODE_GOAL_GREEN);
+}
+
+// place_obj(obj=None, top=(0,0), size=(sw,sh)) rejection sampling (minigrid.py:1028-1053)
+template <class R>
+LG_FN void lg_sample_free(R &r, LgLevel &L, int sw, int sh, bool reject_agent, int *ox, int *oy)
+{
+    const int xw = sw < L.W ? sw : L.W, yh = sh < L.H ? sh : L.H;
+    for (;;) {
+        const int x = lg_randint(r, 0, xw);
+        const int y = lg_randint(r, 0, yh);
+        if (!lg_empty(L, x, y)) continue;
+        if (reject_agent && x == L.ax && y == L.ay) continue;
+        *ox = x; *oy = y;
+        return;
+    }
+}
+
+template <class R>
+LG_FN void lg_gen_empty(const mgx_config &c, R &r, LgLevel &L)
+{
+    lg_room(L);
+    if (c.level_arg0 == 0) { L.ax = 1; L.ay = 1; L.adir = 0; }
+    else { // agent_start_pos=None -> place_agent(size=sizetop)
+        const int sw = c.level_arg1 > 0 ? c.level_arg1 : L.W, sh = c.level_arg1 > 0 ? c.level_arg1 : L.H;
+        L.ax = -1; L.ay = -1;
+        lg_sample_free(r, L, sw, sh, false, &L.ax, &L.ay);
+        L.adir = lg_randint(r, 0, 4);
+    }
+}
+
+template <class R>
+LG_FN void lg_gen_doorkey(const mgx_config &, R &r, LgLevel &L)
+{
+    lg_room(L);
+    const int split = lg_randint(r, 2, L.W - 2);
+    for (int y = 0; y < L.H; y++) lg_set(L, split, y, MGX_CODE_WALL_GREY); // vert_wall(split, 0)
+    L.ax = -1; L.ay = -1;
+    lg_sample_free(r, L, split, L.H, false, &L.ax, &L.ay);                 // place_agent(size=(split, H))
+    L.adir = lg_randint(r, 0, 4);
+    const int door = lg_randint(r, 1, L.W - 2);
+    lg_set(L, split, door, MGX_CODE_DOOR_YELLOW_LOCKED);                   // Door('yellow', is_locked=True)
+    int kx, ky;
+    lg_sample_free(r, L, split, L.H, true, &kx, &ky);                      // Key('yellow'), rejects the agent cell
+    lg_set(L, kx, ky, MGX_CODE_KEY_YELLOW);
+}
+
+template <class R>
+LG_FN void lg_gen_crossing(const mgx_config &c, R &r, LgLevel &L)
+{
+    const int W = L.W, H = L.H, ncross = c.level_arg0;
+    const uint32_t obst = c.level_arg1 == 2 ? (uint32_t)MGX_CODE_WALL_GREY : (uint32_t)MGX_CODE_LAVA;
+    lg_room(L);
+    L.ax = 1; L.ay = 1; L.adir = 0;
+    // candidate rivers: (v, i) for i in range(2, H-2, 2) then (h, j) for j in range(2, W-2, 2); bit 8 = vertical
+    int riv[2 * MGX_LG_MAX_RIVERS], n = 0;
+    for (int i = 2; i < H - 2; i += 2) riv[n++] = 0x100 | i;
+    for (int j = 2; j < W - 2; j += 2) riv[n++] = j;
+    for (int i = n - 1; i >= 1; i--) { // np_random.shuffle(list): j = bounded(i), swap
+        const int j = (int)lg_bounded(r, (uint32_t)i);
+        const int t = riv[i]; riv[i] = riv[j]; riv[j] = t;
+    }
+    if (n > ncross) n = ncross;
+    int rv[MGX_LG_MAX_RIVERS], rh[MGX_LG_MAX_RIVERS], nv = 0, nh = 0;
+    for (int i = 0; i < n; i++) { if (riv[i] & 0x100) rv[nv++] = riv[i] & 0xFF; else rh[nh++] = riv[i]; }
+    for (int i = 1; i < nv; i++) { const int t = rv[i]; int j = i - 1; while (j >= 0 && rv[j] > t) { rv[j + 1] = rv[j]; j--; } rv[j + 1] = t; } // sorted()
+    for (int i = 1; i < nh; i++) { const int t = rh[i]; int j = i - 1; while (j >= 0 && rh[j] > t) { rh[j + 1] = rh[j]; j--; } rh[j + 1] = t; }
+    for (int k = 0; k < nh; k++) for (int i = 1; i < W - 1; i++) lg_set(L, i, rh[k], obst); // product(range(1,W-1), rivers_h)
+    for (int k = 0; k < nv; k++) for (int j = 1; j < H - 1; j++) lg_set(L, rv[k], j, obst); // product(rivers_v, range(1,H-1))
+    int path[2 * MGX_LG_MAX_RIVERS], np_ = 0; // 1 = h step (crosses a vertical river), 0 = v step
+    for (int i = 0; i < nv; i++) path[np_++] = 1;
+    for (int i = 0; i < nh; i++) path[np_++] = 0;
+    for (int i = np_ - 1; i >= 1; i--) {
+        const int j = (int)lg_bounded(r, (uint32_t)i);
+        const int t = path[i]; path[i] = path[j]; path[j] = t;
+    }
+    // limits_v = [0] + rivers_v + [H-1], limits_h = [0] + rivers_h + [W-1]
+    int room_i = 0, room_j = 0;
+    for (int k = 0; k < np_; k++) {
+        const int lv0 = room_i == 0 ? 0 : rv[room_i - 1], lv1 = room_i < nv ? rv[room_i] : H - 1;
+        const int lh0 = room_j == 0 ? 0 : rh[room_j - 1], lh1 = room_j < nh ? rh[room_j] : W - 1;
+        int i, j;
+        if (path[k] == 1) {
+            i = lv1;
+            j = lh0 + 1 + lg_randint(r, 0, lh1 - lh0 - 1); // choice(range(lh0+1, lh1))
+            room_i++;
+        } else {
+            i = lv0 + 1 + lg_randint(r, 0, lv1 - lv0 - 1);
+            j = lh1;
+            room_j++;
+        }
+        lg_set(L, i, j, MGX_CODE_EMPTY);
+    }
+}
+
+template <class R>
+LG_FN void lg_gen_lavagap(const mgx_config &c, R &r, LgLevel &L)
+{
+    const int W = L.W, H = L.H;
+    const uint32_t obst = c.level_arg1 == 2 ? (uint32_t)MGX_CODE_WALL_GREY : (uint32_t)MGX_CODE_LAVA;
+    lg_room(L);
+    L.ax = 1; L.ay = 1; L.adir = 0;
+    int gx, gy;
+    if (!c.level_arg0) { gx = lg_randint(r, 2, W - 2); gy = lg_randint(r, 1, H - 1); }
+    else { gx = W / 2; gy = lg_randint(r, 1, H - 1); }
+    for (int j = 0; j < H - 2; j++) lg_set(L, gx, 1 + j, obst); // vert_wall(gx, 1, H-2, obstacle)
+    lg_set(L, gx, gy, MGX_CODE_EMPTY);
+}
+
+// true if the family draws random numbers (Empty with a fixed start does not)
+LG_FN bool lg_uses_rng(const mgx_config &c) { return !(c.level_kind == MGX_LEVEL_EMPTY && c.level_arg0 == 0); }
+
+template <class R>
+LG_FN void lg_generate(const mgx_config &c, R &r, LgLevel &L)
+{
+    switch (c.level_kind) {
+    case MGX_LEVEL_EMPTY: lg_gen_empty(c, r, L); break;
+    case MGX_LEVEL_DOORKEY: lg_gen_doorkey(c, r, L); break;
+    case MGX_LEVEL_CROSSING: lg_gen_crossing(c, r, L); break;
+    default: lg_gen_lavagap(c, r, L); break;
+    }
+}
+
+// MT19937 tempering
+LG_FN uint32_t lg_temper(uint32_t y)
+{
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680U;
+    y ^= (y << 15) & 0xefc60000U;
+    y ^= (y >> 18);
+    return y;
+}
+
+// one word of the next MT19937 block: new[k] from (old[k], old[k+1]) and m = old[k+397] (k<227) or new[k-227]
+LG_FN uint32_t lg_twist_word(uint32_t a, uint32_t b, uint32_t m)
+{
+    const uint32_t y = (a & 0x80000000U) | (b & 0x7fffffffU);
+    return m ^ (y >> 1) ^ ((y & 1U) ? 0x9908b0dfU : 0U);
+}
+
+#endif

@@ -118,6 +118,11 @@ int mgx_obs_bytes(mgx_handle h, int64_t *per_env);
 int mgx_generate_levels(const mgx_config *cfg, int64_t n, const uint64_t *seeds,
                         uint8_t *grid, int32_t *agent);
 
+/* Plain reference behaviour without ReseedWrapper (pure CPU): `env.seed(seed)` once, then K consecutive
+ * `env.reset()`s -- the env's RNG stream continues, every episode gets a new level (minigrid.py:836-839).
+ * grid uint8 [K][W][H][3], agent int32 [K][3]. */
+int mgx_generate_level_stream(const mgx_config *cfg, uint64_t seed, int64_t K, uint8_t *grid, int32_t *agent);
+
 /* env.seed(seeds[i]); env.reset() for every env with mask[i] != 0 (mask NULL = all).
  * seeds/mask are HOST pointers.  obs (optional) receives the reset observation of ALL envs. */
 int mgx_reset(mgx_handle h, const uint64_t *seeds, const uint8_t *mask, uint8_t *obs);

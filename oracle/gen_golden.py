@@ -28,8 +28,9 @@ File format (one .npz per case), all arrays stacked over traces (leading dim K):
   grid      (K,T,W,H,3) u8  post-step Grid.encode()
   full      (K,T,W,H,3) u8  FullyObsWrapper image (only when meta.full_obs)
   init_full (K,W,H,3)       FullyObsWrapper image at reset (only when meta.full_obs)
-  Episode boundaries (caller-side reset on done, run_tests.py:64-66 convention,
-  re-seeding with the SAME seed = ReseedWrapper(seeds=[s]), wrappers.py:24-28):
+  Episode boundaries (caller-side reset on done, run_tests.py:64-66 convention; meta.reseed=True:
+  re-seeding with the SAME seed = ReseedWrapper(seeds=[s]), wrappers.py:24-28; meta.reseed=False: plain
+  `reset()`, the env's RNG stream continues and every episode gets a new level):
   reset_k (R,) trace index, reset_t (R,) step index after which reset happened,
   reset_grid (R,W,H,3), reset_aux (R,W,H), reset_agent (R,3), reset_obs (R,7,7,3)
 """
@@ -231,12 +232,13 @@ def doorkey_script(env):
 
 
 # --------------------------------------------------------------------------- recorder
-def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False):
+def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False, reseed=True):
     K = len(seeds)
     env0 = make_env()
     W, H = env0.width, env0.height
     meta = dict(env_id=name, W=W, H=H, max_steps=int(env0.max_steps),
-                see_through=bool(env0.see_through_walls), lava_v1=bool(v1), full_obs=bool(full_obs))
+                see_through=bool(env0.see_through_walls), lava_v1=bool(v1), full_obs=bool(full_obs),
+                reseed=bool(reseed))
     z = dict(
         seed=np.zeros(K, np.int64), init_grid=np.zeros((K, W, H, 3), np.uint8),
         init_aux=np.zeros((K, W, H), np.uint8), init_agent=np.zeros((K, 3), np.int32),
@@ -284,8 +286,9 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
             if full_obs:
                 z["full"][k, t] = full_image(env)
             if d:
-                env.seed(int(s))
-                o2 = env.reset()
+                if reseed:
+                    env.seed(int(s))
+                o2 = env.reset()  # reseed=False: the env's own RNG stream continues -> a new level
                 rk.append(k)
                 rt.append(t)
                 rg.append(env.grid.encode())
@@ -304,6 +307,34 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
     np.savez_compressed(path, **z)
     print("%-34s K=%d T=%d resets=%d dones=%d nonzero-reward=%d  %6.1f KB" % (
         name, K, T, R, int(z["done"].sum()), int((z["reward"] != 0).sum()), os.path.getsize(path) / 1024))
+
+
+def record_level_streams():
+    """Plain reference env (no ReseedWrapper): `env.seed(s)` once, then K consecutive `reset()`s continue the env's
+    RNG stream (minigrid.py:836-839) -> a fresh level per episode.  K is large enough to cross several MT19937
+    state regenerations (624 outputs each)."""
+    out = {}
+    for env_id, seeds, K in [("MiniGrid-DoorKey-8x8-v0", [0, 1, 7], 700), ("MiniGrid-DoorKey-5x5-v0", [3], 300),
+                             ("MiniGrid-DoorKey-16x16-v0", [2], 200),
+                             ("MiniGrid-LavaCrossingS9N1-v0", [0, 5], 1500), ("MiniGrid-LavaCrossingS9N3-v0", [1], 500),
+                             ("MiniGrid-LavaCrossingS11N5-v0", [2], 400), ("MiniGrid-SimpleCrossingS9N2-v0", [4], 400),
+                             ("MiniGrid-Empty-Random-6x6-v0", [0, 9], 900), ("MiniGrid-Empty-Random-10x10-v0", [1], 400),
+                             ("MiniGrid-LavaGapS7-v0", [0, 3], 900), ("MiniGrid-LavaGapS6-v1", [1], 900),
+                             ("MiniGrid-NormalGapS6-v0", [2], 300), ("MiniGrid-Empty-8x8-v0", [0], 5)]:
+        env = gym.make(env_id)
+        key = env_id.replace("MiniGrid-", "").replace("-v0", "")
+        for s in seeds:
+            env.seed(int(s))
+            grids, agents = [], []
+            for _ in range(K):
+                env.reset()
+                grids.append(env.grid.encode())
+                agents.append((env.agent_pos[0], env.agent_pos[1], env.agent_dir))
+            out["%s:%d:grid" % (key, s)] = np.asarray(grids, np.uint8)
+            out["%s:%d:agent" % (key, s)] = np.asarray(agents, np.int32)
+    path = os.path.join(OUT, "level_streams.npz")
+    np.savez_compressed(path, **out)
+    print("level_streams.npz %6.1f KB" % (os.path.getsize(path) / 1024))
 
 
 def record_levels():
@@ -366,7 +397,13 @@ def main():
     record_case("Soup-13x6-full", lambda: SoupEnv(13, 6, False, 80, 0.3), list(range(6)), 170, full_obs=True)
     record_case("Soup-9x9-v1", lambda: SoupEnvv1(9, 9, False, 100, 0.35), list(range(6)), 200, v1=True)
     record_case("Soup-19x19", lambda: SoupEnv(19, 19, False, 150, 0.25), list(range(3)), 300)
+    # plain reference semantics at the episode boundary: reset() WITHOUT re-seeding (a new level every episode)
+    record_case("LavaCrossingS9N1-stream", mk("MiniGrid-LavaCrossingS9N1-v0"), list(range(6)), 500, reseed=False)
+    record_case("DoorKey-5x5-stream", mk("MiniGrid-DoorKey-5x5-v0"), [0, 1, 2], 800, reseed=False)
+    record_case("LavaGapS6-stream", mk("MiniGrid-LavaGapS6-v0"), [0, 1, 2, 3], 400, reseed=False)
+    record_case("Empty-Random-6x6-stream", mk("MiniGrid-Empty-Random-6x6-v0"), [0, 1], 450, reseed=False)
     record_levels()
+    record_level_streams()
 
 
 if __name__ == "__main__":

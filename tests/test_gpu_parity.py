@@ -54,12 +54,13 @@ def test_golden_trace_no_autoreset(name, backend):
         assert np.array_equal(done, z["done"][sel, t]), (name, t)
         if t % every == 0 or done.any():
             check_state(env, z["grid"][sel, t], z["agent"][sel, t], z["carry"][sel, t], z["steps"][sel, t], where=(name, t))
-        if done.any():  # caller-side reset with the same seed == the recorded episode start
+        if done.any():  # caller-side reset: the recorded post-reset state (== episode start when re-seeded)
             st = env.get_state()
             d = done.astype(bool)
-            st["grid"][d] = z["init_grid"][sel][d]
-            st["aux"][d] = z["init_aux"][sel][d]
-            st["agent"][d] = z["init_agent"][sel][d]
+            rmap = {int(k): r for r, (k, tt) in enumerate(zip(z["reset_k"], z["reset_t"])) if int(tt) == t}
+            for i in np.flatnonzero(d):
+                r = rmap[int(sel[i])]
+                st["grid"][i], st["aux"][i], st["agent"][i] = z["reset_grid"][r], z["reset_aux"][r], z["reset_agent"][r]
             st["carry"][d] = (1, 0, 0)
             st["steps"][d] = 0
             env.set_state(st["grid"], st["agent"], aux=st["aux"], carry=st["carry"], steps=st["steps"])
@@ -74,6 +75,8 @@ def test_golden_trace_autoreset(name):
     meta, z = load_case(name)
     if meta["full_obs"]:
         pytest.skip("reset observations are recorded for the partial view")
+    if not meta.get("reseed", True):
+        pytest.skip("stream-mode episode boundaries are covered by test_stream_mode")
     K, T = z["actions"].shape
     N = 64 + K
     sel = np.arange(N) % K

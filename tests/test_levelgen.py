@@ -28,3 +28,17 @@ def test_registry_and_errors():
         mg.env_config("MiniGrid-DoesNotExist-v0")
     cfg = mg.env_config("MiniGrid-LavaGapS7-v1")
     assert cfg.lava_v1 == 1 and cfg.width == 7
+
+
+def test_level_streams_match_reference():
+    """seed once, reset() K times: the stream continues across episodes and MT19937 block regenerations."""
+    z = np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "level_streams.npz"))
+    keys = sorted(set(k.rsplit(":", 1)[0] for k in z.files))
+    assert len(keys) >= 15
+    for key in keys:
+        name, seed = key.split(":")
+        env_id = "MiniGrid-%s" % name if name.endswith("-v1") else "MiniGrid-%s-v0" % name
+        want_g, want_a = z[key + ":grid"], z[key + ":agent"]
+        grid, agent = mg.generate_level_stream(env_id, int(seed), want_g.shape[0])
+        assert np.array_equal(grid, want_g), key
+        assert np.array_equal(agent, want_a), key
