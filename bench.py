@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=1048576)
     ap.add_argument("--obs-mode", default="partial", choices=["partial", "full"])
     ap.add_argument("--log-every", type=int, default=256, help="all-reduce (episodes, reward_sum) every L steps")
+    ap.add_argument("--new-level-each-episode", action="store_true",
+                    help="plain reference episode boundary: every reset draws a new level on the GPU (k_levelgen)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -110,7 +112,8 @@ def main():
     offset = rank * n_local
     K, Wm = args.steps, args.warmup
     env = mg.VecMiniGrid(args.env, num_envs=n_local, device=local_rank, seeds=0, obs_mode=args.obs_mode,
-                         auto_reset=True, backend="torch", env_offset=offset)
+                         auto_reset=True, backend="torch", env_offset=offset,
+                         new_level_each_episode=args.new_level_each_episode)
     env.reset()
     # synthetic inputs for every step, resident in HBM before timing starts
     acts = env.fill_actions(0, 0, K + Wm)
@@ -166,7 +169,8 @@ def main():
             "config": {"workload": "%s, %d batched envs per GPU (%d total), obs %s, uniform random actions 0..6 "
                                    "(counter-based), auto-reset on done" % (args.env, n_local, n_total,
                                                                             "uint8 (N,7,7,3)" if args.obs_mode == "partial" else "uint8 (N,W,H,3) FullyObs"),
-                       "env_id": args.env, "envs_per_gpu": n_local, "obs_mode": args.obs_mode, "parallelism": "env-shard x%d" % world},
+                       "env_id": args.env, "envs_per_gpu": n_local, "obs_mode": args.obs_mode, "parallelism": "env-shard x%d" % world,
+                       "new_level_each_episode": bool(args.new_level_each_episode)},
             "episodes": episodes, "reward_sum": reward_sum,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

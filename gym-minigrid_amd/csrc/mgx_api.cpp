@@ -53,6 +53,10 @@ struct mgx_env_s {
     uint8_t *cells_d = nullptr, *cells0_d = nullptr;
     uint2 *agent_d = nullptr, *agent0_d = nullptr;
     MgxCounters *ctr_d = nullptr;
+    // new level each episode: per-env MT19937 block + read index, regeneration flags
+    bool stream_mode = false;
+    uint32_t *mt_d = nullptr, *mt_idx_d = nullptr;
+    uint8_t *regen_d = nullptr;
     Staging st_in[6], st_out[4];
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool profiling = false;
@@ -140,7 +144,19 @@ StepParams base_params(mgx_handle h)
     p.W = h->W; p.H = h->H; p.S = h->S; p.LS = h->LS; p.wave_lds = h->wave_lds;
     p.max_steps = h->cfg.max_steps; p.see_through = h->cfg.see_through_walls; p.lava_v1 = h->cfg.lava_v1;
     p.auto_reset = h->cfg.auto_reset;
+    p.regen = h->stream_mode ? h->regen_d : nullptr;
     return p;
+}
+
+int launch_levelgen(mgx_handle h)
+{
+    LevelGenParams g;
+    memset(&g, 0, sizeof g);
+    g.cfg = h->cfg;
+    g.mt = h->mt_d; g.mt_idx = h->mt_idx_d; g.regen = h->regen_d; g.cells0 = h->cells0_d; g.agent0 = h->agent0_d;
+    g.n = h->n; g.n_tiles = (int)(h->n_pad / 64); g.S = h->S;
+    HIP_TRY(mgx_launch_levelgen(g, h->stream));
+    return MGX_OK;
 }
 
 int check_handle(mgx_handle h, const char *fn)
@@ -221,6 +237,19 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
             return rc_;                                                                      \
         }                                                                                    \
     } while (0)
+    if (cfg->new_level_each_episode) {
+        const char *why = nullptr;
+        if (!cfg->auto_reset) why = "needs auto_reset = 1";
+        else if (cfg->level_kind == MGX_LEVEL_NONE) why = "needs a level_kind with a built-in generator";
+        else if (h->cells > 4096) why = "supports grids up to W*H = 4096";
+        if (why) {
+            int rc = mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_create: new_level_each_episode %s", why);
+            delete h;
+            return rc;
+        }
+        // a family that draws no random numbers (Empty with a fixed start) has only one level: nothing to generate
+        h->stream_mode = !(cfg->level_kind == MGX_LEVEL_EMPTY && cfg->level_arg0 == 0);
+    }
     CREATE_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
     const size_t cb = (size_t)h->n_pad * h->S, ab = (size_t)h->n_pad * sizeof(uint2);
@@ -234,6 +263,14 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     CREATE_TRY(hipMemsetAsync(h->agent_d, 0, ab, h->stream));
     CREATE_TRY(hipMemsetAsync(h->agent0_d, 0, ab, h->stream));
     CREATE_TRY(hipMemsetAsync(h->ctr_d, 0, sizeof(MgxCounters), h->stream));
+    if (h->stream_mode) {
+        CREATE_TRY(hipMalloc((void **)&h->mt_d, (size_t)h->n_pad * 624 * sizeof(uint32_t)));
+        CREATE_TRY(hipMalloc((void **)&h->mt_idx_d, (size_t)h->n_pad * sizeof(uint32_t)));
+        CREATE_TRY(hipMalloc((void **)&h->regen_d, (size_t)h->n_pad));
+        CREATE_TRY(hipMemsetAsync(h->mt_d, 0, (size_t)h->n_pad * 624 * sizeof(uint32_t), h->stream));
+        CREATE_TRY(hipMemsetAsync(h->mt_idx_d, 0, (size_t)h->n_pad * sizeof(uint32_t), h->stream));
+        CREATE_TRY(hipMemsetAsync(h->regen_d, 0, (size_t)h->n_pad, h->stream));
+    }
     CREATE_TRY(hipEventCreate(&h->ev0));
     CREATE_TRY(hipEventCreate(&h->ev1));
     CREATE_TRY(hipStreamSynchronize(h->stream));
@@ -249,6 +286,7 @@ extern "C" int mgx_destroy(mgx_handle h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->cells_d); (void)hipFree(h->cells0_d); (void)hipFree(h->agent_d); (void)hipFree(h->agent0_d);
     (void)hipFree(h->ctr_d);
+    (void)hipFree(h->mt_d); (void)hipFree(h->mt_idx_d); (void)hipFree(h->regen_d);
     for (auto &s : h->st_in) if (s.dev) (void)hipFree(s.dev);
     for (auto &s : h->st_out) if (s.dev) (void)hipFree(s.dev);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -371,6 +409,11 @@ static int set_state_impl(mgx_handle h, const uint8_t *grid, const uint8_t *aux,
     if ((rc = read_counters(h, &before))) return rc;
     HIP_TRY(mgx_launch_pack(p, h->stream));
     if ((rc = read_counters(h, &after))) return rc;
+    if (h->stream_mode) { // the injected state is the CURRENT episode; the next one comes from the env's RNG stream
+        if (mask_host) HIP_TRY(hipMemcpyAsync(h->regen_d, p.mask, n, hipMemcpyDeviceToDevice, h->stream));
+        else HIP_TRY(hipMemsetAsync(h->regen_d, 1, n, h->stream));
+        if ((rc = launch_levelgen(h))) return rc;
+    }
     if (after.invalid_state != before.invalid_state)
         return mgx_fail(MGX_ERR_INVALID_STATE, "mgx_set_state: input holds a cell/agent/carry value the reference cannot produce "
                                                "(type 1..9, color 0..6, state 0 or door 0..2, agent inside the grid, dir 0..3, carry key/ball/box)");
@@ -442,6 +485,7 @@ static int run_step(mgx_handle h, bool do_step, const uint8_t *actions, uint8_t 
     if (do_step) {
         h->steps_total += h->n;
         if (h->profiling) h->prof_launches++;
+        if (h->stream_mode && (rc = launch_levelgen(h))) return rc; // refill the next-level buffers consumed by this step
     }
     return finish_out(h, o, 3);
 }
@@ -469,6 +513,35 @@ extern "C" int mgx_reset(mgx_handle h, const uint64_t *seeds, const uint8_t *mas
         return mgx_fail(MGX_ERR_NO_LEVELGEN, "mgx_reset: this handle has no built-in level generator; use mgx_set_state");
     if (!seeds) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_reset: seeds is required");
     const size_t n = (size_t)h->n, cells = (size_t)h->cells;
+    if (h->stream_mode) {
+        // env.seed(s_i) on the host (SHA-512 + MT19937 init_by_array, threaded), everything after that on the GPU:
+        // generate level 1 into the next-level buffer, make it current, generate level 2 behind it.
+        std::vector<uint32_t> mt(n * 624);
+        mgx_seed_states(h->n, seeds, mask, mt.data());
+        for (size_t e = 0; e < n;) { // upload runs of consecutive masked envs
+            if (mask && !mask[e]) { e++; continue; }
+            size_t f = e;
+            while (f < n && (!mask || mask[f])) f++;
+            HIP_TRY(hipMemcpyAsync(h->mt_d + e * 624, mt.data() + e * 624, (f - e) * 624 * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(h->mt_idx_d + e), 624, f - e, h->stream));
+            if (mask) HIP_TRY(hipMemsetAsync(h->regen_d + e, 1, f - e, h->stream));
+            e = f;
+        }
+        if (!mask) HIP_TRY(hipMemsetAsync(h->regen_d, 1, n, h->stream));
+        if ((rc = launch_levelgen(h))) return rc;
+        ConsumeParams c;
+        memset(&c, 0, sizeof c);
+        const void *dm = nullptr;
+        if ((rc = dev_in(h, 5, mask, n, &dm))) return rc;
+        c.mask = (const uint8_t *)dm;
+        c.cells = h->cells_d; c.cells0 = h->cells0_d; c.agent = h->agent_d; c.agent0 = h->agent0_d; c.regen = h->regen_d;
+        c.n = h->n; c.S = h->S;
+        HIP_TRY(mgx_launch_consume(c, h->stream));
+        if ((rc = launch_levelgen(h))) return rc;
+        HIP_TRY(hipStreamSynchronize(h->stream)); // the host vector above is about to go away
+        if (obs) return run_step(h, false, nullptr, obs, nullptr, nullptr);
+        return MGX_OK;
+    }
     std::vector<uint8_t> grid(n * cells * 3);
     std::vector<int32_t> agent(n * 3);
     // (generation for unmasked envs is wasted work but keeps the code simple; k_pack_state ignores them)

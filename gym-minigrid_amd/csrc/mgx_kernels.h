@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "mgx.h"
+
 #define MGX_NUM_ACTIONS_K 7u
 
 // Running totals.  The per-step counters are SHARDED over 256 cache lines (shard = tile & 255): with one word,
@@ -31,6 +33,7 @@ struct StepParams {
     float *reward;          // may be null
     uint8_t *done;          // may be null
     MgxCounters *ctr;
+    uint8_t *regen;        // stream mode: set to 1 for every env that consumed its next-level buffer (else null)
     int64_t n;
     int n_tiles;
     int W, H, S, LS, wave_lds;
@@ -50,6 +53,25 @@ struct PackParams {
     int W, H, S;
 };
 
+// on-device level generation (new level each episode)
+struct LevelGenParams {
+    mgx_config cfg;
+    uint32_t *mt;      // u32[n_pad][624]  per-env MT19937 block
+    uint32_t *mt_idx;  // u32[n_pad]       next unread word of the block (624 = exhausted / freshly seeded)
+    uint8_t *regen;    // u8[n_pad]        work flags, cleared here
+    uint8_t *cells0;   // next-level buffer (codes) and its agent record
+    uint2 *agent0;
+    int64_t n;
+    int n_tiles, S;
+};
+struct ConsumeParams {
+    const uint8_t *mask; // u8[n] or null
+    uint8_t *cells; const uint8_t *cells0; uint2 *agent; const uint2 *agent0; uint8_t *regen;
+    int64_t n;
+    int S;
+};
+hipError_t mgx_launch_levelgen(const LevelGenParams &p, hipStream_t st);
+hipError_t mgx_launch_consume(const ConsumeParams &p, hipStream_t st);
 hipError_t mgx_launch_step(const StepParams &p, int mode, int waves_per_block, hipStream_t st);
 hipError_t mgx_raise_lds_limit(int W, int H, int mode, int bytes);
 hipError_t mgx_launch_pack(const PackParams &p, hipStream_t st);

@@ -27,6 +27,7 @@
 
 #include "mgx_internal.h"
 #include "mgx_kernels.h"
+#include "levelgen_core.h"
 
 namespace {
 
@@ -472,6 +473,7 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
         if (p.auto_reset && valid && done) {
             restore_own<CS>(p, env, g);
             L = unpack_rec(p.agent0[env]);
+            if (p.regen) p.regen[env] = 1; // the next-level buffer was consumed: k_levelgen refills it after this launch
         }
         if (valid) p.agent[env] = pack_rec(L);
     }
@@ -546,7 +548,11 @@ __global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
             if (p.reward && valid) p.reward[env] = reward;
             if (p.done && valid) p.done[env] = done ? 1 : 0;
             wave_stats(p, valid, done, reward, bad_act, oob, lane, tile);
-            if (p.auto_reset && valid && done) { L = unpack_rec(p.agent0[env]); reset = true; }
+            if (p.auto_reset && valid && done) {
+                L = unpack_rec(p.agent0[env]);
+                reset = true;
+                if (p.regen) p.regen[env] = 1;
+            }
             if (valid) p.agent[env] = pack_rec(L);
         }
         s_info[lane] = (uint32_t)(L.ax * H + L.ay) | ((uint32_t)L.dir << 16) | ((uint32_t)reset << 18) | (changed << 19);
@@ -585,6 +591,117 @@ __global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
         r.b = __builtin_amdgcn_perm(t2, t1, 0x05040201u);
         r.c = __builtin_amdgcn_perm(t3, t2, 0x06050402u);
         dst[u] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// On-device level generation ("new level each episode").  cells0/agent0 always hold the NEXT episode's level of
+// every env; a reset consumes it inside k_step and raises regen[env]; this kernel, launched right after, refills
+// the buffer by continuing the env's own numpy-RandomState stream: MT19937 block u32[624] + read index per env in
+// HBM (seeded on the host by mgx_reset with gym's legacy seeding).  One wave per 64-env tile scans the flags with a
+// ballot; for each flagged env the WAVE regenerates the next MT block cooperatively when the current one is nearly
+// used up (the block recurrence is 3 data-parallel phases + 1 word), lane 0 runs the (tiny, sequential) generator
+// of levelgen_core.h on LDS, and the wave writes level, record and RNG state back coalesced.
+struct DevRng {
+    uint32_t *cur, *nxt; // LDS, 624 words each
+    int idx;             // 0..1247: words < 624 come from cur, the rest from nxt
+    bool nxt_ready;
+
+    __device__ void serial_next_block()
+    {
+        for (int k = 0; k < 227; k++) nxt[k] = lg_twist_word(cur[k], cur[k + 1], cur[k + 397]);
+        for (int k = 227; k < 623; k++) nxt[k] = lg_twist_word(cur[k], cur[k + 1], nxt[k - 227]);
+        nxt[623] = lg_twist_word(cur[623], nxt[0], nxt[396]);
+    }
+    __device__ uint32_t next32()
+    {
+        if (idx >= 1248) { // two whole blocks consumed by ONE level: astronomically rare, keep it correct
+            for (int k = 0; k < 624; k++) cur[k] = nxt[k];
+            serial_next_block();
+            idx -= 624;
+        }
+        if (idx >= 624 && !nxt_ready) { serial_next_block(); nxt_ready = true; }
+        const uint32_t y = idx < 624 ? cur[idx] : nxt[idx - 624];
+        idx++;
+        return lg_temper(y);
+    }
+};
+
+__global__ __launch_bounds__(256) void k_levelgen(const LevelGenParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int tile = blockIdx.x * 4 + wv;
+    if (tile >= p.n_tiles) return;
+    const int per_wave = 2 * 624 * 4 + ((p.S + 15) & ~15) + 16;
+    uint8_t *base = smem + (size_t)wv * per_wave;
+    uint32_t *cur = reinterpret_cast<uint32_t *>(base), *nxt = cur + 624;
+    uint8_t *lvl = base + 2 * 624 * 4;
+    int *res = reinterpret_cast<int *>(lvl + ((p.S + 15) & ~15)); // [0]=idx after, [1]=packed agent
+    const int64_t env0 = (int64_t)tile * 64;
+    const bool valid = env0 + lane < p.n;
+    u64 m = __ballot(valid && p.regen[env0 + lane] != 0);
+    if (!m) return;
+    if (valid && p.regen[env0 + lane]) p.regen[env0 + lane] = 0;
+    while (m) { // wave-uniform
+        const int j = __builtin_ctzll(m);
+        m &= m - 1;
+        const int64_t env = env0 + j;
+        uint32_t *mt = p.mt + env * 624;
+        for (int k = lane; k < 624; k += 64) cur[k] = mt[k];
+        const int idx0 = (int)p.mt_idx[env];
+        wave_sync();
+        const bool pre = idx0 + 64 > 624; // the level will probably run into the next block: build it with the whole wave
+        if (pre) {
+            for (int k = lane; k < 227; k += 64) nxt[k] = lg_twist_word(cur[k], cur[k + 1], cur[k + 397]);
+            wave_sync();
+            for (int k = 227 + lane; k < 454; k += 64) nxt[k] = lg_twist_word(cur[k], cur[k + 1], nxt[k - 227]);
+            wave_sync();
+            for (int k = 454 + lane; k < 623; k += 64) nxt[k] = lg_twist_word(cur[k], cur[k + 1], nxt[k - 227]);
+            wave_sync();
+            if (lane == 0) nxt[623] = lg_twist_word(cur[623], nxt[0], nxt[396]);
+            wave_sync();
+        }
+        if (lane == 0) {
+            DevRng r;
+            r.cur = cur; r.nxt = nxt; r.idx = idx0; r.nxt_ready = pre;
+            LgLevel L;
+            L.g = lvl; L.W = p.cfg.width; L.H = p.cfg.height; L.ax = L.ay = -1; L.adir = 0;
+            lg_generate(p.cfg, r, L);
+            for (int i = p.cfg.width * p.cfg.height; i < p.S; i++) lvl[i] = 0; // padding bytes of the row
+            res[0] = r.idx;
+            res[1] = (L.ax & 255) | ((L.ay & 255) << 8) | ((L.adir & 3) << 16);
+        }
+        wave_sync();
+        const int idx1 = res[0];
+        uint32_t *dst = reinterpret_cast<uint32_t *>(p.cells0 + env * p.S);
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(lvl);
+        for (int k = lane; k < (p.S >> 2); k += 64) dst[k] = src[k];
+        if (idx1 >= 624) { // moved into the next block: it becomes the env's state
+            for (int k = lane; k < 624; k += 64) mt[k] = nxt[k];
+        }
+        if (lane == 0) {
+            p.mt_idx[env] = (uint32_t)(idx1 >= 624 ? idx1 - 624 : idx1);
+            p.agent0[env] = make_uint2((uint32_t)res[1] | ((uint32_t)MGX_CODE_EMPTY << 24), 0u);
+        }
+        wave_sync();
+    }
+}
+
+// reset(): the freshly generated next-level buffer becomes the current episode (for the masked envs) and is flagged
+// for regeneration
+__global__ __launch_bounds__(256) void k_consume(const ConsumeParams p)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int SD = p.S >> 2;
+    const int64_t total = p.n * (int64_t)SD;
+    if (t < total) {
+        const int64_t e = t / SD;
+        if (!p.mask || p.mask[e]) reinterpret_cast<uint32_t *>(p.cells)[t] = reinterpret_cast<const uint32_t *>(p.cells0)[t];
+    }
+    if (t < p.n && (!p.mask || p.mask[t])) {
+        p.agent[t] = p.agent0[t];
+        p.regen[t] = 1;
     }
 }
 
@@ -727,6 +844,20 @@ hipError_t mgx_raise_lds_limit(int W, int H, int mode, int bytes)
     MGX_SIZED(CASE)
 #undef CASE
     return raise_lds_limit<0, 0>(mode, bytes);
+}
+
+hipError_t mgx_launch_levelgen(const LevelGenParams &p, hipStream_t st)
+{
+    const size_t per_wave = 2 * 624 * 4 + ((p.S + 15) & ~15) + 16;
+    hipLaunchKernelGGL(k_levelgen, dim3((p.n_tiles + 3) / 4), dim3(256), 4 * per_wave, st, p);
+    return hipGetLastError();
+}
+
+hipError_t mgx_launch_consume(const ConsumeParams &p, hipStream_t st)
+{
+    const int64_t total = p.n * (int64_t)(p.S >> 2);
+    hipLaunchKernelGGL(k_consume, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+    return hipGetLastError();
 }
 
 hipError_t mgx_launch_pack(const PackParams &p, hipStream_t st)

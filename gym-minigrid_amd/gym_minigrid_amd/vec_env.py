@@ -45,11 +45,14 @@ class VecMiniGrid:
     auto_reset=True: an env that reports done is restored to its episode start inside the same step and `obs`
                      is the first observation of the new episode (VecEnv convention; ReseedWrapper(seeds=[s_i])
                      layout semantics).  auto_reset=False: exact reference semantics, the caller resets.
+    new_level_each_episode=True (with auto_reset): plain reference behaviour -- `seed(s_i)` once at reset(), then every
+                     episode draws a NEW level from the env's own RNG stream (generated on the GPU); False: every
+                     episode replays the level of reset() (ReseedWrapper(seeds=[s_i])).
     seeds: int (env i gets seed+i+env_offset) or an array of N uint64 seeds.
     """
 
     def __init__(self, env_id=None, num_envs=1, device=0, seeds=0, obs_mode="partial", auto_reset=True,
-                 config=None, backend="torch", env_offset=0, check_actions=False):
+                 config=None, backend="torch", env_offset=0, check_actions=False, new_level_each_episode=False):
         L = _lib.lib()
         if config is None:
             if env_id is None:
@@ -60,6 +63,7 @@ class VecMiniGrid:
         ctypes.memmove(ctypes.byref(cfg), ctypes.byref(config), ctypes.sizeof(cfg))
         cfg.obs_mode = {"partial": _lib.OBS_PARTIAL, "full": _lib.OBS_FULL}[obs_mode]
         cfg.auto_reset = int(bool(auto_reset))
+        cfg.new_level_each_episode = int(bool(new_level_each_episode))
         self.cfg = cfg
         self.num_envs = int(num_envs)
         self.device = int(device)

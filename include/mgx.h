@@ -90,7 +90,12 @@ typedef struct {
                                        reward/done still describe the terminal transition. */
     int32_t level_kind;         /* mgx_level_kind */
     int32_t level_arg0, level_arg1;
-    int32_t reserved[6];
+    int32_t new_level_each_episode; /* with auto_reset: 0 = every episode replays the level of mgx_reset/mgx_set_state
+                                   (ReseedWrapper(seeds=[s]), wrappers.py:12-32); 1 = plain reference behaviour: the
+                                   env's own RNG stream (seeded by mgx_reset) continues and every reset() draws a NEW
+                                   level (minigrid.py:836-839), generated on the GPU from a per-env MT19937 state kept
+                                   in HBM.  Needs a level_kind with a generator and W*H <= 4096. */
+    int32_t reserved[5];
 } mgx_config;
 
 typedef struct mgx_env_s *mgx_handle;

@@ -1,0 +1,96 @@
+"""new_level_each_episode: the plain reference behaviour at the episode boundary -- `seed(s)` once, then every
+`reset()` continues the env's RNG stream and draws a NEW level -- generated on the GPU (k_levelgen) from per-env
+MT19937 state.  Checked against (1) traces recorded from the reference itself without re-seeding and (2) the host
+generator (pinned to the reference by tests/test_levelgen.py) + CPU oracle on larger batches."""
+import numpy as np
+import pytest
+
+import gym_minigrid_amd as mg
+from conftest import golden_cases, load_case
+from helpers import make_oracle, to_np
+
+pytestmark = pytest.mark.gpu
+
+STREAM_IDS = {"LavaCrossingS9N1-stream": "MiniGrid-LavaCrossingS9N1-v0", "DoorKey-5x5-stream": "MiniGrid-DoorKey-5x5-v0",
+              "LavaGapS6-stream": "MiniGrid-LavaGapS6-v0", "Empty-Random-6x6-stream": "MiniGrid-Empty-Random-6x6-v0"}
+
+
+@pytest.mark.parametrize("name", sorted(STREAM_IDS))
+def test_reference_stream_traces(name):
+    meta, z = load_case(name)
+    assert meta["reseed"] is False
+    K, T = z["actions"].shape
+    N = 64 + K                     # a full tile + a tail tile; env i replays trace i % K with that trace's seed
+    sel = np.arange(N) % K
+    env = mg.VecMiniGrid(STREAM_IDS[name], num_envs=N, seeds=z["seed"][sel].astype(np.uint64), auto_reset=True,
+                         new_level_each_episode=True, backend="torch")
+    obs = to_np(env.reset())
+    assert np.array_equal(obs, z["init_obs"][sel])
+    st = env.get_state()
+    assert np.array_equal(st["grid"], z["init_grid"][sel]) and np.array_equal(st["agent"], z["init_agent"][sel])
+    rmap = {(int(k), int(t)): r for r, (k, t) in enumerate(zip(z["reset_k"], z["reset_t"]))}
+    for t in range(T):
+        obs, rew, done, _ = env.step(z["actions"][sel, t])
+        obs, rew, done = to_np(obs), to_np(rew), to_np(done)
+        want = z["obs"][sel, t].copy()
+        for i in np.flatnonzero(z["done"][sel, t]):
+            want[i] = z["reset_obs"][rmap[(int(sel[i]), t)]]      # first observation of the NEW level
+        assert np.array_equal(done, z["done"][sel, t]), (name, t)
+        assert np.array_equal(rew, z["reward"][sel, t].astype(np.float32)), (name, t)
+        assert np.array_equal(obs, want), (name, t)
+        if done.any():
+            st = env.get_state()
+            for i in np.flatnonzero(done):
+                r = rmap[(int(sel[i]), t)]
+                assert np.array_equal(st["grid"][i], z["reset_grid"][r]) and np.array_equal(st["agent"][i], z["reset_agent"][r])
+    env.sync()
+    env.close()
+
+
+@pytest.mark.parametrize("env_id,N,T,L", [("MiniGrid-LavaCrossingS9N1-v0", 3000, 260, 100), ("MiniGrid-DoorKey-5x5-v0", 1500, 600, 8),
+                                          ("MiniGrid-LavaGapS7-v1", 900, 450, 8), ("MiniGrid-Empty-Random-8x8-v0", 700, 600, 6),
+                                          ("MiniGrid-SimpleCrossingS11N5-v0", 500, 1000, 6), ("MiniGrid-LavaCrossingS9N3-v0", 2000, 200, 100)])
+def test_stream_vs_host_generator_and_oracle(env_id, N, T, L):
+    """Every env follows its own level stream: level k of env i == host generate_level_stream(seed_i)[k]."""
+    seed = 77
+    cfg = mg.env_config(env_id)
+    env = mg.VecMiniGrid(env_id, num_envs=N, seeds=seed, auto_reset=True, new_level_each_episode=True, backend="torch")
+    obs = to_np(env.reset())
+    levels = [mg.generate_level_stream(env_id, seed + i, L) for i in range(N)]
+    G = np.stack([lv[0] for lv in levels])      # (N, L, W, H, 3)
+    A = np.stack([lv[1] for lv in levels])
+    ep = np.zeros(N, np.int64)
+    orc = make_oracle(cfg.width, cfg.height, cfg.max_steps, cfg.see_through_walls, cfg.lava_v1, G[:, 0],
+                      np.zeros(G[:, 0].shape[:3], np.uint8), A[:, 0])
+    assert np.array_equal(obs, orc.observe())
+    acts = to_np(env.fill_actions(9, 0, T))
+    for t in range(T):
+        obs, rew, done, _ = env.step(acts[t])
+        oo, orew, odone = orc.step(acts[t])
+        d = odone.astype(bool)
+        ep[d] += 1
+        assert ep.max() < L, "raise L"
+        orc.grid0[d], orc.agent0[d] = G[d, ep[d]], A[d, ep[d]]
+        orc.reset_where(odone)
+        want = np.where(d[:, None, None, None], orc.observe(), oo)
+        assert np.array_equal(to_np(done), odone), t
+        assert np.array_equal(to_np(obs), want), t
+        assert np.array_equal(to_np(rew), orew.astype(np.float32)), t
+    st = env.get_state()
+    assert np.array_equal(st["grid"], orc.grid) and np.array_equal(st["agent"], orc.agent) and np.array_equal(st["steps"], orc.steps)
+    assert env.stats()["episodes"] == int(ep.sum()) and ep.sum() > 0
+    env.close()
+
+
+def test_stream_mode_needs_generator():
+    c = mg.Config()
+    c.width, c.height, c.max_steps = 8, 8, 10
+    with pytest.raises(mg.MgxError):
+        mg.VecMiniGrid(config=c, num_envs=4, auto_reset=True, new_level_each_episode=True, backend="numpy")
+    # Empty with a fixed start has a single level: the flag is accepted and is a no-op
+    env = mg.VecMiniGrid("MiniGrid-Empty-5x5-v0", num_envs=70, auto_reset=True, new_level_each_episode=True, backend="numpy")
+    o0 = env.reset().copy()
+    for t in range(100):
+        obs, rew, done, _ = env.step(np.full(70, 1, np.uint8))
+    assert done.all() and np.array_equal(obs, o0)
+    env.close()
