@@ -284,9 +284,12 @@ extern "C" int mgx_generate_levels(const mgx_config *cfg, int64_t n, const uint6
     Rng rng;
     for (int64_t e = 0; e < n; e++) {
         LgLevel L;
-        L.g = codes.data(); L.W = cfg->width; L.H = cfg->height; L.ax = L.ay = -1; L.adir = 0;
+        int16_t ws[MGX_LG_WS_WORDS];
+        LgCmd cmds[MGX_LG_MAX_CMDS];
+        L.cmds = cmds; L.ncmd = 0; L.W = cfg->width; L.H = cfg->height; L.ax = L.ay = -1; L.adir = 0; L.ws = ws;
         if (lg_uses_rng(*cfg)) rng.seed_gym(seeds[e]); // Empty with a fixed start consumes no randomness: skip the seeding
         lg_generate(*cfg, rng, L);
+        lg_paint(L, codes.data());
         codes_to_triples(codes.data(), cells, grid + (size_t)e * cells * 3);
         agent[e * 3] = L.ax; agent[e * 3 + 1] = L.ay; agent[e * 3 + 2] = L.adir;
     }
@@ -306,8 +309,11 @@ extern "C" int mgx_generate_level_stream(const mgx_config *cfg, uint64_t seed, i
     rng.seed_gym(seed);
     for (int64_t k = 0; k < K; k++) {
         LgLevel L;
-        L.g = codes.data(); L.W = cfg->width; L.H = cfg->height; L.ax = L.ay = -1; L.adir = 0;
+        int16_t ws[MGX_LG_WS_WORDS];
+        LgCmd cmds[MGX_LG_MAX_CMDS];
+        L.cmds = cmds; L.ncmd = 0; L.W = cfg->width; L.H = cfg->height; L.ax = L.ay = -1; L.adir = 0; L.ws = ws;
         lg_generate(*cfg, rng, L);
+        lg_paint(L, codes.data());
         codes_to_triples(codes.data(), cells, grid + (size_t)k * cells * 3);
         agent[k * 3] = L.ax; agent[k * 3 + 1] = L.ay; agent[k * 3 + 2] = L.adir;
     }

@@ -29,14 +29,52 @@
 #define MGX_CODE_KEY_YELLOW (MGX_K_KEY | (4 << 4))
 #define MGX_LG_MAX_RIVERS 32
 
+#define MGX_LG_WS_WORDS (6 * MGX_LG_MAX_RIVERS)
+#define MGX_LG_MAX_CMDS (8 + 4 * MGX_LG_MAX_RIVERS)
+
+// A level is described by a short list of paint commands (inclusive rectangles, later ones override earlier ones)
+// instead of being drawn cell by cell: the sequential part of a generator -- the random decisions -- then touches a
+// few bytes only, queries like "is this cell free?" scan the list, and the grid itself is painted afterwards, on the
+// GPU by all 64 lanes in parallel (k_levelgen spent most of its time drawing walls with one lane before this).
+struct LgCmd { uint8_t x0, y0, x1, y1, code, pad[3]; };
+
 struct LgLevel {
-    uint8_t *g; // W*H cell codes, idx = x*H + y
+    LgCmd *cmds; // MGX_LG_MAX_CMDS entries
+    int ncmd;
     int W, H;
     int ax, ay, adir;
+    int16_t *ws; // MGX_LG_WS_WORDS scratch words for the crossing generator's lists.  On the GPU cmds and ws point
+                 // into LDS: dynamically indexed local arrays would live in scratch (HBM) and every access of the
+                 // sequential generator would pay a memory round trip (measured 10x on k_levelgen).
 };
 
-LG_FN void lg_set(LgLevel &L, int x, int y, uint32_t code) { L.g[x * L.H + y] = (uint8_t)code; }
-LG_FN bool lg_empty(const LgLevel &L, int x, int y) { return L.g[x * L.H + y] == MGX_CODE_EMPTY; }
+LG_FN void lg_rect(LgLevel &L, int x0, int y0, int x1, int y1, uint32_t code)
+{
+    LgCmd c;
+    c.x0 = (uint8_t)x0; c.y0 = (uint8_t)y0; c.x1 = (uint8_t)x1; c.y1 = (uint8_t)y1; c.code = (uint8_t)code;
+    c.pad[0] = c.pad[1] = c.pad[2] = 0;
+    L.cmds[L.ncmd++] = c;
+}
+LG_FN void lg_set(LgLevel &L, int x, int y, uint32_t code) { lg_rect(L, x, y, x, y, code); }
+
+// code of cell (x, y) under the first n commands (an unpainted cell is empty)
+LG_FN uint32_t lg_cell_code(const LgCmd *cmds, int n, int x, int y)
+{
+    uint32_t code = MGX_CODE_EMPTY;
+    for (int i = 0; i < n; i++) {
+        const LgCmd c = cmds[i];
+        if (x >= c.x0 && x <= c.x1 && y >= c.y0 && y <= c.y1) code = c.code;
+    }
+    return code;
+}
+LG_FN bool lg_empty(const LgLevel &L, int x, int y) { return lg_cell_code(L.cmds, L.ncmd, x, y) == MGX_CODE_EMPTY; }
+
+// serial paint (host): g[x*H + y]
+LG_FN void lg_paint(const LgLevel &L, uint8_t *g)
+{
+    for (int x = 0; x < L.W; x++)
+        for (int y = 0; y < L.H; y++) g[x * L.H + y] = (uint8_t)lg_cell_code(L.cmds, L.ncmd, x, y);
+}
 
 // uniform integer in [0, max] by masked rejection (numpy legacy bounded_uint32)
 template <class R>
@@ -55,9 +93,11 @@ LG_FN int lg_randint(R &r, int lo, int hi) { return lo + (int)lg_bounded(r, (uin
 // empty room inside a grey wall rectangle, green goal in the bottom-right corner
 LG_FN void lg_room(LgLevel &L)
 {
-    for (int i = 0; i < L.W * L.H; i++) L.g[i] = MGX_CODE_EMPTY;
-    for (int x = 0; x < L.W; x++) { lg_set(L, x, 0, MGX_CODE_WALL_GREY); lg_set(L, x, L.H - 1, MGX_CODE_WALL_GREY); }
-    for (int y = 0; y < L.H; y++) { lg_set(L, 0, y, MGX_CODE_WALL_GREY); lg_set(L, L.W - 1, y, MGX_CODE_WALL_GREY); }
+    L.ncmd = 0;
+    lg_rect(L, 0, 0, L.W - 1, 0, MGX_CODE_WALL_GREY);
+    lg_rect(L, 0, L.H - 1, L.W - 1, L.H - 1, MGX_CODE_WALL_GREY);
+    lg_rect(L, 0, 0, 0, L.H - 1, MGX_CODE_WALL_GREY);
+    lg_rect(L, L.W - 1, 0, L.W - 1, L.H - 1, MGX_CODE_WALL_GREY);
     lg_set(L, L.W - 2, L.H - 2, MGX_CODE_GOAL_GREEN);
 }
 
@@ -94,7 +134,7 @@ LG_FN void lg_gen_doorkey(const mgx_config &, R &r, LgLevel &L)
 {
     lg_room(L);
     const int split = lg_randint(r, 2, L.W - 2);
-    for (int y = 0; y < L.H; y++) lg_set(L, split, y, MGX_CODE_WALL_GREY); // vert_wall(split, 0)
+    lg_rect(L, split, 0, split, L.H - 1, MGX_CODE_WALL_GREY);              // vert_wall(split, 0)
     L.ax = -1; L.ay = -1;
     lg_sample_free(r, L, split, L.H, false, &L.ax, &L.ay);                 // place_agent(size=(split, H))
     L.adir = lg_randint(r, 0, 4);
@@ -113,26 +153,27 @@ LG_FN void lg_gen_crossing(const mgx_config &c, R &r, LgLevel &L)
     lg_room(L);
     L.ax = 1; L.ay = 1; L.adir = 0;
     // candidate rivers: (v, i) for i in range(2, H-2, 2) then (h, j) for j in range(2, W-2, 2); bit 8 = vertical
-    int riv[2 * MGX_LG_MAX_RIVERS], n = 0;
-    for (int i = 2; i < H - 2; i += 2) riv[n++] = 0x100 | i;
-    for (int j = 2; j < W - 2; j += 2) riv[n++] = j;
+    int16_t *riv = L.ws, *rv = L.ws + 2 * MGX_LG_MAX_RIVERS, *rh = L.ws + 3 * MGX_LG_MAX_RIVERS, *path = L.ws + 4 * MGX_LG_MAX_RIVERS;
+    int n = 0;
+    for (int i = 2; i < H - 2; i += 2) riv[n++] = (int16_t)(0x100 | i);
+    for (int j = 2; j < W - 2; j += 2) riv[n++] = (int16_t)j;
     for (int i = n - 1; i >= 1; i--) { // np_random.shuffle(list): j = bounded(i), swap
         const int j = (int)lg_bounded(r, (uint32_t)i);
-        const int t = riv[i]; riv[i] = riv[j]; riv[j] = t;
+        const int16_t t = riv[i]; riv[i] = riv[j]; riv[j] = t;
     }
     if (n > ncross) n = ncross;
-    int rv[MGX_LG_MAX_RIVERS], rh[MGX_LG_MAX_RIVERS], nv = 0, nh = 0;
-    for (int i = 0; i < n; i++) { if (riv[i] & 0x100) rv[nv++] = riv[i] & 0xFF; else rh[nh++] = riv[i]; }
-    for (int i = 1; i < nv; i++) { const int t = rv[i]; int j = i - 1; while (j >= 0 && rv[j] > t) { rv[j + 1] = rv[j]; j--; } rv[j + 1] = t; } // sorted()
-    for (int i = 1; i < nh; i++) { const int t = rh[i]; int j = i - 1; while (j >= 0 && rh[j] > t) { rh[j + 1] = rh[j]; j--; } rh[j + 1] = t; }
-    for (int k = 0; k < nh; k++) for (int i = 1; i < W - 1; i++) lg_set(L, i, rh[k], obst); // product(range(1,W-1), rivers_h)
-    for (int k = 0; k < nv; k++) for (int j = 1; j < H - 1; j++) lg_set(L, rv[k], j, obst); // product(rivers_v, range(1,H-1))
-    int path[2 * MGX_LG_MAX_RIVERS], np_ = 0; // 1 = h step (crosses a vertical river), 0 = v step
+    int nv = 0, nh = 0;
+    for (int i = 0; i < n; i++) { if (riv[i] & 0x100) rv[nv++] = (int16_t)(riv[i] & 0xFF); else rh[nh++] = riv[i]; }
+    for (int i = 1; i < nv; i++) { const int16_t t = rv[i]; int j = i - 1; while (j >= 0 && rv[j] > t) { rv[j + 1] = rv[j]; j--; } rv[j + 1] = t; } // sorted()
+    for (int i = 1; i < nh; i++) { const int16_t t = rh[i]; int j = i - 1; while (j >= 0 && rh[j] > t) { rh[j + 1] = rh[j]; j--; } rh[j + 1] = t; }
+    for (int k = 0; k < nh; k++) lg_rect(L, 1, rh[k], W - 2, rh[k], obst); // product(range(1,W-1), rivers_h)
+    for (int k = 0; k < nv; k++) lg_rect(L, rv[k], 1, rv[k], H - 2, obst); // product(rivers_v, range(1,H-1))
+    int np_ = 0; // path: 1 = h step (crosses a vertical river), 0 = v step
     for (int i = 0; i < nv; i++) path[np_++] = 1;
     for (int i = 0; i < nh; i++) path[np_++] = 0;
     for (int i = np_ - 1; i >= 1; i--) {
         const int j = (int)lg_bounded(r, (uint32_t)i);
-        const int t = path[i]; path[i] = path[j]; path[j] = t;
+        const int16_t t = path[i]; path[i] = path[j]; path[j] = t;
     }
     // limits_v = [0] + rivers_v + [H-1], limits_h = [0] + rivers_h + [W-1]
     int room_i = 0, room_j = 0;
@@ -163,7 +204,7 @@ LG_FN void lg_gen_lavagap(const mgx_config &c, R &r, LgLevel &L)
     int gx, gy;
     if (!c.level_arg0) { gx = lg_randint(r, 2, W - 2); gy = lg_randint(r, 1, H - 1); }
     else { gx = W / 2; gy = lg_randint(r, 1, H - 1); }
-    for (int j = 0; j < H - 2; j++) lg_set(L, gx, 1 + j, obst); // vert_wall(gx, 1, H-2, obstacle)
+    lg_rect(L, gx, 1, gx, H - 2, obst); // vert_wall(gx, 1, H-2, obstacle)
     lg_set(L, gx, gy, MGX_CODE_EMPTY);
 }
 

@@ -154,6 +154,7 @@ int launch_levelgen(mgx_handle h)
     memset(&g, 0, sizeof g);
     g.cfg = h->cfg;
     g.mt = h->mt_d; g.mt_idx = h->mt_idx_d; g.regen = h->regen_d; g.cells0 = h->cells0_d; g.agent0 = h->agent0_d;
+    g.ctr = h->ctr_d;
     g.n = h->n; g.n_tiles = (int)(h->n_pad / 64); g.S = h->S;
     HIP_TRY(mgx_launch_levelgen(g, h->stream));
     return MGX_OK;

@@ -61,6 +61,7 @@ struct LevelGenParams {
     uint8_t *regen;    // u8[n_pad]        work flags, cleared here
     uint8_t *cells0;   // next-level buffer (codes) and its agent record
     uint2 *agent0;
+    MgxCounters *ctr;
     int64_t n;
     int n_tiles, S;
 };

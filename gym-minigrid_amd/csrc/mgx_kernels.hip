@@ -603,56 +603,44 @@ __global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
 // used up (the block recurrence is 3 data-parallel phases + 1 word), lane 0 runs the (tiny, sequential) generator
 // of levelgen_core.h on LDS, and the wave writes level, record and RNG state back coalesced.
 struct DevRng {
-    uint32_t *cur, *nxt; // LDS, 624 words each
-    int idx;             // 0..1247: words < 624 come from cur, the rest from nxt
-    bool nxt_ready;
+    const uint32_t *buf; // LDS: the env's current MT19937 block followed by the next one (624 + 624 words)
+    int idx;             // next unread word
+    int limit;           // words available: 624, or 1248 once the next block has been built
+    bool overflow;       // ran past `limit`: the caller builds the next block and runs the generator again
 
-    __device__ void serial_next_block()
+    __device__ __forceinline__ uint32_t next32()
     {
-        for (int k = 0; k < 227; k++) nxt[k] = lg_twist_word(cur[k], cur[k + 1], cur[k + 397]);
-        for (int k = 227; k < 623; k++) nxt[k] = lg_twist_word(cur[k], cur[k + 1], nxt[k - 227]);
-        nxt[623] = lg_twist_word(cur[623], nxt[0], nxt[396]);
-    }
-    __device__ uint32_t next32()
-    {
-        if (idx >= 1248) { // two whole blocks consumed by ONE level: astronomically rare, keep it correct
-            for (int k = 0; k < 624; k++) cur[k] = nxt[k];
-            serial_next_block();
-            idx -= 624;
-        }
-        if (idx >= 624 && !nxt_ready) { serial_next_block(); nxt_ready = true; }
-        const uint32_t y = idx < 624 ? cur[idx] : nxt[idx - 624];
-        idx++;
-        return lg_temper(y);
+        if (idx >= limit) { overflow = true; return 0u; } // zeros keep every rejection loop of the generators finite
+        return lg_temper(buf[idx++]);
     }
 };
 
-__global__ __launch_bounds__(256) void k_levelgen(const LevelGenParams p)
+// One level, generated by one wave into its LDS workspace and written back coalesced.
+__device__ __forceinline__ void levelgen_one(const LevelGenParams &p, int64_t env, uint8_t *base, int lane)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int tile = blockIdx.x * 4 + wv;
-    if (tile >= p.n_tiles) return;
-    const int per_wave = 2 * 624 * 4 + ((p.S + 15) & ~15) + 16;
-    uint8_t *base = smem + (size_t)wv * per_wave;
     uint32_t *cur = reinterpret_cast<uint32_t *>(base), *nxt = cur + 624;
-    uint8_t *lvl = base + 2 * 624 * 4;
-    int *res = reinterpret_cast<int *>(lvl + ((p.S + 15) & ~15)); // [0]=idx after, [1]=packed agent
-    const int64_t env0 = (int64_t)tile * 64;
-    const bool valid = env0 + lane < p.n;
-    u64 m = __ballot(valid && p.regen[env0 + lane] != 0);
-    if (!m) return;
-    if (valid && p.regen[env0 + lane]) p.regen[env0 + lane] = 0;
-    while (m) { // wave-uniform
-        const int j = __builtin_ctzll(m);
-        m &= m - 1;
-        const int64_t env = env0 + j;
-        uint32_t *mt = p.mt + env * 624;
-        for (int k = lane; k < 624; k += 64) cur[k] = mt[k];
-        const int idx0 = (int)p.mt_idx[env];
-        wave_sync();
-        const bool pre = idx0 + 64 > 624; // the level will probably run into the next block: build it with the whole wave
-        if (pre) {
+    int *res = reinterpret_cast<int *>(base + 2 * 624 * 4); // [0]=idx after, [1]=packed agent, [2]=overflow, [3]=#cmds
+    int16_t *ws = reinterpret_cast<int16_t *>(res + 4);
+    LgCmd *cmds = reinterpret_cast<LgCmd *>(ws + MGX_LG_WS_WORDS);
+    uint32_t *mt = p.mt + env * 624;
+    { // all ten loads of the block in flight before the first LDS write (a rolled loop pays one latency per trip)
+        uint32_t v[10];
+#pragma unroll
+        for (int i = 0; i < 10; i++) { const int k = lane + 64 * i; v[i] = k < 624 ? mt[k] : 0u; }
+#pragma unroll
+        for (int i = 0; i < 10; i++) { const int k = lane + 64 * i; if (k < 624) cur[k] = v[i]; }
+    }
+    const int idx0 = (int)p.mt_idx[env];
+    wave_sync();
+    // Attempt 1 reads the current block only (or both, if the read index is within 64 words of its end: then the
+    // next block is built first, by the whole wave: the recurrence is 3 data-parallel phases + 1 word).  If the
+    // generator runs past the words available (rare), the next block is built and the generator runs again from
+    // the same index.  A level that needs more than one whole extra block (> 624 draws; probability ~2^-100) is
+    // counted as a fault instead of being handled.
+    int limit = idx0 + 64 > 624 ? 1248 : 624;
+    bool have_next = false;
+    for (int attempt = 0; attempt < 2; attempt++) { // wave-uniform
+        if (limit == 1248 && !have_next) {
             for (int k = lane; k < 227; k += 64) nxt[k] = lg_twist_word(cur[k], cur[k + 1], cur[k + 397]);
             wave_sync();
             for (int k = 227 + lane; k < 454; k += 64) nxt[k] = lg_twist_word(cur[k], cur[k + 1], nxt[k - 227]);
@@ -661,30 +649,79 @@ __global__ __launch_bounds__(256) void k_levelgen(const LevelGenParams p)
             wave_sync();
             if (lane == 0) nxt[623] = lg_twist_word(cur[623], nxt[0], nxt[396]);
             wave_sync();
+            have_next = true;
         }
         if (lane == 0) {
             DevRng r;
-            r.cur = cur; r.nxt = nxt; r.idx = idx0; r.nxt_ready = pre;
+            r.buf = cur; r.idx = idx0; r.limit = limit; r.overflow = false;
             LgLevel L;
-            L.g = lvl; L.W = p.cfg.width; L.H = p.cfg.height; L.ax = L.ay = -1; L.adir = 0;
+            L.cmds = cmds; L.ncmd = 0; L.W = p.cfg.width; L.H = p.cfg.height; L.ax = L.ay = -1; L.adir = 0; L.ws = ws;
             lg_generate(p.cfg, r, L);
-            for (int i = p.cfg.width * p.cfg.height; i < p.S; i++) lvl[i] = 0; // padding bytes of the row
             res[0] = r.idx;
             res[1] = (L.ax & 255) | ((L.ay & 255) << 8) | ((L.adir & 3) << 16);
+            res[2] = r.overflow ? 1 : 0;
+            res[3] = L.ncmd;
         }
         wave_sync();
-        const int idx1 = res[0];
+        if (!res[2]) break;
+        if (limit == 1248) { if (lane == 0) atomicAdd(&p.ctr->invalid_state, 1ull); break; }
+        limit = 1248;
+    }
+    const int idx1 = res[0];
+    { // paint: every lane evaluates the command list for 4 consecutive cells and stores one dword of codes
+        const int ncmd = res[3], H = p.cfg.height, cells = p.cfg.width * H;
         uint32_t *dst = reinterpret_cast<uint32_t *>(p.cells0 + env * p.S);
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(lvl);
-        for (int k = lane; k < (p.S >> 2); k += 64) dst[k] = src[k];
-        if (idx1 >= 624) { // moved into the next block: it becomes the env's state
-            for (int k = lane; k < 624; k += 64) mt[k] = nxt[k];
+        for (int k = lane; k < (p.S >> 2); k += 64) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int c = 4 * k + b;
+                if (c < cells) { const int x = c / H; w |= lg_cell_code(cmds, ncmd, x, c - x * H) << (8 * b); }
+            }
+            dst[k] = w;
         }
-        if (lane == 0) {
-            p.mt_idx[env] = (uint32_t)(idx1 >= 624 ? idx1 - 624 : idx1);
-            p.agent0[env] = make_uint2((uint32_t)res[1] | ((uint32_t)MGX_CODE_EMPTY << 24), 0u);
-        }
-        wave_sync();
+    }
+    if (idx1 >= 624) { // moved into the next block: it becomes the env's state
+        for (int k = lane; k < 624; k += 64) mt[k] = nxt[k];
+    }
+    if (lane == 0) {
+        p.mt_idx[env] = (uint32_t)(idx1 >= 624 ? idx1 - 624 : idx1);
+        p.agent0[env] = make_uint2((uint32_t)res[1] | ((uint32_t)MGX_CODE_EMPTY << 24), 0u);
+    }
+    wave_sync();
+}
+
+// A 512-thread block owns 8 tiles (512 envs).  Every thread looks at its env's flag; flagged envs are compacted
+// into an LDS queue (LDS atomics) and the block's 8 waves pull from it, one level per wave at a time.  Sharing the
+// work over 16 waves matters: resets are Poisson per tile, and with one wave per tile the kernel lasted as long as
+// the unluckiest tile (5-6 levels in a row, 84 us) instead of ~2 levels.
+#define MGX_LG_WAVES 8
+#define MGX_LG_LDS_PER_WAVE (2 * 624 * 4 + 16 + 2 * MGX_LG_WS_WORDS + 8 * MGX_LG_MAX_CMDS)
+__global__ __launch_bounds__(64 * MGX_LG_WAVES, 4) void k_levelgen(const LevelGenParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ uint16_t s_queue[64 * MGX_LG_WAVES];
+    __shared__ int s_count, s_head;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t env_base = (int64_t)blockIdx.x * (64 * MGX_LG_WAVES);
+    if (threadIdx.x == 0) { s_count = 0; s_head = 0; }
+    __syncthreads();
+    const int64_t my = env_base + threadIdx.x;
+    if (my < p.n && p.regen[my]) {
+        p.regen[my] = 0;
+        s_queue[atomicAdd(&s_count, 1)] = (uint16_t)threadIdx.x;
+    }
+    __syncthreads();
+    const int count = s_count;
+    if (count == 0) return;
+    const int per_wave = MGX_LG_LDS_PER_WAVE;
+    uint8_t *base = smem + (size_t)wv * per_wave;
+    for (;;) { // wave-uniform
+        int i = 0;
+        if (lane == 0) i = atomicAdd(&s_head, 1);
+        i = __builtin_amdgcn_readfirstlane(i);
+        if (i >= count) break;
+        levelgen_one(p, env_base + s_queue[i], base, lane);
     }
 }
 
@@ -848,8 +885,14 @@ hipError_t mgx_raise_lds_limit(int W, int H, int mode, int bytes)
 
 hipError_t mgx_launch_levelgen(const LevelGenParams &p, hipStream_t st)
 {
-    const size_t per_wave = 2 * 624 * 4 + ((p.S + 15) & ~15) + 16;
-    hipLaunchKernelGGL(k_levelgen, dim3((p.n_tiles + 3) / 4), dim3(256), 4 * per_wave, st, p);
+    const size_t shmem = MGX_LG_WAVES * MGX_LG_LDS_PER_WAVE;
+    static size_t raised = 0;
+    if (shmem > 64 * 1024 && shmem > raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_levelgen), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return e;
+        raised = shmem;
+    }
+    hipLaunchKernelGGL(k_levelgen, dim3((unsigned)((p.n + 64 * MGX_LG_WAVES - 1) / (64 * MGX_LG_WAVES))), dim3(64 * MGX_LG_WAVES), shmem, st, p);
     return hipGetLastError();
 }
 
