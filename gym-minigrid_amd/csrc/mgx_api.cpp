@@ -46,7 +46,7 @@ struct mgx_env_s {
     mgx_config cfg;
     int64_t n = 0, n_pad = 0;
     int device = 0;
-    int W = 0, H = 0, cells = 0, S = 0, LS = 0, wave_lds = 0, wpb = 4;
+    int W = 0, H = 0, cells = 0, S = 0, LS = 0, wave_lds = 0, wpb = 4, view = 7;
     int kernel_mode = 0; // 0 partial view, 1 full obs via the LDS tile image, 2 full obs direct (W*H % 4 == 0)
     int64_t obs_bytes = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -141,7 +141,7 @@ StepParams base_params(mgx_handle h)
     p.cells = h->cells_d; p.agent = h->agent_d; p.cells0 = h->cells0_d; p.agent0 = h->agent0_d;
     p.ctr = h->ctr_d;
     p.n = h->n; p.n_tiles = (int)(h->n_pad / 64);
-    p.W = h->W; p.H = h->H; p.S = h->S; p.LS = h->LS; p.wave_lds = h->wave_lds;
+    p.W = h->W; p.H = h->H; p.S = h->S; p.LS = h->LS; p.wave_lds = h->wave_lds; p.view = h->view;
     p.max_steps = h->cfg.max_steps; p.see_through = h->cfg.see_through_walls; p.lava_v1 = h->cfg.lava_v1;
     p.auto_reset = h->cfg.auto_reset;
     p.regen = h->stream_mode ? h->regen_d : nullptr;
@@ -188,6 +188,9 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     if (cfg->max_steps <= 0) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: max_steps must be positive");
     if (cfg->obs_mode != MGX_OBS_PARTIAL && cfg->obs_mode != MGX_OBS_FULL)
         return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: bad obs_mode %d", cfg->obs_mode);
+    const int view = cfg->agent_view_size ? cfg->agent_view_size : MGX_VIEW;
+    if (view != 3 && view != 5 && view != 7 && view != 9 && view != 11)
+        return mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_create: agent_view_size %d (supported: 3, 5, 7, 9, 11)", view);
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev == 0)
@@ -205,12 +208,13 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     h->cells = h->W * h->H;
     h->S = (h->cells + 3) & ~3;
     h->LS = h->S + (((h->S >> 2) & 1) ? 0 : 4); // odd dword stride per env in LDS
-    const int obs_img = cfg->obs_mode == MGX_OBS_PARTIAL ? 32 * MGX_OBS_PARTIAL_BYTES : 0; // half-tile output image
+    h->view = view;
+    const int obs_img = cfg->obs_mode == MGX_OBS_PARTIAL ? 32 * view * view * 3 : 0; // half-tile output image
     int need = 64 * h->LS;
     if (obs_img > need) need = obs_img;
     if (cfg->obs_mode == MGX_OBS_FULL) need = ((need + 15) & ~15) + 3072; // + transpose scratch of emit_full_obs
     h->wave_lds = (need + 15) & ~15;
-    h->obs_bytes = cfg->obs_mode == MGX_OBS_PARTIAL ? MGX_OBS_PARTIAL_BYTES : (int64_t)h->cells * 3;
+    h->obs_bytes = cfg->obs_mode == MGX_OBS_PARTIAL ? view * view * 3 : (int64_t)h->cells * 3;
     h->kernel_mode = cfg->obs_mode == MGX_OBS_PARTIAL ? 0 : ((h->cells % 4 == 0 && h->cells <= 65535) ? 2 : 1);
     const int LDS_DEFAULT = 64 * 1024, LDS_MAX = 160 * 1024;
     if (h->wave_lds > LDS_MAX) {
@@ -222,7 +226,7 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     if (h->wpb > 4) h->wpb = 4;
     if (h->wpb < 1) {
         h->wpb = 1;
-        hipError_t e2 = mgx_raise_lds_limit(h->W, h->H, h->kernel_mode == 0 ? 0 : 1, h->wave_lds);
+        hipError_t e2 = mgx_raise_lds_limit(h->W, h->H, h->kernel_mode == 0 ? 0 : 1, h->wave_lds, h->view);
         if (e2 != hipSuccess) {
             int rc = mgx_fail(MGX_ERR_HIP, "mgx_create: cannot raise dynamic LDS to %d B: %s", h->wave_lds, hipGetErrorString(e2));
             delete h;

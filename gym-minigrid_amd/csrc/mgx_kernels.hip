@@ -226,12 +226,15 @@ __device__ __forceinline__ void wave_stats(const StepParams &p, bool valid, bool
 }
 
 // ------------------------------------------------------------------------------------------------
-// Partial (7x7x3) observation of lane's env -> wave's LDS image of the tile's output -> HBM.
-template <int CW, int CH>
+// Partial (VxVx3, V = agent_view_size, odd) observation of lane's env -> wave's LDS image of the tile's output -> HBM.
+// B = 3*V*V bytes per env is always 3 mod 4 for odd V, so the byte-phase logic below is the same for every V.
+template <int CW, int CH, int V>
 __device__ __forceinline__ void emit_partial_obs(const StepParams &p, const Lane &L, uint8_t *lds, const uint8_t *g,
                                                  int64_t env0, int lane)
 {
-    constexpr int V = 7;
+    constexpr int B = V * V * 3;       // bytes per observation (147 for V = 7)
+    constexpr int NDW = (B + 1) / 4;   // dwords holding one observation, the last with 3 valid bytes (37)
+    constexpr int NQ = (V * V) / 4;    // groups of 4 cells = 3 dwords (12), plus one last cell
     const int W = CW ? CW : p.W, H = CH ? CH : p.H;
     const int dir = L.dir;
     const int dx = (dir == 0) - (dir == 2), dy = (dir == 1) - (dir == 3);
@@ -244,7 +247,7 @@ __device__ __forceinline__ void emit_partial_obs(const StepParams &p, const Lane
 #pragma unroll
     for (int d = 0; d < V; d++) vf[d] = (unsigned)(L.ax + dx * d) < (unsigned)W && (unsigned)(L.ay + dy * d) < (unsigned)H;
 #pragma unroll
-    for (int k = 0; k < V; k++) vl[k] = (unsigned)(L.ax + rx * (k - 3)) < (unsigned)W && (unsigned)(L.ay + ry * (k - 3)) < (unsigned)H;
+    for (int k = 0; k < V; k++) vl[k] = (unsigned)(L.ax + rx * (k - V / 2)) < (unsigned)W && (unsigned)(L.ay + ry * (k - V / 2)) < (unsigned)H;
 
     // gather: code[vx][vy]; outside the grid -> grey wall (Grid.slice, minigrid.py:465-469)
     uint32_t code[V][V];
@@ -254,7 +257,7 @@ __device__ __forceinline__ void emit_partial_obs(const StepParams &p, const Lane
 #pragma unroll
         for (int vx = 0; vx < V; vx++) {
             const bool inb = vf[V - 1 - vy] && vl[vx];
-            const int idx = inb ? rowbase + (vx - 3) * sr : base;
+            const int idx = inb ? rowbase + (vx - V / 2) * sr : base;
             const uint32_t c = g[idx];
             code[vx][vy] = inb ? c : (uint32_t)MGX_CODE_WALL_GREY;
         }
@@ -291,9 +294,9 @@ __device__ __forceinline__ void emit_partial_obs(const StepParams &p, const Lane
     code[V / 2][V - 1] = L.carry;
 
     // pack 49 triples (image[vx][vy][c], vx-major) into 37 dwords; v_perm_b32 picks 4 of the 8 bytes {S0,S1}
-    uint32_t D[37];
+    uint32_t D[NDW];
 #pragma unroll
-    for (int q = 0; q < 12; q++) {
+    for (int q = 0; q < NQ; q++) {
         const uint32_t c0 = decode_triple(code[(4 * q) / V][(4 * q) % V]);
         const uint32_t c1 = decode_triple(code[(4 * q + 1) / V][(4 * q + 1) % V]);
         const uint32_t c2 = decode_triple(code[(4 * q + 2) / V][(4 * q + 2) % V]);
@@ -302,47 +305,48 @@ __device__ __forceinline__ void emit_partial_obs(const StepParams &p, const Lane
         D[3 * q + 1] = __builtin_amdgcn_perm(c2, c1, 0x05040201u); // c1.b1 c1.b2 c2.b0 c2.b1
         D[3 * q + 2] = __builtin_amdgcn_perm(c3, c2, 0x06050402u); // c2.b2 c3.b0 c3.b1 c3.b2
     }
-    D[36] = decode_triple(code[6][6]); // 3 bytes
+    D[NDW - 1] = decode_triple(code[V - 1][V - 1]); // 3 bytes
 
-    // byte phase of this env inside the tile's contiguous output: 147*lane = 4*P + s.  Q = D delayed by s bytes:
+    // byte phase of this env inside the tile's contiguous output: B*lane = 4*P + s.  Q = D delayed by s bytes:
     // Q[k] = bytes (4-s)..(7-s) of {D[k], D[k-1]}  -> one v_perm_b32 with a per-lane selector
     const uint32_t s = (3u * (uint32_t)lane) & 3u;
     const uint32_t sel = 0x07060504u - s * 0x01010101u;
-    uint32_t Q[38];
+    uint32_t Q[NDW + 1];
     Q[0] = __builtin_amdgcn_perm(D[0], 0u, sel);
 #pragma unroll
-    for (int k = 1; k < 37; k++) Q[k] = __builtin_amdgcn_perm(D[k], D[k - 1], sel);
-    Q[37] = __builtin_amdgcn_perm(0u, D[36], sel);
+    for (int k = 1; k < NDW; k++) Q[k] = __builtin_amdgcn_perm(D[k], D[k - 1], sel);
+    Q[NDW] = __builtin_amdgcn_perm(0u, D[NDW - 1], sel);
     // the last, partial dword belongs to the next lane's first dword
-    const uint32_t tail = (s == 0u) ? Q[36] : Q[37];
+    const uint32_t tail = (s == 0u) ? Q[NDW - 1] : Q[NDW];
     const uint32_t prev_tail = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tail, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
     if (s != 0u) Q[0] |= prev_tail;
 
-    // The tile's 9408 output bytes go through LDS in two halves of 32 envs (4704 B = 294 x 16 B each): the LDS image is
-    // then no larger than the grid image it overlays, which doubles the resident waves per CU (LDS was the limiter).
+    // The tile's 64*B output bytes (9408 for V = 7) go through LDS in two halves of 32 envs (32*B = 16 * 2B bytes): the
+    // LDS image is then no larger than the grid image it overlays, which doubles the resident waves per CU.
+    constexpr int HALF = 32 * B, CHUNKS = 2 * B; // bytes and 16-B chunks per half
     const int64_t nv = p.n - env0; // valid envs in this tile (>= 1)
-    const int lim_all = nv >= 64 ? 9408 : (int)nv * 147;
-    uint32_t *o32 = reinterpret_cast<uint32_t *>(lds) + ((147u * (uint32_t)(lane & 31)) >> 2);
+    const int lim_all = nv >= 64 ? 64 * B : (int)nv * B;
+    uint32_t *o32 = reinterpret_cast<uint32_t *>(lds) + (((uint32_t)B * (uint32_t)(lane & 31)) >> 2);
     const uint4 *l128 = reinterpret_cast<const uint4 *>(lds);
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         wave_sync(); // every lane is done reading what this image overlays (grid image / previous half)
         if ((lane >> 5) == h) {
 #pragma unroll
-            for (int k = 0; k < 36; k++) o32[k] = Q[k];
-            if (s != 0u) o32[36] = Q[36];
+            for (int k = 0; k < NDW - 1; k++) o32[k] = Q[k];
+            if (s != 0u) o32[NDW - 1] = Q[NDW - 1];
         }
         wave_sync();
-        uint8_t *dst = p.obs + env0 * 147 + h * 4704;
-        const int lim = lim_all - h * 4704; // valid bytes of this half (may be <= 0 in a tail tile)
-        if (lim >= 4704) {
+        uint8_t *dst = p.obs + env0 * B + h * HALF;
+        const int lim = lim_all - h * HALF; // valid bytes of this half (may be <= 0 in a tail tile)
+        if (lim >= HALF) {
 #pragma unroll
-            for (int i = 0; i < 5; i++) {
+            for (int i = 0; i < (CHUNKS + 63) / 64; i++) {
                 const int c = lane + 64 * i;
-                if (c < 294) reinterpret_cast<uint4 *>(dst)[c] = l128[c];
+                if (c < CHUNKS) reinterpret_cast<uint4 *>(dst)[c] = l128[c];
             }
         } else if (lim > 0) {
-            for (int c = lane; c < 294; c += 64) {
+            for (int c = lane; c < CHUNKS; c += 64) {
                 if (16 * c + 16 <= lim) reinterpret_cast<uint4 *>(dst)[c] = l128[c];
                 else
                     for (int b = 16 * c; b < lim; b++) dst[b] = lds[b];
@@ -432,7 +436,7 @@ __device__ __forceinline__ void emit_full_obs(const StepParams &p, const Lane &L
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int CW, int CH, int MODE>
+template <int CW, int CH, int MODE, int V>
 __global__ __launch_bounds__(256) void k_step(const StepParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -478,7 +482,7 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
         if (valid) p.agent[env] = pack_rec(L);
     }
     if (p.obs) {
-        if (MODE == 0) emit_partial_obs<CW, CH>(p, L, lds, g, env0, lane);
+        if (MODE == 0) emit_partial_obs<CW, CH, V>(p, L, lds, g, env0, lane);
         else emit_full_obs<CW, CH>(p, L, valid, lds, g, LS, env0, lane);
     }
 }
@@ -847,8 +851,8 @@ __global__ __launch_bounds__(64) void k_read_stats(const MgxCounters *ctr, doubl
 template <int CW, int CH>
 hipError_t launch_sized(const StepParams &p, int mode, dim3 grid, dim3 block, size_t shmem, hipStream_t st)
 {
-    if (mode == 0) hipLaunchKernelGGL((k_step<CW, CH, 0>), grid, block, shmem, st, p);
-    else if (mode == 1) hipLaunchKernelGGL((k_step<CW, CH, 1>), grid, block, shmem, st, p);
+    if (mode == 0) hipLaunchKernelGGL((k_step<CW, CH, 0, 7>), grid, block, shmem, st, p);
+    else if (mode == 1) hipLaunchKernelGGL((k_step<CW, CH, 1, 7>), grid, block, shmem, st, p);
     else hipLaunchKernelGGL((k_step_fulldirect<CW, CH>), dim3(p.n_tiles), dim3(256), 0, st, p);
     return hipGetLastError();
 }
@@ -856,27 +860,40 @@ hipError_t launch_sized(const StepParams &p, int mode, dim3 grid, dim3 block, si
 template <int CW, int CH>
 hipError_t raise_lds_limit(int mode, int bytes)
 {
-    if (mode == 0) return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<CW, CH, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<CW, CH, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (mode == 0) return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<CW, CH, 0, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<CW, CH, 1, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 } // namespace
 
 #define MGX_SIZED(X) X(5, 5) X(6, 6) X(7, 7) X(8, 8) X(9, 9) X(11, 11) X(16, 16)
+#define MGX_VIEWS(X) X(3) X(5) X(9) X(11)  /* agent_view_size other than 7: run-time grid size only */
 
 hipError_t mgx_launch_step(const StepParams &p, int mode, int waves_per_block, hipStream_t st)
 {
     const dim3 block(64 * waves_per_block);
     const dim3 grid((p.n_tiles + waves_per_block - 1) / waves_per_block);
     const size_t shmem = (size_t)waves_per_block * p.wave_lds;
+    if (mode == 0 && p.view != 7) {
+#define VCASE(v) if (p.view == v) { hipLaunchKernelGGL((k_step<0, 0, 0, v>), grid, block, shmem, st, p); return hipGetLastError(); }
+        MGX_VIEWS(VCASE)
+#undef VCASE
+        return hipErrorInvalidValue;
+    }
 #define CASE(w, h) if (p.W == w && p.H == h) return launch_sized<w, h>(p, mode, grid, block, shmem, st);
     MGX_SIZED(CASE)
 #undef CASE
     return launch_sized<0, 0>(p, mode, grid, block, shmem, st);
 }
 
-hipError_t mgx_raise_lds_limit(int W, int H, int mode, int bytes)
+hipError_t mgx_raise_lds_limit(int W, int H, int mode, int bytes, int view)
 {
+    if (mode == 0 && view != 7) {
+#define VCASE(v) if (view == v) return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<0, 0, 0, v>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        MGX_VIEWS(VCASE)
+#undef VCASE
+        return hipErrorInvalidValue;
+    }
 #define CASE(w, h) if (W == w && H == h) return raise_lds_limit<w, h>(mode, bytes);
     MGX_SIZED(CASE)
 #undef CASE

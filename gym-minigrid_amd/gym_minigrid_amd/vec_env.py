@@ -48,11 +48,13 @@ class VecMiniGrid:
     new_level_each_episode=True (with auto_reset): plain reference behaviour -- `seed(s_i)` once at reset(), then every
                      episode draws a NEW level from the env's own RNG stream (generated on the GPU); False: every
                      episode replays the level of reset() (ReseedWrapper(seeds=[s_i])).
+    agent_view_size: ViewSizeWrapper (wrappers.py:579-608): 3, 5, 7 (default), 9 or 11.
     seeds: int (env i gets seed+i+env_offset) or an array of N uint64 seeds.
     """
 
     def __init__(self, env_id=None, num_envs=1, device=0, seeds=0, obs_mode="partial", auto_reset=True,
-                 config=None, backend="torch", env_offset=0, check_actions=False, new_level_each_episode=False):
+                 config=None, backend="torch", env_offset=0, check_actions=False, new_level_each_episode=False,
+                 agent_view_size=7):
         L = _lib.lib()
         if config is None:
             if env_id is None:
@@ -64,6 +66,7 @@ class VecMiniGrid:
         cfg.obs_mode = {"partial": _lib.OBS_PARTIAL, "full": _lib.OBS_FULL}[obs_mode]
         cfg.auto_reset = int(bool(auto_reset))
         cfg.new_level_each_episode = int(bool(new_level_each_episode))
+        cfg.agent_view_size = int(agent_view_size)
         self.cfg = cfg
         self.num_envs = int(num_envs)
         self.device = int(device)
@@ -72,7 +75,8 @@ class VecMiniGrid:
         self.check_actions = bool(check_actions)
         self.width, self.height, self.max_steps = cfg.width, cfg.height, cfg.max_steps
         self.obs_mode = obs_mode
-        self.obs_shape = (7, 7, 3) if obs_mode == "partial" else (cfg.width, cfg.height, 3)
+        self.agent_view_size = int(agent_view_size)
+        self.obs_shape = (self.agent_view_size,) * 2 + (3,) if obs_mode == "partial" else (cfg.width, cfg.height, 3)
         self.action_space = Discrete(7)
         self.observation_space = Dict({"image": Box(0, 255, self.obs_shape, "uint8")})
         self.reward_range = (0, 1)

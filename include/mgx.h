@@ -38,7 +38,7 @@
  *   agent  int32 [N][3]        x, y, dir (0 right, 1 down, 2 left, 3 up; minigrid.py:64-73)
  *   carry  uint8 [N][3]        encode() of the carried object, (1,0,0) = nothing
  *   steps  int32 [N]           step_count
- *   obs    uint8 [N][7][7][3]  obs['image'] (MGX_OBS_PARTIAL) or uint8 [N][W][H][3] (MGX_OBS_FULL)
+ *   obs    uint8 [N][V][V][3]  obs['image'] (MGX_OBS_PARTIAL, V = agent_view_size, default 7) or uint8 [N][W][H][3] (MGX_OBS_FULL)
  *   reward float [N]           the reference's Python double narrowed to f32
  *   done   uint8 [N]           0/1
  */
@@ -95,7 +95,9 @@ typedef struct {
                                    env's own RNG stream (seeded by mgx_reset) continues and every reset() draws a NEW
                                    level (minigrid.py:836-839), generated on the GPU from a per-env MT19937 state kept
                                    in HBM.  Needs a level_kind with a generator and W*H <= 4096. */
-    int32_t reserved[5];
+    int32_t agent_view_size;    /* 0 = 7 (minigrid.py:776).  ViewSizeWrapper (wrappers.py:579-608): 3, 5, 7, 9 or 11;
+                                   obs is then uint8 [N][V][V][3].  Ignored by MGX_OBS_FULL. */
+    int32_t reserved[4];
 } mgx_config;
 
 typedef struct mgx_env_s *mgx_handle;

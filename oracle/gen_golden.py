@@ -16,7 +16,7 @@ generated; the seed is stored as well so that level generation itself can be
 checked (tests/test_levelgen.py).
 
 File format (one .npz per case), all arrays stacked over traces (leading dim K):
-  meta            json: env_id, W, H, max_steps, see_through, lava_v1, full_obs
+  meta            json: env_id, W, H, max_steps, view (agent_view_size), see_through, lava_v1, full_obs, reseed
   seed      (K,)  int64   seed used for `env.seed(s); env.reset()` (-1: hand-built state)
   init_grid (K,W,H,3) u8  Grid.encode() of the initial grid, index [x][y][c]
   init_aux  (K,W,H)   u8  bit0 = Goal.overlap (terminal goal, toggletimes<=0)
@@ -50,7 +50,7 @@ import numpy as np  # noqa: E402
 import gym  # noqa: E402
 import gym_minigrid  # noqa: E402,F401
 from gym_minigrid import minigrid as M  # noqa: E402
-from gym_minigrid.wrappers import FullyObsWrapper  # noqa: E402
+from gym_minigrid.wrappers import FullyObsWrapper, ViewSizeWrapper  # noqa: E402
 
 OUT = os.path.join(REPO, "tests", "golden")
 
@@ -236,14 +236,15 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
     K = len(seeds)
     env0 = make_env()
     W, H = env0.width, env0.height
-    meta = dict(env_id=name, W=W, H=H, max_steps=int(env0.max_steps),
+    V = int(env0.agent_view_size)
+    meta = dict(env_id=name, W=W, H=H, max_steps=int(env0.max_steps), view=V,
                 see_through=bool(env0.see_through_walls), lava_v1=bool(v1), full_obs=bool(full_obs),
                 reseed=bool(reseed))
     z = dict(
         seed=np.zeros(K, np.int64), init_grid=np.zeros((K, W, H, 3), np.uint8),
         init_aux=np.zeros((K, W, H), np.uint8), init_agent=np.zeros((K, 3), np.int32),
-        init_obs=np.zeros((K, 7, 7, 3), np.uint8), actions=np.zeros((K, T), np.uint8),
-        obs=np.zeros((K, T, 7, 7, 3), np.uint8), direction=np.zeros((K, T), np.uint8),
+        init_obs=np.zeros((K, V, V, 3), np.uint8), actions=np.zeros((K, T), np.uint8),
+        obs=np.zeros((K, T, V, V, 3), np.uint8), direction=np.zeros((K, T), np.uint8),
         reward=np.zeros((K, T), np.float64), done=np.zeros((K, T), np.uint8),
         agent=np.zeros((K, T, 3), np.int32), carry=np.zeros((K, T, 3), np.uint8),
         steps=np.zeros((K, T), np.int32), grid=np.zeros((K, T, W, H, 3), np.uint8))
@@ -301,7 +302,7 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
     z["reset_grid"] = np.asarray(rg, np.uint8).reshape(R, W, H, 3)
     z["reset_aux"] = np.asarray(ra, np.uint8).reshape(R, W, H)
     z["reset_agent"] = np.asarray(rag, np.int32).reshape(R, 3)
-    z["reset_obs"] = np.asarray(ro, np.uint8).reshape(R, 7, 7, 3)
+    z["reset_obs"] = np.asarray(ro, np.uint8).reshape(R, V, V, 3)
     z["meta"] = np.frombuffer(json.dumps(meta).encode(), np.uint8)
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **z)
@@ -397,6 +398,20 @@ def main():
     record_case("Soup-13x6-full", lambda: SoupEnv(13, 6, False, 80, 0.3), list(range(6)), 170, full_obs=True)
     record_case("Soup-9x9-v1", lambda: SoupEnvv1(9, 9, False, 100, 0.35), list(range(6)), 200, v1=True)
     record_case("Soup-19x19", lambda: SoupEnv(19, 19, False, 150, 0.25), list(range(3)), 300)
+    # other view sizes (ViewSizeWrapper, wrappers.py:579-608: sets env.unwrapped.agent_view_size)
+    def vs(make, v):
+        def f():
+            e = make()
+            ViewSizeWrapper(e, v)
+            return e
+        return f
+    record_case("DoorKey-8x8-view5", vs(mk("MiniGrid-DoorKey-8x8-v0"), 5), [0, 1, 2, 3], 300, scripts=[doorkey_script] * 2 + [None] * 2)
+    record_case("DoorKey-8x8-view3", vs(mk("MiniGrid-DoorKey-8x8-v0"), 3), [0, 1, 2, 3], 200, scripts=[doorkey_script] * 2 + [None] * 2)
+    record_case("Soup-9x9-view9", vs(lambda: SoupEnv(9, 9, False, 100, 0.35), 9), list(range(6)), 200)
+    record_case("Soup-7x11-view5", vs(lambda: SoupEnv(7, 11, False, 80, 0.3), 5), list(range(6)), 170)
+    record_case("Soup-8x8-see-view3", vs(lambda: SoupEnv(8, 8, True, 64, 0.45), 3), list(range(4)), 130)
+    record_case("Soup-19x19-view11", vs(lambda: SoupEnv(19, 19, False, 150, 0.25), 11), list(range(3)), 200)
+    record_case("LavaCrossingS9N1-view9", vs(mk("MiniGrid-LavaCrossingS9N1-v0"), 9), [0, 1, 2, 3], 300)
     # plain reference semantics at the episode boundary: reset() WITHOUT re-seeding (a new level every episode)
     record_case("LavaCrossingS9N1-stream", mk("MiniGrid-LavaCrossingS9N1-v0"), list(range(6)), 500, reseed=False)
     record_case("DoorKey-5x5-stream", mk("MiniGrid-DoorKey-5x5-v0"), [0, 1, 2], 800, reseed=False)

@@ -38,7 +38,7 @@
 #include <stdint.h>
 #include <string.h>
 
-#define V 7 /* agent_view_size (minigrid.py:776) */
+#define VMAX 15 /* largest agent_view_size handled (minigrid.py:776 default 7; ViewSizeWrapper wrappers.py:579-608) */
 
 enum { T_UNSEEN = 0, T_EMPTY = 1, T_WALL = 2, T_FLOOR = 3, T_DOOR = 4, T_KEY = 5,
        T_BALL = 6, T_BOX = 7, T_GOAL = 8, T_LAVA = 9, T_AGENT = 10 };
@@ -53,6 +53,7 @@ typedef struct { uint8_t t, c, s, a; } cell_t; /* t == T_EMPTY  <=>  Python None
 
 typedef struct {
     int W, H, max_steps, see_through, lava_v1;
+    int view; /* agent_view_size */
 } mgo_cfg;
 
 static const int DIR_TO_VEC[4][2] = { {1, 0}, {0, 1}, {-1, 0}, {0, -1} }; /* minigrid.py:64-73 */
@@ -95,12 +96,13 @@ static int see_behind(cell_t c)
 
 /* gen_obs_grid + gen_obs (minigrid.py:1327-1381): literal slice/rotate/process_vis/encode */
 static void gen_obs(const mgo_cfg *cf, const uint8_t *g, const uint8_t *aux, const int32_t *agent,
-                    const uint8_t *carry, uint8_t *image /* [V][V][3] */)
+                    const uint8_t *carry, uint8_t *image /* [view][view][3] */)
 {
     int ax = agent[0], ay = agent[1], dir = agent[2];
     int topX, topY, i, j, r;
-    cell_t a[V][V], b[V][V]; /* [i][j] = Grid.get(i, j) of the view grid */
-    int mask[V][V];
+    const int V = cf->view;
+    cell_t a[VMAX][VMAX], b[VMAX][VMAX]; /* [i][j] = Grid.get(i, j) of the view grid */
+    int mask[VMAX][VMAX];
 
     /* get_view_exts (minigrid.py:1162-1189) */
     if (dir == 0)      { topX = ax;             topY = ay - V / 2; }
@@ -262,7 +264,7 @@ int mgo_step_batch(const mgo_cfg *cf, int64_t n, uint8_t *grid, uint8_t *aux, in
                             actions[e], reward + e, done + e);
         if (err) err[e] = rc;
         if (rc && !first) first = rc;
-        if (obs) gen_obs(cf, g, ax, agent + e * 3, carry + e * 3, obs + e * (V * V * 3));
+        if (obs) gen_obs(cf, g, ax, agent + e * 3, carry + e * 3, obs + e * (cf->view * cf->view * 3));
         if (full) full_obs(cf, g, agent + e * 3, full + e * cells * 3);
     }
     return first;
@@ -274,7 +276,7 @@ void mgo_obs_batch(const mgo_cfg *cf, int64_t n, const uint8_t *grid, const uint
 {
     const size_t cells = (size_t)cf->W * cf->H;
     for (int64_t e = 0; e < n; e++) {
-        if (obs) gen_obs(cf, grid + e * cells * 3, aux + e * cells, agent + e * 3, carry + e * 3, obs + e * (V * V * 3));
+        if (obs) gen_obs(cf, grid + e * cells * 3, aux + e * cells, agent + e * 3, carry + e * 3, obs + e * (cf->view * cf->view * 3));
         if (full) full_obs(cf, grid + e * cells * 3, agent + e * 3, full + e * cells * 3);
     }
 }
@@ -297,7 +299,7 @@ int64_t mgo_rollout(const mgo_cfg *cf, int64_t n, int64_t T, uint8_t *grid, uint
             memcpy(agent + e * 3, agent0 + e * 3, 3 * sizeof(int32_t));
             carry[e * 3] = T_EMPTY; carry[e * 3 + 1] = 0; carry[e * 3 + 2] = 0; carry_aux[e] = 0;
             steps[e] = 0;
-            if (obs) gen_obs(cf, grid + e * cells * 3, aux + e * cells, agent + e * 3, carry + e * 3, obs + e * (V * V * 3));
+            if (obs) gen_obs(cf, grid + e * cells * 3, aux + e * cells, agent + e * 3, carry + e * 3, obs + e * (cf->view * cf->view * 3));
             if (full) full_obs(cf, grid + e * cells * 3, agent + e * 3, full + e * cells * 3);
         }
     }

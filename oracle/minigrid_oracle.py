@@ -16,7 +16,7 @@ _SO = os.path.join(_HERE, "_build", "libmgoracle.so")
 
 class _Cfg(ctypes.Structure):
     _fields_ = [("W", ctypes.c_int), ("H", ctypes.c_int), ("max_steps", ctypes.c_int),
-                ("see_through", ctypes.c_int), ("lava_v1", ctypes.c_int)]
+                ("see_through", ctypes.c_int), ("lava_v1", ctypes.c_int), ("view", ctypes.c_int)]
 
 
 def build(force=False):
@@ -46,9 +46,10 @@ def _p(a):
 class OracleEnvs:
     """N independent reference-semantics envs of one family, stepped on the CPU."""
 
-    def __init__(self, W, H, max_steps, see_through, lava_v1=False):
-        self.W, self.H = int(W), int(H)
-        self.cfg = _Cfg(self.W, self.H, int(max_steps), int(bool(see_through)), int(bool(lava_v1)))
+    def __init__(self, W, H, max_steps, see_through, lava_v1=False, view=7):
+        self.W, self.H, self.V = int(W), int(H), int(view)
+        assert 1 <= self.V <= 15
+        self.cfg = _Cfg(self.W, self.H, int(max_steps), int(bool(see_through)), int(bool(lava_v1)), self.V)
         self.n = 0
 
     def set_state(self, grid, agent, aux=None, carry=None, steps=None, carry_aux=None):
@@ -67,7 +68,7 @@ class OracleEnvs:
         self.grid0, self.aux0, self.agent0 = self.grid.copy(), self.aux.copy(), self.agent.copy()
 
     def observe(self, full=False):
-        obs = np.zeros((self.n, 7, 7, 3), np.uint8)
+        obs = np.zeros((self.n, self.V, self.V, 3), np.uint8)
         fo = np.zeros((self.n, self.W, self.H, 3), np.uint8) if full else None
         lib().mgo_obs_batch(ctypes.byref(self.cfg), ctypes.c_int64(self.n), _p(self.grid), _p(self.aux),
                             _p(self.agent), _p(self.carry), _p(obs), _p(fo))
@@ -76,7 +77,7 @@ class OracleEnvs:
     def step(self, actions, full=False):
         a = np.ascontiguousarray(actions, np.uint8)
         assert a.shape == (self.n,)
-        obs = np.zeros((self.n, 7, 7, 3), np.uint8)
+        obs = np.zeros((self.n, self.V, self.V, 3), np.uint8)
         fo = np.zeros((self.n, self.W, self.H, 3), np.uint8) if full else None
         reward = np.zeros(self.n, np.float64)
         done = np.zeros(self.n, np.uint8)
@@ -104,7 +105,7 @@ class OracleEnvs:
         a = np.ascontiguousarray(actions, np.uint8)
         T = a.shape[0]
         assert a.shape == (T, self.n)
-        obs = np.zeros((self.n, 7, 7, 3), np.uint8) if with_obs else None
+        obs = np.zeros((self.n, self.V, self.V, 3), np.uint8) if with_obs else None
         fo = np.zeros((self.n, self.W, self.H, 3), np.uint8) if full else None
         reward = np.zeros(self.n, np.float64)
         done = np.zeros(self.n, np.uint8)

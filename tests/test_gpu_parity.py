@@ -39,7 +39,7 @@ def test_golden_trace_no_autoreset(name, backend):
     sel = np.arange(N) % K
     mode = "full" if meta["full_obs"] else "partial"
     env = mg.VecMiniGrid(config=cfg_from(meta["W"], meta["H"], meta["max_steps"], meta["see_through"], meta["lava_v1"]),
-                         num_envs=N, obs_mode=mode, auto_reset=False, backend=backend)
+                         num_envs=N, obs_mode=mode, auto_reset=False, backend=backend, agent_view_size=meta.get("view", 7))
     env.set_state(z["init_grid"][sel], z["init_agent"][sel], aux=z["init_aux"][sel])
     want0 = z["init_full"] if meta["full_obs"] else z["init_obs"]
     assert np.array_equal(to_np(env.observe()), want0[sel])
@@ -81,7 +81,7 @@ def test_golden_trace_autoreset(name):
     N = 64 + K
     sel = np.arange(N) % K
     env = mg.VecMiniGrid(config=cfg_from(meta["W"], meta["H"], meta["max_steps"], meta["see_through"], meta["lava_v1"]),
-                         num_envs=N, auto_reset=True, backend="numpy")
+                         num_envs=N, auto_reset=True, backend="numpy", agent_view_size=meta.get("view", 7))
     env.set_state(z["init_grid"][sel], z["init_agent"][sel], aux=z["init_aux"][sel])
     dones = 0
     for t in range(T):
@@ -223,3 +223,31 @@ def test_faults_and_errors():
         mg.VecMiniGrid(config=cfg_from(2, 8, 10, False), num_envs=4, backend="numpy")
     with pytest.raises(mg.MgxError):
         mg.VecMiniGrid(config=cfg_from(8, 8, 10, False), num_envs=0, backend="numpy")
+
+
+@pytest.mark.parametrize("view", [3, 5, 9, 11])
+@pytest.mark.parametrize("W,H", [(8, 8), (9, 9), (13, 6), (25, 25)])
+def test_view_sizes_vs_oracle(W, H, view):
+    """ViewSizeWrapper (wrappers.py:579-608): agent_view_size 3/5/9/11, random states, HIP vs CPU oracle."""
+    N, T, max_steps = 64 * 5 + 9, 40, 17
+    see = (W + view) % 3 == 0
+    grid, aux, agent, carry, steps = random_states(N, W, H, seed=W * 31 + view)
+    orc = make_oracle(W, H, max_steps, see, False, grid, aux, agent, carry, steps)
+    orc.cfg.view = view
+    orc.V = view
+    env = mg.VecMiniGrid(config=cfg_from(W, H, max_steps, see), num_envs=N, auto_reset=True, backend="torch", agent_view_size=view)
+    env.set_state(grid, agent, aux=aux, carry=carry, steps=steps)
+    assert env.obs_shape == (view, view, 3)
+    assert np.array_equal(to_np(env.observe()), orc.observe())
+    rs = np.random.RandomState(view)
+    for t in range(T):
+        a = rs.randint(0, 7, size=N).astype(np.uint8)
+        obs, rew, done, _ = env.step(a)
+        oo, orew, odone = orc.step(a)
+        orc.reset_where(odone)
+        want = np.where(odone.astype(bool)[:, None, None, None], orc.observe(), oo)
+        assert np.array_equal(to_np(obs), want), t
+        assert np.array_equal(to_np(done), odone) and np.array_equal(to_np(rew), orew.astype(np.float32))
+    env.close()
+    with pytest.raises(mg.MgxError):
+        mg.VecMiniGrid(config=cfg_from(W, H, max_steps, see), num_envs=4, backend="numpy", agent_view_size=4)
