@@ -144,6 +144,7 @@ StepParams base_params(mgx_handle h)
     p.W = h->W; p.H = h->H; p.S = h->S; p.LS = h->LS; p.wave_lds = h->wave_lds; p.view = h->view;
     p.max_steps = h->cfg.max_steps; p.see_through = h->cfg.see_through_walls; p.lava_v1 = h->cfg.lava_v1;
     p.auto_reset = h->cfg.auto_reset;
+    p.extended = h->cfg.extended_actions ? 1 : 0;
     p.regen = h->stream_mode ? h->regen_d : nullptr;
     return p;
 }
@@ -335,9 +336,10 @@ extern "C" int mgx_sync(mgx_handle h)
     if (rc) return rc;
     if (c.invalid_actions > h->base_bad_act)
         return mgx_fail(MGX_ERR_INVALID_ACTION, "%llu env-steps were given an action >= %d (reference: AssertionError 'unknown action')",
-                        c.invalid_actions - h->base_bad_act, MGX_NUM_ACTIONS);
+                        c.invalid_actions - h->base_bad_act, h->cfg.extended_actions ? 9 : MGX_NUM_ACTIONS);
     if (c.out_of_bounds > h->base_oob)
-        return mgx_fail(MGX_ERR_OUT_OF_BOUNDS, "%llu env-steps had a front/left/right cell outside the grid (reference: Grid.get assert)",
+        return mgx_fail(MGX_ERR_OUT_OF_BOUNDS, "%llu env-steps had a front/left/right cell outside the grid (reference: Grid.get assert) or hit the "
+                                                "reference's strafe_right-onto-goal AttributeError (minigrid.py:1310)",
                         c.out_of_bounds - h->base_oob);
     return MGX_OK;
 }

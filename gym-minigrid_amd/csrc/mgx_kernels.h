@@ -37,7 +37,7 @@ struct StepParams {
     int64_t n;
     int n_tiles;
     int W, H, S, LS, wave_lds, view;
-    int max_steps, see_through, lava_v1, auto_reset, do_step;
+    int max_steps, see_through, lava_v1, auto_reset, do_step, extended;
 };
 
 struct PackParams {

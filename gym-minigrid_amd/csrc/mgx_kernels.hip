@@ -115,27 +115,56 @@ __device__ __forceinline__ uint2 pack_rec(const Lane &L)
 // MiniGridEnv.step without the observation (spec S1-S8), in two halves so that the forward cell can come from
 // the LDS tile image (partial-view kernel) or straight from HBM (full-obs kernel).
 // Half 1: step_count += 1, fault checks, index of the forward cell (-1: nothing to read, no transition).
+// With extended_actions the target of strafe_left (7) / strafe_right (8) is the left / right cell (minigrid.py:1295-1314).
 template <int CW, int CH>
 __device__ __forceinline__ int transition_begin(const StepParams &p, Lane &L, uint32_t act, bool valid, bool &bad_act, bool &oob)
 {
     const int W = CW ? CW : p.W, H = CH ? CH : p.H;
     L.steps += 1;
     const int dir = L.dir;
-    const int dx = (dir == 0) - (dir == 2), dy = (dir == 1) - (dir == 3); // DIR_TO_VEC (minigrid.py:64-73)
+    const int td = act == 7 ? (dir + 3) & 3 : (act == 8 ? (dir + 1) & 3 : dir);
+    const int dx = (td == 0) - (td == 2), dy = (td == 1) - (td == 3); // DIR_TO_VEC (minigrid.py:64-73)
     // front/left/right are all read by the reference (minigrid.py:1239-1243): any of them outside -> assert
     const uint32_t okm = (uint32_t)(L.ax + 1 < W) | ((uint32_t)(L.ay + 1 < H) << 1) | ((uint32_t)(L.ax >= 1) << 2) |
                          ((uint32_t)(L.ay >= 1) << 3);
     const uint32_t need = 0xFu & ~(1u << ((dir + 2) & 3));
     oob = valid && ((okm & need) != need);
-    bad_act = valid && act >= MGX_NUM_ACTIONS_K;
+    bad_act = valid && act >= (p.extended ? 9u : MGX_NUM_ACTIONS_K);
     if (!valid || oob || bad_act) return -1;
     return (L.ax + dx) * H + (L.ay + dy);
 }
 
-// Half 2: the action switch on the forward cell code `fc`; returns the cell's new code (== fc: unchanged).
-__device__ __forceinline__ uint32_t transition_apply(const StepParams &p, Lane &L, uint32_t act, uint32_t fc, float &reward, bool &done)
+// Half 2: the action switch on the target cell code `fc`; returns the cell's new code (== fc: unchanged).
+// `cell_at(idx)` reads another cell of the env (only strafe_right onto a goal needs one: the reference tests
+// LEFT_cell.overlap there, minigrid.py:1310, and raises AttributeError unless the left cell is a goal as well;
+// that case is counted as a fault and treated as "not terminal").
+template <int CH, class CellAt>
+__device__ __forceinline__ uint32_t transition_apply(const StepParams &p, Lane &L, uint32_t act, uint32_t fc, float &reward, bool &done,
+                                                     CellAt cell_at, bool &refbug)
 {
     const int dir = L.dir;
+    if (act >= 7) { // strafe: only reachable with extended_actions
+        const int H = CH ? CH : p.H;
+        const int td = act == 7 ? (dir + 3) & 3 : (dir + 1) & 3;
+        const int tx = (td == 0) - (td == 2), ty = (td == 1) - (td == 3);
+        const uint32_t k = fc & 15u;
+        const uint32_t OVERLAP = (1u << MGX_K_EMPTY) | (1u << MGX_K_FLOOR) | (1u << MGX_K_DOOR_OPEN) | (1u << MGX_K_GOAL) | (1u << MGX_K_LAVA);
+        const int ax0 = L.ax, ay0 = L.ay;
+        if ((OVERLAP >> k) & 1u) { L.ax += tx; L.ay += ty; }
+        if (k == MGX_K_GOAL) {
+            bool ov;
+            if (act == 7) ov = (fc & 0x80u) != 0;
+            else {
+                const int ld = (dir + 3) & 3;
+                const uint32_t lc = cell_at((ax0 + (ld == 0) - (ld == 2)) * H + ay0 + (ld == 1) - (ld == 3));
+                if ((lc & 15u) == MGX_K_GOAL) ov = (lc & 0x80u) != 0;
+                else { ov = false; refbug = true; }
+            }
+            if (ov) { done = true; reward = (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps)); }
+        }
+        if (k == MGX_K_LAVA) done = true; // no 'v1' special case on the strafe path (minigrid.py:1304-1305,1313-1314)
+        return fc;
+    }
     const int dx = (dir == 0) - (dir == 2), dy = (dir == 1) - (dir == 3);
     const uint32_t k = fc & 15u;
     uint32_t nc = fc;
@@ -465,7 +494,7 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
         const int fidx = transition_begin<CW, CH>(p, L, act, valid, bad_act, oob);
         if (fidx >= 0) {
             const uint32_t fc = g[fidx];
-            const uint32_t nc = transition_apply(p, L, act, fc, reward, done);
+            const uint32_t nc = transition_apply<CH>(p, L, act, fc, reward, done, [&](int i) -> uint32_t { return g[i]; }, oob);
             if (nc != fc) g[fidx] = (uint8_t)nc;
             if (valid && L.steps >= p.max_steps) done = true; // minigrid.py:1320-1321
             // the one cell a transition can change; skipped when the env is about to be restored anyway
@@ -541,7 +570,8 @@ __global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
             const int fidx = transition_begin<CW, CH>(p, L, act, valid, bad_act, oob);
             if (fidx >= 0) {
                 const uint32_t fc = p.cells[env * S + fidx];
-                const uint32_t nc = transition_apply(p, L, act, fc, reward, done);
+                const uint32_t nc = transition_apply<CH>(p, L, act, fc, reward, done,
+                                                         [&](int i) -> uint32_t { return p.cells[env * S + i]; }, oob);
                 if (valid && L.steps >= p.max_steps) done = true;
                 if (nc != fc && !(p.auto_reset && done)) {
                     p.cells[env * S + fidx] = (uint8_t)nc;

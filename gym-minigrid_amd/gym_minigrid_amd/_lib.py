@@ -32,7 +32,7 @@ class Config(ctypes.Structure):
                 ("see_through_walls", ctypes.c_int32), ("lava_v1", ctypes.c_int32), ("obs_mode", ctypes.c_int32),
                 ("auto_reset", ctypes.c_int32), ("level_kind", ctypes.c_int32), ("level_arg0", ctypes.c_int32),
                 ("level_arg1", ctypes.c_int32), ("new_level_each_episode", ctypes.c_int32), ("agent_view_size", ctypes.c_int32),
-                ("reserved", ctypes.c_int32 * 4)]
+                ("extended_actions", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3)]
 
 
 class Stats(ctypes.Structure):

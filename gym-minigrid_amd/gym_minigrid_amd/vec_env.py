@@ -48,13 +48,14 @@ class VecMiniGrid:
     new_level_each_episode=True (with auto_reset): plain reference behaviour -- `seed(s_i)` once at reset(), then every
                      episode draws a NEW level from the env's own RNG stream (generated on the GPU); False: every
                      episode replays the level of reset() (ReseedWrapper(seeds=[s_i])).
+    extended_actions: ExtendedActions (minigrid.py:747-764): actions 7 / 8 strafe left / right.
     agent_view_size: ViewSizeWrapper (wrappers.py:579-608): 3, 5, 7 (default), 9 or 11.
     seeds: int (env i gets seed+i+env_offset) or an array of N uint64 seeds.
     """
 
     def __init__(self, env_id=None, num_envs=1, device=0, seeds=0, obs_mode="partial", auto_reset=True,
                  config=None, backend="torch", env_offset=0, check_actions=False, new_level_each_episode=False,
-                 agent_view_size=7):
+                 agent_view_size=7, extended_actions=False):
         L = _lib.lib()
         if config is None:
             if env_id is None:
@@ -67,6 +68,7 @@ class VecMiniGrid:
         cfg.auto_reset = int(bool(auto_reset))
         cfg.new_level_each_episode = int(bool(new_level_each_episode))
         cfg.agent_view_size = int(agent_view_size)
+        cfg.extended_actions = int(bool(extended_actions))
         self.cfg = cfg
         self.num_envs = int(num_envs)
         self.device = int(device)
@@ -77,7 +79,8 @@ class VecMiniGrid:
         self.obs_mode = obs_mode
         self.agent_view_size = int(agent_view_size)
         self.obs_shape = (self.agent_view_size,) * 2 + (3,) if obs_mode == "partial" else (cfg.width, cfg.height, 3)
-        self.action_space = Discrete(7)
+        self.n_actions = 9 if extended_actions else 7
+        self.action_space = Discrete(self.n_actions)  # minigrid.py:788-792
         self.observation_space = Dict({"image": Box(0, 255, self.obs_shape, "uint8")})
         self.reward_range = (0, 1)
         m = MISSIONS.get(cfg.level_kind, "")
@@ -125,14 +128,14 @@ class VecMiniGrid:
             t = self._torch
             if not isinstance(actions, t.Tensor):
                 actions = t.as_tensor(np.asarray(actions), device=self._dev)
-            if self.check_actions and bool((actions >= 7).any() | (actions < 0).any()):
+            if self.check_actions and bool((actions >= self.n_actions).any() | (actions < 0).any()):
                 raise AssertionError("unknown action")  # minigrid.py:1318
             if actions.dtype != t.uint8 or actions.device != self._dev:
                 actions = actions.to(device=self._dev, dtype=t.uint8)
             actions = actions.contiguous()
         else:
             actions = np.asarray(actions)
-            if self.check_actions and ((actions >= 7).any() or (actions < 0).any()):
+            if self.check_actions and ((actions >= self.n_actions).any() or (actions < 0).any()):
                 raise AssertionError("unknown action")
             actions = np.ascontiguousarray(actions, dtype=np.uint8)
         if tuple(actions.shape) != (self.num_envs,):

@@ -60,7 +60,8 @@ typedef enum {
     MGX_ERR_INVALID_ARG = -1,
     MGX_ERR_INVALID_STATE = -2,  /* set_state: a cell / agent / carry value the reference cannot produce */
     MGX_ERR_INVALID_ACTION = -3, /* an action >= 7 was stepped (reference: AssertionError, minigrid.py:1318) */
-    MGX_ERR_OUT_OF_BOUNDS = -4,  /* agent neighbour outside the grid (reference: Grid.get assert, :417-418) */
+    MGX_ERR_OUT_OF_BOUNDS = -4,  /* agent neighbour outside the grid (reference: Grid.get assert, :417-418), or strafe_right
+                                    onto a goal while the left cell is not a goal (reference: AttributeError, :1310) */
     MGX_ERR_UNSUPPORTED = -5,    /* grid too large for one wavefront's LDS tile, unknown env id, ... */
     MGX_ERR_HIP = -6,            /* HIP runtime failure (message has hipGetErrorString) */
     MGX_ERR_NO_LEVELGEN = -7     /* mgx_reset on a handle whose family has no built-in generator */
@@ -97,7 +98,8 @@ typedef struct {
                                    in HBM.  Needs a level_kind with a generator and W*H <= 4096. */
     int32_t agent_view_size;    /* 0 = 7 (minigrid.py:776).  ViewSizeWrapper (wrappers.py:579-608): 3, 5, 7, 9 or 11;
                                    obs is then uint8 [N][V][V][3].  Ignored by MGX_OBS_FULL. */
-    int32_t reserved[4];
+    int32_t extended_actions;   /* 1 = ExtendedActions (minigrid.py:747-764): 7 = strafe_left, 8 = strafe_right */
+    int32_t reserved[3];
 } mgx_config;
 
 typedef struct mgx_env_s *mgx_handle;

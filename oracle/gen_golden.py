@@ -86,10 +86,10 @@ class SoupEnv(M.MiniGridEnv):
     """Our own level: walled room filled at random with every object kind the
     hot path distinguishes (reference classes, reference step/gen_obs)."""
 
-    def __init__(self, width, height, see_through, max_steps, density, v1=False):
+    def __init__(self, width, height, see_through, max_steps, density, v1=False, extended=False):
         self._density = density
         super().__init__(width=width, height=height, max_steps=max_steps,
-                         see_through_walls=see_through)
+                         see_through_walls=see_through, extended_actions=extended)
 
     def _gen_grid(self, width, height):
         rs = self.np_random
@@ -232,14 +232,14 @@ def doorkey_script(env):
 
 
 # --------------------------------------------------------------------------- recorder
-def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False, reseed=True):
+def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False, reseed=True, n_actions=7):
     K = len(seeds)
     env0 = make_env()
     W, H = env0.width, env0.height
     V = int(env0.agent_view_size)
     meta = dict(env_id=name, W=W, H=H, max_steps=int(env0.max_steps), view=V,
                 see_through=bool(env0.see_through_walls), lava_v1=bool(v1), full_obs=bool(full_obs),
-                reseed=bool(reseed))
+                reseed=bool(reseed), extended=bool(n_actions > 7))
     z = dict(
         seed=np.zeros(K, np.int64), init_grid=np.zeros((K, W, H, 3), np.uint8),
         init_aux=np.zeros((K, W, H), np.uint8), init_agent=np.zeros((K, 3), np.int32),
@@ -270,9 +270,14 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
             scratch.seed(int(s))
             scratch.reset()
             acts = scripts[k](scratch)
-        rnd = np.random.RandomState(1000 + k).randint(0, 7, size=T)
+        rnd = np.random.RandomState(1000 + k).randint(0, n_actions, size=T)
         stream = (list(acts) + list(rnd))[:T]
         for t, a in enumerate(stream):
+            if a == 8:  # strafe_right onto a goal reads left_cell.overlap (minigrid.py:1310): AttributeError unless
+                rc = env.grid.get(*env.right_pos)   # the LEFT cell is a goal too -> keep such steps out of the fixtures
+                lc = env.grid.get(*env.left_pos)
+                if rc is not None and rc.type == "goal" and not (lc is not None and lc.type == "goal"):
+                    a = 6
             o, r, d, info = env.step(int(a))
             assert info == {}
             z["actions"][k, t] = a
@@ -412,6 +417,10 @@ def main():
     record_case("Soup-8x8-see-view3", vs(lambda: SoupEnv(8, 8, True, 64, 0.45), 3), list(range(4)), 130)
     record_case("Soup-19x19-view11", vs(lambda: SoupEnv(19, 19, False, 150, 0.25), 11), list(range(3)), 200)
     record_case("LavaCrossingS9N1-view9", vs(mk("MiniGrid-LavaCrossingS9N1-v0"), 9), [0, 1, 2, 3], 300)
+    # ExtendedActions: strafe_left / strafe_right (minigrid.py:747-764,1295-1314)
+    record_case("Soup-8x8-strafe", lambda: SoupEnv(8, 8, False, 96, 0.45, extended=True), list(range(12)), 250, n_actions=9)
+    record_case("Soup-9x9-v1-strafe", lambda: SoupEnvv1(9, 9, False, 100, 0.35, extended=True), list(range(6)), 250, v1=True, n_actions=9)
+    record_case("Soup-13x6-see-strafe", lambda: SoupEnv(13, 6, True, 80, 0.4, extended=True), list(range(6)), 200, n_actions=9)
     # plain reference semantics at the episode boundary: reset() WITHOUT re-seeding (a new level every episode)
     record_case("LavaCrossingS9N1-stream", mk("MiniGrid-LavaCrossingS9N1-v0"), list(range(6)), 500, reseed=False)
     record_case("DoorKey-5x5-stream", mk("MiniGrid-DoorKey-5x5-v0"), [0, 1, 2], 800, reseed=False)

@@ -43,17 +43,20 @@
 enum { T_UNSEEN = 0, T_EMPTY = 1, T_WALL = 2, T_FLOOR = 3, T_DOOR = 4, T_KEY = 5,
        T_BALL = 6, T_BOX = 7, T_GOAL = 8, T_LAVA = 9, T_AGENT = 10 };
 enum { ST_OPEN = 0, ST_CLOSED = 1, ST_LOCKED = 2 };
-enum { A_LEFT = 0, A_RIGHT = 1, A_FORWARD = 2, A_PICKUP = 3, A_DROP = 4, A_TOGGLE = 5, A_DONE = 6 };
+enum { A_LEFT = 0, A_RIGHT = 1, A_FORWARD = 2, A_PICKUP = 3, A_DROP = 4, A_TOGGLE = 5, A_DONE = 6,
+       A_STRAFE_LEFT = 7, A_STRAFE_RIGHT = 8 /* ExtendedActions, minigrid.py:747-764 */ };
 
 #define MGO_OK 0
 #define MGO_ERR_ACTION (-1) /* reference: assert False, "unknown action"  (minigrid.py:1318) */
 #define MGO_ERR_OOB (-2)    /* reference: Grid.get bounds assert         (minigrid.py:417-418) */
+#define MGO_ERR_REFBUG (-3) /* reference: AttributeError in strafe_right (minigrid.py:1310 reads left_cell.overlap) */
 
 typedef struct { uint8_t t, c, s, a; } cell_t; /* t == T_EMPTY  <=>  Python None */
 
 typedef struct {
     int W, H, max_steps, see_through, lava_v1;
     int view; /* agent_view_size */
+    int extended; /* extended_actions (minigrid.py:774,787-789) */
 } mgo_cfg;
 
 static const int DIR_TO_VEC[4][2] = { {1, 0}, {0, 1}, {-1, 0}, {0, -1} }; /* minigrid.py:64-73 */
@@ -191,8 +194,8 @@ static int step_state(const mgo_cfg *cf, uint8_t *g, uint8_t *aux, int32_t *agen
         if (*steps >= cf->max_steps) *done = 1;
         return MGO_ERR_OOB;
     }
-    if (action < 0 || action > A_DONE) {
-        /* extended (strafe) actions are out of scope; the reference asserts here */
+    if (action < 0 || action > (cf->extended ? A_STRAFE_RIGHT : A_DONE)) {
+        /* the reference asserts here */
         if (*steps >= cf->max_steps) *done = 1;
         return MGO_ERR_ACTION;
     }
@@ -241,6 +244,21 @@ static int step_state(const mgo_cfg *cf, uint8_t *g, uint8_t *aux, int32_t *agen
                 grid_set(cf, g, aux, fx, fy, NONE());
             }
         }
+    } else if (action == A_STRAFE_LEFT || action == A_STRAFE_RIGHT) { /* minigrid.py:1295-1314 */
+        const int tx = action == A_STRAFE_LEFT ? lx : rx, ty = action == A_STRAFE_LEFT ? ly : ry;
+        cell_t tc = grid_get(cf, g, aux, tx, ty), lc = grid_get(cf, g, aux, lx, ly);
+        int rc = MGO_OK;
+        if (is_none(tc) || can_overlap(tc)) { agent[0] = tx; agent[1] = ty; }
+        if (!is_none(tc) && tc.t == T_GOAL) {
+            int ov;
+            if (action == A_STRAFE_LEFT) ov = tc.a & 1;
+            else if (!is_none(lc) && lc.t == T_GOAL) ov = lc.a & 1;  /* the reference reads LEFT_cell.overlap here */
+            else { ov = 0; rc = MGO_ERR_REFBUG; }                   /* ... which raises AttributeError otherwise */
+            if (ov) { *done = 1; *reward = 1 - 0.9 * ((double)*steps / (double)cf->max_steps); }
+        }
+        if (!is_none(tc) && tc.t == T_LAVA) *done = 1;              /* no 'v1' special case on the strafe path */
+        if (*steps >= cf->max_steps) *done = 1;
+        return rc;
     } /* A_DONE: pass */
 
     if (*steps >= cf->max_steps) *done = 1;

@@ -39,7 +39,7 @@ def test_golden_trace_no_autoreset(name, backend):
     sel = np.arange(N) % K
     mode = "full" if meta["full_obs"] else "partial"
     env = mg.VecMiniGrid(config=cfg_from(meta["W"], meta["H"], meta["max_steps"], meta["see_through"], meta["lava_v1"]),
-                         num_envs=N, obs_mode=mode, auto_reset=False, backend=backend, agent_view_size=meta.get("view", 7))
+                         num_envs=N, obs_mode=mode, auto_reset=False, backend=backend, agent_view_size=meta.get("view", 7), extended_actions=meta.get("extended", False))
     env.set_state(z["init_grid"][sel], z["init_agent"][sel], aux=z["init_aux"][sel])
     want0 = z["init_full"] if meta["full_obs"] else z["init_obs"]
     assert np.array_equal(to_np(env.observe()), want0[sel])
@@ -81,7 +81,7 @@ def test_golden_trace_autoreset(name):
     N = 64 + K
     sel = np.arange(N) % K
     env = mg.VecMiniGrid(config=cfg_from(meta["W"], meta["H"], meta["max_steps"], meta["see_through"], meta["lava_v1"]),
-                         num_envs=N, auto_reset=True, backend="numpy", agent_view_size=meta.get("view", 7))
+                         num_envs=N, auto_reset=True, backend="numpy", agent_view_size=meta.get("view", 7), extended_actions=meta.get("extended", False))
     env.set_state(z["init_grid"][sel], z["init_agent"][sel], aux=z["init_aux"][sel])
     dones = 0
     for t in range(T):
@@ -251,3 +251,35 @@ def test_view_sizes_vs_oracle(W, H, view):
     env.close()
     with pytest.raises(mg.MgxError):
         mg.VecMiniGrid(config=cfg_from(W, H, max_steps, see), num_envs=4, backend="numpy", agent_view_size=4)
+
+
+def test_strafe_vs_oracle_and_refbug():
+    """ExtendedActions on random states; the reference's strafe_right-onto-goal AttributeError is a counted fault."""
+    W, H, N, T, max_steps = 9, 8, 64 * 6 + 5, 60, 19
+    grid, aux, agent, carry, steps = random_states(N, W, H, seed=99, density=0.5)
+    orc = make_oracle(W, H, max_steps, False, True, grid, aux, agent, carry, steps)
+    orc.cfg.extended = 1
+    env = mg.VecMiniGrid(config=cfg_from(W, H, max_steps, False, True), num_envs=N, auto_reset=True, backend="torch", extended_actions=True)
+    env.set_state(grid, agent, aux=aux, carry=carry, steps=steps)
+    assert env.action_space.n == 9
+    rs = np.random.RandomState(5)
+    faults = 0
+    for t in range(T):
+        a = rs.randint(0, 9, size=N).astype(np.uint8)
+        obs, rew, done, _ = env.step(a)
+        oo, orew, odone = orc.step(a)
+        faults += int((orc.err == -3).sum())
+        assert ((orc.err == 0) | (orc.err == -3)).all()
+        orc.reset_where(odone)
+        want = np.where(odone.astype(bool)[:, None, None, None], orc.observe(), oo)
+        assert np.array_equal(to_np(obs), want), t
+        assert np.array_equal(to_np(done), odone) and np.array_equal(to_np(rew), orew.astype(np.float32))
+    assert env.stats()["out_of_bounds"] == faults and faults > 0
+    env.close()
+    # without extended_actions 7/8 are unknown actions
+    env = mg.VecMiniGrid(config=cfg_from(W, H, max_steps, False), num_envs=N, auto_reset=True, backend="numpy")
+    env.set_state(grid, agent, aux=aux)
+    env.step(np.full(N, 7, np.uint8))
+    with pytest.raises(AssertionError):
+        env.sync()
+    env.close()
