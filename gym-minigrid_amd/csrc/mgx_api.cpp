@@ -145,6 +145,7 @@ StepParams base_params(mgx_handle h)
     p.max_steps = h->cfg.max_steps; p.see_through = h->cfg.see_through_walls; p.lava_v1 = h->cfg.lava_v1;
     p.auto_reset = h->cfg.auto_reset;
     p.extended = h->cfg.extended_actions ? 1 : 0;
+    p.alt_vis = h->cfg.alt_visibility ? 1 : 0;
     p.regen = h->stream_mode ? h->regen_d : nullptr;
     return p;
 }
@@ -227,7 +228,7 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     if (h->wpb > 4) h->wpb = 4;
     if (h->wpb < 1) {
         h->wpb = 1;
-        hipError_t e2 = mgx_raise_lds_limit(h->W, h->H, h->kernel_mode == 0 ? 0 : 1, h->wave_lds, h->view);
+        hipError_t e2 = mgx_raise_lds_limit(h->W, h->H, h->kernel_mode == 0 ? 0 : 1, h->wave_lds, h->view, h->cfg.alt_visibility ? 1 : 0);
         if (e2 != hipSuccess) {
             int rc = mgx_fail(MGX_ERR_HIP, "mgx_create: cannot raise dynamic LDS to %d B: %s", h->wave_lds, hipGetErrorString(e2));
             delete h;

@@ -37,7 +37,7 @@ struct StepParams {
     int64_t n;
     int n_tiles;
     int W, H, S, LS, wave_lds, view;
-    int max_steps, see_through, lava_v1, auto_reset, do_step, extended;
+    int max_steps, see_through, lava_v1, auto_reset, do_step, extended, alt_vis;
 };
 
 struct PackParams {
@@ -74,7 +74,7 @@ struct ConsumeParams {
 hipError_t mgx_launch_levelgen(const LevelGenParams &p, hipStream_t st);
 hipError_t mgx_launch_consume(const ConsumeParams &p, hipStream_t st);
 hipError_t mgx_launch_step(const StepParams &p, int mode, int waves_per_block, hipStream_t st);
-hipError_t mgx_raise_lds_limit(int W, int H, int mode, int bytes, int view);
+hipError_t mgx_raise_lds_limit(int W, int H, int mode, int bytes, int view, int alt_vis);
 hipError_t mgx_launch_pack(const PackParams &p, hipStream_t st);
 hipError_t mgx_launch_unpack(const PackParams &p, hipStream_t st);
 hipError_t mgx_launch_fill_actions(uint8_t *out, uint64_t seed, int64_t env0, int64_t t0, int64_t n, int64_t T, hipStream_t st);

@@ -257,7 +257,7 @@ __device__ __forceinline__ void wave_stats(const StepParams &p, bool valid, bool
 // ------------------------------------------------------------------------------------------------
 // Partial (VxVx3, V = agent_view_size, odd) observation of lane's env -> wave's LDS image of the tile's output -> HBM.
 // B = 3*V*V bytes per env is always 3 mod 4 for odd V, so the byte-phase logic below is the same for every V.
-template <int CW, int CH, int V>
+template <int CW, int CH, int V, bool ALT>
 __device__ __forceinline__ void emit_partial_obs(const StepParams &p, const Lane &L, uint8_t *lds, const uint8_t *g,
                                                  int64_t env0, int lane)
 {
@@ -292,8 +292,60 @@ __device__ __forceinline__ void emit_partial_obs(const StepParams &p, const Lane
         }
     }
 
+    if (ALT && !p.see_through) {
+        // the fork's alternative visibility model, default_vis=False (minigrid.py:649-709), per lane on column bit
+        // masks (bit j of m[i] = view cell (i, j) visible): its data-dependent `break`s become per-lane alive flags.
+        constexpr int PX = V / 2, PY = V - 1;
+        uint32_t m[V], oq[V];
+#pragma unroll
+        for (int i = 0; i < V; i++) {
+            m[i] = 0u;
+            uint32_t o = 0u;
+#pragma unroll
+            for (int j = 0; j < V; j++) o |= (uint32_t)is_opaque(code[i][j]) << j;
+            oq[i] = o;
+        }
+        m[PX] = 1u << PY;
+        bool alive = true;
+#pragma unroll
+        for (int i = PX + 1; i < V; i++) { if (alive) m[i] |= 1u << PY; alive = alive && !((oq[i] >> PY) & 1u); }
+        alive = true;
+#pragma unroll
+        for (int i = PX - 1; i >= 0; i--) { if (alive) m[i] |= 1u << PY; alive = alive && !((oq[i] >> PY) & 1u); }
+        alive = true;
+#pragma unroll
+        for (int j = V - 2; j >= 0; j--) { if (alive) m[PX] |= 1u << j; alive = alive && !((oq[PX] >> j) & 1u); }
+#pragma unroll
+        for (int i = PX + 1; i < V; i++) { // right side; hideside = True
+            alive = true;
+#pragma unroll
+            for (int j = V - 2; j >= 0; j--) {
+                const bool cond = alive && ((m[i] >> (j + 1)) & 1u) && ((m[i - 1] >> j) & 1u);
+                const bool c = (oq[i] >> j) & 1u, ca = (oq[i] >> (j + 1)) & 1u, cb = (oq[i - 1] >> j) & 1u;
+                const bool brk = cond && !c && (ca || cb);
+                alive = alive && !brk;
+                if (cond && !brk) m[i] |= 1u << j;
+            }
+        }
+#pragma unroll
+        for (int i = PX - 1; i >= 0; i--) { // left side
+            alive = true;
+#pragma unroll
+            for (int j = V - 2; j >= 0; j--) {
+                const bool cond = alive && ((m[i] >> (j + 1)) & 1u) && ((m[i + 1] >> j) & 1u);
+                const bool c = (oq[i] >> j) & 1u, ca = (oq[i] >> (j + 1)) & 1u, cb = (oq[i + 1] >> j) & 1u;
+                const bool brk = cond && !c && (ca || cb);
+                alive = alive && !brk;
+                if (cond && !brk) m[i] |= 1u << j;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < V; i++)
+#pragma unroll
+            for (int j = 0; j < V; j++) code[i][j] = ((m[i] >> j) & 1u) ? code[i][j] : 0u;
+    }
     // occlusion, bit-sliced over the wave (process_vis default branch, minigrid.py:617-648; spec O4)
-    if (!p.see_through) {
+    if (!ALT && !p.see_through) {
         u64 vis[V];
 #pragma unroll
         for (int i = 0; i < V; i++) vis[i] = (i == V / 2) ? ~0ull : 0ull;
@@ -465,7 +517,7 @@ __device__ __forceinline__ void emit_full_obs(const StepParams &p, const Lane &L
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int CW, int CH, int MODE, int V>
+template <int CW, int CH, int MODE, int V, bool ALT = false>
 __global__ __launch_bounds__(256) void k_step(const StepParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -511,7 +563,7 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
         if (valid) p.agent[env] = pack_rec(L);
     }
     if (p.obs) {
-        if (MODE == 0) emit_partial_obs<CW, CH, V>(p, L, lds, g, env0, lane);
+        if (MODE == 0) emit_partial_obs<CW, CH, V, ALT>(p, L, lds, g, env0, lane);
         else emit_full_obs<CW, CH>(p, L, valid, lds, g, LS, env0, lane);
     }
 }
@@ -904,6 +956,12 @@ hipError_t mgx_launch_step(const StepParams &p, int mode, int waves_per_block, h
     const dim3 block(64 * waves_per_block);
     const dim3 grid((p.n_tiles + waves_per_block - 1) / waves_per_block);
     const size_t shmem = (size_t)waves_per_block * p.wave_lds;
+    if (mode == 0 && p.alt_vis) { // default_vis=False: run-time grid size only
+#define VCASE(v) if (p.view == v) { hipLaunchKernelGGL((k_step<0, 0, 0, v, true>), grid, block, shmem, st, p); return hipGetLastError(); }
+        MGX_VIEWS(VCASE) VCASE(7)
+#undef VCASE
+        return hipErrorInvalidValue;
+    }
     if (mode == 0 && p.view != 7) {
 #define VCASE(v) if (p.view == v) { hipLaunchKernelGGL((k_step<0, 0, 0, v>), grid, block, shmem, st, p); return hipGetLastError(); }
         MGX_VIEWS(VCASE)
@@ -916,8 +974,14 @@ hipError_t mgx_launch_step(const StepParams &p, int mode, int waves_per_block, h
     return launch_sized<0, 0>(p, mode, grid, block, shmem, st);
 }
 
-hipError_t mgx_raise_lds_limit(int W, int H, int mode, int bytes, int view)
+hipError_t mgx_raise_lds_limit(int W, int H, int mode, int bytes, int view, int alt_vis)
 {
+    if (mode == 0 && alt_vis) {
+#define VCASE(v) if (view == v) return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<0, 0, 0, v, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        MGX_VIEWS(VCASE) VCASE(7)
+#undef VCASE
+        return hipErrorInvalidValue;
+    }
     if (mode == 0 && view != 7) {
 #define VCASE(v) if (view == v) return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<0, 0, 0, v>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         MGX_VIEWS(VCASE)

@@ -32,7 +32,8 @@ class Config(ctypes.Structure):
                 ("see_through_walls", ctypes.c_int32), ("lava_v1", ctypes.c_int32), ("obs_mode", ctypes.c_int32),
                 ("auto_reset", ctypes.c_int32), ("level_kind", ctypes.c_int32), ("level_arg0", ctypes.c_int32),
                 ("level_arg1", ctypes.c_int32), ("new_level_each_episode", ctypes.c_int32), ("agent_view_size", ctypes.c_int32),
-                ("extended_actions", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3)]
+                ("extended_actions", ctypes.c_int32), ("alt_visibility", ctypes.c_int32),
+                ("reserved", ctypes.c_int32 * 2)]
 
 
 class Stats(ctypes.Structure):

@@ -48,6 +48,7 @@ class VecMiniGrid:
     new_level_each_episode=True (with auto_reset): plain reference behaviour -- `seed(s_i)` once at reset(), then every
                      episode draws a NEW level from the env's own RNG stream (generated on the GPU); False: every
                      episode replays the level of reset() (ReseedWrapper(seeds=[s_i])).
+    default_vis=False: the fork's alternative occlusion model (minigrid.py:649-709).
     extended_actions: ExtendedActions (minigrid.py:747-764): actions 7 / 8 strafe left / right.
     agent_view_size: ViewSizeWrapper (wrappers.py:579-608): 3, 5, 7 (default), 9 or 11.
     seeds: int (env i gets seed+i+env_offset) or an array of N uint64 seeds.
@@ -55,7 +56,7 @@ class VecMiniGrid:
 
     def __init__(self, env_id=None, num_envs=1, device=0, seeds=0, obs_mode="partial", auto_reset=True,
                  config=None, backend="torch", env_offset=0, check_actions=False, new_level_each_episode=False,
-                 agent_view_size=7, extended_actions=False):
+                 agent_view_size=7, extended_actions=False, default_vis=True):
         L = _lib.lib()
         if config is None:
             if env_id is None:
@@ -69,6 +70,7 @@ class VecMiniGrid:
         cfg.new_level_each_episode = int(bool(new_level_each_episode))
         cfg.agent_view_size = int(agent_view_size)
         cfg.extended_actions = int(bool(extended_actions))
+        cfg.alt_visibility = int(not default_vis)
         self.cfg = cfg
         self.num_envs = int(num_envs)
         self.device = int(device)

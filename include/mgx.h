@@ -99,7 +99,8 @@ typedef struct {
     int32_t agent_view_size;    /* 0 = 7 (minigrid.py:776).  ViewSizeWrapper (wrappers.py:579-608): 3, 5, 7, 9 or 11;
                                    obs is then uint8 [N][V][V][3].  Ignored by MGX_OBS_FULL. */
     int32_t extended_actions;   /* 1 = ExtendedActions (minigrid.py:747-764): 7 = strafe_left, 8 = strafe_right */
-    int32_t reserved[3];
+    int32_t alt_visibility;     /* 1 = default_vis=False: the fork's alternative occlusion model (minigrid.py:649-709) */
+    int32_t reserved[2];
 } mgx_config;
 
 typedef struct mgx_env_s *mgx_handle;

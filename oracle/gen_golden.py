@@ -86,10 +86,10 @@ class SoupEnv(M.MiniGridEnv):
     """Our own level: walled room filled at random with every object kind the
     hot path distinguishes (reference classes, reference step/gen_obs)."""
 
-    def __init__(self, width, height, see_through, max_steps, density, v1=False, extended=False):
+    def __init__(self, width, height, see_through, max_steps, density, v1=False, extended=False, default_vis=True):
         self._density = density
         super().__init__(width=width, height=height, max_steps=max_steps,
-                         see_through_walls=see_through, extended_actions=extended)
+                         see_through_walls=see_through, extended_actions=extended, default_vis=default_vis)
 
     def _gen_grid(self, width, height):
         rs = self.np_random
@@ -239,7 +239,7 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
     V = int(env0.agent_view_size)
     meta = dict(env_id=name, W=W, H=H, max_steps=int(env0.max_steps), view=V,
                 see_through=bool(env0.see_through_walls), lava_v1=bool(v1), full_obs=bool(full_obs),
-                reseed=bool(reseed), extended=bool(n_actions > 7))
+                reseed=bool(reseed), extended=bool(n_actions > 7), alt_vis=not bool(env0.default_vis))
     z = dict(
         seed=np.zeros(K, np.int64), init_grid=np.zeros((K, W, H, 3), np.uint8),
         init_aux=np.zeros((K, W, H), np.uint8), init_agent=np.zeros((K, 3), np.int32),
@@ -421,6 +421,12 @@ def main():
     record_case("Soup-8x8-strafe", lambda: SoupEnv(8, 8, False, 96, 0.45, extended=True), list(range(12)), 250, n_actions=9)
     record_case("Soup-9x9-v1-strafe", lambda: SoupEnvv1(9, 9, False, 100, 0.35, extended=True), list(range(6)), 250, v1=True, n_actions=9)
     record_case("Soup-13x6-see-strafe", lambda: SoupEnv(13, 6, True, 80, 0.4, extended=True), list(range(6)), 200, n_actions=9)
+    # the fork's alternative visibility model, default_vis=False (minigrid.py:649-709)
+    record_case("Soup-8x8-altvis", lambda: SoupEnv(8, 8, False, 96, 0.45, default_vis=False), list(range(12)), 200)
+    record_case("Soup-9x9-altvis", lambda: SoupEnv(9, 9, False, 100, 0.3, default_vis=False), list(range(8)), 200)
+    record_case("Soup-19x19-altvis", lambda: SoupEnv(19, 19, False, 150, 0.2, default_vis=False), list(range(4)), 300)
+    record_case("Soup-7x11-altvis-view5", vs(lambda: SoupEnv(7, 11, False, 80, 0.3, default_vis=False), 5), list(range(6)), 170)
+    record_case("Soup-9x9-altvis-view9-strafe", vs(lambda: SoupEnv(9, 9, False, 100, 0.3, extended=True, default_vis=False), 9), list(range(6)), 200, n_actions=9)
     # plain reference semantics at the episode boundary: reset() WITHOUT re-seeding (a new level every episode)
     record_case("LavaCrossingS9N1-stream", mk("MiniGrid-LavaCrossingS9N1-v0"), list(range(6)), 500, reseed=False)
     record_case("DoorKey-5x5-stream", mk("MiniGrid-DoorKey-5x5-v0"), [0, 1, 2], 800, reseed=False)

@@ -20,7 +20,7 @@
  *   minigrid.py:411-419   Grid.get/set  (row-major j*W+i, bounds asserts)
  *   minigrid.py:439-473   Grid.rotate_left / Grid.slice
  *   minigrid.py:571-594   Grid.encode(vis_mask)
- *   minigrid.py:617-648   Grid.process_vis (default_vis branch)
+ *   minigrid.py:617-648   Grid.process_vis (default_vis branch); :649-709 the fork's alternative model (default_vis=False)
  *   minigrid.py:933-937   _reward
  *   minigrid.py:1112-1133 front_pos / left_pos / right_pos
  *   minigrid.py:1162-1189 get_view_exts
@@ -57,6 +57,7 @@ typedef struct {
     int W, H, max_steps, see_through, lava_v1;
     int view; /* agent_view_size */
     int extended; /* extended_actions (minigrid.py:774,787-789) */
+    int alt_vis;  /* default_vis=False (minigrid.py:777,786,1343): the fork's own visibility model */
 } mgo_cfg;
 
 static const int DIR_TO_VEC[4][2] = { {1, 0}, {0, 1}, {-1, 0}, {0, -1} }; /* minigrid.py:64-73 */
@@ -129,6 +130,37 @@ static void gen_obs(const mgo_cfg *cf, const uint8_t *g, const uint8_t *aux, con
         memcpy(a, b, sizeof a);
     }
 
+    if (!cf->see_through && cf->alt_vis) {
+        /* process_vis, "custom visualization" branch (minigrid.py:649-709), restated loop for loop */
+#define OPQ(ii, jj) (!is_none(a[ii][jj]) && !see_behind(a[ii][jj]))
+        const int px = V / 2, py = V - 1;
+        memset(mask, 0, sizeof mask);
+        mask[px][py] = 1;
+        j = py;
+        for (i = px + 1; i < V; i++) { mask[i][j] = 1; if (OPQ(i, j)) break; }
+        for (i = px - 1; i >= 0; i--) { mask[i][j] = 1; if (OPQ(i, j)) break; }
+        i = px;
+        for (j = V - 2; j >= 0; j--) { mask[i][j] = 1; if (OPQ(i, j)) break; }
+        for (i = px + 1; i < V; i++)
+            for (j = V - 2; j >= 0; j--) {
+                int c, ca, cb;
+                if (!mask[i][j + 1] || !mask[i - 1][j]) continue;
+                c = OPQ(i, j); ca = OPQ(i, j + 1); cb = OPQ(i - 1, j);
+                if (!c && ca) break;
+                if (!c && cb) break; /* hideside = True */
+                mask[i][j] = 1;
+            }
+        for (i = px - 1; i >= 0; i--)
+            for (j = V - 2; j >= 0; j--) {
+                int c, ca, cb;
+                if (!mask[i][j + 1] || !mask[i + 1][j]) continue;
+                c = OPQ(i, j); ca = OPQ(i, j + 1); cb = OPQ(i + 1, j);
+                if (!c && ca) break;
+                if (!c && cb) break;
+                mask[i][j] = 1;
+            }
+#undef OPQ
+    } else
     /* process_vis, default_vis branch (minigrid.py:617-648) */
     if (!cf->see_through) {
         memset(mask, 0, sizeof mask);

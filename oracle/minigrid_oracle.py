@@ -16,7 +16,7 @@ _SO = os.path.join(_HERE, "_build", "libmgoracle.so")
 
 class _Cfg(ctypes.Structure):
     _fields_ = [("W", ctypes.c_int), ("H", ctypes.c_int), ("max_steps", ctypes.c_int),
-                ("see_through", ctypes.c_int), ("lava_v1", ctypes.c_int), ("view", ctypes.c_int), ("extended", ctypes.c_int)]
+                ("see_through", ctypes.c_int), ("lava_v1", ctypes.c_int), ("view", ctypes.c_int), ("extended", ctypes.c_int), ("alt_vis", ctypes.c_int)]
 
 
 def build(force=False):
@@ -46,10 +46,10 @@ def _p(a):
 class OracleEnvs:
     """N independent reference-semantics envs of one family, stepped on the CPU."""
 
-    def __init__(self, W, H, max_steps, see_through, lava_v1=False, view=7, extended=False):
+    def __init__(self, W, H, max_steps, see_through, lava_v1=False, view=7, extended=False, alt_vis=False):
         self.W, self.H, self.V = int(W), int(H), int(view)
         assert 1 <= self.V <= 15
-        self.cfg = _Cfg(self.W, self.H, int(max_steps), int(bool(see_through)), int(bool(lava_v1)), self.V, int(bool(extended)))
+        self.cfg = _Cfg(self.W, self.H, int(max_steps), int(bool(see_through)), int(bool(lava_v1)), self.V, int(bool(extended)), int(bool(alt_vis)))
         self.n = 0
 
     def set_state(self, grid, agent, aux=None, carry=None, steps=None, carry_aux=None):

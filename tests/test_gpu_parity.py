@@ -39,7 +39,7 @@ def test_golden_trace_no_autoreset(name, backend):
     sel = np.arange(N) % K
     mode = "full" if meta["full_obs"] else "partial"
     env = mg.VecMiniGrid(config=cfg_from(meta["W"], meta["H"], meta["max_steps"], meta["see_through"], meta["lava_v1"]),
-                         num_envs=N, obs_mode=mode, auto_reset=False, backend=backend, agent_view_size=meta.get("view", 7), extended_actions=meta.get("extended", False))
+                         num_envs=N, obs_mode=mode, auto_reset=False, backend=backend, agent_view_size=meta.get("view", 7), extended_actions=meta.get("extended", False), default_vis=not meta.get("alt_vis", False))
     env.set_state(z["init_grid"][sel], z["init_agent"][sel], aux=z["init_aux"][sel])
     want0 = z["init_full"] if meta["full_obs"] else z["init_obs"]
     assert np.array_equal(to_np(env.observe()), want0[sel])
@@ -81,7 +81,7 @@ def test_golden_trace_autoreset(name):
     N = 64 + K
     sel = np.arange(N) % K
     env = mg.VecMiniGrid(config=cfg_from(meta["W"], meta["H"], meta["max_steps"], meta["see_through"], meta["lava_v1"]),
-                         num_envs=N, auto_reset=True, backend="numpy", agent_view_size=meta.get("view", 7), extended_actions=meta.get("extended", False))
+                         num_envs=N, auto_reset=True, backend="numpy", agent_view_size=meta.get("view", 7), extended_actions=meta.get("extended", False), default_vis=not meta.get("alt_vis", False))
     env.set_state(z["init_grid"][sel], z["init_agent"][sel], aux=z["init_aux"][sel])
     dones = 0
     for t in range(T):
@@ -282,4 +282,27 @@ def test_strafe_vs_oracle_and_refbug():
     env.step(np.full(N, 7, np.uint8))
     with pytest.raises(AssertionError):
         env.sync()
+    env.close()
+
+
+@pytest.mark.parametrize("view", [3, 5, 7, 9, 11])
+def test_alt_visibility_vs_oracle(view):
+    """default_vis=False (minigrid.py:649-709) on random states, every view size."""
+    W, H, N, T, max_steps = 10, 9, 64 * 5 + 3, 40, 21
+    grid, aux, agent, carry, steps = random_states(N, W, H, seed=view + 40, density=0.35)
+    orc = make_oracle(W, H, max_steps, False, False, grid, aux, agent, carry, steps)
+    orc.cfg.view, orc.V, orc.cfg.alt_vis = view, view, 1
+    env = mg.VecMiniGrid(config=cfg_from(W, H, max_steps, False), num_envs=N, auto_reset=True, backend="torch",
+                         agent_view_size=view, default_vis=False)
+    env.set_state(grid, agent, aux=aux, carry=carry, steps=steps)
+    assert np.array_equal(to_np(env.observe()), orc.observe())
+    rs = np.random.RandomState(view)
+    for t in range(T):
+        a = rs.randint(0, 7, size=N).astype(np.uint8)
+        obs, rew, done, _ = env.step(a)
+        oo, orew, odone = orc.step(a)
+        orc.reset_where(odone)
+        want = np.where(odone.astype(bool)[:, None, None, None], orc.observe(), oo)
+        assert np.array_equal(to_np(obs), want), t
+        assert np.array_equal(to_np(done), odone)
     env.close()

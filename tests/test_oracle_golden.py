@@ -13,7 +13,7 @@ def test_oracle_replays_reference_trace(name):
     meta, z = load_case(name)
     K, T = z["actions"].shape
     full = meta["full_obs"]
-    env = OracleEnvs(meta["W"], meta["H"], meta["max_steps"], meta["see_through"], meta["lava_v1"], view=meta.get("view", 7), extended=meta.get("extended", False))
+    env = OracleEnvs(meta["W"], meta["H"], meta["max_steps"], meta["see_through"], meta["lava_v1"], view=meta.get("view", 7), extended=meta.get("extended", False), alt_vis=meta.get("alt_vis", False))
     env.set_state(z["init_grid"], z["init_agent"], aux=z["init_aux"])
     if full:
         o, f = env.observe(full=True)
