@@ -36,20 +36,30 @@ for p in (ROOT, os.path.join(ROOT, "gym-minigrid_amd")):
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s is the measured streaming ceiling
 
 
-def survey_bytes_per_step(W, H, obs_mode):
+OBS_CHANNELS = {"partial": 3, "full": 3, "partial_onehot": 21, "full_onehot": 22, "full_onehot_nocolor": 15}
+
+
+def obs_cells(W, H, obs_mode, view=7):
+    return view * view if obs_mode.startswith("partial") else W * H
+
+
+def survey_bytes_per_step(W, H, obs_mode, view=7):
     """SURVEY.md section 8d figure (3-byte cells, 12-byte agent records): action 1 + agent 12 rd + 12 wr + grid W*H*3 rd
     + <=1 cell (3) wr + obs + reward 4 + done 1  ->  372 B for an 8x8 grid with the 7x7 view."""
     grid = W * H * 3
-    obs = 147 if obs_mode == "partial" else W * H * 3
+    obs = obs_cells(W, H, obs_mode, view) * OBS_CHANNELS[obs_mode]
     return 1 + 12 + 12 + grid + 3 + obs + 4 + 1
 
 
-def layout_bytes_per_step(W, H, obs_mode):
+def layout_bytes_per_step(W, H, obs_mode, view=7):
     """Bytes THIS layout has to move per env-step: 1-byte cell codes (W*H rounded up to 4) read,
     8-byte agent record read + written, action 1, obs written, reward 4, done 1  ->  233 B for 8x8 + 7x7 view.
     The roofline is priced on this (smaller, conservative) figure: it is what the kernel really streams."""
     cells = (W * H + 3) // 4 * 4
-    obs = 147 if obs_mode == "partial" else W * H * 3
+    n = obs_cells(W, H, obs_mode, view)
+    obs = n * OBS_CHANNELS[obs_mode]
+    if obs_mode.endswith("onehot") or obs_mode.endswith("nocolor"):
+        obs += 2 * 3 * n  # the one-hot epilogue is a second kernel: triples written by k_step and read back
     return cells + 8 + 8 + 1 + obs + 4 + 1
 
 
@@ -62,7 +72,7 @@ def cpu_baseline(env_id, obs_mode, target_seconds=12.0):
     cfg = mg.env_config(env_id)
     n = 2048
     grid, agent = mg.generate_levels(env_id, np.arange(n, dtype=np.uint64))
-    full = obs_mode == "full"
+    full = obs_mode.startswith("full")
 
     def run(T):
         orc = OracleEnvs(cfg.width, cfg.height, cfg.max_steps, cfg.see_through_walls, cfg.lava_v1)
@@ -87,7 +97,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--env", default="MiniGrid-Empty-8x8-v0")
     ap.add_argument("--envs-per-gpu", type=int, default=1048576)
-    ap.add_argument("--obs-mode", default="partial", choices=["partial", "full"])
+    ap.add_argument("--obs-mode", default="partial", choices=sorted(OBS_CHANNELS))
+    ap.add_argument("--view", type=int, default=7, help="agent_view_size (ViewSizeWrapper)")
     ap.add_argument("--log-every", type=int, default=256, help="all-reduce (episodes, reward_sum) every L steps")
     ap.add_argument("--new-level-each-episode", action="store_true",
                     help="plain reference episode boundary: every reset draws a new level on the GPU (k_levelgen)")
@@ -113,7 +124,7 @@ def main():
     K, Wm = args.steps, args.warmup
     env = mg.VecMiniGrid(args.env, num_envs=n_local, device=local_rank, seeds=0, obs_mode=args.obs_mode,
                          auto_reset=True, backend="torch", env_offset=offset,
-                         new_level_each_episode=args.new_level_each_episode)
+                         new_level_each_episode=args.new_level_each_episode, agent_view_size=args.view)
     env.reset()
     # synthetic inputs for every step, resident in HBM before timing starts
     acts = env.fill_actions(0, 0, K + Wm)
@@ -149,8 +160,8 @@ def main():
 
     if rank == 0:
         cfg = mg.env_config(args.env)
-        bps = layout_bytes_per_step(cfg.width, cfg.height, args.obs_mode)
-        sbps = survey_bytes_per_step(cfg.width, cfg.height, args.obs_mode)
+        bps = layout_bytes_per_step(cfg.width, cfg.height, args.obs_mode, args.view)
+        sbps = survey_bytes_per_step(cfg.width, cfg.height, args.obs_mode, args.view)
         avg_kernel_s = kernel_ms * 1e-3 / max(launches, 1)
         achieved = bps * n_local / avg_kernel_s / 1e9
         traffic = None
@@ -168,13 +179,14 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s, %d batched envs per GPU (%d total), obs %s, uniform random actions 0..6 "
                                    "(counter-based), auto-reset on done" % (args.env, n_local, n_total,
-                                                                            "uint8 (N,7,7,3)" if args.obs_mode == "partial" else "uint8 (N,W,H,3) FullyObs"),
+                                                                            "uint8 (N,%d,%d,%d)" % (args.view, args.view, OBS_CHANNELS[args.obs_mode]) if args.obs_mode.startswith("partial")
+                                                                            else "uint8 (N,W,H,%d) FullyObs" % OBS_CHANNELS[args.obs_mode]),
                        "env_id": args.env, "envs_per_gpu": n_local, "obs_mode": args.obs_mode, "parallelism": "env-shard x%d" % world,
                        "new_level_each_episode": bool(args.new_level_each_episode)},
             "episodes": episodes, "reward_sum": reward_sum,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_step", "avg_kernel_us": avg_kernel_s * 1e6, "launches": launches,
+                         "kernel": "k_step" + ("+k_onehot" if "onehot" in args.obs_mode else "") + ("+k_levelgen" if args.new_level_each_episode else ""), "avg_kernel_us": avg_kernel_s * 1e6, "launches": launches,
                          "algorithmic_bytes_per_env_step": bps, "measured_streaming_ceiling": 6290.0,
                          "survey_bytes_per_env_step": sbps, "achieved_on_survey_bytes": sbps * n_local / avg_kernel_s / 1e9},
         }

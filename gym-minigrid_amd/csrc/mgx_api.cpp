@@ -47,6 +47,10 @@ struct mgx_env_s {
     int64_t n = 0, n_pad = 0;
     int device = 0;
     int W = 0, H = 0, cells = 0, S = 0, LS = 0, wave_lds = 0, wpb = 4, view = 7;
+    bool partial = true;   // the simulator emits the VxV view (else the full grid)
+    int oh_nc = -1, oh_ns = 0; // one-hot epilogue channels (oh_nc < 0: none)
+    uint8_t *tri_d = nullptr;  // triples scratch feeding the one-hot epilogue
+    int64_t tri_bytes = 0;     // per env
     int kernel_mode = 0; // 0 partial view, 1 full obs via the LDS tile image, 2 full obs direct (W*H % 4 == 0)
     int64_t obs_bytes = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -188,7 +192,7 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     if (cfg->width < 3 || cfg->height < 3 || cfg->width > 255 || cfg->height > 255)
         return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: grid %dx%d outside 3..255 (Grid.__init__ asserts >= 3)", cfg->width, cfg->height);
     if (cfg->max_steps <= 0) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: max_steps must be positive");
-    if (cfg->obs_mode != MGX_OBS_PARTIAL && cfg->obs_mode != MGX_OBS_FULL)
+    if (cfg->obs_mode < MGX_OBS_PARTIAL || cfg->obs_mode > MGX_OBS_FULL_ONEHOT_NOCOLOR)
         return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: bad obs_mode %d", cfg->obs_mode);
     const int view = cfg->agent_view_size ? cfg->agent_view_size : MGX_VIEW;
     if (view != 3 && view != 5 && view != 7 && view != 9 && view != 11)
@@ -211,13 +215,18 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     h->S = (h->cells + 3) & ~3;
     h->LS = h->S + (((h->S >> 2) & 1) ? 0 : 4); // odd dword stride per env in LDS
     h->view = view;
-    const int obs_img = cfg->obs_mode == MGX_OBS_PARTIAL ? 32 * view * view * 3 : 0; // half-tile output image
+    h->partial = cfg->obs_mode == MGX_OBS_PARTIAL || cfg->obs_mode == MGX_OBS_PARTIAL_ONEHOT;
+    if (cfg->obs_mode == MGX_OBS_PARTIAL_ONEHOT) { h->oh_nc = 7; h->oh_ns = 3; }
+    else if (cfg->obs_mode == MGX_OBS_FULL_ONEHOT) { h->oh_nc = 7; h->oh_ns = 4; }
+    else if (cfg->obs_mode == MGX_OBS_FULL_ONEHOT_NOCOLOR) { h->oh_nc = 0; h->oh_ns = 4; }
+    const int obs_img = h->partial ? 32 * view * view * 3 : 0; // half-tile output image
     int need = 64 * h->LS;
     if (obs_img > need) need = obs_img;
-    if (cfg->obs_mode == MGX_OBS_FULL) need = ((need + 15) & ~15) + 3072; // + transpose scratch of emit_full_obs
+    if (!h->partial) need = ((need + 15) & ~15) + 3072; // + transpose scratch of emit_full_obs
     h->wave_lds = (need + 15) & ~15;
-    h->obs_bytes = cfg->obs_mode == MGX_OBS_PARTIAL ? view * view * 3 : (int64_t)h->cells * 3;
-    h->kernel_mode = cfg->obs_mode == MGX_OBS_PARTIAL ? 0 : ((h->cells % 4 == 0 && h->cells <= 65535) ? 2 : 1);
+    h->tri_bytes = h->partial ? view * view * 3 : (int64_t)h->cells * 3;
+    h->obs_bytes = h->oh_nc < 0 ? h->tri_bytes : h->tri_bytes / 3 * (11 + h->oh_nc + h->oh_ns);
+    h->kernel_mode = h->partial ? 0 : ((h->cells % 4 == 0 && h->cells <= 65535) ? 2 : 1);
     const int LDS_DEFAULT = 64 * 1024, LDS_MAX = 160 * 1024;
     if (h->wave_lds > LDS_MAX) {
         int rc = mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_create: a %dx%d tile (64 envs) needs %d B of LDS > %d", h->W, h->H, h->wave_lds, LDS_MAX);
@@ -265,6 +274,7 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     CREATE_TRY(hipMalloc((void **)&h->agent_d, ab));
     CREATE_TRY(hipMalloc((void **)&h->agent0_d, ab));
     CREATE_TRY(hipMalloc((void **)&h->ctr_d, sizeof(MgxCounters)));
+    if (h->oh_nc >= 0) CREATE_TRY(hipMalloc((void **)&h->tri_d, (size_t)h->n * h->tri_bytes + 16));
     CREATE_TRY(hipMemsetAsync(h->cells_d, 0, cb, h->stream));
     CREATE_TRY(hipMemsetAsync(h->cells0_d, 0, cb, h->stream));
     CREATE_TRY(hipMemsetAsync(h->agent_d, 0, ab, h->stream));
@@ -292,7 +302,7 @@ extern "C" int mgx_destroy(mgx_handle h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->cells_d); (void)hipFree(h->cells0_d); (void)hipFree(h->agent_d); (void)hipFree(h->agent0_d);
-    (void)hipFree(h->ctr_d);
+    (void)hipFree(h->ctr_d); (void)hipFree(h->tri_d);
     (void)hipFree(h->mt_d); (void)hipFree(h->mt_idx_d); (void)hipFree(h->regen_d);
     for (auto &s : h->st_in) if (s.dev) (void)hipFree(s.dev);
     for (auto &s : h->st_out) if (s.dev) (void)hipFree(s.dev);
@@ -489,7 +499,10 @@ static int run_step(mgx_handle h, bool do_step, const uint8_t *actions, uint8_t 
     if ((rc = dev_out(h, 1, reward, (size_t)h->n * sizeof(float), &o[1], 4))) return rc;
     if ((rc = dev_out(h, 2, done, (size_t)h->n, &o[2]))) return rc;
     p.obs = (uint8_t *)o[0].dev; p.reward = (float *)o[1].dev; p.done = (uint8_t *)o[2].dev;
+    if (h->oh_nc >= 0 && p.obs) p.obs = h->tri_d; // the simulator writes triples; the epilogue below expands them
     HIP_TRY(mgx_launch_step(p, h->kernel_mode, h->wpb, h->stream));
+    if (h->oh_nc >= 0 && o[0].dev)
+        HIP_TRY(mgx_launch_onehot(h->tri_d, (uint8_t *)o[0].dev, h->n * (h->tri_bytes / 3), h->oh_nc, h->oh_ns, h->stream));
     if (do_step) {
         h->steps_total += h->n;
         if (h->profiling) h->prof_launches++;

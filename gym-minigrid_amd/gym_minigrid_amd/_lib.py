@@ -10,7 +10,7 @@ SO_PATH = os.path.join(CSRC, "libmgx.so")
 MGX_OK = 0
 ERR_NAMES = {-1: "INVALID_ARG", -2: "INVALID_STATE", -3: "INVALID_ACTION", -4: "OUT_OF_BOUNDS",
              -5: "UNSUPPORTED", -6: "HIP", -7: "NO_LEVELGEN"}
-OBS_PARTIAL, OBS_FULL = 0, 1
+OBS_PARTIAL, OBS_FULL, OBS_PARTIAL_ONEHOT, OBS_FULL_ONEHOT, OBS_FULL_ONEHOT_NOCOLOR = 0, 1, 2, 3, 4
 
 
 class MgxError(RuntimeError):

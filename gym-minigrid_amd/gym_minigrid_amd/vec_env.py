@@ -40,6 +40,8 @@ def _ptr(a):
 class VecMiniGrid:
     """N independent MiniGrid envs of one registered id (or an explicit config), stepped on one GPU.
 
+    obs_mode: 'partial' (V,V,3) | 'full' (W,H,3, FullyObsWrapper) | 'partial_onehot' (V,V,21, OneHotPartialObsWrapper
+              formula) | 'full_onehot' (W,H,22, FullyObsOneHotWrapper(flatten=False)) | 'full_onehot_nocolor' (W,H,15).
     backend='torch': outputs are torch tensors on cuda:<device> (zero-copy device pointers, asynchronous on
                      torch's current stream).  backend='numpy': host arrays (staged copies, synchronous).
     auto_reset=True: an env that reports done is restored to its episode start inside the same step and `obs`
@@ -65,7 +67,8 @@ class VecMiniGrid:
         self.env_id = env_id
         cfg = _lib.Config()
         ctypes.memmove(ctypes.byref(cfg), ctypes.byref(config), ctypes.sizeof(cfg))
-        cfg.obs_mode = {"partial": _lib.OBS_PARTIAL, "full": _lib.OBS_FULL}[obs_mode]
+        cfg.obs_mode = {"partial": _lib.OBS_PARTIAL, "full": _lib.OBS_FULL, "partial_onehot": _lib.OBS_PARTIAL_ONEHOT,
+                        "full_onehot": _lib.OBS_FULL_ONEHOT, "full_onehot_nocolor": _lib.OBS_FULL_ONEHOT_NOCOLOR}[obs_mode]
         cfg.auto_reset = int(bool(auto_reset))
         cfg.new_level_each_episode = int(bool(new_level_each_episode))
         cfg.agent_view_size = int(agent_view_size)
@@ -80,7 +83,8 @@ class VecMiniGrid:
         self.width, self.height, self.max_steps = cfg.width, cfg.height, cfg.max_steps
         self.obs_mode = obs_mode
         self.agent_view_size = int(agent_view_size)
-        self.obs_shape = (self.agent_view_size,) * 2 + (3,) if obs_mode == "partial" else (cfg.width, cfg.height, 3)
+        chan = {"partial": 3, "full": 3, "partial_onehot": 21, "full_onehot": 22, "full_onehot_nocolor": 15}[obs_mode]
+        self.obs_shape = ((self.agent_view_size,) * 2 if obs_mode.startswith("partial") else (cfg.width, cfg.height)) + (chan,)
         self.n_actions = 9 if extended_actions else 7
         self.action_space = Discrete(self.n_actions)  # minigrid.py:788-792
         self.observation_space = Dict({"image": Box(0, 255, self.obs_shape, "uint8")})

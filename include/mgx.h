@@ -67,7 +67,13 @@ typedef enum {
     MGX_ERR_NO_LEVELGEN = -7     /* mgx_reset on a handle whose family has no built-in generator */
 } mgx_status;
 
-typedef enum { MGX_OBS_PARTIAL = 0, MGX_OBS_FULL = 1 } mgx_obs_mode;
+typedef enum {
+    MGX_OBS_PARTIAL = 0,          /* uint8 [N][V][V][3]   obs['image']                                                  */
+    MGX_OBS_FULL = 1,             /* uint8 [N][W][H][3]   FullyObsWrapper (wrappers.py:311-338)                          */
+    MGX_OBS_PARTIAL_ONEHOT = 2,   /* uint8 [N][V][V][21]  OneHotPartialObsWrapper formula (wrappers.py:203-243)          */
+    MGX_OBS_FULL_ONEHOT = 3,      /* uint8 [N][W][H][22]  FullyObsOneHotWrapper(flatten=False) (wrappers.py:340-415)     */
+    MGX_OBS_FULL_ONEHOT_NOCOLOR = 4 /* uint8 [N][W][H][15]  ... with drop_color=True                                    */
+} mgx_obs_mode;
 
 /* level families with a built-in seeded generator */
 typedef enum {

@@ -343,6 +343,36 @@ def record_level_streams():
     print("level_streams.npz %6.1f KB" % (os.path.getsize(path) / 1024))
 
 
+def record_onehot():
+    """Known answers for the one-hot epilogue: FullyObsOneHotWrapper.observation (wrappers.py:340-415, default and
+    drop_color, flatten=False) applied to FullyObs images of a DoorKey rollout.  (OneHotPartialObsWrapper,
+    wrappers.py:203-243, cannot be run: it allocates `np.zeros(self.observation_space.shape)` on a Dict space, whose
+    shape is None, and raises IndexError on the first cell; its formula is restated in tests/helpers.py.)"""
+    from gym_minigrid.wrappers import FullyObsOneHotWrapper, ImgObsWrapper
+    env = gym.make("MiniGrid-DoorKey-8x8-v0")
+    env.seed(3)
+    env.reset()
+    scr = gym.make("MiniGrid-DoorKey-8x8-v0")
+    scr.seed(3)
+    scr.reset()
+    acts = doorkey_script(scr) + list(np.random.RandomState(0).randint(0, 7, size=40))
+    fenv = ImgObsWrapper(FullyObsWrapper(env))
+    f1 = FullyObsOneHotWrapper(fenv, flatten=False)
+    f2 = FullyObsOneHotWrapper(fenv, drop_color=True, flatten=False)
+    part, part_oh, full, full_oh, full_oh_nc = [], [], [], [], []
+    for a in acts:
+        o, r, d, _ = env.step(int(a))
+        part.append(o["image"])
+        fo = full_image(env)
+        full.append(fo)
+        full_oh.append(f1.observation(fo))
+        full_oh_nc.append(f2.observation(fo))
+    path = os.path.join(OUT, "onehot.npz")
+    np.savez_compressed(path, part=np.asarray(part), full=np.asarray(full),
+                        full_oh=np.asarray(full_oh), full_oh_nc=np.asarray(full_oh_nc))
+    print("onehot.npz %6.1f KB  shapes %s %s" % (os.path.getsize(path) / 1024, np.asarray(full_oh).shape, np.asarray(full_oh_nc).shape))
+
+
 def record_levels():
     """Seeded level generation known answers: seed -> initial grid/agent."""
     out = {}
@@ -434,6 +464,7 @@ def main():
     record_case("Empty-Random-6x6-stream", mk("MiniGrid-Empty-Random-6x6-v0"), [0, 1], 450, reseed=False)
     record_levels()
     record_level_streams()
+    record_onehot()
 
 
 if __name__ == "__main__":

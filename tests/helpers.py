@@ -54,3 +54,16 @@ def make_oracle(W, H, max_steps, see_through, lava_v1, grid, aux, agent, carry=N
 
 def to_np(x):
     return x if isinstance(x, np.ndarray) else x.detach().cpu().numpy()
+
+
+def onehot(img, nc=7, ns=3):
+    """One-hot expansion of (type, color, state) images, restating the reference wrappers' formula:
+    OneHotPartialObsWrapper.observation (wrappers.py:226-243): out[.., type] = out[.., 11+color] = out[.., 18+state] = 1
+    FullyObsOneHotWrapper.observation (wrappers.py:391-415): class (11) | color (7, or 0 with drop_color) | state (4)."""
+    img = np.asarray(img)
+    out = np.zeros(img.shape[:-1] + (11 + nc + ns,), np.uint8)
+    np.put_along_axis(out, img[..., 0:1].astype(np.int64), 1, axis=-1)
+    if nc:
+        np.put_along_axis(out, 11 + img[..., 1:2].astype(np.int64), 1, axis=-1)
+    np.put_along_axis(out, 11 + nc + img[..., 2:3].astype(np.int64), 1, axis=-1)
+    return out

@@ -1,0 +1,46 @@
+"""One-hot epilogue.  CPU: the numpy restatement of the wrappers' formula is pinned to
+FullyObsOneHotWrapper outputs recorded from the reference.  GPU: k_onehot vs that restatement on the oracle's images."""
+import os
+
+import numpy as np
+import pytest
+
+import gym_minigrid_amd as mg
+from conftest import GOLDEN
+from helpers import make_oracle, onehot, random_states, to_np
+
+
+def test_numpy_restatement_matches_reference_wrapper():
+    z = np.load(os.path.join(GOLDEN, "onehot.npz"))
+    assert np.array_equal(onehot(z["full"], 7, 4), z["full_oh"])
+    assert np.array_equal(onehot(z["full"], 0, 4), z["full_oh_nc"])
+    oh = onehot(z["part"], 7, 3)
+    assert oh.shape == z["part"].shape[:-1] + (21,) and (oh.sum(-1) == 3).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,nc,ns", [("partial_onehot", 7, 3), ("full_onehot", 7, 4), ("full_onehot_nocolor", 0, 4)])
+@pytest.mark.parametrize("W,H,view,N", [(8, 8, 7, 64 * 5 + 7), (9, 9, 5, 131), (16, 16, 7, 200), (7, 11, 3, 65), (5, 5, 7, 1)])
+def test_onehot_epilogue(mode, nc, ns, W, H, view, N):
+    T, max_steps = 24, 11
+    grid, aux, agent, carry, steps = random_states(N, W, H, seed=W + view, density=0.4)
+    orc = make_oracle(W, H, max_steps, False, False, grid, aux, agent, carry, steps)
+    orc.cfg.view, orc.V = view, view
+    c = mg.Config()
+    c.width, c.height, c.max_steps = W, H, max_steps
+    env = mg.VecMiniGrid(config=c, num_envs=N, obs_mode=mode, auto_reset=True, backend="torch", agent_view_size=view)
+    env.set_state(grid, agent, aux=aux, carry=carry, steps=steps)
+    full = mode.startswith("full")
+    pick = (lambda o: o[1]) if full else (lambda o: o[0])
+    assert np.array_equal(to_np(env.observe()), onehot(pick(orc.observe(full=True)), nc, ns))
+    rs = np.random.RandomState(1)
+    for t in range(T):
+        a = rs.randint(0, 7, size=N).astype(np.uint8)
+        obs, rew, done, _ = env.step(a)
+        oo, of, orew, odone = orc.step(a, full=True)
+        orc.reset_where(odone)
+        ro = orc.observe(full=True)
+        want = np.where(odone.astype(bool)[:, None, None, None], pick(ro), of if full else oo)
+        assert np.array_equal(to_np(obs), onehot(want, nc, ns)), t
+        assert np.array_equal(to_np(done), odone)
+    env.close()
