@@ -103,6 +103,10 @@ def main():
     ap.add_argument("--new-level-each-episode", action="store_true",
                     help="plain reference episode boundary: every reset draws a new level on the GPU (k_levelgen)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="REHEARSAL ONLY: every rank uses cuda:0 (with --backend gloo) to exercise the multi-rank code "
+                         "path on a one-GPU box; the numbers it prints are meaningless")
     args = ap.parse_args()
 
     import torch
@@ -110,7 +114,9 @@ def main():
     from gym_minigrid_amd import dist as mdist
     import torch.distributed as dist
 
-    rank, local_rank, world = mdist.init_process_group()
+    rank, local_rank, world = mdist.init_process_group(args.backend)
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
     if not torch.cuda.is_available():

@@ -36,64 +36,6 @@
 
 namespace {
 
-// ----------------------------------------------------------------------------- SHA-512 (FIPS 180-4)
-const uint64_t K512[80] = {
-    0x428a2f98d728ae22ULL, 0x7137449123ef65cdULL, 0xb5c0fbcfec4d3b2fULL, 0xe9b5dba58189dbbcULL, 0x3956c25bf348b538ULL,
-    0x59f111f1b605d019ULL, 0x923f82a4af194f9bULL, 0xab1c5ed5da6d8118ULL, 0xd807aa98a3030242ULL, 0x12835b0145706fbeULL,
-    0x243185be4ee4b28cULL, 0x550c7dc3d5ffb4e2ULL, 0x72be5d74f27b896fULL, 0x80deb1fe3b1696b1ULL, 0x9bdc06a725c71235ULL,
-    0xc19bf174cf692694ULL, 0xe49b69c19ef14ad2ULL, 0xefbe4786384f25e3ULL, 0x0fc19dc68b8cd5b5ULL, 0x240ca1cc77ac9c65ULL,
-    0x2de92c6f592b0275ULL, 0x4a7484aa6ea6e483ULL, 0x5cb0a9dcbd41fbd4ULL, 0x76f988da831153b5ULL, 0x983e5152ee66dfabULL,
-    0xa831c66d2db43210ULL, 0xb00327c898fb213fULL, 0xbf597fc7beef0ee4ULL, 0xc6e00bf33da88fc2ULL, 0xd5a79147930aa725ULL,
-    0x06ca6351e003826fULL, 0x142929670a0e6e70ULL, 0x27b70a8546d22ffcULL, 0x2e1b21385c26c926ULL, 0x4d2c6dfc5ac42aedULL,
-    0x53380d139d95b3dfULL, 0x650a73548baf63deULL, 0x766a0abb3c77b2a8ULL, 0x81c2c92e47edaee6ULL, 0x92722c851482353bULL,
-    0xa2bfe8a14cf10364ULL, 0xa81a664bbc423001ULL, 0xc24b8b70d0f89791ULL, 0xc76c51a30654be30ULL, 0xd192e819d6ef5218ULL,
-    0xd69906245565a910ULL, 0xf40e35855771202aULL, 0x106aa07032bbd1b8ULL, 0x19a4c116b8d2d0c8ULL, 0x1e376c085141ab53ULL,
-    0x2748774cdf8eeb99ULL, 0x34b0bcb5e19b48a8ULL, 0x391c0cb3c5c95a63ULL, 0x4ed8aa4ae3418acbULL, 0x5b9cca4f7763e373ULL,
-    0x682e6ff3d6b2b8a3ULL, 0x748f82ee5defb2fcULL, 0x78a5636f43172f60ULL, 0x84c87814a1f0ab72ULL, 0x8cc702081a6439ecULL,
-    0x90befffa23631e28ULL, 0xa4506cebde82bde9ULL, 0xbef9a3f7b2c67915ULL, 0xc67178f2e372532bULL, 0xca273eceea26619cULL,
-    0xd186b8c721c0c207ULL, 0xeada7dd6cde0eb1eULL, 0xf57d4f7fee6ed178ULL, 0x06f067aa72176fbaULL, 0x0a637dc5a2c898a6ULL,
-    0x113f9804bef90daeULL, 0x1b710b35131c471bULL, 0x28db77f523047d84ULL, 0x32caab7b40c72493ULL, 0x3c9ebe0a15c9bebcULL,
-    0x431d67c49c100d4cULL, 0x4cc5d4becb3e42b6ULL, 0x597f299cfc657e2aULL, 0x5fcb6fab3ad6faecULL, 0x6c44198c4a475817ULL};
-
-inline uint64_t rotr(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
-
-// digest of a message shorter than 112 bytes (one block) -- all we need for str(seed)
-void sha512_short(const uint8_t *msg, size_t len, uint8_t out[64])
-{
-    uint8_t blk[128];
-    memset(blk, 0, sizeof blk);
-    memcpy(blk, msg, len);
-    blk[len] = 0x80;
-    uint64_t bits = (uint64_t)len * 8;
-    for (int i = 0; i < 8; i++) blk[127 - i] = (uint8_t)(bits >> (8 * i));
-    uint64_t w[80];
-    for (int t = 0; t < 16; t++) {
-        uint64_t v = 0;
-        for (int i = 0; i < 8; i++) v = (v << 8) | blk[t * 8 + i];
-        w[t] = v;
-    }
-    for (int t = 16; t < 80; t++) {
-        uint64_t s0 = rotr(w[t - 15], 1) ^ rotr(w[t - 15], 8) ^ (w[t - 15] >> 7);
-        uint64_t s1 = rotr(w[t - 2], 19) ^ rotr(w[t - 2], 61) ^ (w[t - 2] >> 6);
-        w[t] = w[t - 16] + s0 + w[t - 7] + s1;
-    }
-    uint64_t h[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
-                     0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
-    uint64_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
-    for (int t = 0; t < 80; t++) {
-        uint64_t S1 = rotr(e, 14) ^ rotr(e, 18) ^ rotr(e, 41);
-        uint64_t ch = (e & f) ^ (~e & g);
-        uint64_t t1 = hh + S1 + ch + K512[t] + w[t];
-        uint64_t S0 = rotr(a, 28) ^ rotr(a, 34) ^ rotr(a, 39);
-        uint64_t mj = (a & b) ^ (a & c) ^ (b & c);
-        uint64_t t2 = S0 + mj;
-        hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
-    }
-    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
-    for (int i = 0; i < 8; i++)
-        for (int j = 0; j < 8; j++) out[i * 8 + j] = (uint8_t)(h[i] >> (56 - 8 * j));
-}
-
 // ----------------------------------------------------------------------------- MT19937 + numpy legacy draws
 struct Rng {
     uint32_t mt[624];
@@ -162,14 +104,8 @@ struct Rng {
     // gym.utils.seeding.np_random(seed)
     void seed_gym(uint64_t seed)
     {
-        char txt[32];
-        int n = snprintf(txt, sizeof txt, "%llu", (unsigned long long)seed);
-        uint8_t dg[64];
-        sha512_short((const uint8_t *)txt, (size_t)n, dg);
         uint32_t key[2];
-        key[0] = (uint32_t)dg[0] | ((uint32_t)dg[1] << 8) | ((uint32_t)dg[2] << 16) | ((uint32_t)dg[3] << 24);
-        key[1] = (uint32_t)dg[4] | ((uint32_t)dg[5] << 8) | ((uint32_t)dg[6] << 16) | ((uint32_t)dg[7] << 24);
-        int klen = key[1] ? 2 : 1; // _int_list_from_bigint drops a zero high word; 0 -> [0]
+        const int klen = lg_seed_key(seed, key);
         init_by_array(key, klen);
     }
 };
@@ -320,24 +256,10 @@ extern "C" int mgx_generate_level_stream(const mgx_config *cfg, uint64_t seed, i
     return MGX_OK;
 }
 
-// MT19937 states right after `env.seed(seeds[i])`: mt u32[n][624] (the index is 624: nothing drawn yet).
-// Used by mgx_reset in stream mode to initialise the per-env generators kept in HBM.
-int mgx_seed_states(int64_t n, const uint64_t *seeds, const uint8_t *mask, uint32_t *mt)
+// init_genrand(19650218): the seed-independent first pass of init_by_array, used by the device seeding kernel
+void mgx_mt_init_table(uint32_t out[624])
 {
-    unsigned nt = std::thread::hardware_concurrency();
-    if (nt == 0) nt = 1;
-    if (nt > 16) nt = 16;
-    if ((int64_t)nt > n) nt = (unsigned)(n > 0 ? n : 1);
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < nt; t++)
-        th.emplace_back([=]() {
-            Rng rng;
-            for (int64_t e = t; e < n; e += nt) {
-                if (mask && !mask[e]) continue;
-                rng.seed_gym(seeds[e]);
-                memcpy(mt + (size_t)e * 624, rng.mt, 624 * sizeof(uint32_t));
-            }
-        });
-    for (auto &x : th) x.join();
-    return MGX_OK;
+    Rng r;
+    r.init_genrand(19650218U);
+    memcpy(out, r.mt, sizeof r.mt);
 }

@@ -222,6 +222,87 @@ LG_FN void lg_generate(const mgx_config &c, R &r, LgLevel &L)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// env.seed(s): gym's legacy seeding (gym.utils.seeding.np_random, gym < 0.22) on top of numpy RandomState:
+//   seed mod 2^64 -> SHA-512(str(seed)) -> first 8 digest bytes as two little-endian uint32 words (a zero high word
+//   is dropped, 0 -> [0]) -> MT19937 init_by_array(words).  Only the first digest word h[0] is needed.
+LG_FN uint64_t lg_rotr64(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
+
+LG_FN uint64_t lg_sha512_h0(const uint8_t *msg, int len) // len < 112: one block
+{
+    const uint64_t K[80] = {
+        0x428a2f98d728ae22ULL, 0x7137449123ef65cdULL, 0xb5c0fbcfec4d3b2fULL, 0xe9b5dba58189dbbcULL, 0x3956c25bf348b538ULL,
+        0x59f111f1b605d019ULL, 0x923f82a4af194f9bULL, 0xab1c5ed5da6d8118ULL, 0xd807aa98a3030242ULL, 0x12835b0145706fbeULL,
+        0x243185be4ee4b28cULL, 0x550c7dc3d5ffb4e2ULL, 0x72be5d74f27b896fULL, 0x80deb1fe3b1696b1ULL, 0x9bdc06a725c71235ULL,
+        0xc19bf174cf692694ULL, 0xe49b69c19ef14ad2ULL, 0xefbe4786384f25e3ULL, 0x0fc19dc68b8cd5b5ULL, 0x240ca1cc77ac9c65ULL,
+        0x2de92c6f592b0275ULL, 0x4a7484aa6ea6e483ULL, 0x5cb0a9dcbd41fbd4ULL, 0x76f988da831153b5ULL, 0x983e5152ee66dfabULL,
+        0xa831c66d2db43210ULL, 0xb00327c898fb213fULL, 0xbf597fc7beef0ee4ULL, 0xc6e00bf33da88fc2ULL, 0xd5a79147930aa725ULL,
+        0x06ca6351e003826fULL, 0x142929670a0e6e70ULL, 0x27b70a8546d22ffcULL, 0x2e1b21385c26c926ULL, 0x4d2c6dfc5ac42aedULL,
+        0x53380d139d95b3dfULL, 0x650a73548baf63deULL, 0x766a0abb3c77b2a8ULL, 0x81c2c92e47edaee6ULL, 0x92722c851482353bULL,
+        0xa2bfe8a14cf10364ULL, 0xa81a664bbc423001ULL, 0xc24b8b70d0f89791ULL, 0xc76c51a30654be30ULL, 0xd192e819d6ef5218ULL,
+        0xd69906245565a910ULL, 0xf40e35855771202aULL, 0x106aa07032bbd1b8ULL, 0x19a4c116b8d2d0c8ULL, 0x1e376c085141ab53ULL,
+        0x2748774cdf8eeb99ULL, 0x34b0bcb5e19b48a8ULL, 0x391c0cb3c5c95a63ULL, 0x4ed8aa4ae3418acbULL, 0x5b9cca4f7763e373ULL,
+        0x682e6ff3d6b2b8a3ULL, 0x748f82ee5defb2fcULL, 0x78a5636f43172f60ULL, 0x84c87814a1f0ab72ULL, 0x8cc702081a6439ecULL,
+        0x90befffa23631e28ULL, 0xa4506cebde82bde9ULL, 0xbef9a3f7b2c67915ULL, 0xc67178f2e372532bULL, 0xca273eceea26619cULL,
+        0xd186b8c721c0c207ULL, 0xeada7dd6cde0eb1eULL, 0xf57d4f7fee6ed178ULL, 0x06f067aa72176fbaULL, 0x0a637dc5a2c898a6ULL,
+        0x113f9804bef90daeULL, 0x1b710b35131c471bULL, 0x28db77f523047d84ULL, 0x32caab7b40c72493ULL, 0x3c9ebe0a15c9bebcULL,
+        0x431d67c49c100d4cULL, 0x4cc5d4becb3e42b6ULL, 0x597f299cfc657e2aULL, 0x5fcb6fab3ad6faecULL, 0x6c44198c4a475817ULL};
+    uint64_t w[16]; // rolling message schedule
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+        uint64_t v = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int b = t * 8 + i;
+            const uint64_t byte = b < len ? msg[b] : (b == len ? 0x80u : 0u);
+            v = (v << 8) | byte;
+        }
+        w[t] = v;
+    }
+    w[15] = (uint64_t)len * 8; // message length in bits (len < 112, so the length field is the last word alone)
+    uint64_t a = 0x6a09e667f3bcc908ULL, b = 0xbb67ae8584caa73bULL, c = 0x3c6ef372fe94f82bULL, d = 0xa54ff53a5f1d36f1ULL,
+             e = 0x510e527fade682d1ULL, f = 0x9b05688c2b3e6c1fULL, g = 0x1f83d9abfb41bd6bULL, h = 0x5be0cd19137e2179ULL;
+#pragma unroll
+    for (int t = 0; t < 80; t++) {
+        uint64_t wt;
+        if (t < 16) wt = w[t];
+        else {
+            const uint64_t w15 = w[(t - 15) & 15], w2 = w[(t - 2) & 15];
+            const uint64_t s0 = lg_rotr64(w15, 1) ^ lg_rotr64(w15, 8) ^ (w15 >> 7);
+            const uint64_t s1 = lg_rotr64(w2, 19) ^ lg_rotr64(w2, 61) ^ (w2 >> 6);
+            wt = w[t & 15] + s0 + w[(t - 7) & 15] + s1;
+            w[t & 15] = wt;
+        }
+        const uint64_t S1 = lg_rotr64(e, 14) ^ lg_rotr64(e, 18) ^ lg_rotr64(e, 41);
+        const uint64_t ch = (e & f) ^ (~e & g);
+        const uint64_t t1 = h + S1 + ch + K[t] + wt;
+        const uint64_t S0 = lg_rotr64(a, 28) ^ lg_rotr64(a, 34) ^ lg_rotr64(a, 39);
+        const uint64_t mj = (a & b) ^ (a & c) ^ (b & c);
+        const uint64_t t2 = S0 + mj;
+        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    return 0x6a09e667f3bcc908ULL + a;
+}
+
+LG_FN uint32_t lg_bswap32(uint32_t x) { return (x >> 24) | ((x >> 8) & 0xFF00u) | ((x << 8) & 0xFF0000u) | (x << 24); }
+
+// init_by_array key of `env.seed(seed)`; returns the key length (1 or 2)
+LG_FN int lg_seed_key(uint64_t seed, uint32_t key[2])
+{
+    uint8_t txt[20];
+    int n = 0;
+    { // str(seed)
+        uint8_t rev[20];
+        uint64_t v = seed;
+        do { rev[n++] = (uint8_t)('0' + (int)(v % 10)); v /= 10; } while (v);
+        for (int i = 0; i < n; i++) txt[i] = rev[n - 1 - i];
+    }
+    const uint64_t h0 = lg_sha512_h0(txt, n); // digest bytes 0..7 = h0 big-endian
+    key[0] = lg_bswap32((uint32_t)(h0 >> 32));
+    key[1] = lg_bswap32((uint32_t)h0);
+    return key[1] ? 2 : 1; // _int_list_from_bigint drops a zero high word; 0 -> [0]
+}
+
 // MT19937 tempering
 LG_FN uint32_t lg_temper(uint32_t y)
 {

@@ -58,8 +58,9 @@ struct mgx_env_s {
     uint2 *agent_d = nullptr, *agent0_d = nullptr;
     MgxCounters *ctr_d = nullptr;
     // new level each episode: per-env MT19937 block + read index, regeneration flags
-    bool stream_mode = false;
-    uint32_t *mt_d = nullptr, *mt_idx_d = nullptr;
+    bool stream_mode = false; // new level each episode
+    bool device_levels = false; // the family draws random numbers: mgx_reset seeds and generates on the GPU
+    uint32_t *mt_d = nullptr, *mt_idx_d = nullptr, *mt_init_d = nullptr;
     uint8_t *regen_d = nullptr;
     Staging st_in[6], st_out[4];
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -263,9 +264,11 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
             delete h;
             return rc;
         }
-        // a family that draws no random numbers (Empty with a fixed start) has only one level: nothing to generate
-        h->stream_mode = !(cfg->level_kind == MGX_LEVEL_EMPTY && cfg->level_arg0 == 0);
     }
+    // a family that draws no random numbers (Empty with a fixed start) has only one level: nothing to generate
+    const bool uses_rng = cfg->level_kind != MGX_LEVEL_NONE && !(cfg->level_kind == MGX_LEVEL_EMPTY && cfg->level_arg0 == 0);
+    h->device_levels = uses_rng && h->cells <= 4096;
+    h->stream_mode = cfg->new_level_each_episode && uses_rng;
     CREATE_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
     h->stream = h->own_stream;
     const size_t cb = (size_t)h->n_pad * h->S, ab = (size_t)h->n_pad * sizeof(uint2);
@@ -280,7 +283,12 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     CREATE_TRY(hipMemsetAsync(h->agent_d, 0, ab, h->stream));
     CREATE_TRY(hipMemsetAsync(h->agent0_d, 0, ab, h->stream));
     CREATE_TRY(hipMemsetAsync(h->ctr_d, 0, sizeof(MgxCounters), h->stream));
-    if (h->stream_mode) {
+    if (h->device_levels) {
+        uint32_t init[624];
+        mgx_mt_init_table(init);
+        CREATE_TRY(hipMalloc((void **)&h->mt_init_d, sizeof init));
+        CREATE_TRY(hipMemcpyAsync(h->mt_init_d, init, sizeof init, hipMemcpyHostToDevice, h->stream));
+        CREATE_TRY(hipStreamSynchronize(h->stream)); // `init` is a stack array
         CREATE_TRY(hipMalloc((void **)&h->mt_d, (size_t)h->n_pad * 624 * sizeof(uint32_t)));
         CREATE_TRY(hipMalloc((void **)&h->mt_idx_d, (size_t)h->n_pad * sizeof(uint32_t)));
         CREATE_TRY(hipMalloc((void **)&h->regen_d, (size_t)h->n_pad));
@@ -303,7 +311,7 @@ extern "C" int mgx_destroy(mgx_handle h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->cells_d); (void)hipFree(h->cells0_d); (void)hipFree(h->agent_d); (void)hipFree(h->agent0_d);
     (void)hipFree(h->ctr_d); (void)hipFree(h->tri_d);
-    (void)hipFree(h->mt_d); (void)hipFree(h->mt_idx_d); (void)hipFree(h->regen_d);
+    (void)hipFree(h->mt_d); (void)hipFree(h->mt_idx_d); (void)hipFree(h->regen_d); (void)hipFree(h->mt_init_d);
     for (auto &s : h->st_in) if (s.dev) (void)hipFree(s.dev);
     for (auto &s : h->st_out) if (s.dev) (void)hipFree(s.dev);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -534,32 +542,23 @@ extern "C" int mgx_reset(mgx_handle h, const uint64_t *seeds, const uint8_t *mas
         return mgx_fail(MGX_ERR_NO_LEVELGEN, "mgx_reset: this handle has no built-in level generator; use mgx_set_state");
     if (!seeds) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_reset: seeds is required");
     const size_t n = (size_t)h->n, cells = (size_t)h->cells;
-    if (h->stream_mode) {
-        // env.seed(s_i) on the host (SHA-512 + MT19937 init_by_array, threaded), everything after that on the GPU:
-        // generate level 1 into the next-level buffer, make it current, generate level 2 behind it.
-        std::vector<uint32_t> mt(n * 624);
-        mgx_seed_states(h->n, seeds, mask, mt.data());
-        for (size_t e = 0; e < n;) { // upload runs of consecutive masked envs
-            if (mask && !mask[e]) { e++; continue; }
-            size_t f = e;
-            while (f < n && (!mask || mask[f])) f++;
-            HIP_TRY(hipMemcpyAsync(h->mt_d + e * 624, mt.data() + e * 624, (f - e) * 624 * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
-            HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(h->mt_idx_d + e), 624, f - e, h->stream));
-            if (mask) HIP_TRY(hipMemsetAsync(h->regen_d + e, 1, f - e, h->stream));
-            e = f;
-        }
-        if (!mask) HIP_TRY(hipMemsetAsync(h->regen_d, 1, n, h->stream));
+    if (h->device_levels) {
+        // Everything on the GPU: env.seed(s_i) (k_seed: SHA-512 key + MT19937 init_by_array per env), level 1 into the
+        // next-level buffer (k_levelgen), make it current (k_consume); with new_level_each_episode level 2 is
+        // generated behind it, otherwise the buffer keeps level 1 as the episode-start snapshot.
+        const void *ds = nullptr, *dm = nullptr;
+        if ((rc = dev_in(h, 4, seeds, n * sizeof(uint64_t), &ds, 8))) return rc;
+        if ((rc = dev_in(h, 5, mask, n, &dm))) return rc;
+        HIP_TRY(hipMemsetAsync(h->regen_d, 0, n, h->stream));
+        HIP_TRY(mgx_launch_seed((const uint64_t *)ds, (const uint8_t *)dm, h->mt_init_d, h->mt_d, h->mt_idx_d, h->regen_d, h->n, h->stream));
         if ((rc = launch_levelgen(h))) return rc;
         ConsumeParams c;
         memset(&c, 0, sizeof c);
-        const void *dm = nullptr;
-        if ((rc = dev_in(h, 5, mask, n, &dm))) return rc;
         c.mask = (const uint8_t *)dm;
         c.cells = h->cells_d; c.cells0 = h->cells0_d; c.agent = h->agent_d; c.agent0 = h->agent0_d; c.regen = h->regen_d;
-        c.n = h->n; c.S = h->S;
+        c.n = h->n; c.S = h->S; c.flag_regen = h->stream_mode ? 1 : 0;
         HIP_TRY(mgx_launch_consume(c, h->stream));
-        if ((rc = launch_levelgen(h))) return rc;
-        HIP_TRY(hipStreamSynchronize(h->stream)); // the host vector above is about to go away
+        if (h->stream_mode && (rc = launch_levelgen(h))) return rc;
         if (obs) return run_step(h, false, nullptr, obs, nullptr, nullptr);
         return MGX_OK;
     }

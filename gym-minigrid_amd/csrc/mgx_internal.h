@@ -7,9 +7,8 @@
 // Records a thread-local error message and returns `status` (so callers can `return mgx_fail(...)`).
 int mgx_fail(int status, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
-// MT19937 states right after `env.seed(seeds[i])` for every env with mask[i] != 0 (mask may be null):
-// mt u32[n][624]; the read index of such a state is 624 (nothing drawn yet).  levelgen.cpp.
-int mgx_seed_states(int64_t n, const uint64_t *seeds, const uint8_t *mask, uint32_t *mt);
+// init_genrand(19650218): the seed-independent first pass of MT19937 init_by_array (levelgen.cpp).
+void mgx_mt_init_table(uint32_t out[624]);
 
 // ---- internal cell code (1 byte per cell, x-major like Grid.encode()):
 //   bits 3:0  kind    0 unseen*, 1 empty, 2 wall, 3 floor, 4 door-open, 5 key, 6 ball, 7 box, 8 goal,

@@ -69,9 +69,11 @@ struct ConsumeParams {
     const uint8_t *mask; // u8[n] or null
     uint8_t *cells; const uint8_t *cells0; uint2 *agent; const uint2 *agent0; uint8_t *regen;
     int64_t n;
-    int S;
+    int S, flag_regen;
 };
 hipError_t mgx_launch_levelgen(const LevelGenParams &p, hipStream_t st);
+hipError_t mgx_launch_seed(const uint64_t *seeds, const uint8_t *mask, const uint32_t *init, uint32_t *mt, uint32_t *mt_idx,
+                           uint8_t *regen, int64_t n, hipStream_t st);
 hipError_t mgx_launch_consume(const ConsumeParams &p, hipStream_t st);
 hipError_t mgx_launch_step(const StepParams &p, int mode, int waves_per_block, hipStream_t st);
 hipError_t mgx_raise_lds_limit(int W, int H, int mode, int bytes, int view, int alt_vis);

@@ -824,7 +824,7 @@ __global__ __launch_bounds__(256) void k_consume(const ConsumeParams p)
     }
     if (t < p.n && (!p.mask || p.mask[t])) {
         p.agent[t] = p.agent0[t];
-        p.regen[t] = 1;
+        p.regen[t] = p.flag_regen ? 1 : 0;
     }
 }
 
@@ -883,6 +883,53 @@ __global__ __launch_bounds__(256) void k_onehot(const uint8_t *__restrict__ tri,
         else
             for (int b = 16 * i; b < n_bytes; b++) dst[b] = reinterpret_cast<const uint8_t *>(s_x[wv])[b];
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// env.seed(s) on the device, lane-per-env: gym's legacy key derivation (SHA-512 of str(seed), levelgen_core.h) and
+// MT19937 init_by_array written into the env's state block in HBM.  The recurrences are sequential per env (each
+// word depends on the previous one); 64 envs advance in lock-step per wave.  Pass 3 re-reads what pass 2 stored, 16
+// words at a time so that the loads are in flight together.
+__global__ __launch_bounds__(256) void k_seed(const uint64_t *__restrict__ seeds, const uint8_t *__restrict__ mask,
+                                              const uint32_t *__restrict__ init, uint32_t *mt, uint32_t *mt_idx,
+                                              uint8_t *regen, int64_t n)
+{
+    const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= n || (mask && !mask[env])) return;
+    uint32_t key[2];
+    const int klen = lg_seed_key(seeds[env], key);
+    uint32_t *m = mt + env * 624;
+    // pass 2: mt[i] = (init[i] ^ ((mt[i-1] ^ mt[i-1] >> 30) * 1664525)) + key[j] + j for i = 1..623, then once more for i = 1
+    uint32_t prev = init[0], v1 = 0;
+    int j = 0;
+    for (int i = 1; i < 624; i++) {
+        const uint32_t x = (init[i] ^ ((prev ^ (prev >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+        if (i == 1) v1 = x; else m[i] = x;
+        prev = x;
+        j = (j + 1 == klen) ? 0 : j + 1;
+    }
+    const uint32_t m1 = (v1 ^ ((prev ^ (prev >> 30)) * 1664525u)) + key[j] + (uint32_t)j; // mt[0] = mt[623]; i = 1 again
+    prev = m1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // this lane re-reads its own stores below
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // pass 3: mt[i] = (mt[i] ^ ((mt[i-1] ^ mt[i-1] >> 30) * 1566083941)) - i for i = 2..623, then for i = 1
+    for (int i0 = 2; i0 < 624; i0 += 16) {
+        uint32_t old[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) old[k] = (i0 + k < 624) ? m[i0 + k] : 0u;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if (i0 + k < 624) {
+                const uint32_t x = (old[k] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)(i0 + k);
+                m[i0 + k] = x;
+                prev = x;
+            }
+        }
+    }
+    m[1] = (m1 ^ ((prev ^ (prev >> 30)) * 1566083941u)) - 1u; // mt[0] = mt[623]; i = 1
+    m[0] = 0x80000000u;
+    mt_idx[env] = 624; // nothing drawn yet
+    regen[env] = 1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1061,6 +1108,13 @@ hipError_t mgx_launch_levelgen(const LevelGenParams &p, hipStream_t st)
         raised = shmem;
     }
     hipLaunchKernelGGL(k_levelgen, dim3((unsigned)((p.n + 64 * MGX_LG_WAVES - 1) / (64 * MGX_LG_WAVES))), dim3(64 * MGX_LG_WAVES), shmem, st, p);
+    return hipGetLastError();
+}
+
+hipError_t mgx_launch_seed(const uint64_t *seeds, const uint8_t *mask, const uint32_t *init, uint32_t *mt, uint32_t *mt_idx,
+                           uint8_t *regen, int64_t n, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_seed, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, seeds, mask, init, mt, mt_idx, regen, n);
     return hipGetLastError();
 }
 

@@ -140,7 +140,8 @@ int mgx_generate_levels(const mgx_config *cfg, int64_t n, const uint64_t *seeds,
 int mgx_generate_level_stream(const mgx_config *cfg, uint64_t seed, int64_t K, uint8_t *grid, int32_t *agent);
 
 /* env.seed(seeds[i]); env.reset() for every env with mask[i] != 0 (mask NULL = all).
- * seeds/mask are HOST pointers.  obs (optional) receives the reset observation of ALL envs. */
+ * For the families that draw random numbers the whole reset runs on the GPU (k_seed: SHA-512 key + MT19937
+ * init_by_array per env, then k_levelgen).  obs (optional) receives the reset observation of ALL envs. */
 int mgx_reset(mgx_handle h, const uint64_t *seeds, const uint8_t *mask, uint8_t *obs);
 
 /* Inject / read back the full simulator state.  set_state also records the state as the

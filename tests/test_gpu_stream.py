@@ -94,3 +94,19 @@ def test_stream_mode_needs_generator():
         obs, rew, done, _ = env.step(np.full(70, 1, np.uint8))
     assert done.all() and np.array_equal(obs, o0)
     env.close()
+
+
+@pytest.mark.parametrize("stream", [False, True])
+def test_device_seeding_matches_host(stream):
+    """k_seed (SHA-512 of str(seed) + init_by_array on the GPU) against the host generator, incl. seeds around 2^32 / 2^64
+    (one- vs two-word keys, 20-digit decimal strings)."""
+    special = [0, 1, 9, 10, 1337, 2 ** 31 - 1, 2 ** 32 - 1, 2 ** 32, 2 ** 32 + 1, 2 ** 40 + 12345, 10 ** 19, 2 ** 63, 2 ** 64 - 2, 2 ** 64 - 1]
+    rs = np.random.RandomState(0)
+    seeds = np.array(special + [int(x) for x in rs.randint(0, 2 ** 62, size=300)], dtype=np.uint64)
+    for env_id in ("MiniGrid-DoorKey-8x8-v0", "MiniGrid-LavaCrossingS11N5-v0"):
+        env = mg.VecMiniGrid(env_id, num_envs=len(seeds), seeds=seeds, auto_reset=True, new_level_each_episode=stream, backend="torch")
+        env.reset()
+        st = env.get_state()
+        grid, agent = mg.generate_levels(env_id, seeds)
+        assert np.array_equal(st["grid"], grid) and np.array_equal(st["agent"], agent)
+        env.close()
