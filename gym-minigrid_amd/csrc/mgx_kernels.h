@@ -8,6 +8,7 @@
 #include "mgx.h"
 
 #define MGX_NUM_ACTIONS_K 7u
+#define MGX_LG_LDS_PER_WAVE_BYTES (2 * 624 * 4 + 16 + 2 * (6 * 32) + 8 * (8 + 4 * 32)) /* == MGX_LG_LDS_PER_WAVE in mgx_kernels.hip */
 
 // Running totals.  The per-step counters are SHARDED over 256 cache lines (shard = tile & 255): with one word,
 // LavaCrossing (40% of the waves see a done every step) spent >half of the step serialising ~3,300 same-address
@@ -23,6 +24,18 @@ struct MgxCounters {
     unsigned long long invalid_actions, out_of_bounds, invalid_state;
 };
 
+// on-device level generation (new level each episode)
+struct LevelGenParams {
+    mgx_config cfg;
+    uint32_t *mt;      // u32[n_pad][624]  per-env MT19937 block
+    uint32_t *mt_idx;  // u32[n_pad]       next unread word of the block (624 = exhausted / freshly seeded)
+    uint8_t *regen;    // u8[n_pad]        work flags, cleared here
+    uint8_t *cells0;   // next-level buffer (codes) and its agent record
+    uint2 *agent0;
+    MgxCounters *ctr;
+    int64_t n;
+    int n_tiles, S;
+};
 struct StepParams {
     uint8_t *cells;        // u8[n_pad][S]   internal cell codes, x-major
     uint2 *agent;          // [n_pad]        x | y<<8 | dir<<16 | carry<<24 ; step_count
@@ -38,6 +51,8 @@ struct StepParams {
     int n_tiles;
     int W, H, S, LS, wave_lds, view;
     int max_steps, see_through, lava_v1, auto_reset, do_step, extended, alt_vis;
+    int fused_levelgen;    // 1: k_step<..., FUSED> refills the next-level buffers itself (p.lg), no k_levelgen launch
+    LevelGenParams lg;
 };
 
 struct PackParams {
@@ -53,18 +68,6 @@ struct PackParams {
     int W, H, S;
 };
 
-// on-device level generation (new level each episode)
-struct LevelGenParams {
-    mgx_config cfg;
-    uint32_t *mt;      // u32[n_pad][624]  per-env MT19937 block
-    uint32_t *mt_idx;  // u32[n_pad]       next unread word of the block (624 = exhausted / freshly seeded)
-    uint8_t *regen;    // u8[n_pad]        work flags, cleared here
-    uint8_t *cells0;   // next-level buffer (codes) and its agent record
-    uint2 *agent0;
-    MgxCounters *ctr;
-    int64_t n;
-    int n_tiles, S;
-};
 struct ConsumeParams {
     const uint8_t *mask; // u8[n] or null
     uint8_t *cells; const uint8_t *cells0; uint2 *agent; const uint2 *agent0; uint8_t *regen;

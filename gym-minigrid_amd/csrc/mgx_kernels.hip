@@ -517,8 +517,100 @@ __device__ __forceinline__ void emit_full_obs(const StepParams &p, const Lane &L
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int CW, int CH, int MODE, int V, bool ALT = false>
-__global__ __launch_bounds__(256) void k_step(const StepParams p)
+// (device RNG + per-level generator: used by k_levelgen below and by the fused tail of k_step)
+struct DevRng {
+    const uint32_t *buf; // LDS: the env's current MT19937 block followed by the next one (624 + 624 words)
+    int idx;             // next unread word
+    int limit;           // words available: 624, or 1248 once the next block has been built
+    bool overflow;       // ran past `limit`: the caller builds the next block and runs the generator again
+
+    __device__ __forceinline__ uint32_t next32()
+    {
+        if (idx >= limit) { overflow = true; return 0u; } // zeros keep every rejection loop of the generators finite
+        return lg_temper(buf[idx++]);
+    }
+};
+
+// One level, generated by one wave into its LDS workspace and written back coalesced.
+__device__ __forceinline__ void levelgen_one(const LevelGenParams &p, int64_t env, uint8_t *base, int lane)
+{
+    uint32_t *cur = reinterpret_cast<uint32_t *>(base), *nxt = cur + 624;
+    int *res = reinterpret_cast<int *>(base + 2 * 624 * 4); // [0]=idx after, [1]=packed agent, [2]=overflow, [3]=#cmds
+    int16_t *ws = reinterpret_cast<int16_t *>(res + 4);
+    LgCmd *cmds = reinterpret_cast<LgCmd *>(ws + MGX_LG_WS_WORDS);
+    uint32_t *mt = p.mt + env * 624;
+    { // all ten loads of the block in flight before the first LDS write (a rolled loop pays one latency per trip)
+        uint32_t v[10];
+#pragma unroll
+        for (int i = 0; i < 10; i++) { const int k = lane + 64 * i; v[i] = k < 624 ? mt[k] : 0u; }
+#pragma unroll
+        for (int i = 0; i < 10; i++) { const int k = lane + 64 * i; if (k < 624) cur[k] = v[i]; }
+    }
+    const int idx0 = (int)p.mt_idx[env];
+    wave_sync();
+    // Attempt 1 reads the current block only (or both, if the read index is within 64 words of its end: then the
+    // next block is built first, by the whole wave: the recurrence is 3 data-parallel phases + 1 word).  If the
+    // generator runs past the words available (rare), the next block is built and the generator runs again from
+    // the same index.  A level that needs more than one whole extra block (> 624 draws; probability ~2^-100) is
+    // counted as a fault instead of being handled.
+    int limit = idx0 + 64 > 624 ? 1248 : 624;
+    bool have_next = false;
+    for (int attempt = 0; attempt < 2; attempt++) { // wave-uniform
+        if (limit == 1248 && !have_next) {
+            for (int k = lane; k < 227; k += 64) nxt[k] = lg_twist_word(cur[k], cur[k + 1], cur[k + 397]);
+            wave_sync();
+            for (int k = 227 + lane; k < 454; k += 64) nxt[k] = lg_twist_word(cur[k], cur[k + 1], nxt[k - 227]);
+            wave_sync();
+            for (int k = 454 + lane; k < 623; k += 64) nxt[k] = lg_twist_word(cur[k], cur[k + 1], nxt[k - 227]);
+            wave_sync();
+            if (lane == 0) nxt[623] = lg_twist_word(cur[623], nxt[0], nxt[396]);
+            wave_sync();
+            have_next = true;
+        }
+        if (lane == 0) {
+            DevRng r;
+            r.buf = cur; r.idx = idx0; r.limit = limit; r.overflow = false;
+            LgLevel L;
+            L.cmds = cmds; L.ncmd = 0; L.W = p.cfg.width; L.H = p.cfg.height; L.ax = L.ay = -1; L.adir = 0; L.ws = ws;
+            lg_generate(p.cfg, r, L);
+            res[0] = r.idx;
+            res[1] = (L.ax & 255) | ((L.ay & 255) << 8) | ((L.adir & 3) << 16);
+            res[2] = r.overflow ? 1 : 0;
+            res[3] = L.ncmd;
+        }
+        wave_sync();
+        if (!res[2]) break;
+        if (limit == 1248) { if (lane == 0) atomicAdd(&p.ctr->invalid_state, 1ull); break; }
+        limit = 1248;
+    }
+    const int idx1 = res[0];
+    { // paint: every lane evaluates the command list for 4 consecutive cells and stores one dword of codes
+        const int ncmd = res[3], H = p.cfg.height, cells = p.cfg.width * H;
+        uint32_t *dst = reinterpret_cast<uint32_t *>(p.cells0 + env * p.S);
+        for (int k = lane; k < (p.S >> 2); k += 64) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int c = 4 * k + b;
+                if (c < cells) { const int x = c / H; w |= lg_cell_code(cmds, ncmd, x, c - x * H) << (8 * b); }
+            }
+            dst[k] = w;
+        }
+    }
+    if (idx1 >= 624) { // moved into the next block: it becomes the env's state
+        for (int k = lane; k < 624; k += 64) mt[k] = nxt[k];
+    }
+    if (lane == 0) {
+        p.mt_idx[env] = (uint32_t)(idx1 >= 624 ? idx1 - 624 : idx1);
+        p.agent0[env] = make_uint2((uint32_t)res[1] | ((uint32_t)MGX_CODE_EMPTY << 24), 0u);
+    }
+    wave_sync();
+}
+
+// FUSED: with new_level_each_episode the wave refills the next-level buffer of the envs it has just reset, at the end
+// of the same launch (no second kernel, no flags, and the refill is ordered before the env can reset again).
+template <int CW, int CH, int MODE, int V, bool ALT = false, bool FUSED = false>
+__global__ __launch_bounds__(256, FUSED ? 6 : 1) void k_step(const StepParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -565,6 +657,15 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
     if (p.obs) {
         if (MODE == 0) emit_partial_obs<CW, CH, V, ALT>(p, L, lds, g, env0, lane);
         else emit_full_obs<CW, CH>(p, L, valid, lds, g, LS, env0, lane);
+    }
+    if constexpr (FUSED) {
+        u64 md = __ballot(p.do_step && p.auto_reset && valid && done);
+        if (md) wave_sync(); // the LDS images above are dead; the level generator reuses the wave's region
+        while (md) { // wave-uniform; usually 0-2 envs
+            const int j = __builtin_ctzll(md);
+            md &= md - 1;
+            levelgen_one(p.lg, env0 + j, lds, lane);
+        }
     }
 }
 
@@ -688,101 +789,13 @@ __global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
 // ballot; for each flagged env the WAVE regenerates the next MT block cooperatively when the current one is nearly
 // used up (the block recurrence is 3 data-parallel phases + 1 word), lane 0 runs the (tiny, sequential) generator
 // of levelgen_core.h on LDS, and the wave writes level, record and RNG state back coalesced.
-struct DevRng {
-    const uint32_t *buf; // LDS: the env's current MT19937 block followed by the next one (624 + 624 words)
-    int idx;             // next unread word
-    int limit;           // words available: 624, or 1248 once the next block has been built
-    bool overflow;       // ran past `limit`: the caller builds the next block and runs the generator again
-
-    __device__ __forceinline__ uint32_t next32()
-    {
-        if (idx >= limit) { overflow = true; return 0u; } // zeros keep every rejection loop of the generators finite
-        return lg_temper(buf[idx++]);
-    }
-};
-
-// One level, generated by one wave into its LDS workspace and written back coalesced.
-__device__ __forceinline__ void levelgen_one(const LevelGenParams &p, int64_t env, uint8_t *base, int lane)
-{
-    uint32_t *cur = reinterpret_cast<uint32_t *>(base), *nxt = cur + 624;
-    int *res = reinterpret_cast<int *>(base + 2 * 624 * 4); // [0]=idx after, [1]=packed agent, [2]=overflow, [3]=#cmds
-    int16_t *ws = reinterpret_cast<int16_t *>(res + 4);
-    LgCmd *cmds = reinterpret_cast<LgCmd *>(ws + MGX_LG_WS_WORDS);
-    uint32_t *mt = p.mt + env * 624;
-    { // all ten loads of the block in flight before the first LDS write (a rolled loop pays one latency per trip)
-        uint32_t v[10];
-#pragma unroll
-        for (int i = 0; i < 10; i++) { const int k = lane + 64 * i; v[i] = k < 624 ? mt[k] : 0u; }
-#pragma unroll
-        for (int i = 0; i < 10; i++) { const int k = lane + 64 * i; if (k < 624) cur[k] = v[i]; }
-    }
-    const int idx0 = (int)p.mt_idx[env];
-    wave_sync();
-    // Attempt 1 reads the current block only (or both, if the read index is within 64 words of its end: then the
-    // next block is built first, by the whole wave: the recurrence is 3 data-parallel phases + 1 word).  If the
-    // generator runs past the words available (rare), the next block is built and the generator runs again from
-    // the same index.  A level that needs more than one whole extra block (> 624 draws; probability ~2^-100) is
-    // counted as a fault instead of being handled.
-    int limit = idx0 + 64 > 624 ? 1248 : 624;
-    bool have_next = false;
-    for (int attempt = 0; attempt < 2; attempt++) { // wave-uniform
-        if (limit == 1248 && !have_next) {
-            for (int k = lane; k < 227; k += 64) nxt[k] = lg_twist_word(cur[k], cur[k + 1], cur[k + 397]);
-            wave_sync();
-            for (int k = 227 + lane; k < 454; k += 64) nxt[k] = lg_twist_word(cur[k], cur[k + 1], nxt[k - 227]);
-            wave_sync();
-            for (int k = 454 + lane; k < 623; k += 64) nxt[k] = lg_twist_word(cur[k], cur[k + 1], nxt[k - 227]);
-            wave_sync();
-            if (lane == 0) nxt[623] = lg_twist_word(cur[623], nxt[0], nxt[396]);
-            wave_sync();
-            have_next = true;
-        }
-        if (lane == 0) {
-            DevRng r;
-            r.buf = cur; r.idx = idx0; r.limit = limit; r.overflow = false;
-            LgLevel L;
-            L.cmds = cmds; L.ncmd = 0; L.W = p.cfg.width; L.H = p.cfg.height; L.ax = L.ay = -1; L.adir = 0; L.ws = ws;
-            lg_generate(p.cfg, r, L);
-            res[0] = r.idx;
-            res[1] = (L.ax & 255) | ((L.ay & 255) << 8) | ((L.adir & 3) << 16);
-            res[2] = r.overflow ? 1 : 0;
-            res[3] = L.ncmd;
-        }
-        wave_sync();
-        if (!res[2]) break;
-        if (limit == 1248) { if (lane == 0) atomicAdd(&p.ctr->invalid_state, 1ull); break; }
-        limit = 1248;
-    }
-    const int idx1 = res[0];
-    { // paint: every lane evaluates the command list for 4 consecutive cells and stores one dword of codes
-        const int ncmd = res[3], H = p.cfg.height, cells = p.cfg.width * H;
-        uint32_t *dst = reinterpret_cast<uint32_t *>(p.cells0 + env * p.S);
-        for (int k = lane; k < (p.S >> 2); k += 64) {
-            uint32_t w = 0;
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const int c = 4 * k + b;
-                if (c < cells) { const int x = c / H; w |= lg_cell_code(cmds, ncmd, x, c - x * H) << (8 * b); }
-            }
-            dst[k] = w;
-        }
-    }
-    if (idx1 >= 624) { // moved into the next block: it becomes the env's state
-        for (int k = lane; k < 624; k += 64) mt[k] = nxt[k];
-    }
-    if (lane == 0) {
-        p.mt_idx[env] = (uint32_t)(idx1 >= 624 ? idx1 - 624 : idx1);
-        p.agent0[env] = make_uint2((uint32_t)res[1] | ((uint32_t)MGX_CODE_EMPTY << 24), 0u);
-    }
-    wave_sync();
-}
-
 // A 512-thread block owns 8 tiles (512 envs).  Every thread looks at its env's flag; flagged envs are compacted
 // into an LDS queue (LDS atomics) and the block's 8 waves pull from it, one level per wave at a time.  Sharing the
 // work over 16 waves matters: resets are Poisson per tile, and with one wave per tile the kernel lasted as long as
 // the unluckiest tile (5-6 levels in a row, 84 us) instead of ~2 levels.
 #define MGX_LG_WAVES 8
 #define MGX_LG_LDS_PER_WAVE (2 * 624 * 4 + 16 + 2 * MGX_LG_WS_WORDS + 8 * MGX_LG_MAX_CMDS)
+static_assert(MGX_LG_LDS_PER_WAVE == MGX_LG_LDS_PER_WAVE_BYTES, "keep mgx_kernels.h in sync");
 __global__ __launch_bounds__(64 * MGX_LG_WAVES, 4) void k_levelgen(const LevelGenParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1037,7 +1050,8 @@ __global__ __launch_bounds__(64) void k_read_stats(const MgxCounters *ctr, doubl
 template <int CW, int CH>
 hipError_t launch_sized(const StepParams &p, int mode, dim3 grid, dim3 block, size_t shmem, hipStream_t st)
 {
-    if (mode == 0) hipLaunchKernelGGL((k_step<CW, CH, 0, 7>), grid, block, shmem, st, p);
+    if (mode == 0 && p.fused_levelgen) hipLaunchKernelGGL((k_step<CW, CH, 0, 7, false, true>), grid, block, shmem, st, p);
+    else if (mode == 0) hipLaunchKernelGGL((k_step<CW, CH, 0, 7>), grid, block, shmem, st, p);
     else if (mode == 1) hipLaunchKernelGGL((k_step<CW, CH, 1, 7>), grid, block, shmem, st, p);
     else hipLaunchKernelGGL((k_step_fulldirect<CW, CH>), dim3(p.n_tiles), dim3(256), 0, st, p);
     return hipGetLastError();
@@ -1046,7 +1060,11 @@ hipError_t launch_sized(const StepParams &p, int mode, dim3 grid, dim3 block, si
 template <int CW, int CH>
 hipError_t raise_lds_limit(int mode, int bytes)
 {
-    if (mode == 0) return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<CW, CH, 0, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (mode == 0) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<CW, CH, 0, 7, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return e;
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<CW, CH, 0, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    }
     return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<CW, CH, 1, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
