@@ -66,6 +66,7 @@ struct Rng {
         mt[0] = 0x80000000U;
         idx = 624;
     }
+    bool alive() const { return true; }
     uint32_t next32()
     {
         if (idx >= 624) {

@@ -8,7 +8,8 @@
 //            LavaGapEnv._gen_grid   /root/reference/gym_minigrid/envs/lavagap.py:21-59
 //            place_obj/place_agent  /root/reference/gym_minigrid/minigrid.py:1003-1090
 // Random draws follow numpy's legacy RandomState on top of MT19937 (see levelgen.cpp's header): every draw is
-// "raw 32-bit output & mask, redraw while > max".  `R` is any type with `uint32_t next32()`.
+// "raw 32-bit output & mask, redraw while > max".  `R` is any type with `uint32_t next32()` and `bool alive()`
+// (false once a bounded source of words has run dry: the rejection loops then stop and the caller discards the level).
 #ifndef MGX_LEVELGEN_CORE_H
 #define MGX_LEVELGEN_CORE_H
 
@@ -36,20 +37,23 @@
 // instead of being drawn cell by cell: the sequential part of a generator -- the random decisions -- then touches a
 // few bytes only, queries like "is this cell free?" scan the list, and the grid itself is painted afterwards, on the
 // GPU by all 64 lanes in parallel (k_levelgen spent most of its time drawing walls with one lane before this).
-struct LgCmd { uint8_t x0, y0, x1, y1, code, pad[3]; };
+struct alignas(4) LgCmd { uint8_t x0, y0, x1, y1, code, pad[3]; }; // two dwords (never 8-byte accesses: GPU slices are 4-byte aligned)
 
 struct LgLevel {
-    LgCmd *cmds; // MGX_LG_MAX_CMDS entries
+    LgCmd *cmds; // max_cmds entries (MGX_LG_MAX_CMDS always suffices)
     int ncmd;
     int W, H;
     int ax, ay, adir;
-    int16_t *ws; // MGX_LG_WS_WORDS scratch words for the crossing generator's lists.  On the GPU cmds and ws point
+    int16_t *ws; // 6*max_rivers scratch words for the crossing generator's lists.  On the GPU cmds and ws point
                  // into LDS: dynamically indexed local arrays would live in scratch (HBM) and every access of the
                  // sequential generator would pay a memory round trip (measured 10x on k_levelgen).
+    int max_cmds = MGX_LG_MAX_CMDS, max_rivers = MGX_LG_MAX_RIVERS; // capacities of cmds / ws (the GPU fast path has small ones)
+    bool too_big = false; // a capacity was exceeded: the level is invalid and must be regenerated with full-size buffers
 };
 
 LG_FN void lg_rect(LgLevel &L, int x0, int y0, int x1, int y1, uint32_t code)
 {
+    if (L.ncmd >= L.max_cmds) { L.too_big = true; return; }
     LgCmd c;
     c.x0 = (uint8_t)x0; c.y0 = (uint8_t)y0; c.x1 = (uint8_t)x1; c.y1 = (uint8_t)y1; c.code = (uint8_t)code;
     c.pad[0] = c.pad[1] = c.pad[2] = 0;
@@ -109,6 +113,7 @@ LG_FN void lg_sample_free(R &r, LgLevel &L, int sw, int sh, bool reject_agent, i
     for (;;) {
         const int x = lg_randint(r, 0, xw);
         const int y = lg_randint(r, 0, yh);
+        if (!r.alive()) { *ox = 0; *oy = 0; return; } // the word source ran dry: this level is discarded by the caller
         if (!lg_empty(L, x, y)) continue;
         if (reject_agent && x == L.ax && y == L.ay) continue;
         *ox = x; *oy = y;
@@ -153,7 +158,9 @@ LG_FN void lg_gen_crossing(const mgx_config &c, R &r, LgLevel &L)
     lg_room(L);
     L.ax = 1; L.ay = 1; L.adir = 0;
     // candidate rivers: (v, i) for i in range(2, H-2, 2) then (h, j) for j in range(2, W-2, 2); bit 8 = vertical
-    int16_t *riv = L.ws, *rv = L.ws + 2 * MGX_LG_MAX_RIVERS, *rh = L.ws + 3 * MGX_LG_MAX_RIVERS, *path = L.ws + 4 * MGX_LG_MAX_RIVERS;
+    const int MR = L.max_rivers;
+    if ((H - 3) / 2 > MR || (W - 3) / 2 > MR) { L.too_big = true; return; }
+    int16_t *riv = L.ws, *rv = L.ws + 2 * MR, *rh = L.ws + 3 * MR, *path = L.ws + 4 * MR;
     int n = 0;
     for (int i = 2; i < H - 2; i += 2) riv[n++] = (int16_t)(0x100 | i);
     for (int j = 2; j < W - 2; j += 2) riv[n++] = (int16_t)j;

@@ -7,6 +7,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -59,7 +60,6 @@ struct mgx_env_s {
     MgxCounters *ctr_d = nullptr;
     // new level each episode: per-env MT19937 block + read index, regeneration flags
     bool stream_mode = false; // new level each episode
-    bool fused_levelgen = false; // ... refilled by k_step itself (partial view, V = 7, default visibility)
     bool device_levels = false; // the family draws random numbers: mgx_reset seeds and generates on the GPU
     uint32_t *mt_d = nullptr, *mt_idx_d = nullptr, *mt_init_d = nullptr;
     uint8_t *regen_d = nullptr;
@@ -235,8 +235,6 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     const bool uses_rng = cfg->level_kind != MGX_LEVEL_NONE && !(cfg->level_kind == MGX_LEVEL_EMPTY && cfg->level_arg0 == 0);
     h->device_levels = uses_rng && h->cells <= 4096;
     h->stream_mode = cfg->new_level_each_episode && uses_rng;
-    h->fused_levelgen = h->stream_mode && h->partial && view == MGX_VIEW && !cfg->alt_visibility;
-    if (h->fused_levelgen && h->wave_lds < MGX_LG_LDS_PER_WAVE_BYTES) h->wave_lds = MGX_LG_LDS_PER_WAVE_BYTES;
     h->tri_bytes = h->partial ? view * view * 3 : (int64_t)h->cells * 3;
     h->obs_bytes = h->oh_nc < 0 ? h->tri_bytes : h->tri_bytes / 3 * (11 + h->oh_nc + h->oh_ns);
     h->kernel_mode = h->partial ? 0 : ((h->cells % 4 == 0 && h->cells <= 65535) ? 2 : 1);
@@ -515,7 +513,6 @@ static int run_step(mgx_handle h, bool do_step, const uint8_t *actions, uint8_t 
     if ((rc = dev_out(h, 1, reward, (size_t)h->n * sizeof(float), &o[1], 4))) return rc;
     if ((rc = dev_out(h, 2, done, (size_t)h->n, &o[2]))) return rc;
     p.obs = (uint8_t *)o[0].dev; p.reward = (float *)o[1].dev; p.done = (uint8_t *)o[2].dev;
-    if (h->fused_levelgen) { p.fused_levelgen = 1; p.lg = levelgen_params(h); p.regen = nullptr; }
     if (h->oh_nc >= 0 && p.obs) p.obs = h->tri_d; // the simulator writes triples; the epilogue below expands them
     HIP_TRY(mgx_launch_step(p, h->kernel_mode, h->wpb, h->stream));
     if (h->oh_nc >= 0 && o[0].dev)
@@ -523,7 +520,7 @@ static int run_step(mgx_handle h, bool do_step, const uint8_t *actions, uint8_t 
     if (do_step) {
         h->steps_total += h->n;
         if (h->profiling) h->prof_launches++;
-        if (h->stream_mode && !h->fused_levelgen && (rc = launch_levelgen(h))) return rc; // refill the buffers this step consumed
+        if (h->stream_mode && (rc = launch_levelgen(h))) return rc; // refill the next-level buffers this step consumed
     }
     return finish_out(h, o, 3);
 }

@@ -51,8 +51,6 @@ struct StepParams {
     int n_tiles;
     int W, H, S, LS, wave_lds, view;
     int max_steps, see_through, lava_v1, auto_reset, do_step, extended, alt_vis;
-    int fused_levelgen;    // 1: k_step<..., FUSED> refills the next-level buffers itself (p.lg), no k_levelgen launch
-    LevelGenParams lg;
 };
 
 struct PackParams {

@@ -517,16 +517,17 @@ __device__ __forceinline__ void emit_full_obs(const StepParams &p, const Lane &L
 }
 
 // ------------------------------------------------------------------------------------------------
-// (device RNG + per-level generator: used by k_levelgen below and by the fused tail of k_step)
+// (device RNG + per-level generator, used by k_levelgen below)
 struct DevRng {
     const uint32_t *buf; // LDS: the env's current MT19937 block followed by the next one (624 + 624 words)
     int idx;             // next unread word
     int limit;           // words available: 624, or 1248 once the next block has been built
     bool overflow;       // ran past `limit`: the caller builds the next block and runs the generator again
 
+    __device__ __forceinline__ bool alive() const { return !overflow; }
     __device__ __forceinline__ uint32_t next32()
     {
-        if (idx >= limit) { overflow = true; return 0u; } // zeros keep every rejection loop of the generators finite
+        if (idx >= limit) { overflow = true; return 0u; } // masked draws end on 0; place_obj-style loops test alive()
         return lg_temper(buf[idx++]);
     }
 };
@@ -607,10 +608,8 @@ __device__ __forceinline__ void levelgen_one(const LevelGenParams &p, int64_t en
     wave_sync();
 }
 
-// FUSED: with new_level_each_episode the wave refills the next-level buffer of the envs it has just reset, at the end
-// of the same launch (no second kernel, no flags, and the refill is ordered before the env can reset again).
-template <int CW, int CH, int MODE, int V, bool ALT = false, bool FUSED = false>
-__global__ __launch_bounds__(256, FUSED ? 6 : 1) void k_step(const StepParams p)
+template <int CW, int CH, int MODE, int V, bool ALT = false>
+__global__ __launch_bounds__(256) void k_step(const StepParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -657,15 +656,6 @@ __global__ __launch_bounds__(256, FUSED ? 6 : 1) void k_step(const StepParams p)
     if (p.obs) {
         if (MODE == 0) emit_partial_obs<CW, CH, V, ALT>(p, L, lds, g, env0, lane);
         else emit_full_obs<CW, CH>(p, L, valid, lds, g, LS, env0, lane);
-    }
-    if constexpr (FUSED) {
-        u64 md = __ballot(p.do_step && p.auto_reset && valid && done);
-        if (md) wave_sync(); // the LDS images above are dead; the level generator reuses the wave's region
-        while (md) { // wave-uniform; usually 0-2 envs
-            const int j = __builtin_ctzll(md);
-            md &= md - 1;
-            levelgen_one(p.lg, env0 + j, lds, lane);
-        }
     }
 }
 
@@ -789,38 +779,99 @@ __global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
 // ballot; for each flagged env the WAVE regenerates the next MT block cooperatively when the current one is nearly
 // used up (the block recurrence is 3 data-parallel phases + 1 word), lane 0 runs the (tiny, sequential) generator
 // of levelgen_core.h on LDS, and the wave writes level, record and RNG state back coalesced.
-// A 512-thread block owns 8 tiles (512 envs).  Every thread looks at its env's flag; flagged envs are compacted
-// into an LDS queue (LDS atomics) and the block's 8 waves pull from it, one level per wave at a time.  Sharing the
-// work over 16 waves matters: resets are Poisson per tile, and with one wave per tile the kernel lasted as long as
-// the unluckiest tile (5-6 levels in a row, 84 us) instead of ~2 levels.
-#define MGX_LG_WAVES 8
+// A 256-thread block owns 2048 envs.  Every thread looks at 8 flags; flagged envs are compacted into an LDS queue (LDS
+// atomics).  FAST PATH, one LANE per level (wave 0): the lane copies the next 32 words of its env's MT19937 block into
+// its own LDS slice and runs the generator of levelgen_core.h there with small buffers (24 paint commands, 8 rivers per
+// axis), paints its level into the slice command by command and stores it.  64 levels advance per wave instruction;
+// the first version of this kernel used one WAVE per level with a single active lane, and its ~1,750 instructions
+// per level made it cost as much as k_step itself (50 us at 8,400 levels per step).  Levels that do not fit the fast
+// path -- grid rows longer than 128 bytes, the read index within 32 words of the end of the block, more than 32 draws,
+// too many commands/rivers -- go to a second LDS queue and are generated afterwards by all 4 waves, one level per
+// wave at a time (levelgen_one: cooperative next-block build, full-size buffers).
 #define MGX_LG_LDS_PER_WAVE (2 * 624 * 4 + 16 + 2 * MGX_LG_WS_WORDS + 8 * MGX_LG_MAX_CMDS)
 static_assert(MGX_LG_LDS_PER_WAVE == MGX_LG_LDS_PER_WAVE_BYTES, "keep mgx_kernels.h in sync");
-__global__ __launch_bounds__(64 * MGX_LG_WAVES, 4) void k_levelgen(const LevelGenParams p)
+#define MGX_LGF_ENVS 2048
+#define MGX_LGF_WIN 32
+#define MGX_LGF_CMDS 24
+#define MGX_LGF_RIVERS 8
+#define MGX_LGF_MAXS 128 /* largest grid row (bytes) painted in a lane slice */
+#define MGX_LGF_SLICE_DW (MGX_LGF_WIN + 2 * MGX_LGF_CMDS + 3 * MGX_LGF_RIVERS + MGX_LGF_MAXS / 4 + 1) /* 137 dwords: odd */
+__global__ __launch_bounds__(256) void k_levelgen(const LevelGenParams p)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    __shared__ uint16_t s_queue[64 * MGX_LG_WAVES];
-    __shared__ int s_count, s_head;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t env_base = (int64_t)blockIdx.x * (64 * MGX_LG_WAVES);
-    if (threadIdx.x == 0) { s_count = 0; s_head = 0; }
+    __shared__ __attribute__((aligned(16))) uint32_t s_slices[64 * MGX_LGF_SLICE_DW]; // 35 KB; reused by the slow path
+    __shared__ uint16_t s_queue[MGX_LGF_ENVS], s_slow[MGX_LGF_ENVS];
+    __shared__ int s_count, s_nslow, s_head;
+    static_assert(sizeof(uint32_t) * 64 * MGX_LGF_SLICE_DW >= 4 * MGX_LG_LDS_PER_WAVE, "the slow path reuses the lane slices");
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t env_base = (int64_t)blockIdx.x * MGX_LGF_ENVS;
+    if (tid == 0) { s_count = 0; s_nslow = 0; s_head = 0; }
     __syncthreads();
-    const int64_t my = env_base + threadIdx.x;
-    if (my < p.n && p.regen[my]) {
-        p.regen[my] = 0;
-        s_queue[atomicAdd(&s_count, 1)] = (uint16_t)threadIdx.x;
+    { // scan 8 flags per thread (the regen array is padded to whole tiles and 2048 is a multiple of 64)
+        const int64_t e0 = env_base + (int64_t)tid * 8;
+        if (e0 < p.n) {
+            uint2 *f2 = reinterpret_cast<uint2 *>(p.regen + e0);
+            const uint2 a = *f2;
+            if (a.x | a.y) {
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                    if ((((i < 4 ? a.x : a.y) >> (8 * (i & 3))) & 255u) && e0 + i < p.n) s_queue[atomicAdd(&s_count, 1)] = (uint16_t)(tid * 8 + i);
+                *f2 = make_uint2(0, 0);
+            }
+        }
     }
     __syncthreads();
     const int count = s_count;
     if (count == 0) return;
-    const int per_wave = MGX_LG_LDS_PER_WAVE;
-    uint8_t *base = smem + (size_t)wv * per_wave;
+    const int W = p.cfg.width, H = p.cfg.height, cells = W * H;
+    if (wv == 0) {
+        uint32_t *slice = s_slices + (size_t)lane * MGX_LGF_SLICE_DW;
+        for (int i = lane; i < ((count + 63) & ~63); i += 64) {
+            if (i >= count) continue;
+            const int64_t env = env_base + s_queue[i];
+            const int idx0 = (int)p.mt_idx[env];
+            bool ok = idx0 + MGX_LGF_WIN <= 624 && p.S <= MGX_LGF_MAXS;
+            if (ok) {
+                const uint32_t *mt = p.mt + env * 624 + idx0;
+#pragma unroll
+                for (int k = 0; k < MGX_LGF_WIN; k++) slice[k] = mt[k];
+                DevRng r;
+                r.buf = slice - idx0; r.idx = idx0; r.limit = idx0 + MGX_LGF_WIN; r.overflow = false;
+                LgLevel L;
+                L.cmds = reinterpret_cast<LgCmd *>(slice + MGX_LGF_WIN); L.ncmd = 0; L.max_cmds = MGX_LGF_CMDS;
+                L.ws = reinterpret_cast<int16_t *>(slice + MGX_LGF_WIN + 2 * MGX_LGF_CMDS); L.max_rivers = MGX_LGF_RIVERS;
+                L.W = W; L.H = H; L.ax = L.ay = -1; L.adir = 0;
+                lg_generate(p.cfg, r, L);
+                ok = !r.overflow && !L.too_big;
+                if (ok) {
+                    // paint command by command into the slice, then one pass of dword stores
+                    uint32_t *img32 = slice + MGX_LGF_WIN + 2 * MGX_LGF_CMDS + 3 * MGX_LGF_RIVERS;
+                    uint8_t *img = reinterpret_cast<uint8_t *>(img32);
+                    for (int k = 0; k < (p.S >> 2); k++) img32[k] = 4 * k + 3 < cells ? 0x01010101u * MGX_CODE_EMPTY : 0u;
+                    for (int c = cells & ~3; c < cells; c++) img[c] = MGX_CODE_EMPTY;
+                    for (int q = 0; q < L.ncmd; q++) {
+                        const LgCmd c = L.cmds[q];
+                        for (int x = c.x0; x <= c.x1; x++)
+                            for (int y = c.y0; y <= c.y1; y++) img[x * H + y] = c.code;
+                    }
+                    uint32_t *dst = reinterpret_cast<uint32_t *>(p.cells0 + env * p.S);
+                    for (int k = 0; k < (p.S >> 2); k++) dst[k] = img32[k];
+                    p.mt_idx[env] = (uint32_t)r.idx;
+                    p.agent0[env] = make_uint2((uint32_t)((L.ax & 255) | ((L.ay & 255) << 8) | ((L.adir & 3) << 16)) | ((uint32_t)MGX_CODE_EMPTY << 24), 0u);
+                }
+            }
+            if (!ok) s_slow[atomicAdd(&s_nslow, 1)] = s_queue[i];
+        }
+    }
+    __syncthreads();
+    const int nslow = s_nslow;
+    if (nslow == 0) return;
+    uint8_t *base = reinterpret_cast<uint8_t *>(s_slices) + (size_t)wv * MGX_LG_LDS_PER_WAVE;
     for (;;) { // wave-uniform
         int i = 0;
         if (lane == 0) i = atomicAdd(&s_head, 1);
         i = __builtin_amdgcn_readfirstlane(i);
-        if (i >= count) break;
-        levelgen_one(p, env_base + s_queue[i], base, lane);
+        if (i >= nslow) break;
+        levelgen_one(p, env_base + s_slow[i], base, lane);
     }
 }
 
@@ -1050,8 +1101,7 @@ __global__ __launch_bounds__(64) void k_read_stats(const MgxCounters *ctr, doubl
 template <int CW, int CH>
 hipError_t launch_sized(const StepParams &p, int mode, dim3 grid, dim3 block, size_t shmem, hipStream_t st)
 {
-    if (mode == 0 && p.fused_levelgen) hipLaunchKernelGGL((k_step<CW, CH, 0, 7, false, true>), grid, block, shmem, st, p);
-    else if (mode == 0) hipLaunchKernelGGL((k_step<CW, CH, 0, 7>), grid, block, shmem, st, p);
+    if (mode == 0) hipLaunchKernelGGL((k_step<CW, CH, 0, 7>), grid, block, shmem, st, p);
     else if (mode == 1) hipLaunchKernelGGL((k_step<CW, CH, 1, 7>), grid, block, shmem, st, p);
     else hipLaunchKernelGGL((k_step_fulldirect<CW, CH>), dim3(p.n_tiles), dim3(256), 0, st, p);
     return hipGetLastError();
@@ -1060,11 +1110,7 @@ hipError_t launch_sized(const StepParams &p, int mode, dim3 grid, dim3 block, si
 template <int CW, int CH>
 hipError_t raise_lds_limit(int mode, int bytes)
 {
-    if (mode == 0) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<CW, CH, 0, 7, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        if (e != hipSuccess) return e;
-        return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<CW, CH, 0, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    }
+    if (mode == 0) return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<CW, CH, 0, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<CW, CH, 1, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
@@ -1118,14 +1164,7 @@ hipError_t mgx_raise_lds_limit(int W, int H, int mode, int bytes, int view, int 
 
 hipError_t mgx_launch_levelgen(const LevelGenParams &p, hipStream_t st)
 {
-    const size_t shmem = MGX_LG_WAVES * MGX_LG_LDS_PER_WAVE;
-    static size_t raised = 0;
-    if (shmem > 64 * 1024 && shmem > raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_levelgen), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        if (e != hipSuccess) return e;
-        raised = shmem;
-    }
-    hipLaunchKernelGGL(k_levelgen, dim3((unsigned)((p.n + 64 * MGX_LG_WAVES - 1) / (64 * MGX_LG_WAVES))), dim3(64 * MGX_LG_WAVES), shmem, st, p);
+    hipLaunchKernelGGL(k_levelgen, dim3((unsigned)((p.n + MGX_LGF_ENVS - 1) / MGX_LGF_ENVS)), dim3(256), 0, st, p);
     return hipGetLastError();
 }
 
