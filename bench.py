@@ -70,7 +70,7 @@ def cpu_baseline(env_id, obs_mode, target_seconds=12.0):
     from oracle.minigrid_oracle import OracleEnvs
 
     cfg = mg.env_config(env_id)
-    n = 2048
+    n = 4096
     grid, agent = mg.generate_levels(env_id, np.arange(n, dtype=np.uint64))
     full = obs_mode.startswith("full")
 
@@ -82,8 +82,8 @@ def cpu_baseline(env_id, obs_mode, target_seconds=12.0):
         steps = orc.rollout(acts, with_obs=not full, full=full)
         return steps, time.perf_counter() - t0
 
-    steps, dt = run(32)                       # calibrate
-    T = int(max(32, min(20000, 32 * target_seconds / max(dt, 1e-6))))
+    steps, dt = run(64)                       # calibrate
+    T = int(max(64, min(100000, 64 * target_seconds / max(dt, 1e-6))))
     steps, dt = run(T)
     return {"value": steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
             "sample": "%s, %d envs x %d steps (%.1f s), oracle/minigrid_oracle.c single thread, same action stream; "

@@ -67,7 +67,6 @@ struct mgx_env_s {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool profiling = false;
     int64_t prof_launches = 0, steps_total = 0;
-    bool faults_cleared_base_set = false;
     unsigned long long base_bad_act = 0, base_oob = 0;
 };
 
@@ -83,8 +82,19 @@ int ensure(Staging &s, size_t bytes)
     return MGX_OK;
 }
 
-// Is `p` device memory we can hand to a kernel directly?
+// Is `p` device memory we can hand to a kernel directly?  A VecEnv loop passes the same few buffers every step, so
+// the last answers are remembered (hipPointerGetAttributes costs ~1 us per call).
+bool is_device_ptr_query(const void *p);
 bool is_device_ptr(const void *p)
+{
+    static thread_local struct { const void *p; bool dev; } cache[8] = {};
+    static thread_local unsigned next = 0;
+    for (auto &c : cache) if (c.p == p && p) return c.dev;
+    const bool d = is_device_ptr_query(p);
+    cache[next++ & 7] = {p, d};
+    return d;
+}
+bool is_device_ptr_query(const void *p)
 {
     hipPointerAttribute_t a;
     memset(&a, 0, sizeof a);
@@ -230,6 +240,8 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     int need = 64 * h->LS;
     if (obs_img > need) need = obs_img;
     if (!h->partial) need = ((need + 15) & ~15) + 3072; // + transpose scratch of emit_full_obs
+    h->kernel_mode = h->partial ? 0 : ((h->cells % 4 == 0 && h->cells <= 65535) ? 2 : 1);
+    if (h->kernel_mode == 2) need = 16; // k_step_fulldirect keeps no tile image in LDS
     h->wave_lds = (need + 15) & ~15;
     // a family that draws no random numbers (Empty with a fixed start) has only one level: nothing to generate
     const bool uses_rng = cfg->level_kind != MGX_LEVEL_NONE && !(cfg->level_kind == MGX_LEVEL_EMPTY && cfg->level_arg0 == 0);
@@ -237,7 +249,6 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     h->stream_mode = cfg->new_level_each_episode && uses_rng;
     h->tri_bytes = h->partial ? view * view * 3 : (int64_t)h->cells * 3;
     h->obs_bytes = h->oh_nc < 0 ? h->tri_bytes : h->tri_bytes / 3 * (11 + h->oh_nc + h->oh_ns);
-    h->kernel_mode = h->partial ? 0 : ((h->cells % 4 == 0 && h->cells <= 65535) ? 2 : 1);
     const int LDS_DEFAULT = 64 * 1024, LDS_MAX = 160 * 1024;
     if (h->wave_lds > LDS_MAX) {
         int rc = mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_create: a %dx%d tile (64 envs) needs %d B of LDS > %d", h->W, h->H, h->wave_lds, LDS_MAX);
@@ -538,6 +549,17 @@ extern "C" int mgx_observe(mgx_handle h, uint8_t *obs)
     if (rc) return rc;
     if (!obs) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_observe: obs is required");
     return run_step(h, false, nullptr, obs, nullptr, nullptr);
+}
+
+extern "C" int mgx_get_direction(mgx_handle h, uint8_t *direction)
+{
+    int rc = check_handle(h, "mgx_get_direction");
+    if (rc) return rc;
+    if (!direction) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_get_direction: null argument");
+    OutArg o;
+    if ((rc = dev_out(h, 3, direction, (size_t)h->n, &o))) return rc;
+    HIP_TRY(mgx_launch_direction(h->agent_d, (uint8_t *)o.dev, h->n, h->stream));
+    return finish_out(h, &o, 1);
 }
 
 extern "C" int mgx_reset(mgx_handle h, const uint64_t *seeds, const uint8_t *mask, uint8_t *obs)

@@ -79,6 +79,7 @@ hipError_t mgx_launch_consume(const ConsumeParams &p, hipStream_t st);
 hipError_t mgx_launch_step(const StepParams &p, int mode, int waves_per_block, hipStream_t st);
 hipError_t mgx_raise_lds_limit(int W, int H, int mode, int bytes, int view, int alt_vis);
 hipError_t mgx_launch_onehot(const uint8_t *tri, uint8_t *out, int64_t n_cells, int nc, int ns, hipStream_t st);
+hipError_t mgx_launch_direction(const uint2 *rec, uint8_t *out, int64_t n, hipStream_t st);
 hipError_t mgx_launch_pack(const PackParams &p, hipStream_t st);
 hipError_t mgx_launch_unpack(const PackParams &p, hipStream_t st);
 hipError_t mgx_launch_fill_actions(uint8_t *out, uint64_t seed, int64_t env0, int64_t t0, int64_t n, int64_t T, hipStream_t st);

@@ -1192,6 +1192,20 @@ hipError_t mgx_launch_onehot(const uint8_t *tri, uint8_t *out, int64_t n_cells, 
     return hipGetLastError();
 }
 
+namespace {
+__global__ __launch_bounds__(256) void k_direction(const uint2 *__restrict__ rec, uint8_t *__restrict__ out, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (uint8_t)((rec[i].x >> 16) & 3u);
+}
+} // namespace
+
+hipError_t mgx_launch_direction(const uint2 *rec, uint8_t *out, int64_t n, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_direction, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rec, out, n);
+    return hipGetLastError();
+}
+
 hipError_t mgx_launch_pack(const PackParams &p, hipStream_t st)
 {
     const int64_t total = p.n * (int64_t)p.S;

@@ -182,6 +182,15 @@ class VecMiniGrid:
         _lib.check(_lib.lib().mgx_observe(self._h, _ptr(self._obs)))
         return self._obs
 
+    def direction(self):
+        """obs['direction'] of the reference (minigrid.py:1375-1379): agent_dir per env, uint8 (N,)."""
+        if getattr(self, "_dir", None) is None:
+            self._dir = self._new((self.num_envs,), "uint8")
+        if self._torch is not None:
+            self._bind_stream()
+        _lib.check(_lib.lib().mgx_get_direction(self._h, _ptr(self._dir)))
+        return self._dir
+
     # ------------------------------------------------------------------ state injection / inspection
     def set_state(self, grid, agent, aux=None, carry=None, steps=None):
         """Reference-encoded state (host numpy arrays): grid (N,W,H,3) u8, agent (N,3) i32, aux (N,W,H) u8,

@@ -154,6 +154,9 @@ int mgx_get_state(mgx_handle h, uint8_t *grid, uint8_t *aux, int32_t *agent, uin
 /* gen_obs() of the current state, no transition. */
 int mgx_observe(mgx_handle h, uint8_t *obs);
 
+/* obs['direction'] (minigrid.py:1375-1379): agent_dir of every env, uint8 [N]. */
+int mgx_get_direction(mgx_handle h, uint8_t *direction);
+
 /* One lockstep env.step(actions[i]) for all N envs.  reward / done may be NULL. */
 int mgx_step(mgx_handle h, const uint8_t *actions, uint8_t *obs, float *reward, uint8_t *done);
 

@@ -53,6 +53,7 @@ def test_golden_trace_no_autoreset(name, backend):
         assert np.array_equal(rew, z["reward"][sel, t].astype(np.float32)), (name, t)
         assert np.array_equal(done, z["done"][sel, t]), (name, t)
         if t % every == 0 or done.any():
+            assert np.array_equal(to_np(env.direction()), z["direction"][sel, t]), (name, t)
             check_state(env, z["grid"][sel, t], z["agent"][sel, t], z["carry"][sel, t], z["steps"][sel, t], where=(name, t))
         if done.any():  # caller-side reset: the recorded post-reset state (== episode start when re-seeded)
             st = env.get_state()
@@ -306,3 +307,52 @@ def test_alt_visibility_vs_oracle(view):
         assert np.array_equal(to_np(obs), want), t
         assert np.array_equal(to_np(done), odone)
     env.close()
+
+
+@pytest.mark.parametrize("N", [1, 2, 63, 64, 65, 127, 129])
+def test_ragged_batch_sizes(N):
+    """Every tail-tile shape of the batch dimension, partial and full observations."""
+    for mode, W, H in (("partial", 8, 8), ("full", 8, 8), ("full", 9, 7), ("partial", 6, 11)):
+        grid, aux, agent, carry, steps = random_states(N, W, H, seed=N + W)
+        orc = make_oracle(W, H, 13, False, False, grid, aux, agent, carry, steps)
+        env = mg.VecMiniGrid(config=cfg_from(W, H, 13, False), num_envs=N, obs_mode=mode, auto_reset=True, backend="torch")
+        env.set_state(grid, agent, aux=aux, carry=carry, steps=steps)
+        rs = np.random.RandomState(N)
+        for t in range(20):
+            a = rs.randint(0, 7, size=N).astype(np.uint8)
+            obs, rew, done, _ = env.step(a)
+            oo, of, orew, odone = orc.step(a, full=True)
+            orc.reset_where(odone)
+            ro = orc.observe(full=True)
+            full = mode == "full"
+            want = np.where(odone.astype(bool)[:, None, None, None], ro[1] if full else ro[0], of if full else oo)
+            assert np.array_equal(to_np(obs), want) and np.array_equal(to_np(done), odone)
+        env.close()
+
+
+def test_largest_grids():
+    """50x50 is about the largest tile (64 envs x 2,504 B) that fits one wave's 160 KiB of LDS; beyond that the partial
+    view is refused loudly, while FullyObs (no LDS image when W*H % 4 == 0) still works."""
+    W = H = 50
+    N = 70
+    grid, aux, agent, carry, steps = random_states(N, W, H, seed=5, density=0.2)
+    orc = make_oracle(W, H, 9, False, False, grid, aux, agent, carry, steps)
+    env = mg.VecMiniGrid(config=cfg_from(W, H, 9, False), num_envs=N, auto_reset=True, backend="torch")
+    env.set_state(grid, agent, aux=aux, carry=carry, steps=steps)
+    rs = np.random.RandomState(0)
+    for t in range(12):
+        a = rs.randint(0, 7, size=N).astype(np.uint8)
+        obs, rew, done, _ = env.step(a)
+        oo, orew, odone = orc.step(a)
+        orc.reset_where(odone)
+        want = np.where(odone.astype(bool)[:, None, None, None], orc.observe(), oo)
+        assert np.array_equal(to_np(obs), want)
+    env.close()
+    with pytest.raises(mg.MgxError):
+        mg.VecMiniGrid(config=cfg_from(60, 60, 9, False), num_envs=4, backend="numpy")
+    big = mg.VecMiniGrid(config=cfg_from(60, 60, 9, False), num_envs=5, obs_mode="full", auto_reset=False, backend="numpy")
+    g2, x2, ag2, c2, s2 = random_states(5, 60, 60, seed=1, density=0.1)
+    big.set_state(g2, ag2, aux=x2)
+    o2 = make_oracle(60, 60, 9, False, False, g2, x2, ag2)
+    assert np.array_equal(big.observe(), o2.observe(full=True)[1])
+    big.close()
