@@ -130,6 +130,9 @@ int check_levelgen_cfg(const mgx_config *cfg, const char *fn)
     if (W < 3 || H < 3 || W > 255 || H > 255) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: grid %dx%d outside 3..255", fn, W, H);
     switch (cfg->level_kind) {
     case MGX_LEVEL_EMPTY: break;
+    case MGX_LEVEL_DISTSHIFT:
+        if (cfg->level_arg0 < 1 || cfg->level_arg0 > H - 2) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: DistShift strip2_row %d outside the room", fn, cfg->level_arg0);
+        break;
     case MGX_LEVEL_DOORKEY:
         if (W < 5 || H < 5) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: DoorKey needs at least 5x5", fn);
         break;
@@ -176,6 +179,7 @@ const std::vector<EnvId> &registry()
         {"MiniGrid-DoorKey-16x16-v0", mk(16, 16, 2560, 0, 0, MGX_LEVEL_DOORKEY, 0, 0)},
         // CrossingEnv: max_steps = 4*size^2 (envs/crossing.py:12-22,94-172)
         {"MiniGrid-LavaCrossingS9N1-v0", mk(9, 9, 324, 0, 0, MGX_LEVEL_CROSSING, 1, 9)},
+        {"MiniGrid-LavaCrossingS9N0-v0", mk(9, 9, 324, 0, 0, MGX_LEVEL_CROSSING, 1, 9 + 16 * 2)}, // LavaCrossingEnvVert: ori=1
         {"MiniGrid-LavaCrossingS9N2-v0", mk(9, 9, 324, 0, 0, MGX_LEVEL_CROSSING, 2, 9)},
         {"MiniGrid-LavaCrossingS9N3-v0", mk(9, 9, 324, 0, 0, MGX_LEVEL_CROSSING, 3, 9)},
         {"MiniGrid-LavaCrossingS11N5-v0", mk(11, 11, 484, 0, 0, MGX_LEVEL_CROSSING, 5, 9)},
@@ -183,6 +187,10 @@ const std::vector<EnvId> &registry()
         {"MiniGrid-SimpleCrossingS9N2-v0", mk(9, 9, 324, 0, 0, MGX_LEVEL_CROSSING, 2, 2)},
         {"MiniGrid-SimpleCrossingS9N3-v0", mk(9, 9, 324, 0, 0, MGX_LEVEL_CROSSING, 3, 2)},
         {"MiniGrid-SimpleCrossingS11N5-v0", mk(11, 11, 484, 0, 0, MGX_LEVEL_CROSSING, 5, 2)},
+        // DistShiftEnv: 7x7 in this fork, max_steps = 4*W*H, see_through_walls=True; class DistShiftv1 has 'v1' in its name
+        {"MiniGrid-DistShift1-v0", mk(7, 7, 196, 1, 0, MGX_LEVEL_DISTSHIFT, 2, 0)},
+        {"MiniGrid-DistShift1-v1", mk(7, 7, 196, 1, 1, MGX_LEVEL_DISTSHIFT, 2, 0)},
+        {"MiniGrid-DistShift2-v0", mk(7, 7, 196, 1, 0, MGX_LEVEL_DISTSHIFT, 5, 0)},
         // LavaGapEnv: max_steps = 4*size^2; 'v1' classes are const-gap AND change lava semantics
         // (envs/lavagap.py:10-19,62-85; minigrid.py:1263)
         {"MiniGrid-LavaGapS5-v0", mk(5, 5, 100, 0, 0, MGX_LEVEL_LAVAGAP, 0, 9)},

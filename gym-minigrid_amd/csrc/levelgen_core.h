@@ -154,7 +154,8 @@ template <class R>
 LG_FN void lg_gen_crossing(const mgx_config &c, R &r, LgLevel &L)
 {
     const int W = L.W, H = L.H, ncross = c.level_arg0;
-    const uint32_t obst = c.level_arg1 == 2 ? (uint32_t)MGX_CODE_WALL_GREY : (uint32_t)MGX_CODE_LAVA;
+    const uint32_t obst = (c.level_arg1 & 15) == 2 ? (uint32_t)MGX_CODE_WALL_GREY : (uint32_t)MGX_CODE_LAVA;
+    const int ori = c.level_arg1 >> 4; // 0 = both (ori=2), 1 = horizontal rivers only (ori=0), 2 = vertical only (ori=1)
     lg_room(L);
     L.ax = 1; L.ay = 1; L.adir = 0;
     // candidate rivers: (v, i) for i in range(2, H-2, 2) then (h, j) for j in range(2, W-2, 2); bit 8 = vertical
@@ -162,8 +163,8 @@ LG_FN void lg_gen_crossing(const mgx_config &c, R &r, LgLevel &L)
     if ((H - 3) / 2 > MR || (W - 3) / 2 > MR) { L.too_big = true; return; }
     int16_t *riv = L.ws, *rv = L.ws + 2 * MR, *rh = L.ws + 3 * MR, *path = L.ws + 4 * MR;
     int n = 0;
-    for (int i = 2; i < H - 2; i += 2) riv[n++] = (int16_t)(0x100 | i);
-    for (int j = 2; j < W - 2; j += 2) riv[n++] = (int16_t)j;
+    if (ori != 1) for (int i = 2; i < H - 2; i += 2) riv[n++] = (int16_t)(0x100 | i);
+    if (ori != 2) for (int j = 2; j < W - 2; j += 2) riv[n++] = (int16_t)j;
     for (int i = n - 1; i >= 1; i--) { // np_random.shuffle(list): j = bounded(i), swap
         const int j = (int)lg_bounded(r, (uint32_t)i);
         const int16_t t = riv[i]; riv[i] = riv[j]; riv[j] = t;
@@ -205,7 +206,7 @@ template <class R>
 LG_FN void lg_gen_lavagap(const mgx_config &c, R &r, LgLevel &L)
 {
     const int W = L.W, H = L.H;
-    const uint32_t obst = c.level_arg1 == 2 ? (uint32_t)MGX_CODE_WALL_GREY : (uint32_t)MGX_CODE_LAVA;
+    const uint32_t obst = (c.level_arg1 & 15) == 2 ? (uint32_t)MGX_CODE_WALL_GREY : (uint32_t)MGX_CODE_LAVA;
     lg_room(L);
     L.ax = 1; L.ay = 1; L.adir = 0;
     int gx, gy;
@@ -215,8 +216,26 @@ LG_FN void lg_gen_lavagap(const mgx_config &c, R &r, LgLevel &L)
     lg_set(L, gx, gy, MGX_CODE_EMPTY);
 }
 
+// DistShiftEnv._gen_grid (envs/distshift.py:30-52): goal at (W-2, 1), two lava strips of W-6 cells from x = 3 in rows 1
+// and strip2_row (level_arg0), agent (1,1) facing right.  No randomness.
+template <class R>
+LG_FN void lg_gen_distshift(const mgx_config &c, R &, LgLevel &L)
+{
+    L.ncmd = 0;
+    lg_rect(L, 0, 0, L.W - 1, 0, MGX_CODE_WALL_GREY);
+    lg_rect(L, 0, L.H - 1, L.W - 1, L.H - 1, MGX_CODE_WALL_GREY);
+    lg_rect(L, 0, 0, 0, L.H - 1, MGX_CODE_WALL_GREY);
+    lg_rect(L, L.W - 1, 0, L.W - 1, L.H - 1, MGX_CODE_WALL_GREY);
+    lg_set(L, L.W - 2, 1, MGX_CODE_GOAL_GREEN);
+    if (L.W > 6) {
+        lg_rect(L, 3, 1, L.W - 4, 1, MGX_CODE_LAVA);
+        lg_rect(L, 3, c.level_arg0, L.W - 4, c.level_arg0, MGX_CODE_LAVA);
+    }
+    L.ax = 1; L.ay = 1; L.adir = 0;
+}
+
 // true if the family draws random numbers (Empty with a fixed start does not)
-LG_FN bool lg_uses_rng(const mgx_config &c) { return !(c.level_kind == MGX_LEVEL_EMPTY && c.level_arg0 == 0); }
+LG_FN bool lg_uses_rng(const mgx_config &c) { return !(c.level_kind == MGX_LEVEL_EMPTY && c.level_arg0 == 0) && c.level_kind != MGX_LEVEL_DISTSHIFT; }
 
 template <class R>
 LG_FN void lg_generate(const mgx_config &c, R &r, LgLevel &L)
@@ -225,6 +244,7 @@ LG_FN void lg_generate(const mgx_config &c, R &r, LgLevel &L)
     case MGX_LEVEL_EMPTY: lg_gen_empty(c, r, L); break;
     case MGX_LEVEL_DOORKEY: lg_gen_doorkey(c, r, L); break;
     case MGX_LEVEL_CROSSING: lg_gen_crossing(c, r, L); break;
+    case MGX_LEVEL_DISTSHIFT: lg_gen_distshift(c, r, L); break;
     default: lg_gen_lavagap(c, r, L); break;
     }
 }

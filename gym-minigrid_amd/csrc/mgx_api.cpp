@@ -244,7 +244,8 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     if (h->kernel_mode == 2) need = 16; // k_step_fulldirect keeps no tile image in LDS
     h->wave_lds = (need + 15) & ~15;
     // a family that draws no random numbers (Empty with a fixed start) has only one level: nothing to generate
-    const bool uses_rng = cfg->level_kind != MGX_LEVEL_NONE && !(cfg->level_kind == MGX_LEVEL_EMPTY && cfg->level_arg0 == 0);
+    const bool uses_rng = cfg->level_kind != MGX_LEVEL_NONE && cfg->level_kind != MGX_LEVEL_DISTSHIFT &&
+                          !(cfg->level_kind == MGX_LEVEL_EMPTY && cfg->level_arg0 == 0);
     h->device_levels = uses_rng && h->cells <= 4096;
     h->stream_mode = cfg->new_level_each_episode && uses_rng;
     h->tri_bytes = h->partial ? view * view * 3 : (int64_t)h->cells * 3;

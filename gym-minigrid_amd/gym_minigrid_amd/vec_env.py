@@ -23,7 +23,8 @@ MISSIONS = {1: "get to the green goal square",
             3: {9: "avoid the lava and get to the green goal square",
                 2: "find the opening and get to the green goal square"},
             4: {9: "avoid the lava and get to the green goal square",
-                2: "find the opening and get to the green goal square"}}
+                2: "find the opening and get to the green goal square"},
+            5: "get to the green goal square"}
 
 
 def _ptr(a):
@@ -90,7 +91,7 @@ class VecMiniGrid:
         self.observation_space = Dict({"image": Box(0, 255, self.obs_shape, "uint8")})
         self.reward_range = (0, 1)
         m = MISSIONS.get(cfg.level_kind, "")
-        self.mission = m.get(cfg.level_arg1, "") if isinstance(m, dict) else m
+        self.mission = m.get(cfg.level_arg1 & 15, "") if isinstance(m, dict) else m
         self._h = ctypes.c_void_p()
         _lib.check(L.mgx_create(ctypes.byref(cfg), self.num_envs, self.device, ctypes.byref(self._h)))
         self._torch = None

@@ -16,7 +16,8 @@
  *   mgx_step                   step(action)                       minigrid.py:1227-1325
  *                              (+ FullyObsWrapper.observation     wrappers.py:326-338 when obs_mode = MGX_OBS_FULL)
  *   mgx_generate_levels        _gen_grid of the built-in families envs/empty.py:30-57, envs/doorkey.py:15-44,
- *                                                                 envs/crossing.py:24-92, envs/lavagap.py:21-59
+ *                                                                 envs/crossing.py:24-92, envs/lavagap.py:21-59,
+ *                                                                 envs/distshift.py:30-52
  *
  * Conventions
  *   - every function returns 0 (MGX_OK) or a negative mgx_status; mgx_last_error()
@@ -80,8 +81,10 @@ typedef enum {
     MGX_LEVEL_NONE = 0,     /* state is injected with mgx_set_state only */
     MGX_LEVEL_EMPTY = 1,    /* EmptyEnv: level_arg0 = 1 -> random agent start (Empty-Random-*), arg1 = sizetop (0 = none) */
     MGX_LEVEL_DOORKEY = 2,  /* DoorKeyEnv */
-    MGX_LEVEL_CROSSING = 3, /* CrossingEnv: level_arg0 = num_crossings, level_arg1 = obstacle type (9 lava, 2 wall) */
-    MGX_LEVEL_LAVAGAP = 4   /* LavaGapEnv:  level_arg0 = const gap column (0/1), level_arg1 = obstacle type */
+    MGX_LEVEL_CROSSING = 3, /* CrossingEnv: level_arg0 = num_crossings, level_arg1 = obstacle type (9 lava, 2 wall)
+                               + 16 * (0 both river directions, 1 horizontal only (ori=0), 2 vertical only (ori=1)) */
+    MGX_LEVEL_LAVAGAP = 4,  /* LavaGapEnv:  level_arg0 = const gap column (0/1), level_arg1 = obstacle type */
+    MGX_LEVEL_DISTSHIFT = 5 /* DistShiftEnv (envs/distshift.py): level_arg0 = strip2_row; no randomness */
 } mgx_level_kind;
 
 typedef struct {

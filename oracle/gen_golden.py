@@ -381,6 +381,12 @@ def record_levels():
                           ("MiniGrid-DoorKey-5x5-v0", range(64)), ("MiniGrid-DoorKey-6x6-v0", range(64)),
                           ("MiniGrid-DoorKey-8x8-v0", range(256)), ("MiniGrid-DoorKey-16x16-v0", range(32)),
                           ("MiniGrid-LavaCrossingS9N1-v0", range(256)), ("MiniGrid-LavaCrossingS9N2-v0", range(64)),
+                          ("MiniGrid-LavaCrossingS9N0-v0", range(64)), ("MiniGrid-DistShift1-v0", range(2)),
+                          ("MiniGrid-DistShift1-v1", range(2)), ("MiniGrid-DistShift2-v0", range(2)),
+                          ("MiniGrid-LavaGapS5-v0", range(32)), ("MiniGrid-LavaGapS7-v0", range(64)),
+                          ("MiniGrid-NormalGapS6-v0", range(32)), ("MiniGrid-LavaGapS6-v1", range(32)),
+                          ("MiniGrid-Empty-Random-5x5-v0", range(32)), ("MiniGrid-Empty-Random-8x8-v0", range(32)),
+                          ("MiniGrid-Empty-Random-10x10-v0", range(32)),
                           ("MiniGrid-LavaCrossingS9N3-v0", range(64)), ("MiniGrid-LavaCrossingS11N5-v0", range(64)),
                           ("MiniGrid-SimpleCrossingS9N1-v0", range(64)), ("MiniGrid-SimpleCrossingS9N2-v0", range(64)),
                           ("MiniGrid-SimpleCrossingS9N3-v0", range(64)), ("MiniGrid-SimpleCrossingS11N5-v0", range(64))]:
@@ -393,7 +399,8 @@ def record_levels():
             env.reset()
             grids.append(env.grid.encode())
             agents.append((env.agent_pos[0], env.agent_pos[1], env.agent_dir))
-        key = env_id.replace("MiniGrid-", "").replace("-v0", "")
+        key = env_id.replace("MiniGrid-", "")
+        key = key[:-3] if key.endswith("-v0") else key
         out[key + ":seeds"] = np.asarray(ss, np.uint64)
         out[key + ":grid"] = np.asarray(grids, np.uint8)
         out[key + ":agent"] = np.asarray(agents, np.int32)
@@ -433,6 +440,9 @@ def main():
     record_case("Soup-13x6-full", lambda: SoupEnv(13, 6, False, 80, 0.3), list(range(6)), 170, full_obs=True)
     record_case("Soup-9x9-v1", lambda: SoupEnvv1(9, 9, False, 100, 0.35), list(range(6)), 200, v1=True)
     record_case("Soup-19x19", lambda: SoupEnv(19, 19, False, 150, 0.25), list(range(3)), 300)
+    record_case("DistShift1-v1", mk("MiniGrid-DistShift1-v1"), [0, 1], 260, v1=True)
+    record_case("DistShift2", mk("MiniGrid-DistShift2-v0"), [0, 1], 260)
+    record_case("LavaCrossingS9N0", mk("MiniGrid-LavaCrossingS9N0-v0"), [0, 1, 2, 3], 200)
     # other view sizes (ViewSizeWrapper, wrappers.py:579-608: sets env.unwrapped.agent_view_size)
     def vs(make, v):
         def f():

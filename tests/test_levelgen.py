@@ -7,12 +7,14 @@ import gym_minigrid_amd as mg
 
 IDS = ["Empty-8x8", "Empty-16x16", "Empty-5x5", "Empty-6x6", "DoorKey-5x5", "DoorKey-6x6", "DoorKey-8x8",
        "DoorKey-16x16", "LavaCrossingS9N1", "LavaCrossingS9N2", "LavaCrossingS9N3", "LavaCrossingS11N5",
-       "SimpleCrossingS9N1", "SimpleCrossingS9N2", "SimpleCrossingS9N3", "SimpleCrossingS11N5"]
+       "SimpleCrossingS9N1", "SimpleCrossingS9N2", "SimpleCrossingS9N3", "SimpleCrossingS11N5",
+       "LavaCrossingS9N0", "DistShift1", "DistShift1-v1", "DistShift2", "LavaGapS5", "LavaGapS7", "NormalGapS6",
+       "LavaGapS6-v1", "Empty-Random-5x5", "Empty-Random-8x8", "Empty-Random-10x10"]
 
 
 @pytest.mark.parametrize("key", IDS)
 def test_levels_match_reference(levels, key):
-    env_id = "MiniGrid-%s-v0" % key
+    env_id = "MiniGrid-%s" % key if key.endswith("-v1") else "MiniGrid-%s-v0" % key
     seeds = levels[key + ":seeds"]
     grid, agent = mg.generate_levels(env_id, seeds)
     assert np.array_equal(grid, levels[key + ":grid"])
