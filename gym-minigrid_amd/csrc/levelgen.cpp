@@ -130,6 +130,12 @@ int check_levelgen_cfg(const mgx_config *cfg, const char *fn)
     if (W < 3 || H < 3 || W > 255 || H > 255) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: grid %dx%d outside 3..255", fn, W, H);
     switch (cfg->level_kind) {
     case MGX_LEVEL_EMPTY: break;
+    case MGX_LEVEL_MULTIROOM: {
+        const int mn = cfg->level_arg0 & 255, mx = (cfg->level_arg0 >> 8) & 255;
+        if (mn < 1 || mx < mn || mx > 8 || cfg->level_arg1 < 4 || W != H)
+            return mgx_fail(MGX_ERR_INVALID_ARG, "%s: MultiRoom needs 1 <= minNumRooms <= maxNumRooms <= 8, maxRoomSize >= 4, square grid", fn);
+        break;
+    }
     case MGX_LEVEL_DISTSHIFT:
         if (cfg->level_arg0 < 1 || cfg->level_arg0 > H - 2) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: DistShift strip2_row %d outside the room", fn, cfg->level_arg0);
         break;
@@ -187,6 +193,10 @@ const std::vector<EnvId> &registry()
         {"MiniGrid-SimpleCrossingS9N2-v0", mk(9, 9, 324, 0, 0, MGX_LEVEL_CROSSING, 2, 2)},
         {"MiniGrid-SimpleCrossingS9N3-v0", mk(9, 9, 324, 0, 0, MGX_LEVEL_CROSSING, 3, 2)},
         {"MiniGrid-SimpleCrossingS11N5-v0", mk(11, 11, 484, 0, 0, MGX_LEVEL_CROSSING, 5, 2)},
+        // MultiRoomEnv: 25x25, max_steps = maxNumRooms*20 (envs/multiroom.py:36-39,223-246)
+        {"MiniGrid-MultiRoom-N2-S4-v0", mk(25, 25, 40, 0, 0, MGX_LEVEL_MULTIROOM, 2 | (2 << 8), 4)},
+        {"MiniGrid-MultiRoom-N4-S5-v0", mk(25, 25, 80, 0, 0, MGX_LEVEL_MULTIROOM, 4 | (4 << 8), 5)},
+        {"MiniGrid-MultiRoom-N6-v0", mk(25, 25, 120, 0, 0, MGX_LEVEL_MULTIROOM, 6 | (6 << 8), 10)},
         // DistShiftEnv: 7x7 in this fork, max_steps = 4*W*H, see_through_walls=True; class DistShiftv1 has 'v1' in its name
         {"MiniGrid-DistShift1-v0", mk(7, 7, 196, 1, 0, MGX_LEVEL_DISTSHIFT, 2, 0)},
         {"MiniGrid-DistShift1-v1", mk(7, 7, 196, 1, 1, MGX_LEVEL_DISTSHIFT, 2, 0)},

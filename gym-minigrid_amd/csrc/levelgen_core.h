@@ -234,6 +234,119 @@ LG_FN void lg_gen_distshift(const mgx_config &c, R &, LgLevel &L)
     L.ax = 1; L.ay = 1; L.adir = 0;
 }
 
+// MultiRoomEnv._gen_grid / _placeRoom (envs/multiroom.py:40-219).  level_arg0 = minNumRooms | maxNumRooms << 8,
+// level_arg1 = maxRoomSize.  The reference's recursion never removes a placed room and a parent stops at its first
+// successful child, so it is a plain chain: place room 0, then up to 8 tries to attach the next room to the last one,
+// and so on; a chain that ends early is retried from scratch and the longest one wins (multiroom.py:46-66).
+// Rooms live in L.ws as 6 words each (topX, topY, sizeX, sizeY, entryX, entryY): two lists of up to 8 rooms.
+template <class R>
+LG_FN int lg_multiroom_chain(R &r, LgLevel &L, int16_t *rooms, int numRooms, int maxSz)
+{
+    const int W = L.W, H = L.H;
+    int n = 0;
+    int entryWall = 2;
+    int ex = lg_randint(r, 0, W - 2), ey = lg_randint(r, 0, W - 2);
+    int tries = 0;
+    for (;;) {
+        // _placeRoom: size, position relative to the entry door, bounds, overlap with all rooms but the parent
+        const int sx = lg_randint(r, 4, maxSz + 1), sy = lg_randint(r, 4, maxSz + 1);
+        int tx, ty;
+        if (n == 0) { tx = ex; ty = ey; }
+        else if (entryWall == 0) { tx = ex - sx + 1; ty = lg_randint(r, ey - sy + 2, ey); }
+        else if (entryWall == 1) { tx = lg_randint(r, ex - sx + 2, ex); ty = ey - sy + 1; }
+        else if (entryWall == 2) { tx = ex; ty = lg_randint(r, ey - sy + 2, ey); }
+        else { tx = lg_randint(r, ex - sx + 2, ex); ty = ey; }
+        bool ok = !(tx < 0 || ty < 0) && !(tx + sx > W || ty + sy >= H);
+        for (int k = 0; ok && k < n - 1; k++) {
+            const int16_t *q = rooms + 6 * k;
+            const bool nonOverlap = tx + sx < q[0] || q[0] + q[2] <= tx || ty + sy < q[1] || q[1] + q[3] <= ty;
+            if (!nonOverlap) ok = false;
+        }
+        if (!r.alive()) return n;
+        if (ok) {
+            int16_t *q = rooms + 6 * n;
+            q[0] = (int16_t)tx; q[1] = (int16_t)ty; q[2] = (int16_t)sx; q[3] = (int16_t)sy; q[4] = (int16_t)ex; q[5] = (int16_t)ey;
+            n++;
+            tries = 0;
+            if (n == numRooms) return n; // numLeft == 1
+        } else {
+            if (n == 0) return 0;        // the first room did not fit: the caller starts over
+            if (++tries == 8) return n;  // the parent gives up after 8 exit doors
+        }
+        // parent = last placed room: pick the exit wall (not its entry wall) and the exit door on it
+        const int16_t *pr = rooms + 6 * (n - 1);
+        const int pEntryWall = (n == 1) ? 2 : L.ws[96 + n - 1]; // entry wall of each placed room, kept behind the lists
+        int walls[3], nw = 0;
+        for (int w = 0; w < 4; w++) if (w != pEntryWall) walls[nw++] = w;
+        const int exitWall = walls[lg_randint(r, 0, 3)];
+        entryWall = (exitWall + 2) % 4;
+        if (exitWall == 0) { ex = pr[0] + pr[2] - 1; ey = pr[1] + lg_randint(r, 1, pr[3] - 1); }
+        else if (exitWall == 1) { ex = pr[0] + lg_randint(r, 1, pr[2] - 1); ey = pr[1] + pr[3] - 1; }
+        else if (exitWall == 2) { ex = pr[0]; ey = pr[1] + lg_randint(r, 1, pr[3] - 1); }
+        else { ex = pr[0] + lg_randint(r, 1, pr[2] - 1); ey = pr[1]; }
+        L.ws[96 + n] = (int16_t)entryWall; // becomes the entry wall of room n if it gets placed
+    }
+}
+
+template <class R>
+LG_FN void lg_gen_multiroom(const mgx_config &c, R &r, LgLevel &L)
+{
+    const int minRooms = c.level_arg0 & 255, maxRooms = (c.level_arg0 >> 8) & 255, maxSz = c.level_arg1;
+    L.ncmd = 0;
+    if (6 * L.max_rivers < 96 + 8 || maxRooms > 8) { L.too_big = true; return; } // needs the full-size workspace
+    int16_t *best = L.ws, *cur = L.ws + 48;
+    const int numRooms = lg_randint(r, minRooms, maxRooms + 1);
+    int nbest = 0;
+    while (nbest < numRooms) {
+        const int n = lg_multiroom_chain(r, L, cur, numRooms, maxSz);
+        if (!r.alive()) return;
+        if (n > nbest) { for (int i = 0; i < 6 * n; i++) best[i] = cur[i]; nbest = n; }
+    }
+    // draw: walls of every room, then (from the second room on) its entry door in a colour other than the previous door's
+    const int sortedColors[7] = {2, 1, 5, 3, 0, 6, 4}; // sorted(COLOR_NAMES): blue green grey purple red white yellow
+    int prevColor = -1;
+    for (int i = 0; i < nbest; i++) {
+        const int16_t *q = best + 6 * i;
+        lg_rect(L, q[0], q[1], q[0] + q[2] - 1, q[1], MGX_CODE_WALL_GREY);
+        lg_rect(L, q[0], q[1] + q[3] - 1, q[0] + q[2] - 1, q[1] + q[3] - 1, MGX_CODE_WALL_GREY);
+        lg_rect(L, q[0], q[1], q[0], q[1] + q[3] - 1, MGX_CODE_WALL_GREY);
+        lg_rect(L, q[0] + q[2] - 1, q[1], q[0] + q[2] - 1, q[1] + q[3] - 1, MGX_CODE_WALL_GREY);
+        if (i > 0) {
+            int k = lg_randint(r, 0, prevColor < 0 ? 7 : 6);
+            int color = -1;
+            for (int j = 0; j < 7; j++) {
+                if (sortedColors[j] == prevColor) continue;
+                if (k-- == 0) { color = sortedColors[j]; break; }
+            }
+            lg_set(L, q[4], q[5], MGX_K_DOOR_CLOSED | ((uint32_t)color << 4)); // Door(color): closed, unlocked
+            prevColor = color;
+        }
+    }
+    // place_agent(top, size) in the first room, then the goal in the last room (minigrid.py:1003-1090)
+    {
+        const int16_t *q = best;
+        for (;;) {
+            const int x = lg_randint(r, q[0], (q[0] + q[2] < L.W ? q[0] + q[2] : L.W));
+            const int y = lg_randint(r, q[1], (q[1] + q[3] < L.H ? q[1] + q[3] : L.H));
+            if (!r.alive()) return;
+            if (!lg_empty(L, x, y)) continue;
+            L.ax = x; L.ay = y;
+            break;
+        }
+        L.adir = lg_randint(r, 0, 4);
+        q = best + 6 * (nbest - 1);
+        for (;;) {
+            const int x = lg_randint(r, q[0], (q[0] + q[2] < L.W ? q[0] + q[2] : L.W));
+            const int y = lg_randint(r, q[1], (q[1] + q[3] < L.H ? q[1] + q[3] : L.H));
+            if (!r.alive()) return;
+            if (!lg_empty(L, x, y)) continue;
+            if (x == L.ax && y == L.ay) continue;
+            lg_set(L, x, y, MGX_CODE_GOAL_GREEN);
+            break;
+        }
+    }
+}
+
 // true if the family draws random numbers (Empty with a fixed start does not)
 LG_FN bool lg_uses_rng(const mgx_config &c) { return !(c.level_kind == MGX_LEVEL_EMPTY && c.level_arg0 == 0) && c.level_kind != MGX_LEVEL_DISTSHIFT; }
 
@@ -245,6 +358,7 @@ LG_FN void lg_generate(const mgx_config &c, R &r, LgLevel &L)
     case MGX_LEVEL_DOORKEY: lg_gen_doorkey(c, r, L); break;
     case MGX_LEVEL_CROSSING: lg_gen_crossing(c, r, L); break;
     case MGX_LEVEL_DISTSHIFT: lg_gen_distshift(c, r, L); break;
+    case MGX_LEVEL_MULTIROOM: lg_gen_multiroom(c, r, L); break;
     default: lg_gen_lavagap(c, r, L); break;
     }
 }

@@ -518,17 +518,47 @@ __device__ __forceinline__ void emit_full_obs(const StepParams &p, const Lane &L
 
 // ------------------------------------------------------------------------------------------------
 // (device RNG + per-level generator, used by k_levelgen below)
-struct DevRng {
-    const uint32_t *buf; // LDS: the env's current MT19937 block followed by the next one (624 + 624 words)
-    int idx;             // next unread word
-    int limit;           // words available: 624, or 1248 once the next block has been built
-    bool overflow;       // ran past `limit`: the caller builds the next block and runs the generator again
+// Word source of the lane-per-level fast path: a bounded window of the env's MT19937 block copied into LDS.  Running
+// past it marks the level for the slow path (alive() == false stops the generators' rejection loops).
+struct WinRng {
+    const uint32_t *buf; // LDS window, indexed by the absolute position in the block
+    int idx, limit;
+    bool overflow;
 
     __device__ __forceinline__ bool alive() const { return !overflow; }
     __device__ __forceinline__ uint32_t next32()
     {
         if (idx >= limit) { overflow = true; return 0u; } // masked draws end on 0; place_obj-style loops test alive()
         return lg_temper(buf[idx++]);
+    }
+};
+
+// Word source of the slow path (one lane of a wave): the env's whole block in LDS, unlimited length.  When the block is
+// used up it switches to the next one -- prebuilt by the whole wave if that was foreseeable, else built here word by
+// word (rare; loops kept rolled: this sits in a dozen call sites of the generators).
+struct DevRng {
+    uint32_t *a, *b; // current block / scratch for the next one (624 words each, LDS)
+    int idx;
+    bool have_b;
+    int advanced;    // blocks consumed: > 0 means `a` must be written back as the env's new state
+
+    __device__ __forceinline__ bool alive() const { return true; }
+    __device__ __forceinline__ uint32_t next32()
+    {
+        if (idx >= 624) {
+            if (!have_b) {
+#pragma nounroll
+                for (int k = 0; k < 227; k++) b[k] = lg_twist_word(a[k], a[k + 1], a[k + 397]);
+#pragma nounroll
+                for (int k = 227; k < 623; k++) b[k] = lg_twist_word(a[k], a[k + 1], b[k - 227]);
+                b[623] = lg_twist_word(a[623], b[0], b[396]);
+            }
+            uint32_t *t = a; a = b; b = t;
+            have_b = false;
+            idx = 0;
+            advanced++;
+        }
+        return lg_temper(a[idx++]);
     }
 };
 
@@ -549,41 +579,31 @@ __device__ __forceinline__ void levelgen_one(const LevelGenParams &p, int64_t en
     }
     const int idx0 = (int)p.mt_idx[env];
     wave_sync();
-    // Attempt 1 reads the current block only (or both, if the read index is within 64 words of its end: then the
-    // next block is built first, by the whole wave: the recurrence is 3 data-parallel phases + 1 word).  If the
-    // generator runs past the words available (rare), the next block is built and the generator runs again from
-    // the same index.  A level that needs more than one whole extra block (> 624 draws; probability ~2^-100) is
-    // counted as a fault instead of being handled.
-    int limit = idx0 + 64 > 624 ? 1248 : 624;
-    bool have_next = false;
-    for (int attempt = 0; attempt < 2; attempt++) { // wave-uniform
-        if (limit == 1248 && !have_next) {
-            for (int k = lane; k < 227; k += 64) nxt[k] = lg_twist_word(cur[k], cur[k + 1], cur[k + 397]);
-            wave_sync();
-            for (int k = 227 + lane; k < 454; k += 64) nxt[k] = lg_twist_word(cur[k], cur[k + 1], nxt[k - 227]);
-            wave_sync();
-            for (int k = 454 + lane; k < 623; k += 64) nxt[k] = lg_twist_word(cur[k], cur[k + 1], nxt[k - 227]);
-            wave_sync();
-            if (lane == 0) nxt[623] = lg_twist_word(cur[623], nxt[0], nxt[396]);
-            wave_sync();
-            have_next = true;
-        }
-        if (lane == 0) {
-            DevRng r;
-            r.buf = cur; r.idx = idx0; r.limit = limit; r.overflow = false;
-            LgLevel L;
-            L.cmds = cmds; L.ncmd = 0; L.W = p.cfg.width; L.H = p.cfg.height; L.ax = L.ay = -1; L.adir = 0; L.ws = ws;
-            lg_generate(p.cfg, r, L);
-            res[0] = r.idx;
-            res[1] = (L.ax & 255) | ((L.ay & 255) << 8) | ((L.adir & 3) << 16);
-            res[2] = r.overflow ? 1 : 0;
-            res[3] = L.ncmd;
-        }
+    // If the read index is within 64 words of the end of the block the level will probably run into the next block:
+    // the whole wave builds it first (the recurrence is 3 data-parallel phases + 1 word).
+    const bool pre = idx0 + 64 > 624;
+    if (pre) {
+        for (int k = lane; k < 227; k += 64) nxt[k] = lg_twist_word(cur[k], cur[k + 1], cur[k + 397]);
         wave_sync();
-        if (!res[2]) break;
-        if (limit == 1248) { if (lane == 0) atomicAdd(&p.ctr->invalid_state, 1ull); break; }
-        limit = 1248;
+        for (int k = 227 + lane; k < 454; k += 64) nxt[k] = lg_twist_word(cur[k], cur[k + 1], nxt[k - 227]);
+        wave_sync();
+        for (int k = 454 + lane; k < 623; k += 64) nxt[k] = lg_twist_word(cur[k], cur[k + 1], nxt[k - 227]);
+        wave_sync();
+        if (lane == 0) nxt[623] = lg_twist_word(cur[623], nxt[0], nxt[396]);
+        wave_sync();
     }
+    if (lane == 0) {
+        DevRng r;
+        r.a = cur; r.b = nxt; r.idx = idx0; r.have_b = pre; r.advanced = 0;
+        LgLevel L;
+        L.cmds = cmds; L.ncmd = 0; L.W = p.cfg.width; L.H = p.cfg.height; L.ax = L.ay = -1; L.adir = 0; L.ws = ws;
+        lg_generate(p.cfg, r, L);
+        res[0] = r.idx;
+        res[1] = (L.ax & 255) | ((L.ay & 255) << 8) | ((L.adir & 3) << 16);
+        res[2] = r.advanced ? (r.a == cur ? 1 : 2) : 0; // which LDS buffer holds the env's new current block
+        res[3] = L.ncmd;
+    }
+    wave_sync();
     const int idx1 = res[0];
     { // paint: every lane evaluates the command list for 4 consecutive cells and stores one dword of codes
         const int ncmd = res[3], H = p.cfg.height, cells = p.cfg.width * H;
@@ -598,11 +618,12 @@ __device__ __forceinline__ void levelgen_one(const LevelGenParams &p, int64_t en
             dst[k] = w;
         }
     }
-    if (idx1 >= 624) { // moved into the next block: it becomes the env's state
-        for (int k = lane; k < 624; k += 64) mt[k] = nxt[k];
+    if (res[2]) { // moved into a later block: it becomes the env's state
+        const uint32_t *blk = res[2] == 1 ? cur : nxt;
+        for (int k = lane; k < 624; k += 64) mt[k] = blk[k];
     }
     if (lane == 0) {
-        p.mt_idx[env] = (uint32_t)(idx1 >= 624 ? idx1 - 624 : idx1);
+        p.mt_idx[env] = (uint32_t)idx1;
         p.agent0[env] = make_uint2((uint32_t)res[1] | ((uint32_t)MGX_CODE_EMPTY << 24), 0u);
     }
     wave_sync();
@@ -834,7 +855,7 @@ __global__ __launch_bounds__(256) void k_levelgen(const LevelGenParams p)
                 const uint32_t *mt = p.mt + env * 624 + idx0;
 #pragma unroll
                 for (int k = 0; k < MGX_LGF_WIN; k++) slice[k] = mt[k];
-                DevRng r;
+                WinRng r;
                 r.buf = slice - idx0; r.idx = idx0; r.limit = idx0 + MGX_LGF_WIN; r.overflow = false;
                 LgLevel L;
                 L.cmds = reinterpret_cast<LgCmd *>(slice + MGX_LGF_WIN); L.ncmd = 0; L.max_cmds = MGX_LGF_CMDS;

@@ -24,7 +24,7 @@ MISSIONS = {1: "get to the green goal square",
                 2: "find the opening and get to the green goal square"},
             4: {9: "avoid the lava and get to the green goal square",
                 2: "find the opening and get to the green goal square"},
-            5: "get to the green goal square"}
+            5: "get to the green goal square", 6: "traverse the rooms to get to the goal"}
 
 
 def _ptr(a):

@@ -17,7 +17,7 @@
  *                              (+ FullyObsWrapper.observation     wrappers.py:326-338 when obs_mode = MGX_OBS_FULL)
  *   mgx_generate_levels        _gen_grid of the built-in families envs/empty.py:30-57, envs/doorkey.py:15-44,
  *                                                                 envs/crossing.py:24-92, envs/lavagap.py:21-59,
- *                                                                 envs/distshift.py:30-52
+ *                                                                 envs/distshift.py:30-52, envs/multiroom.py:40-219
  *
  * Conventions
  *   - every function returns 0 (MGX_OK) or a negative mgx_status; mgx_last_error()
@@ -84,7 +84,9 @@ typedef enum {
     MGX_LEVEL_CROSSING = 3, /* CrossingEnv: level_arg0 = num_crossings, level_arg1 = obstacle type (9 lava, 2 wall)
                                + 16 * (0 both river directions, 1 horizontal only (ori=0), 2 vertical only (ori=1)) */
     MGX_LEVEL_LAVAGAP = 4,  /* LavaGapEnv:  level_arg0 = const gap column (0/1), level_arg1 = obstacle type */
-    MGX_LEVEL_DISTSHIFT = 5 /* DistShiftEnv (envs/distshift.py): level_arg0 = strip2_row; no randomness */
+    MGX_LEVEL_DISTSHIFT = 5, /* DistShiftEnv (envs/distshift.py): level_arg0 = strip2_row; no randomness */
+    MGX_LEVEL_MULTIROOM = 6  /* MultiRoomEnv (envs/multiroom.py): level_arg0 = minNumRooms | maxNumRooms << 8 (<= 8),
+                                level_arg1 = maxRoomSize */
 } mgx_level_kind;
 
 typedef struct {

@@ -326,7 +326,8 @@ def record_level_streams():
                              ("MiniGrid-LavaCrossingS11N5-v0", [2], 400), ("MiniGrid-SimpleCrossingS9N2-v0", [4], 400),
                              ("MiniGrid-Empty-Random-6x6-v0", [0, 9], 900), ("MiniGrid-Empty-Random-10x10-v0", [1], 400),
                              ("MiniGrid-LavaGapS7-v0", [0, 3], 900), ("MiniGrid-LavaGapS6-v1", [1], 900),
-                             ("MiniGrid-NormalGapS6-v0", [2], 300), ("MiniGrid-Empty-8x8-v0", [0], 5)]:
+                             ("MiniGrid-NormalGapS6-v0", [2], 300), ("MiniGrid-Empty-8x8-v0", [0], 5),
+                             ("MiniGrid-MultiRoom-N2-S4-v0", [0], 300), ("MiniGrid-MultiRoom-N6-v0", [1, 4], 400)]:
         env = gym.make(env_id)
         key = env_id.replace("MiniGrid-", "").replace("-v0", "")
         for s in seeds:
@@ -381,7 +382,8 @@ def record_levels():
                           ("MiniGrid-DoorKey-5x5-v0", range(64)), ("MiniGrid-DoorKey-6x6-v0", range(64)),
                           ("MiniGrid-DoorKey-8x8-v0", range(256)), ("MiniGrid-DoorKey-16x16-v0", range(32)),
                           ("MiniGrid-LavaCrossingS9N1-v0", range(256)), ("MiniGrid-LavaCrossingS9N2-v0", range(64)),
-                          ("MiniGrid-LavaCrossingS9N0-v0", range(64)), ("MiniGrid-DistShift1-v0", range(2)),
+                          ("MiniGrid-LavaCrossingS9N0-v0", range(64)), ("MiniGrid-MultiRoom-N2-S4-v0", range(128)),
+                          ("MiniGrid-MultiRoom-N4-S5-v0", range(128)), ("MiniGrid-MultiRoom-N6-v0", range(128)), ("MiniGrid-DistShift1-v0", range(2)),
                           ("MiniGrid-DistShift1-v1", range(2)), ("MiniGrid-DistShift2-v0", range(2)),
                           ("MiniGrid-LavaGapS5-v0", range(32)), ("MiniGrid-LavaGapS7-v0", range(64)),
                           ("MiniGrid-NormalGapS6-v0", range(32)), ("MiniGrid-LavaGapS6-v1", range(32)),

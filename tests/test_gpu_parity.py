@@ -151,7 +151,8 @@ def test_random_batch_vs_oracle(W, H, auto_reset, mode):
 
 @pytest.mark.parametrize("env_id", ["MiniGrid-Empty-8x8-v0", "MiniGrid-DoorKey-8x8-v0", "MiniGrid-LavaCrossingS9N1-v0",
                                     "MiniGrid-Empty-Random-6x6-v0", "MiniGrid-LavaGapS7-v1", "MiniGrid-SimpleCrossingS11N5-v0",
-                                    "MiniGrid-DistShift1-v1", "MiniGrid-DistShift2-v0", "MiniGrid-LavaCrossingS9N0-v0", "MiniGrid-Empty-Random-10x10-v0"])
+                                    "MiniGrid-DistShift1-v1", "MiniGrid-DistShift2-v0", "MiniGrid-LavaCrossingS9N0-v0", "MiniGrid-Empty-Random-10x10-v0",
+                                    "MiniGrid-MultiRoom-N2-S4-v0", "MiniGrid-MultiRoom-N6-v0"])
 def test_seeded_reset_on_device(env_id):
     N = 300
     env = mg.VecMiniGrid(env_id, num_envs=N, seeds=5, auto_reset=True, backend="torch")

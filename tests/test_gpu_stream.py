@@ -49,7 +49,8 @@ def test_reference_stream_traces(name):
 
 @pytest.mark.parametrize("env_id,N,T,L", [("MiniGrid-LavaCrossingS9N1-v0", 3000, 260, 100), ("MiniGrid-DoorKey-5x5-v0", 1500, 600, 8),
                                           ("MiniGrid-LavaGapS7-v1", 900, 450, 8), ("MiniGrid-Empty-Random-8x8-v0", 700, 600, 6),
-                                          ("MiniGrid-SimpleCrossingS11N5-v0", 500, 1000, 6), ("MiniGrid-LavaCrossingS9N3-v0", 2000, 200, 100)])
+                                          ("MiniGrid-SimpleCrossingS11N5-v0", 500, 1000, 6), ("MiniGrid-LavaCrossingS9N3-v0", 2000, 200, 100),
+                                          ("MiniGrid-MultiRoom-N4-S5-v0", 400, 330, 8), ("MiniGrid-MultiRoom-N2-S4-v0", 300, 170, 8)])
 def test_stream_vs_host_generator_and_oracle(env_id, N, T, L):
     """Every env follows its own level stream: level k of env i == host generate_level_stream(seed_i)[k]."""
     seed = 77

@@ -9,7 +9,8 @@ IDS = ["Empty-8x8", "Empty-16x16", "Empty-5x5", "Empty-6x6", "DoorKey-5x5", "Doo
        "DoorKey-16x16", "LavaCrossingS9N1", "LavaCrossingS9N2", "LavaCrossingS9N3", "LavaCrossingS11N5",
        "SimpleCrossingS9N1", "SimpleCrossingS9N2", "SimpleCrossingS9N3", "SimpleCrossingS11N5",
        "LavaCrossingS9N0", "DistShift1", "DistShift1-v1", "DistShift2", "LavaGapS5", "LavaGapS7", "NormalGapS6",
-       "LavaGapS6-v1", "Empty-Random-5x5", "Empty-Random-8x8", "Empty-Random-10x10"]
+       "LavaGapS6-v1", "Empty-Random-5x5", "Empty-Random-8x8", "Empty-Random-10x10",
+       "MultiRoom-N2-S4", "MultiRoom-N4-S5", "MultiRoom-N6"]
 
 
 @pytest.mark.parametrize("key", IDS)
