@@ -139,6 +139,12 @@ int check_levelgen_cfg(const mgx_config *cfg, const char *fn)
     case MGX_LEVEL_DISTSHIFT:
         if (cfg->level_arg0 < 1 || cfg->level_arg0 > H - 2) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: DistShift strip2_row %d outside the room", fn, cfg->level_arg0);
         break;
+    case MGX_LEVEL_FETCH:
+        if (cfg->level_arg0 < 1 || cfg->level_arg0 > (W - 2) * (H - 2) - 1) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: Fetch numObjs %d does not fit", fn, cfg->level_arg0);
+        break;
+    case MGX_LEVEL_GOTODOOR:
+        if (W < 5 || H < 5) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: GoToDoor needs at least 5x5 (envs/gotodoor.py:14)", fn);
+        break;
     case MGX_LEVEL_DOORKEY:
         if (W < 5 || H < 5) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: DoorKey needs at least 5x5", fn);
         break;
@@ -163,6 +169,13 @@ mgx_config mk(int w, int h, int max_steps, int see, int v1, int kind, int a0, in
     memset(&c, 0, sizeof c);
     c.width = w; c.height = h; c.max_steps = max_steps; c.see_through_walls = see; c.lava_v1 = v1;
     c.level_kind = kind; c.level_arg0 = a0; c.level_arg1 = a1;
+    return c;
+}
+
+mgx_config mkt(int w, int h, int max_steps, int see, int kind, int a0, int task)
+{
+    mgx_config c = mk(w, h, max_steps, see, 0, kind, a0, 0);
+    c.task_kind = task;
     return c;
 }
 
@@ -193,6 +206,13 @@ const std::vector<EnvId> &registry()
         {"MiniGrid-SimpleCrossingS9N2-v0", mk(9, 9, 324, 0, 0, MGX_LEVEL_CROSSING, 2, 2)},
         {"MiniGrid-SimpleCrossingS9N3-v0", mk(9, 9, 324, 0, 0, MGX_LEVEL_CROSSING, 3, 2)},
         {"MiniGrid-SimpleCrossingS11N5-v0", mk(11, 11, 484, 0, 0, MGX_LEVEL_CROSSING, 5, 2)},
+        // FetchEnv / GoToDoorEnv: max_steps = 5*size^2, see_through_walls=True; task rules (envs/fetch.py:74-86, gotodoor.py:71-93)
+        {"MiniGrid-Fetch-5x5-N2-v0", mkt(5, 5, 125, 1, MGX_LEVEL_FETCH, 2, MGX_TASK_FETCH)},
+        {"MiniGrid-Fetch-6x6-N2-v0", mkt(6, 6, 180, 1, MGX_LEVEL_FETCH, 2, MGX_TASK_FETCH)},
+        {"MiniGrid-Fetch-8x8-N3-v0", mkt(8, 8, 320, 1, MGX_LEVEL_FETCH, 3, MGX_TASK_FETCH)},
+        {"MiniGrid-GoToDoor-5x5-v0", mkt(5, 5, 125, 1, MGX_LEVEL_GOTODOOR, 0, MGX_TASK_GOTODOOR)},
+        {"MiniGrid-GoToDoor-6x6-v0", mkt(6, 6, 180, 1, MGX_LEVEL_GOTODOOR, 0, MGX_TASK_GOTODOOR)},
+        {"MiniGrid-GoToDoor-8x8-v0", mkt(8, 8, 320, 1, MGX_LEVEL_GOTODOOR, 0, MGX_TASK_GOTODOOR)},
         // MultiRoomEnv: 25x25, max_steps = maxNumRooms*20 (envs/multiroom.py:36-39,223-246)
         {"MiniGrid-MultiRoom-N2-S4-v0", mk(25, 25, 40, 0, 0, MGX_LEVEL_MULTIROOM, 2 | (2 << 8), 4)},
         {"MiniGrid-MultiRoom-N4-S5-v0", mk(25, 25, 80, 0, 0, MGX_LEVEL_MULTIROOM, 4 | (4 << 8), 5)},
@@ -231,6 +251,11 @@ extern "C" const char *mgx_env_id(int i)
 
 extern "C" int mgx_generate_levels(const mgx_config *cfg, int64_t n, const uint64_t *seeds, uint8_t *grid, int32_t *agent)
 {
+    return mgx_generate_levels_ex(cfg, n, seeds, grid, agent, nullptr);
+}
+
+extern "C" int mgx_generate_levels_ex(const mgx_config *cfg, int64_t n, const uint64_t *seeds, uint8_t *grid, int32_t *agent, uint32_t *task)
+{
     if (!cfg || !seeds || !grid || !agent || n < 0) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_generate_levels: null argument");
     int rc = check_levelgen_cfg(cfg, "mgx_generate_levels");
     if (rc) return rc;
@@ -247,6 +272,7 @@ extern "C" int mgx_generate_levels(const mgx_config *cfg, int64_t n, const uint6
         lg_paint(L, codes.data());
         codes_to_triples(codes.data(), cells, grid + (size_t)e * cells * 3);
         agent[e * 3] = L.ax; agent[e * 3 + 1] = L.ay; agent[e * 3 + 2] = L.adir;
+        if (task) task[e] = L.task;
     }
     return MGX_OK;
 }

@@ -47,6 +47,7 @@ struct LgLevel {
     int16_t *ws; // 6*max_rivers scratch words for the crossing generator's lists.  On the GPU cmds and ws point
                  // into LDS: dynamically indexed local arrays would live in scratch (HBM) and every access of the
                  // sequential generator would pay a memory round trip (measured 10x on k_levelgen).
+    uint32_t task = 0; // per-env task word of the families with a task rule (Fetch: target code | mission template << 8)
     int max_cmds = MGX_LG_MAX_CMDS, max_rivers = MGX_LG_MAX_RIVERS; // capacities of cmds / ws (the GPU fast path has small ones)
     bool too_big = false; // a capacity was exceeded: the level is invalid and must be regenerated with full-size buffers
 };
@@ -347,6 +348,76 @@ LG_FN void lg_gen_multiroom(const mgx_config &c, R &r, LgLevel &L)
     }
 }
 
+// sorted(COLOR_NAMES) (minigrid.py:24): blue green grey purple red white yellow -> COLOR_TO_IDX
+LG_FN int lg_sorted_color(int k)
+{
+    const int sortedColors[7] = {2, 1, 5, 3, 0, 6, 4};
+    return sortedColors[k];
+}
+
+// FetchEnv._gen_grid (envs/fetch.py:24-72): numObjs (level_arg0) random keys/balls anywhere, random agent, random target
+// among them, random mission template.  task = target cell code | template << 8.
+template <class R>
+LG_FN void lg_gen_fetch(const mgx_config &c, R &r, LgLevel &L)
+{
+    L.ncmd = 0;
+    lg_rect(L, 0, 0, L.W - 1, 0, MGX_CODE_WALL_GREY);
+    lg_rect(L, 0, L.H - 1, L.W - 1, L.H - 1, MGX_CODE_WALL_GREY);
+    lg_rect(L, 0, 0, 0, L.H - 1, MGX_CODE_WALL_GREY);
+    lg_rect(L, L.W - 1, 0, L.W - 1, L.H - 1, MGX_CODE_WALL_GREY);
+    const int first_obj = L.ncmd, n = c.level_arg0;
+    L.ax = -1; L.ay = -1;
+    for (int i = 0; i < n; i++) {
+        const int type = lg_randint(r, 0, 2);                 // _rand_elem(['key', 'ball'])
+        const int color = lg_sorted_color(lg_randint(r, 0, 7)); // _rand_elem(COLOR_NAMES)
+        int x, y;
+        lg_sample_free(r, L, L.W, L.H, false, &x, &y);        // place_obj(obj): anywhere empty
+        if (!r.alive()) return;
+        lg_set(L, x, y, (type == 0 ? MGX_K_KEY : MGX_K_BALL) | ((uint32_t)color << 4));
+    }
+    lg_sample_free(r, L, L.W, L.H, false, &L.ax, &L.ay);      // place_agent()
+    L.adir = lg_randint(r, 0, 4);
+    const int t = lg_randint(r, 0, n);                        // target = objs[_rand_int(0, len(objs))]
+    const int tmpl = lg_randint(r, 0, 5);                     // mission template
+    if (L.too_big || !r.alive()) return;
+    L.task = (uint32_t)L.cmds[first_obj + t].code | ((uint32_t)tmpl << 8);
+}
+
+// GoToDoorEnv._gen_grid (envs/gotodoor.py:23-69, as modified by the fork): four locked doors on the four walls in four
+// distinct colours, redrawn until one of them is red (the target); random agent.
+template <class R>
+LG_FN void lg_gen_gotodoor(const mgx_config &, R &r, LgLevel &L)
+{
+    const int W = L.W, H = L.H;
+    L.ncmd = 0;
+    lg_rect(L, 0, 0, W - 1, 0, MGX_CODE_WALL_GREY);
+    lg_rect(L, 0, H - 1, W - 1, H - 1, MGX_CODE_WALL_GREY);
+    lg_rect(L, 0, 0, 0, H - 1, MGX_CODE_WALL_GREY);
+    lg_rect(L, W - 1, 0, W - 1, H - 1, MGX_CODE_WALL_GREY);
+    int dx[4], dy[4], col[4];
+    dx[0] = lg_randint(r, 2, W - 2); dy[0] = 0;
+    dx[1] = lg_randint(r, 2, W - 2); dy[1] = H - 1;
+    dx[2] = 0; dy[2] = lg_randint(r, 2, H - 2);
+    dx[3] = W - 1; dy[3] = lg_randint(r, 2, H - 2);
+    bool have_red = false;
+    while (!have_red) { // doorIdx is None: draw the four colours again
+        int n = 0;
+        while (n < 4) {
+            const int color = lg_sorted_color(lg_randint(r, 0, 7));
+            if (!r.alive()) return;
+            bool dup = false;
+            for (int k = 0; k < n; k++) dup = dup || col[k] == color;
+            if (dup) continue;
+            if (color == 0) have_red = true;
+            col[n++] = color;
+        }
+    }
+    for (int k = 0; k < 4; k++) lg_set(L, dx[k], dy[k], MGX_K_DOOR_LOCKED | ((uint32_t)col[k] << 4));
+    L.ax = -1; L.ay = -1;
+    lg_sample_free(r, L, W, H, false, &L.ax, &L.ay); // place_agent(size=(W, H))
+    L.adir = lg_randint(r, 0, 4);
+}
+
 // true if the family draws random numbers (Empty with a fixed start does not)
 LG_FN bool lg_uses_rng(const mgx_config &c) { return !(c.level_kind == MGX_LEVEL_EMPTY && c.level_arg0 == 0) && c.level_kind != MGX_LEVEL_DISTSHIFT; }
 
@@ -359,6 +430,8 @@ LG_FN void lg_generate(const mgx_config &c, R &r, LgLevel &L)
     case MGX_LEVEL_CROSSING: lg_gen_crossing(c, r, L); break;
     case MGX_LEVEL_DISTSHIFT: lg_gen_distshift(c, r, L); break;
     case MGX_LEVEL_MULTIROOM: lg_gen_multiroom(c, r, L); break;
+    case MGX_LEVEL_FETCH: lg_gen_fetch(c, r, L); break;
+    case MGX_LEVEL_GOTODOOR: lg_gen_gotodoor(c, r, L); break;
     default: lg_gen_lavagap(c, r, L); break;
     }
 }

@@ -162,6 +162,7 @@ StepParams base_params(mgx_handle h)
     p.auto_reset = h->cfg.auto_reset;
     p.extended = h->cfg.extended_actions ? 1 : 0;
     p.alt_vis = h->cfg.alt_visibility ? 1 : 0;
+    p.task = h->cfg.task_kind;
     p.regen = h->stream_mode ? h->regen_d : nullptr;
     return p;
 }
@@ -209,6 +210,10 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     if (cfg->width < 3 || cfg->height < 3 || cfg->width > 255 || cfg->height > 255)
         return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: grid %dx%d outside 3..255 (Grid.__init__ asserts >= 3)", cfg->width, cfg->height);
     if (cfg->max_steps <= 0) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: max_steps must be positive");
+    if (cfg->task_kind < MGX_TASK_NONE || cfg->task_kind > MGX_TASK_GOTODOOR)
+        return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: bad task_kind %d", cfg->task_kind);
+    if (cfg->task_kind != MGX_TASK_NONE && cfg->max_steps > 65535)
+        return mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_create: task rules need max_steps <= 65535");
     if (cfg->obs_mode < MGX_OBS_PARTIAL || cfg->obs_mode > MGX_OBS_FULL_ONEHOT_NOCOLOR)
         return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: bad obs_mode %d", cfg->obs_mode);
     const int view = cfg->agent_view_size ? cfg->agent_view_size : MGX_VIEW;
@@ -448,7 +453,7 @@ static int set_state_impl(mgx_handle h, const uint8_t *grid, const uint8_t *aux,
     p.mask = (const uint8_t *)d;
     p.cells = h->cells_d; p.cells0 = h->cells0_d; p.rec = h->agent_d; p.rec0 = h->agent0_d;
     p.ctr = h->ctr_d;
-    p.n = h->n; p.W = h->W; p.H = h->H; p.S = h->S;
+    p.n = h->n; p.W = h->W; p.H = h->H; p.S = h->S; p.has_task = h->cfg.task_kind != MGX_TASK_NONE;
     MgxCounters before, after;
     if ((rc = read_counters(h, &before))) return rc;
     HIP_TRY(mgx_launch_pack(p, h->stream));
@@ -498,7 +503,7 @@ extern "C" int mgx_get_state(mgx_handle h, uint8_t *grid, uint8_t *aux, int32_t 
     p.cells = h->cells_d; p.rec = h->agent_d;
     p.grid_out = (uint8_t *)t[0].dev; p.aux_out = (uint8_t *)t[1].dev; p.agent_out = (int32_t *)t[2].dev;
     p.carry_out = (uint8_t *)t[3].dev; p.steps_out = (int32_t *)t[4].dev;
-    p.n = h->n; p.W = h->W; p.H = h->H; p.S = h->S;
+    p.n = h->n; p.W = h->W; p.H = h->H; p.S = h->S; p.has_task = h->cfg.task_kind != MGX_TASK_NONE;
     hipError_t e = mgx_launch_unpack(p, h->stream);
     for (int i = 0; i < 5 && e == hipSuccess; i++)
         if (t[i].dev && !t[i].direct) e = hipMemcpyAsync(t[i].user, t[i].dev, t[i].bytes, hipMemcpyDeviceToHost, h->stream);
@@ -552,6 +557,30 @@ extern "C" int mgx_observe(mgx_handle h, uint8_t *obs)
     return run_step(h, false, nullptr, obs, nullptr, nullptr);
 }
 
+extern "C" int mgx_set_task(mgx_handle h, const uint32_t *task)
+{
+    int rc = check_handle(h, "mgx_set_task");
+    if (rc) return rc;
+    if (!task) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_set_task: null argument");
+    if (h->cfg.task_kind == MGX_TASK_NONE) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_set_task: this handle has no task rule");
+    const void *d;
+    if ((rc = dev_in(h, 4, task, (size_t)h->n * sizeof(uint32_t), &d, 4))) return rc;
+    HIP_TRY(mgx_launch_task(h->agent_d, h->agent0_d, (const uint32_t *)d, nullptr, h->n, h->stream));
+    return MGX_OK;
+}
+
+extern "C" int mgx_get_task(mgx_handle h, uint32_t *task)
+{
+    int rc = check_handle(h, "mgx_get_task");
+    if (rc) return rc;
+    if (!task) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_get_task: null argument");
+    if (h->cfg.task_kind == MGX_TASK_NONE) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_get_task: this handle has no task rule");
+    OutArg o;
+    if ((rc = dev_out(h, 3, task, (size_t)h->n * sizeof(uint32_t), &o, 4))) return rc;
+    HIP_TRY(mgx_launch_task(h->agent_d, h->agent0_d, nullptr, (uint32_t *)o.dev, h->n, h->stream));
+    return finish_out(h, &o, 1);
+}
+
 extern "C" int mgx_get_direction(mgx_handle h, uint8_t *direction)
 {
     int rc = check_handle(h, "mgx_get_direction");
@@ -594,10 +623,12 @@ extern "C" int mgx_reset(mgx_handle h, const uint64_t *seeds, const uint8_t *mas
     std::vector<uint8_t> grid(n * cells * 3);
     std::vector<int32_t> agent(n * 3);
     // (generation for unmasked envs is wasted work but keeps the code simple; k_pack_state ignores them)
-    rc = mgx_generate_levels(&h->cfg, h->n, seeds, grid.data(), agent.data());
+    std::vector<uint32_t> task(h->cfg.task_kind != MGX_TASK_NONE ? n : 0);
+    rc = mgx_generate_levels_ex(&h->cfg, h->n, seeds, grid.data(), agent.data(), task.empty() ? nullptr : task.data());
     if (rc) return rc;
     rc = set_state_impl(h, grid.data(), nullptr, agent.data(), nullptr, nullptr, mask);
     if (rc) return rc;
+    if (!task.empty() && (rc = mgx_set_task(h, task.data()))) return rc; // (unmasked envs get their old word back: regenerated identically)
     HIP_TRY(hipStreamSynchronize(h->stream)); // the host vectors above are about to go away
     if (obs) return run_step(h, false, nullptr, obs, nullptr, nullptr);
     return MGX_OK;

@@ -50,7 +50,7 @@ struct StepParams {
     int64_t n;
     int n_tiles;
     int W, H, S, LS, wave_lds, view;
-    int max_steps, see_through, lava_v1, auto_reset, do_step, extended, alt_vis;
+    int max_steps, see_through, lava_v1, auto_reset, do_step, extended, alt_vis, task;
 };
 
 struct PackParams {
@@ -63,7 +63,7 @@ struct PackParams {
     uint8_t *grid_out; uint8_t *aux_out; int32_t *agent_out; uint8_t *carry_out; int32_t *steps_out;
     MgxCounters *ctr;
     int64_t n;
-    int W, H, S;
+    int W, H, S, has_task;
 };
 
 struct ConsumeParams {
@@ -79,6 +79,7 @@ hipError_t mgx_launch_consume(const ConsumeParams &p, hipStream_t st);
 hipError_t mgx_launch_step(const StepParams &p, int mode, int waves_per_block, hipStream_t st);
 hipError_t mgx_raise_lds_limit(int W, int H, int mode, int bytes, int view, int alt_vis);
 hipError_t mgx_launch_onehot(const uint8_t *tri, uint8_t *out, int64_t n_cells, int nc, int ns, hipStream_t st);
+hipError_t mgx_launch_task(uint2 *rec, uint2 *rec0, const uint32_t *set, uint32_t *get, int64_t n, hipStream_t st);
 hipError_t mgx_launch_direction(const uint2 *rec, uint8_t *out, int64_t n, hipStream_t st);
 hipError_t mgx_launch_pack(const PackParams &p, hipStream_t st);
 hipError_t mgx_launch_unpack(const PackParams &p, hipStream_t st);

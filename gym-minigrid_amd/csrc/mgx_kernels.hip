@@ -99,17 +99,47 @@ struct Lane {
     int ax, ay, dir;
     uint32_t carry; // cell code, MGX_CODE_EMPTY = nothing
     int steps;
+    uint32_t task;  // per-env task word (16 bits), only with a task rule
 };
 
-__device__ __forceinline__ Lane unpack_rec(uint2 r)
+// record word 1 = step_count, or step_count | task << 16 for handles with a task rule (max_steps <= 65535 there)
+__device__ __forceinline__ Lane unpack_rec(uint2 r, int has_task = 0)
 {
     Lane L;
-    L.ax = r.x & 255u; L.ay = (r.x >> 8) & 255u; L.dir = (r.x >> 16) & 3u; L.carry = r.x >> 24; L.steps = (int)r.y;
+    L.ax = r.x & 255u; L.ay = (r.x >> 8) & 255u; L.dir = (r.x >> 16) & 3u; L.carry = r.x >> 24;
+    L.steps = has_task ? (int)(r.y & 0xFFFFu) : (int)r.y;
+    L.task = has_task ? r.y >> 16 : 0u;
     return L;
 }
-__device__ __forceinline__ uint2 pack_rec(const Lane &L)
+__device__ __forceinline__ uint2 pack_rec(const Lane &L, int has_task = 0)
 {
-    return make_uint2((uint32_t)L.ax | ((uint32_t)L.ay << 8) | ((uint32_t)L.dir << 16) | (L.carry << 24), (uint32_t)L.steps);
+    return make_uint2((uint32_t)L.ax | ((uint32_t)L.ay << 8) | ((uint32_t)L.dir << 16) | (L.carry << 24),
+                      has_task ? ((uint32_t)L.steps & 0xFFFFu) | (L.task << 16) : (uint32_t)L.steps);
+}
+
+// Task rules that env subclasses layer on MiniGridEnv.step (they run after the base step, time-out included).
+template <int CH, class CellAt>
+__device__ __forceinline__ void task_rule(const StepParams &p, const Lane &L, uint32_t act, float &reward, bool &done, CellAt cell_at)
+{
+    if (p.task == MGX_TASK_FETCH) { // envs/fetch.py:74-86
+        if (L.carry != MGX_CODE_EMPTY) {
+            done = true;
+            reward = ((L.carry & 0x7Fu) == (L.task & 0x7Fu)) ? (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps)) : 0.f;
+        }
+    } else if (p.task == MGX_TASK_GOTODOOR) { // envs/gotodoor.py:71-93: `done` next to a door; the target door is the red one
+        if (act == 6) {
+            const int H = CH ? CH : p.H;
+            const int base = L.ax * H + L.ay;
+            const uint32_t n4[4] = {cell_at(base + H), cell_at(base - H), cell_at(base + 1), cell_at(base - 1)};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t k = n4[i] & 15u;
+                const bool door = k == MGX_K_DOOR_OPEN || k == MGX_K_DOOR_CLOSED || k == MGX_K_DOOR_LOCKED;
+                if (door) done = true;
+                if (door && ((n4[i] >> 4) & 7u) == 0u) reward = (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps));
+            }
+        }
+    }
 }
 
 // MiniGridEnv.step without the observation (spec S1-S8), in two halves so that the forward cell can come from
@@ -602,6 +632,7 @@ __device__ __forceinline__ void levelgen_one(const LevelGenParams &p, int64_t en
         res[1] = (L.ax & 255) | ((L.ay & 255) << 8) | ((L.adir & 3) << 16);
         res[2] = r.advanced ? (r.a == cur ? 1 : 2) : 0; // which LDS buffer holds the env's new current block
         res[3] = L.ncmd;
+        ws[MGX_LG_WS_WORDS - 1] = (int16_t)L.task; // hand the task word to the write-back below
     }
     wave_sync();
     const int idx1 = res[0];
@@ -624,7 +655,7 @@ __device__ __forceinline__ void levelgen_one(const LevelGenParams &p, int64_t en
     }
     if (lane == 0) {
         p.mt_idx[env] = (uint32_t)idx1;
-        p.agent0[env] = make_uint2((uint32_t)res[1] | ((uint32_t)MGX_CODE_EMPTY << 24), 0u);
+        p.agent0[env] = make_uint2((uint32_t)res[1] | ((uint32_t)MGX_CODE_EMPTY << 24), (uint32_t)(uint16_t)ws[MGX_LG_WS_WORDS - 1] << 16);
     }
     wave_sync();
 }
@@ -650,7 +681,7 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
     stage_tile<CS>(p.cells, env0, S, LS, lds, lane);
     wave_sync();
 
-    Lane L = unpack_rec(rec);
+    Lane L = unpack_rec(rec, p.task);
     uint8_t *g = lds + lane * LS;
     float reward = 0.f;
     bool done = false, bad_act = false, oob = false;
@@ -661,6 +692,7 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
             const uint32_t nc = transition_apply<CH>(p, L, act, fc, reward, done, [&](int i) -> uint32_t { return g[i]; }, oob);
             if (nc != fc) g[fidx] = (uint8_t)nc;
             if (valid && L.steps >= p.max_steps) done = true; // minigrid.py:1320-1321
+            if (p.task) task_rule<CH>(p, L, act, reward, done, [&](int i) -> uint32_t { return g[i]; });
             // the one cell a transition can change; skipped when the env is about to be restored anyway
             if (nc != fc && !(p.auto_reset && done)) p.cells[env * S + fidx] = (uint8_t)nc;
         } else if (valid && L.steps >= p.max_steps) done = true;
@@ -669,10 +701,10 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
         wave_stats(p, valid, done, reward, bad_act, oob, lane, tile);
         if (p.auto_reset && valid && done) {
             restore_own<CS>(p, env, g);
-            L = unpack_rec(p.agent0[env]);
+            L = unpack_rec(p.agent0[env], p.task);
             if (p.regen) p.regen[env] = 1; // the next-level buffer was consumed: k_levelgen refills it after this launch
         }
-        if (valid) p.agent[env] = pack_rec(L);
+        if (valid) p.agent[env] = pack_rec(L, p.task);
     }
     if (p.obs) {
         if (MODE == 0) emit_partial_obs<CW, CH, V, ALT>(p, L, lds, g, env0, lane);
@@ -724,7 +756,7 @@ __global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
         const int lane = tid;
         const int64_t env = env0 + lane;
         const bool valid = env < p.n;
-        Lane L = unpack_rec(p.agent[env]);
+        Lane L = unpack_rec(p.agent[env], p.task);
         uint32_t act = 6;
         if (p.do_step && valid) act = p.actions[env];
         float reward = 0.f;
@@ -737,6 +769,7 @@ __global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
                 const uint32_t nc = transition_apply<CH>(p, L, act, fc, reward, done,
                                                          [&](int i) -> uint32_t { return p.cells[env * S + i]; }, oob);
                 if (valid && L.steps >= p.max_steps) done = true;
+                if (p.task) task_rule<CH>(p, L, act, reward, done, [&](int i) -> uint32_t { return (i == fidx) ? nc : (uint32_t)p.cells[env * S + i]; });
                 if (nc != fc && !(p.auto_reset && done)) {
                     p.cells[env * S + fidx] = (uint8_t)nc;
                     wr = (uint32_t)fidx | (nc << 16);
@@ -747,11 +780,11 @@ __global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
             if (p.done && valid) p.done[env] = done ? 1 : 0;
             wave_stats(p, valid, done, reward, bad_act, oob, lane, tile);
             if (p.auto_reset && valid && done) {
-                L = unpack_rec(p.agent0[env]);
+                L = unpack_rec(p.agent0[env], p.task);
                 reset = true;
                 if (p.regen) p.regen[env] = 1;
             }
-            if (valid) p.agent[env] = pack_rec(L);
+            if (valid) p.agent[env] = pack_rec(L, p.task);
         }
         s_info[lane] = (uint32_t)(L.ax * H + L.ay) | ((uint32_t)L.dir << 16) | ((uint32_t)reset << 18) | (changed << 19);
         s_wr[lane] = wr;
@@ -877,7 +910,7 @@ __global__ __launch_bounds__(256) void k_levelgen(const LevelGenParams p)
                     uint32_t *dst = reinterpret_cast<uint32_t *>(p.cells0 + env * p.S);
                     for (int k = 0; k < (p.S >> 2); k++) dst[k] = img32[k];
                     p.mt_idx[env] = (uint32_t)r.idx;
-                    p.agent0[env] = make_uint2((uint32_t)((L.ax & 255) | ((L.ay & 255) << 8) | ((L.adir & 3) << 16)) | ((uint32_t)MGX_CODE_EMPTY << 24), 0u);
+                    p.agent0[env] = make_uint2((uint32_t)((L.ax & 255) | ((L.ay & 255) << 8) | ((L.adir & 3) << 16)) | ((uint32_t)MGX_CODE_EMPTY << 24), L.task << 16);
                 }
             }
             if (!ok) s_slow[atomicAdd(&s_nslow, 1)] = s_queue[i];
@@ -1057,10 +1090,15 @@ __global__ __launch_bounds__(256) void k_pack_state(const PackParams p)
         }
         const int32_t sc = p.steps ? p.steps[t] : 0;
         if (sc < 0) bad = true;
-        const uint2 rec = make_uint2((uint32_t)(x & 255) | ((uint32_t)(y & 255) << 8) | ((uint32_t)(d & 3) << 16) | (cc << 24), (uint32_t)sc);
+        uint32_t w1 = (uint32_t)sc;
+        if (p.has_task) { // the task word of the env survives a state injection
+            if (sc > 0xFFFF) bad = true;
+            w1 = ((uint32_t)sc & 0xFFFFu) | (p.rec[t].y & 0xFFFF0000u);
+        }
+        const uint2 rec = make_uint2((uint32_t)(x & 255) | ((uint32_t)(y & 255) << 8) | ((uint32_t)(d & 3) << 16) | (cc << 24), w1);
         p.rec[t] = rec;
         // the episode start always has nothing carried and step_count 0 (reset(), minigrid.py:851-854)
-        p.rec0[t] = make_uint2((rec.x & 0x00FFFFFFu) | ((uint32_t)MGX_CODE_EMPTY << 24), 0u);
+        p.rec0[t] = make_uint2((rec.x & 0x00FFFFFFu) | ((uint32_t)MGX_CODE_EMPTY << 24), p.has_task ? (w1 & 0xFFFF0000u) : 0u);
     }
     if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicAdd(&p.ctr->invalid_state, 1ull);
 }
@@ -1082,7 +1120,7 @@ __global__ __launch_bounds__(256) void k_unpack_state(const PackParams p)
         if (p.aux_out) p.aux_out[t] = (uint8_t)(code >> 7);
     }
     if (t < p.n) {
-        const Lane L = unpack_rec(p.rec[t]);
+        const Lane L = unpack_rec(p.rec[t], p.has_task);
         if (p.agent_out) { p.agent_out[t * 3] = L.ax; p.agent_out[t * 3 + 1] = L.ay; p.agent_out[t * 3 + 2] = L.dir; }
         if (p.carry_out) {
             const uint32_t tr = decode_triple(L.carry);
@@ -1220,6 +1258,25 @@ __global__ __launch_bounds__(256) void k_direction(const uint2 *__restrict__ rec
     if (i < n) out[i] = (uint8_t)((rec[i].x >> 16) & 3u);
 }
 } // namespace
+
+namespace {
+__global__ __launch_bounds__(256) void k_task(uint2 *rec, uint2 *rec0, const uint32_t *set, uint32_t *get, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (set) {
+        rec[i].y = (rec[i].y & 0xFFFFu) | (set[i] << 16);
+        rec0[i].y = (rec0[i].y & 0xFFFFu) | (set[i] << 16);
+    }
+    if (get) get[i] = rec[i].y >> 16;
+}
+} // namespace
+
+hipError_t mgx_launch_task(uint2 *rec, uint2 *rec0, const uint32_t *set, uint32_t *get, int64_t n, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_task, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rec, rec0, set, get, n);
+    return hipGetLastError();
+}
 
 hipError_t mgx_launch_direction(const uint2 *rec, uint8_t *out, int64_t n, hipStream_t st)
 {

@@ -33,7 +33,7 @@ class Config(ctypes.Structure):
                 ("auto_reset", ctypes.c_int32), ("level_kind", ctypes.c_int32), ("level_arg0", ctypes.c_int32),
                 ("level_arg1", ctypes.c_int32), ("new_level_each_episode", ctypes.c_int32), ("agent_view_size", ctypes.c_int32),
                 ("extended_actions", ctypes.c_int32), ("alt_visibility", ctypes.c_int32),
-                ("reserved", ctypes.c_int32 * 2)]
+                ("task_kind", ctypes.c_int32), ("reserved", ctypes.c_int32 * 1)]
 
 
 class Stats(ctypes.Structure):
@@ -55,6 +55,9 @@ SIGNATURES = {
     "mgx_clear_faults": (_int, [_vp]),
     "mgx_obs_bytes": (_int, [_vp, ctypes.POINTER(_i64)]),
     "mgx_generate_levels": (_int, [ctypes.POINTER(Config), _i64, _vp, _vp, _vp]),
+    "mgx_generate_levels_ex": (_int, [ctypes.POINTER(Config), _i64, _vp, _vp, _vp, _vp]),
+    "mgx_set_task": (_int, [_vp, _vp]),
+    "mgx_get_task": (_int, [_vp, _vp]),
     "mgx_generate_level_stream": (_int, [ctypes.POINTER(Config), ctypes.c_uint64, _i64, _vp, _vp]),
     "mgx_reset": (_int, [_vp, _vp, _vp, _vp]),
     "mgx_set_state": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),

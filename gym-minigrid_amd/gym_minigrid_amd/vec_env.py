@@ -24,7 +24,8 @@ MISSIONS = {1: "get to the green goal square",
                 2: "find the opening and get to the green goal square"},
             4: {9: "avoid the lava and get to the green goal square",
                 2: "find the opening and get to the green goal square"},
-            5: "get to the green goal square", 6: "traverse the rooms to get to the goal"}
+            5: "get to the green goal square", 6: "traverse the rooms to get to the goal",
+            7: "fetch a <color> <type>: see get_task()", 8: "go to the red door"}
 
 
 def _ptr(a):
@@ -218,6 +219,17 @@ class VecMiniGrid:
                                             _ptr(out["carry"]), _ptr(out["steps"])))
         return out
 
+    def set_task(self, task):
+        """Per-env task word (Fetch: target cell code = type | color << 4), host uint32 array (N,)."""
+        t = np.ascontiguousarray(task, np.uint32)
+        assert t.shape == (self.num_envs,)
+        _lib.check(_lib.lib().mgx_set_task(self._h, _ptr(t)))
+
+    def get_task(self):
+        t = np.empty(self.num_envs, np.uint32)
+        _lib.check(_lib.lib().mgx_get_task(self._h, _ptr(t)))
+        return t
+
     def sync(self):
         """Wait for all enqueued work; raises AssertionError subclasses for recorded faults (like the reference)."""
         _lib.check(_lib.lib().mgx_sync(self._h))
@@ -255,15 +267,16 @@ class VecMiniGrid:
         return n.value, ms.value
 
 
-def generate_levels(env_id_or_cfg, seeds):
-    """Host-side `env.seed(s); env.reset()` of a built-in family -> (grid (n,W,H,3) u8, agent (n,3) i32)."""
+def generate_levels(env_id_or_cfg, seeds, with_task=False):
+    """Host-side `env.seed(s); env.reset()` of a built-in family -> (grid (n,W,H,3) u8, agent (n,3) i32[, task (n,) u32])."""
     cfg = _lib.env_config(env_id_or_cfg) if isinstance(env_id_or_cfg, str) else env_id_or_cfg
     s = np.ascontiguousarray(seeds, dtype=np.uint64)
     n = s.shape[0]
     grid = np.empty((n, cfg.width, cfg.height, 3), np.uint8)
     agent = np.empty((n, 3), np.int32)
-    _lib.check(_lib.lib().mgx_generate_levels(ctypes.byref(cfg), n, _ptr(s), _ptr(grid), _ptr(agent)))
-    return grid, agent
+    task = np.zeros(n, np.uint32)
+    _lib.check(_lib.lib().mgx_generate_levels_ex(ctypes.byref(cfg), n, _ptr(s), _ptr(grid), _ptr(agent), _ptr(task)))
+    return (grid, agent, task) if with_task else (grid, agent)
 
 
 def generate_level_stream(env_id_or_cfg, seed, K):

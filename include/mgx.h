@@ -85,9 +85,20 @@ typedef enum {
                                + 16 * (0 both river directions, 1 horizontal only (ori=0), 2 vertical only (ori=1)) */
     MGX_LEVEL_LAVAGAP = 4,  /* LavaGapEnv:  level_arg0 = const gap column (0/1), level_arg1 = obstacle type */
     MGX_LEVEL_DISTSHIFT = 5, /* DistShiftEnv (envs/distshift.py): level_arg0 = strip2_row; no randomness */
+    MGX_LEVEL_FETCH = 7,     /* FetchEnv (envs/fetch.py): level_arg0 = numObjs; use with task_kind = MGX_TASK_FETCH */
+    MGX_LEVEL_GOTODOOR = 8,  /* GoToDoorEnv (envs/gotodoor.py); use with task_kind = MGX_TASK_GOTODOOR */
     MGX_LEVEL_MULTIROOM = 6  /* MultiRoomEnv (envs/multiroom.py): level_arg0 = minNumRooms | maxNumRooms << 8 (<= 8),
                                 level_arg1 = maxRoomSize */
 } mgx_level_kind;
+
+/* task rules layered on MiniGridEnv.step by env subclasses (`step` overrides that only reshape reward/done) */
+typedef enum {
+    MGX_TASK_NONE = 0,
+    MGX_TASK_FETCH = 1,    /* envs/fetch.py:74-86: once something is carried the episode ends; reward = _reward() iff it is
+                              the target object.  Per-env task word = target cell code | mission template << 8. */
+    MGX_TASK_GOTODOOR = 2  /* envs/gotodoor.py:71-93: the `done` action next to any door ends the episode, next to the
+                              target (red) door it also pays _reward(). */
+} mgx_task_kind;
 
 typedef struct {
     int32_t width, height;      /* grid size, >= 3 */
@@ -111,7 +122,8 @@ typedef struct {
                                    obs is then uint8 [N][V][V][3].  Ignored by MGX_OBS_FULL. */
     int32_t extended_actions;   /* 1 = ExtendedActions (minigrid.py:747-764): 7 = strafe_left, 8 = strafe_right */
     int32_t alt_visibility;     /* 1 = default_vis=False: the fork's alternative occlusion model (minigrid.py:649-709) */
-    int32_t reserved[2];
+    int32_t task_kind;          /* mgx_task_kind; needs max_steps <= 65535 (the step counter shares a word with the task) */
+    int32_t reserved[1];
 } mgx_config;
 
 typedef struct mgx_env_s *mgx_handle;
@@ -139,6 +151,9 @@ int mgx_obs_bytes(mgx_handle h, int64_t *per_env);
 int mgx_generate_levels(const mgx_config *cfg, int64_t n, const uint64_t *seeds,
                         uint8_t *grid, int32_t *agent);
 
+/* Same, also returning the per-env task word (uint32 [n], may be NULL) of the families that have one (Fetch). */
+int mgx_generate_levels_ex(const mgx_config *cfg, int64_t n, const uint64_t *seeds, uint8_t *grid, int32_t *agent, uint32_t *task);
+
 /* Plain reference behaviour without ReseedWrapper (pure CPU): `env.seed(seed)` once, then K consecutive
  * `env.reset()`s -- the env's RNG stream continues, every episode gets a new level (minigrid.py:836-839).
  * grid uint8 [K][W][H][3], agent int32 [K][3]. */
@@ -155,6 +170,11 @@ int mgx_reset(mgx_handle h, const uint64_t *seeds, const uint8_t *mask, uint8_t 
 int mgx_set_state(mgx_handle h, const uint8_t *grid, const uint8_t *aux, const int32_t *agent,
                   const uint8_t *carry, const int32_t *steps);
 int mgx_get_state(mgx_handle h, uint8_t *grid, uint8_t *aux, int32_t *agent, uint8_t *carry, int32_t *steps);
+
+/* Per-env task word (uint32 [N], 16 bits used; handles with task_kind != MGX_TASK_NONE): Fetch target etc.
+ * set_task also records it for the episode-start snapshot. */
+int mgx_set_task(mgx_handle h, const uint32_t *task);
+int mgx_get_task(mgx_handle h, uint32_t *task);
 
 /* gen_obs() of the current state, no transition. */
 int mgx_observe(mgx_handle h, uint8_t *obs);

@@ -67,6 +67,13 @@ def aux_plane(env):
     return a
 
 
+def task_word(env):
+    """Fetch: target object as a cell code (type | color << 4)."""
+    if hasattr(env, "targetType"):
+        return M.OBJECT_TO_IDX[env.targetType] | (M.COLOR_TO_IDX[env.targetColor] << 4)
+    return 0
+
+
 def carry_triple(env):
     return env.carrying.encode() if env.carrying is not None else (1, 0, 0)
 
@@ -239,7 +246,8 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
     V = int(env0.agent_view_size)
     meta = dict(env_id=name, W=W, H=H, max_steps=int(env0.max_steps), view=V,
                 see_through=bool(env0.see_through_walls), lava_v1=bool(v1), full_obs=bool(full_obs),
-                reseed=bool(reseed), extended=bool(n_actions > 7), alt_vis=not bool(env0.default_vis))
+                reseed=bool(reseed), extended=bool(n_actions > 7), alt_vis=not bool(env0.default_vis),
+                task=1 if hasattr(env0, "targetType") else (2 if hasattr(env0, "target_pos") else 0))
     z = dict(
         seed=np.zeros(K, np.int64), init_grid=np.zeros((K, W, H, 3), np.uint8),
         init_aux=np.zeros((K, W, H), np.uint8), init_agent=np.zeros((K, 3), np.int32),
@@ -247,11 +255,11 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
         obs=np.zeros((K, T, V, V, 3), np.uint8), direction=np.zeros((K, T), np.uint8),
         reward=np.zeros((K, T), np.float64), done=np.zeros((K, T), np.uint8),
         agent=np.zeros((K, T, 3), np.int32), carry=np.zeros((K, T, 3), np.uint8),
-        steps=np.zeros((K, T), np.int32), grid=np.zeros((K, T, W, H, 3), np.uint8))
+        steps=np.zeros((K, T), np.int32), grid=np.zeros((K, T, W, H, 3), np.uint8), init_task=np.zeros(K, np.uint32))
     if full_obs:
         z["full"] = np.zeros((K, T, W, H, 3), np.uint8)
         z["init_full"] = np.zeros((K, W, H, 3), np.uint8)
-    rk, rt, rg, ra, rag, ro = [], [], [], [], [], []
+    rk, rt, rg, ra, rag, ro, rtask = [], [], [], [], [], [], []
     for k, s in enumerate(seeds):
         env = make_env()
         env.seed(int(s))
@@ -261,6 +269,7 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
         z["init_aux"][k] = aux_plane(env)
         z["init_agent"][k] = (env.agent_pos[0], env.agent_pos[1], env.agent_dir)
         z["init_obs"][k] = o["image"]
+        z["init_task"][k] = task_word(env)
         if full_obs:
             z["init_full"][k] = full_image(env)
         # action stream: optional scripted prefix (computed on a scratch copy), then random
@@ -301,6 +310,7 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
                 ra.append(aux_plane(env))
                 rag.append((env.agent_pos[0], env.agent_pos[1], env.agent_dir))
                 ro.append(o2["image"])
+                rtask.append(task_word(env))
     R = len(rk)
     z["reset_k"] = np.asarray(rk, np.int32)
     z["reset_t"] = np.asarray(rt, np.int32)
@@ -308,6 +318,7 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
     z["reset_aux"] = np.asarray(ra, np.uint8).reshape(R, W, H)
     z["reset_agent"] = np.asarray(rag, np.int32).reshape(R, 3)
     z["reset_obs"] = np.asarray(ro, np.uint8).reshape(R, V, V, 3)
+    z["reset_task"] = np.asarray(rtask, np.uint32)
     z["meta"] = np.frombuffer(json.dumps(meta).encode(), np.uint8)
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **z)
@@ -327,7 +338,8 @@ def record_level_streams():
                              ("MiniGrid-Empty-Random-6x6-v0", [0, 9], 900), ("MiniGrid-Empty-Random-10x10-v0", [1], 400),
                              ("MiniGrid-LavaGapS7-v0", [0, 3], 900), ("MiniGrid-LavaGapS6-v1", [1], 900),
                              ("MiniGrid-NormalGapS6-v0", [2], 300), ("MiniGrid-Empty-8x8-v0", [0], 5),
-                             ("MiniGrid-MultiRoom-N2-S4-v0", [0], 300), ("MiniGrid-MultiRoom-N6-v0", [1, 4], 400)]:
+                             ("MiniGrid-MultiRoom-N2-S4-v0", [0], 300), ("MiniGrid-MultiRoom-N6-v0", [1, 4], 400),
+                             ("MiniGrid-Fetch-8x8-N3-v0", [0, 2], 700), ("MiniGrid-GoToDoor-6x6-v0", [1], 700)]:
         env = gym.make(env_id)
         key = env_id.replace("MiniGrid-", "").replace("-v0", "")
         for s in seeds:
@@ -383,6 +395,9 @@ def record_levels():
                           ("MiniGrid-DoorKey-8x8-v0", range(256)), ("MiniGrid-DoorKey-16x16-v0", range(32)),
                           ("MiniGrid-LavaCrossingS9N1-v0", range(256)), ("MiniGrid-LavaCrossingS9N2-v0", range(64)),
                           ("MiniGrid-LavaCrossingS9N0-v0", range(64)), ("MiniGrid-MultiRoom-N2-S4-v0", range(128)),
+                          ("MiniGrid-Fetch-5x5-N2-v0", range(64)), ("MiniGrid-Fetch-6x6-N2-v0", range(64)),
+                          ("MiniGrid-Fetch-8x8-N3-v0", range(128)), ("MiniGrid-GoToDoor-5x5-v0", range(64)),
+                          ("MiniGrid-GoToDoor-6x6-v0", range(64)), ("MiniGrid-GoToDoor-8x8-v0", range(128)),
                           ("MiniGrid-MultiRoom-N4-S5-v0", range(128)), ("MiniGrid-MultiRoom-N6-v0", range(128)), ("MiniGrid-DistShift1-v0", range(2)),
                           ("MiniGrid-DistShift1-v1", range(2)), ("MiniGrid-DistShift2-v0", range(2)),
                           ("MiniGrid-LavaGapS5-v0", range(32)), ("MiniGrid-LavaGapS7-v0", range(64)),
@@ -393,7 +408,7 @@ def record_levels():
                           ("MiniGrid-SimpleCrossingS9N1-v0", range(64)), ("MiniGrid-SimpleCrossingS9N2-v0", range(64)),
                           ("MiniGrid-SimpleCrossingS9N3-v0", range(64)), ("MiniGrid-SimpleCrossingS11N5-v0", range(64))]:
         env = gym.make(env_id)
-        grids, agents = [], []
+        grids, agents, tasks = [], [], []
         big = [1337, 2 ** 32 - 1, 2 ** 32, 2 ** 40 + 12345, 2 ** 64 - 1]
         ss = list(seeds) + big
         for s in ss:
@@ -401,11 +416,13 @@ def record_levels():
             env.reset()
             grids.append(env.grid.encode())
             agents.append((env.agent_pos[0], env.agent_pos[1], env.agent_dir))
+            tasks.append(task_word(env))
         key = env_id.replace("MiniGrid-", "")
         key = key[:-3] if key.endswith("-v0") else key
         out[key + ":seeds"] = np.asarray(ss, np.uint64)
         out[key + ":grid"] = np.asarray(grids, np.uint8)
         out[key + ":agent"] = np.asarray(agents, np.int32)
+        out[key + ":task"] = np.asarray(tasks, np.uint32)
         out[key + ":max_steps"] = np.asarray([env.max_steps, int(env.see_through_walls)], np.int32)
     path = os.path.join(OUT, "levels.npz")
     np.savez_compressed(path, **out)
@@ -469,6 +486,30 @@ def main():
     record_case("Soup-19x19-altvis", lambda: SoupEnv(19, 19, False, 150, 0.2, default_vis=False), list(range(4)), 300)
     record_case("Soup-7x11-altvis-view5", vs(lambda: SoupEnv(7, 11, False, 80, 0.3, default_vis=False), 5), list(range(6)), 170)
     record_case("Soup-9x9-altvis-view9-strafe", vs(lambda: SoupEnv(9, 9, False, 100, 0.3, extended=True, default_vis=False), 9), list(range(6)), 200, n_actions=9)
+    # task rules layered on the base step: FetchEnv (envs/fetch.py:74-86), GoToDoorEnv (envs/gotodoor.py:71-93)
+    def fetch_script(which):
+        def f(env):
+            # walk to the target (which=0) or to another object (which=1) and pick it up
+            objs = [(x, y) for x in range(env.width) for y in range(env.height)
+                    if env.grid.get(x, y) is not None and env.grid.get(x, y).type in ("key", "ball")]
+            tgt = [p for p in objs if env.grid.get(*p).type == env.targetType and env.grid.get(*p).color == env.targetColor]
+            oth = [p for p in objs if p not in tgt]
+            pick = (tgt if which == 0 or not oth else oth)[0]
+            acts = plan_face(env, pick) or []
+            return acts + [3]
+        return f
+
+    def gotodoor_script(which):
+        def f(env):
+            doors = env.doorPos
+            pos = env.target_pos if which == 0 else [d for d in doors if tuple(d) != tuple(env.target_pos)][0]
+            acts = plan_face(env, pos) or []
+            return acts + [5, 6]   # toggle the locked door (nothing happens), then `done`
+        return f
+    record_case("Fetch-8x8-N3", mk("MiniGrid-Fetch-8x8-N3-v0"), list(range(8)), 400, scripts=[fetch_script(0), fetch_script(1)] * 2 + [None] * 4, reseed=False)
+    record_case("Fetch-5x5-N2", mk("MiniGrid-Fetch-5x5-N2-v0"), list(range(4)), 300, scripts=[fetch_script(1), fetch_script(0), None, None], reseed=False)
+    record_case("GoToDoor-8x8", mk("MiniGrid-GoToDoor-8x8-v0"), list(range(8)), 400, scripts=[gotodoor_script(0), gotodoor_script(1)] * 2 + [None] * 4, reseed=False)
+    record_case("GoToDoor-5x5", mk("MiniGrid-GoToDoor-5x5-v0"), list(range(4)), 300, scripts=[gotodoor_script(1), gotodoor_script(0), None, None], reseed=False)
     # plain reference semantics at the episode boundary: reset() WITHOUT re-seeding (a new level every episode)
     record_case("LavaCrossingS9N1-stream", mk("MiniGrid-LavaCrossingS9N1-v0"), list(range(6)), 500, reseed=False)
     record_case("DoorKey-5x5-stream", mk("MiniGrid-DoorKey-5x5-v0"), [0, 1, 2], 800, reseed=False)

@@ -27,6 +27,7 @@
  *   minigrid.py:1227-1325 MiniGridEnv.step
  *   minigrid.py:1327-1381 gen_obs_grid / gen_obs
  *   wrappers.py:311-338   FullyObsWrapper.observation
+ *   envs/fetch.py:74-86, envs/gotodoor.py:71-93   task rules layered on MiniGridEnv.step
  *
  * State representation used here = the reference's own encoding:
  *   grid  u8[W][H][3]   Grid.encode() layout, index [x][y][channel]; (1,0,0) = None
@@ -58,6 +59,7 @@ typedef struct {
     int view; /* agent_view_size */
     int extended; /* extended_actions (minigrid.py:774,787-789) */
     int alt_vis;  /* default_vis=False (minigrid.py:777,786,1343): the fork's own visibility model */
+    int task;     /* 0 none, 1 FetchEnv.step (envs/fetch.py:74-86), 2 GoToDoorEnv.step (envs/gotodoor.py:71-93) */
 } mgo_cfg;
 
 static const int DIR_TO_VEC[4][2] = { {1, 0}, {0, 1}, {-1, 0}, {0, -1} }; /* minigrid.py:64-73 */
@@ -297,11 +299,41 @@ static int step_state(const mgo_cfg *cf, uint8_t *g, uint8_t *aux, int32_t *agen
     return MGO_OK;
 }
 
+/* step() overrides that only reshape reward/done after MiniGridEnv.step.  task word: Fetch = target (type | color<<4). */
+static void task_rule(const mgo_cfg *cf, const uint8_t *g, const uint8_t *aux, const int32_t *agent, const uint8_t *carry,
+                      int32_t steps, uint32_t task, int action, double *reward, uint8_t *done)
+{
+    if (cf->task == 1) {
+        if (carry[0] != T_EMPTY) { /* if self.carrying: */
+            *done = 1;
+            if (carry[0] == (task & 15u) && carry[1] == ((task >> 4) & 7u)) *reward = 1 - 0.9 * ((double)steps / (double)cf->max_steps);
+            else *reward = 0;
+        }
+    } else if (cf->task == 2) {
+        if (action == A_DONE) {
+            static const int D4[4][2] = { {1, 0}, {-1, 0}, {0, 1}, {0, -1} };
+            int k;
+            for (k = 0; k < 4; k++) {
+                int x = agent[0] + D4[k][0], y = agent[1] + D4[k][1];
+                cell_t c;
+                if (x < 0 || x >= cf->W || y < 0 || y >= cf->H) continue;
+                c = grid_get(cf, g, aux, x, y);
+                if (c.t != T_DOOR) continue;
+                *done = 1;                                                   /* adjacent to any of the doors */
+                if (c.c == 0) *reward = 1 - 0.9 * ((double)steps / (double)cf->max_steps); /* the target door is the red one */
+            }
+        }
+    }
+}
+
 /* ------------------------------------------------------------------ exported, batched */
 
 /* One reference `env.step(a)` per env, in place.  obs may be NULL.  full may be NULL.
  * Returns 0, or the first per-env error code (processing continues for the rest);
  * err (optional, i32[n]) receives the per-env code. */
+static const uint32_t *g_task = 0; /* per-env task words for the next mgo_step_batch / mgo_rollout call (test harness state) */
+void mgo_set_task(const uint32_t *task) { g_task = task; }
+
 int mgo_step_batch(const mgo_cfg *cf, int64_t n, uint8_t *grid, uint8_t *aux, int32_t *agent,
                    uint8_t *carry, uint8_t *carry_aux, int32_t *steps, const uint8_t *actions,
                    uint8_t *obs, uint8_t *full, double *reward, uint8_t *done, int32_t *err)
@@ -312,6 +344,8 @@ int mgo_step_batch(const mgo_cfg *cf, int64_t n, uint8_t *grid, uint8_t *aux, in
         uint8_t *g = grid + e * cells * 3, *ax = aux + e * cells;
         int rc = step_state(cf, g, ax, agent + e * 3, carry + e * 3, carry_aux + e, steps + e,
                             actions[e], reward + e, done + e);
+        if (cf->task && rc == MGO_OK)
+            task_rule(cf, g, ax, agent + e * 3, carry + e * 3, steps[e], g_task ? g_task[e] : 0u, actions[e], reward + e, done + e);
         if (err) err[e] = rc;
         if (rc && !first) first = rc;
         if (obs) gen_obs(cf, g, ax, agent + e * 3, carry + e * 3, obs + e * (cf->view * cf->view * 3));

@@ -16,7 +16,7 @@ _SO = os.path.join(_HERE, "_build", "libmgoracle.so")
 
 class _Cfg(ctypes.Structure):
     _fields_ = [("W", ctypes.c_int), ("H", ctypes.c_int), ("max_steps", ctypes.c_int),
-                ("see_through", ctypes.c_int), ("lava_v1", ctypes.c_int), ("view", ctypes.c_int), ("extended", ctypes.c_int), ("alt_vis", ctypes.c_int)]
+                ("see_through", ctypes.c_int), ("lava_v1", ctypes.c_int), ("view", ctypes.c_int), ("extended", ctypes.c_int), ("alt_vis", ctypes.c_int), ("task", ctypes.c_int)]
 
 
 def build(force=False):
@@ -36,6 +36,7 @@ def lib():
         _lib.mgo_step_batch.restype = ctypes.c_int
         _lib.mgo_rollout.restype = ctypes.c_int64
         _lib.mgo_obs_batch.restype = None
+        _lib.mgo_set_task.restype = None
     return _lib
 
 
@@ -46,10 +47,11 @@ def _p(a):
 class OracleEnvs:
     """N independent reference-semantics envs of one family, stepped on the CPU."""
 
-    def __init__(self, W, H, max_steps, see_through, lava_v1=False, view=7, extended=False, alt_vis=False):
+    def __init__(self, W, H, max_steps, see_through, lava_v1=False, view=7, extended=False, alt_vis=False, task=0):
         self.W, self.H, self.V = int(W), int(H), int(view)
         assert 1 <= self.V <= 15
-        self.cfg = _Cfg(self.W, self.H, int(max_steps), int(bool(see_through)), int(bool(lava_v1)), self.V, int(bool(extended)), int(bool(alt_vis)))
+        self.cfg = _Cfg(self.W, self.H, int(max_steps), int(bool(see_through)), int(bool(lava_v1)), self.V, int(bool(extended)), int(bool(alt_vis)), int(task))
+        self.task = None
         self.n = 0
 
     def set_state(self, grid, agent, aux=None, carry=None, steps=None, carry_aux=None):
@@ -82,6 +84,9 @@ class OracleEnvs:
         reward = np.zeros(self.n, np.float64)
         done = np.zeros(self.n, np.uint8)
         err = np.zeros(self.n, np.int32)
+        if self.cfg.task:
+            self._task = np.ascontiguousarray(self.task if self.task is not None else np.zeros(self.n), np.uint32)
+            lib().mgo_set_task(_p(self._task))
         lib().mgo_step_batch(ctypes.byref(self.cfg), ctypes.c_int64(self.n), _p(self.grid), _p(self.aux),
                              _p(self.agent), _p(self.carry), _p(self.carry_aux), _p(self.steps), _p(a),
                              _p(obs), _p(fo), _p(reward), _p(done), _p(err))

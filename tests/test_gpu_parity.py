@@ -11,10 +11,11 @@ from helpers import make_oracle, random_states, to_np
 pytestmark = pytest.mark.gpu
 
 
-def cfg_from(W, H, max_steps, see_through, lava_v1=False):
+def cfg_from(W, H, max_steps, see_through, lava_v1=False, task=0):
     c = mg.Config()
     c.width, c.height, c.max_steps = W, H, max_steps
     c.see_through_walls, c.lava_v1 = int(see_through), int(lava_v1)
+    c.task_kind = int(task)
     return c
 
 
@@ -38,9 +39,13 @@ def test_golden_trace_no_autoreset(name, backend):
     N = 197 if backend == "numpy" else K
     sel = np.arange(N) % K
     mode = "full" if meta["full_obs"] else "partial"
-    env = mg.VecMiniGrid(config=cfg_from(meta["W"], meta["H"], meta["max_steps"], meta["see_through"], meta["lava_v1"]),
+    task = meta.get("task", 0)
+    env = mg.VecMiniGrid(config=cfg_from(meta["W"], meta["H"], meta["max_steps"], meta["see_through"], meta["lava_v1"], task),
                          num_envs=N, obs_mode=mode, auto_reset=False, backend=backend, agent_view_size=meta.get("view", 7), extended_actions=meta.get("extended", False), default_vis=not meta.get("alt_vis", False))
     env.set_state(z["init_grid"][sel], z["init_agent"][sel], aux=z["init_aux"][sel])
+    if task:
+        cur_task = z["init_task"][sel].copy()
+        env.set_task(cur_task)
     want0 = z["init_full"] if meta["full_obs"] else z["init_obs"]
     assert np.array_equal(to_np(env.observe()), want0[sel])
     want_obs = z["full"] if meta["full_obs"] else z["obs"]
@@ -62,9 +67,14 @@ def test_golden_trace_no_autoreset(name, backend):
             for i in np.flatnonzero(d):
                 r = rmap[int(sel[i])]
                 st["grid"][i], st["aux"][i], st["agent"][i] = z["reset_grid"][r], z["reset_aux"][r], z["reset_agent"][r]
+                if task:
+                    cur_task[i] = z["reset_task"][r]
             st["carry"][d] = (1, 0, 0)
             st["steps"][d] = 0
             env.set_state(st["grid"], st["agent"], aux=st["aux"], carry=st["carry"], steps=st["steps"])
+            if task:
+                env.set_task(cur_task)
+                assert np.array_equal(env.get_task(), cur_task)
     env.sync()
     env.close()
 

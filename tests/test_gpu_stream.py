@@ -12,7 +12,9 @@ from helpers import make_oracle, to_np
 pytestmark = pytest.mark.gpu
 
 STREAM_IDS = {"LavaCrossingS9N1-stream": "MiniGrid-LavaCrossingS9N1-v0", "DoorKey-5x5-stream": "MiniGrid-DoorKey-5x5-v0",
-              "LavaGapS6-stream": "MiniGrid-LavaGapS6-v0", "Empty-Random-6x6-stream": "MiniGrid-Empty-Random-6x6-v0"}
+              "LavaGapS6-stream": "MiniGrid-LavaGapS6-v0", "Empty-Random-6x6-stream": "MiniGrid-Empty-Random-6x6-v0",
+              "Fetch-8x8-N3": "MiniGrid-Fetch-8x8-N3-v0", "Fetch-5x5-N2": "MiniGrid-Fetch-5x5-N2-v0",
+              "GoToDoor-8x8": "MiniGrid-GoToDoor-8x8-v0", "GoToDoor-5x5": "MiniGrid-GoToDoor-5x5-v0"}
 
 
 @pytest.mark.parametrize("name", sorted(STREAM_IDS))
@@ -28,6 +30,8 @@ def test_reference_stream_traces(name):
     assert np.array_equal(obs, z["init_obs"][sel])
     st = env.get_state()
     assert np.array_equal(st["grid"], z["init_grid"][sel]) and np.array_equal(st["agent"], z["init_agent"][sel])
+    if meta.get("task", 0) == 1:
+        assert np.array_equal(env.get_task() & 0xFF, z["init_task"][sel])
     rmap = {(int(k), int(t)): r for r, (k, t) in enumerate(zip(z["reset_k"], z["reset_t"]))}
     for t in range(T):
         obs, rew, done, _ = env.step(z["actions"][sel, t])

@@ -10,16 +10,18 @@ IDS = ["Empty-8x8", "Empty-16x16", "Empty-5x5", "Empty-6x6", "DoorKey-5x5", "Doo
        "SimpleCrossingS9N1", "SimpleCrossingS9N2", "SimpleCrossingS9N3", "SimpleCrossingS11N5",
        "LavaCrossingS9N0", "DistShift1", "DistShift1-v1", "DistShift2", "LavaGapS5", "LavaGapS7", "NormalGapS6",
        "LavaGapS6-v1", "Empty-Random-5x5", "Empty-Random-8x8", "Empty-Random-10x10",
-       "MultiRoom-N2-S4", "MultiRoom-N4-S5", "MultiRoom-N6"]
+       "MultiRoom-N2-S4", "MultiRoom-N4-S5", "MultiRoom-N6", "Fetch-5x5-N2", "Fetch-6x6-N2", "Fetch-8x8-N3",
+       "GoToDoor-5x5", "GoToDoor-6x6", "GoToDoor-8x8"]
 
 
 @pytest.mark.parametrize("key", IDS)
 def test_levels_match_reference(levels, key):
     env_id = "MiniGrid-%s" % key if key.endswith("-v1") else "MiniGrid-%s-v0" % key
     seeds = levels[key + ":seeds"]
-    grid, agent = mg.generate_levels(env_id, seeds)
+    grid, agent, task = mg.generate_levels(env_id, seeds, with_task=True)
     assert np.array_equal(grid, levels[key + ":grid"])
     assert np.array_equal(agent, levels[key + ":agent"])
+    assert np.array_equal(task & 0xFF, levels[key + ":task"])   # Fetch target (the high byte is the mission template)
     cfg = mg.env_config(env_id)
     assert (cfg.max_steps, cfg.see_through_walls) == tuple(levels[key + ":max_steps"])
 

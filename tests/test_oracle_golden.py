@@ -13,8 +13,10 @@ def test_oracle_replays_reference_trace(name):
     meta, z = load_case(name)
     K, T = z["actions"].shape
     full = meta["full_obs"]
-    env = OracleEnvs(meta["W"], meta["H"], meta["max_steps"], meta["see_through"], meta["lava_v1"], view=meta.get("view", 7), extended=meta.get("extended", False), alt_vis=meta.get("alt_vis", False))
+    env = OracleEnvs(meta["W"], meta["H"], meta["max_steps"], meta["see_through"], meta["lava_v1"], view=meta.get("view", 7), extended=meta.get("extended", False), alt_vis=meta.get("alt_vis", False), task=meta.get("task", 0))
     env.set_state(z["init_grid"], z["init_agent"], aux=z["init_aux"])
+    if meta.get("task", 0):
+        env.task = z["init_task"].copy()
     if full:
         o, f = env.observe(full=True)
         assert np.array_equal(f, z["init_full"])
@@ -50,6 +52,8 @@ def test_oracle_replays_reference_trace(name):
                 assert np.array_equal(z["reset_obs"][r], z["init_obs"][k])
             else:                         # the RNG stream continued: a new level, injected from the recording
                 env.grid0[k], env.aux0[k], env.agent0[k] = z["reset_grid"][r], z["reset_aux"][r], z["reset_agent"][r]
+                if meta.get("task", 0):
+                    env.task[k] = z["reset_task"][r]
         env.reset_where(done)
         if done.any():
             o = env.observe()
