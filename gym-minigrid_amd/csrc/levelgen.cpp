@@ -130,6 +130,9 @@ int check_levelgen_cfg(const mgx_config *cfg, const char *fn)
     if (W < 3 || H < 3 || W > 255 || H > 255) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: grid %dx%d outside 3..255", fn, W, H);
     switch (cfg->level_kind) {
     case MGX_LEVEL_EMPTY: break;
+    case MGX_LEVEL_FOURROOMS:
+        if (W < 7 || H < 7) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: FourRooms needs at least 7x7", fn);
+        break;
     case MGX_LEVEL_MULTIROOM: {
         const int mn = cfg->level_arg0 & 255, mx = (cfg->level_arg0 >> 8) & 255;
         if (mn < 1 || mx < mn || mx > 8 || cfg->level_arg1 < 4 || W != H)
@@ -213,6 +216,8 @@ const std::vector<EnvId> &registry()
         {"MiniGrid-GoToDoor-5x5-v0", mkt(5, 5, 125, 1, MGX_LEVEL_GOTODOOR, 0, MGX_TASK_GOTODOOR)},
         {"MiniGrid-GoToDoor-6x6-v0", mkt(6, 6, 180, 1, MGX_LEVEL_GOTODOOR, 0, MGX_TASK_GOTODOOR)},
         {"MiniGrid-GoToDoor-8x8-v0", mkt(8, 8, 320, 1, MGX_LEVEL_GOTODOOR, 0, MGX_TASK_GOTODOOR)},
+        // FourRoomsEnv: 19x19, max_steps=500 (envs/fourrooms.py:14-17)
+        {"MiniGrid-FourRooms-v0", mk(19, 19, 500, 0, 0, MGX_LEVEL_FOURROOMS, 0, 0)},
         // MultiRoomEnv: 25x25, max_steps = maxNumRooms*20 (envs/multiroom.py:36-39,223-246)
         {"MiniGrid-MultiRoom-N2-S4-v0", mk(25, 25, 40, 0, 0, MGX_LEVEL_MULTIROOM, 2 | (2 << 8), 4)},
         {"MiniGrid-MultiRoom-N4-S5-v0", mk(25, 25, 80, 0, 0, MGX_LEVEL_MULTIROOM, 4 | (4 << 8), 5)},

@@ -418,6 +418,38 @@ LG_FN void lg_gen_gotodoor(const mgx_config &, R &r, LgLevel &L)
     L.adir = lg_randint(r, 0, 4);
 }
 
+// FourRoomsEnv._gen_grid (envs/fourrooms.py:19-67): outer walls, a cross of inner walls with one random gap per arm,
+// random agent pose, random goal.
+template <class R>
+LG_FN void lg_gen_fourrooms(const mgx_config &, R &r, LgLevel &L)
+{
+    const int W = L.W, H = L.H, rw = W / 2, rh = H / 2;
+    L.ncmd = 0;
+    lg_rect(L, 0, 0, W - 1, 0, MGX_CODE_WALL_GREY);
+    lg_rect(L, 0, H - 1, W - 1, H - 1, MGX_CODE_WALL_GREY);
+    lg_rect(L, 0, 0, 0, H - 1, MGX_CODE_WALL_GREY);
+    lg_rect(L, W - 1, 0, W - 1, H - 1, MGX_CODE_WALL_GREY);
+    for (int j = 0; j < 2; j++)
+        for (int i = 0; i < 2; i++) {
+            const int xL = i * rw, yT = j * rh, xR = xL + rw, yB = yT + rh;
+            if (i + 1 < 2) {
+                lg_rect(L, xR, yT, xR, yT + rh - 1, MGX_CODE_WALL_GREY);       // vert_wall(xR, yT, room_h)
+                lg_set(L, xR, lg_randint(r, yT + 1, yB), MGX_CODE_EMPTY);
+            }
+            if (j + 1 < 2) {
+                lg_rect(L, xL, yB, xL + rw - 1, yB, MGX_CODE_WALL_GREY);       // horz_wall(xL, yB, room_w)
+                lg_set(L, lg_randint(r, xL + 1, xR), yB, MGX_CODE_EMPTY);
+            }
+        }
+    L.ax = -1; L.ay = -1;
+    lg_sample_free(r, L, W, H, false, &L.ax, &L.ay); // place_agent()
+    L.adir = lg_randint(r, 0, 4);
+    int gx, gy;
+    lg_sample_free(r, L, W, H, true, &gx, &gy);      // place_obj(Goal())
+    if (!r.alive()) return;
+    lg_set(L, gx, gy, MGX_CODE_GOAL_GREEN);
+}
+
 // true if the family draws random numbers (Empty with a fixed start does not)
 LG_FN bool lg_uses_rng(const mgx_config &c) { return !(c.level_kind == MGX_LEVEL_EMPTY && c.level_arg0 == 0) && c.level_kind != MGX_LEVEL_DISTSHIFT; }
 
@@ -432,6 +464,7 @@ LG_FN void lg_generate(const mgx_config &c, R &r, LgLevel &L)
     case MGX_LEVEL_MULTIROOM: lg_gen_multiroom(c, r, L); break;
     case MGX_LEVEL_FETCH: lg_gen_fetch(c, r, L); break;
     case MGX_LEVEL_GOTODOOR: lg_gen_gotodoor(c, r, L); break;
+    case MGX_LEVEL_FOURROOMS: lg_gen_fourrooms(c, r, L); break;
     default: lg_gen_lavagap(c, r, L); break;
     }
 }

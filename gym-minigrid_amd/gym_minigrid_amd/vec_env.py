@@ -25,7 +25,7 @@ MISSIONS = {1: "get to the green goal square",
             4: {9: "avoid the lava and get to the green goal square",
                 2: "find the opening and get to the green goal square"},
             5: "get to the green goal square", 6: "traverse the rooms to get to the goal",
-            7: "fetch a <color> <type>: see get_task()", 8: "go to the red door"}
+            7: "fetch a <color> <type>: see get_task()", 8: "go to the red door", 9: "Reach the goal"}
 
 
 def _ptr(a):

@@ -87,6 +87,7 @@ typedef enum {
     MGX_LEVEL_DISTSHIFT = 5, /* DistShiftEnv (envs/distshift.py): level_arg0 = strip2_row; no randomness */
     MGX_LEVEL_FETCH = 7,     /* FetchEnv (envs/fetch.py): level_arg0 = numObjs; use with task_kind = MGX_TASK_FETCH */
     MGX_LEVEL_GOTODOOR = 8,  /* GoToDoorEnv (envs/gotodoor.py); use with task_kind = MGX_TASK_GOTODOOR */
+    MGX_LEVEL_FOURROOMS = 9, /* FourRoomsEnv (envs/fourrooms.py:8-70), random agent and goal */
     MGX_LEVEL_MULTIROOM = 6  /* MultiRoomEnv (envs/multiroom.py): level_arg0 = minNumRooms | maxNumRooms << 8 (<= 8),
                                 level_arg1 = maxRoomSize */
 } mgx_level_kind;

@@ -339,7 +339,8 @@ def record_level_streams():
                              ("MiniGrid-LavaGapS7-v0", [0, 3], 900), ("MiniGrid-LavaGapS6-v1", [1], 900),
                              ("MiniGrid-NormalGapS6-v0", [2], 300), ("MiniGrid-Empty-8x8-v0", [0], 5),
                              ("MiniGrid-MultiRoom-N2-S4-v0", [0], 300), ("MiniGrid-MultiRoom-N6-v0", [1, 4], 400),
-                             ("MiniGrid-Fetch-8x8-N3-v0", [0, 2], 700), ("MiniGrid-GoToDoor-6x6-v0", [1], 700)]:
+                             ("MiniGrid-Fetch-8x8-N3-v0", [0, 2], 700), ("MiniGrid-GoToDoor-6x6-v0", [1], 700),
+                             ("MiniGrid-FourRooms-v0", [0, 3], 600)]:
         env = gym.make(env_id)
         key = env_id.replace("MiniGrid-", "").replace("-v0", "")
         for s in seeds:
@@ -395,7 +396,7 @@ def record_levels():
                           ("MiniGrid-DoorKey-8x8-v0", range(256)), ("MiniGrid-DoorKey-16x16-v0", range(32)),
                           ("MiniGrid-LavaCrossingS9N1-v0", range(256)), ("MiniGrid-LavaCrossingS9N2-v0", range(64)),
                           ("MiniGrid-LavaCrossingS9N0-v0", range(64)), ("MiniGrid-MultiRoom-N2-S4-v0", range(128)),
-                          ("MiniGrid-Fetch-5x5-N2-v0", range(64)), ("MiniGrid-Fetch-6x6-N2-v0", range(64)),
+                          ("MiniGrid-FourRooms-v0", range(128)), ("MiniGrid-Fetch-5x5-N2-v0", range(64)), ("MiniGrid-Fetch-6x6-N2-v0", range(64)),
                           ("MiniGrid-Fetch-8x8-N3-v0", range(128)), ("MiniGrid-GoToDoor-5x5-v0", range(64)),
                           ("MiniGrid-GoToDoor-6x6-v0", range(64)), ("MiniGrid-GoToDoor-8x8-v0", range(128)),
                           ("MiniGrid-MultiRoom-N4-S5-v0", range(128)), ("MiniGrid-MultiRoom-N6-v0", range(128)), ("MiniGrid-DistShift1-v0", range(2)),
@@ -462,6 +463,7 @@ def main():
     record_case("DistShift1-v1", mk("MiniGrid-DistShift1-v1"), [0, 1], 260, v1=True)
     record_case("DistShift2", mk("MiniGrid-DistShift2-v0"), [0, 1], 260)
     record_case("LavaCrossingS9N0", mk("MiniGrid-LavaCrossingS9N0-v0"), [0, 1, 2, 3], 200)
+    record_case("FourRooms", mk("MiniGrid-FourRooms-v0"), [0, 1, 2], 520, reseed=False)
     # other view sizes (ViewSizeWrapper, wrappers.py:579-608: sets env.unwrapped.agent_view_size)
     def vs(make, v):
         def f():

@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 STREAM_IDS = {"LavaCrossingS9N1-stream": "MiniGrid-LavaCrossingS9N1-v0", "DoorKey-5x5-stream": "MiniGrid-DoorKey-5x5-v0",
               "LavaGapS6-stream": "MiniGrid-LavaGapS6-v0", "Empty-Random-6x6-stream": "MiniGrid-Empty-Random-6x6-v0",
               "Fetch-8x8-N3": "MiniGrid-Fetch-8x8-N3-v0", "Fetch-5x5-N2": "MiniGrid-Fetch-5x5-N2-v0",
-              "GoToDoor-8x8": "MiniGrid-GoToDoor-8x8-v0", "GoToDoor-5x5": "MiniGrid-GoToDoor-5x5-v0"}
+              "GoToDoor-8x8": "MiniGrid-GoToDoor-8x8-v0", "GoToDoor-5x5": "MiniGrid-GoToDoor-5x5-v0",
+              "FourRooms": "MiniGrid-FourRooms-v0"}
 
 
 @pytest.mark.parametrize("name", sorted(STREAM_IDS))

@@ -11,7 +11,7 @@ IDS = ["Empty-8x8", "Empty-16x16", "Empty-5x5", "Empty-6x6", "DoorKey-5x5", "Doo
        "LavaCrossingS9N0", "DistShift1", "DistShift1-v1", "DistShift2", "LavaGapS5", "LavaGapS7", "NormalGapS6",
        "LavaGapS6-v1", "Empty-Random-5x5", "Empty-Random-8x8", "Empty-Random-10x10",
        "MultiRoom-N2-S4", "MultiRoom-N4-S5", "MultiRoom-N6", "Fetch-5x5-N2", "Fetch-6x6-N2", "Fetch-8x8-N3",
-       "GoToDoor-5x5", "GoToDoor-6x6", "GoToDoor-8x8"]
+       "GoToDoor-5x5", "GoToDoor-6x6", "GoToDoor-8x8", "FourRooms"]
 
 
 @pytest.mark.parametrize("key", IDS)
