@@ -42,6 +42,22 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// The observation stream is written once and never read back by this library: non-temporal stores keep it from
+// displacing the env state (re-read every step) in L2 / Infinity Cache.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nt_store16(uint4 *p, const uint4 &v)
+{
+    u32x4 x = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(x, reinterpret_cast<u32x4 *>(p));
+}
+
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ void nt_store12(uint32_t *p, uint32_t a, uint32_t b, uint32_t c)
+{
+    u32x3 x = {a, b, c};
+    __builtin_nontemporal_store(x, reinterpret_cast<u32x3 *>(p));
+}
+
 __device__ __forceinline__ bool lane_bit(u64 m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
 // cell code -> (type | color<<8 | state<<16), the reference's WorldObj.encode()/Door.encode() (minigrid.py:113-115,264-275)
@@ -454,7 +470,7 @@ __device__ __forceinline__ void emit_partial_obs(const StepParams &p, const Lane
 #pragma unroll
             for (int i = 0; i < (CHUNKS + 63) / 64; i++) {
                 const int c = lane + 64 * i;
-                if (c < CHUNKS) reinterpret_cast<uint4 *>(dst)[c] = l128[c];
+                if (c < CHUNKS) nt_store16(reinterpret_cast<uint4 *>(dst) + c, l128[c]);
             }
         } else if (lim > 0) {
             for (int c = lane; c < CHUNKS; c += 64) {
@@ -821,7 +837,7 @@ __global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
         r.a = __builtin_amdgcn_perm(t1, t0, 0x04020100u);
         r.b = __builtin_amdgcn_perm(t2, t1, 0x05040201u);
         r.c = __builtin_amdgcn_perm(t3, t2, 0x06050402u);
-        dst[u] = r;
+        nt_store12(&dst[u].a, r.a, r.b, r.c);
     }
 }
 
@@ -997,7 +1013,7 @@ __global__ __launch_bounds__(256) void k_onehot(const uint8_t *__restrict__ tri,
     uint8_t *dst = out + cell0 * NB; // 256*NB bytes per wave: 16-B aligned
     const uint4 *x4 = reinterpret_cast<const uint4 *>(s_x[wv]);
     for (int i = lane; i < (n_bytes + 15) / 16; i += 64) {
-        if (16 * i + 16 <= n_bytes) reinterpret_cast<uint4 *>(dst)[i] = x4[i];
+        if (16 * i + 16 <= n_bytes) nt_store16(reinterpret_cast<uint4 *>(dst) + i, x4[i]);
         else
             for (int b = 16 * i; b < n_bytes; b++) dst[b] = reinterpret_cast<const uint8_t *>(s_x[wv])[b];
     }
