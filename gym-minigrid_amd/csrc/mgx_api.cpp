@@ -63,6 +63,9 @@ struct mgx_env_s {
     bool device_levels = false; // the family draws random numbers: mgx_reset seeds and generates on the GPU
     uint32_t *mt_d = nullptr, *mt_idx_d = nullptr, *mt_init_d = nullptr;
     uint8_t *regen_d = nullptr;
+    // object_state: hidden Goal/Box planes (+ episode-start snapshots) and the carried object's pair
+    uint8_t *objaux_d = nullptr, *objaux0_d = nullptr, *objcont_d = nullptr, *objcont0_d = nullptr;
+    uint16_t *objcarry_d = nullptr;
     Staging st_in[6], st_out[4];
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool profiling = false;
@@ -164,6 +167,7 @@ StepParams base_params(mgx_handle h)
     p.alt_vis = h->cfg.alt_visibility ? 1 : 0;
     p.task = h->cfg.task_kind;
     p.regen = h->stream_mode ? h->regen_d : nullptr;
+    p.objaux = h->objaux_d; p.objcont = h->objcont_d; p.objaux0 = h->objaux0_d; p.objcont0 = h->objcont0_d; p.objcarry = h->objcarry_d;
     return p;
 }
 
@@ -281,6 +285,11 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
             return rc_;                                                                      \
         }                                                                                    \
     } while (0)
+    if (cfg->object_state && cfg->new_level_each_episode) {
+        int rc = mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_create: object_state cannot be combined with new_level_each_episode (generated levels hold default objects only)");
+        delete h;
+        return rc;
+    }
     if (cfg->new_level_each_episode) {
         const char *why = nullptr;
         if (!cfg->auto_reset) why = "needs auto_reset = 1";
@@ -301,6 +310,12 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     CREATE_TRY(hipMalloc((void **)&h->agent0_d, ab));
     CREATE_TRY(hipMalloc((void **)&h->ctr_d, sizeof(MgxCounters)));
     if (h->oh_nc >= 0) CREATE_TRY(hipMalloc((void **)&h->tri_d, (size_t)h->n * h->tri_bytes + 16));
+    if (cfg->object_state) {
+        for (uint8_t **pp : {&h->objaux_d, &h->objaux0_d}) { CREATE_TRY(hipMalloc((void **)pp, cb)); CREATE_TRY(hipMemsetAsync(*pp, 0, cb, h->stream)); }
+        for (uint8_t **pp : {&h->objcont_d, &h->objcont0_d}) { CREATE_TRY(hipMalloc((void **)pp, cb)); CREATE_TRY(hipMemsetAsync(*pp, MGX_CODE_EMPTY, cb, h->stream)); }
+        CREATE_TRY(hipMalloc((void **)&h->objcarry_d, (size_t)h->n_pad * sizeof(uint16_t)));
+        CREATE_TRY(hipMemsetD16Async((hipDeviceptr_t)h->objcarry_d, (unsigned short)(MGX_CODE_EMPTY << 8), (size_t)h->n_pad, h->stream));
+    }
     CREATE_TRY(hipMemsetAsync(h->cells_d, 0, cb, h->stream));
     CREATE_TRY(hipMemsetAsync(h->cells0_d, 0, cb, h->stream));
     CREATE_TRY(hipMemsetAsync(h->agent_d, 0, ab, h->stream));
@@ -334,6 +349,7 @@ extern "C" int mgx_destroy(mgx_handle h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->cells_d); (void)hipFree(h->cells0_d); (void)hipFree(h->agent_d); (void)hipFree(h->agent0_d);
     (void)hipFree(h->ctr_d); (void)hipFree(h->tri_d);
+    (void)hipFree(h->objaux_d); (void)hipFree(h->objaux0_d); (void)hipFree(h->objcont_d); (void)hipFree(h->objcont0_d); (void)hipFree(h->objcarry_d);
     (void)hipFree(h->mt_d); (void)hipFree(h->mt_idx_d); (void)hipFree(h->regen_d); (void)hipFree(h->mt_init_d);
     for (auto &s : h->st_in) if (s.dev) (void)hipFree(s.dev);
     for (auto &s : h->st_out) if (s.dev) (void)hipFree(s.dev);
@@ -452,6 +468,7 @@ static int set_state_impl(mgx_handle h, const uint8_t *grid, const uint8_t *aux,
     if ((rc = dev_in(h, 5, mask_host, n, &d))) return rc;
     p.mask = (const uint8_t *)d;
     p.cells = h->cells_d; p.cells0 = h->cells0_d; p.rec = h->agent_d; p.rec0 = h->agent0_d;
+    p.objaux = h->objaux_d; p.objaux0 = h->objaux0_d; p.objcont = h->objcont_d; p.objcont0 = h->objcont0_d; p.objcarry = h->objcarry_d;
     p.ctr = h->ctr_d;
     p.n = h->n; p.W = h->W; p.H = h->H; p.S = h->S; p.has_task = h->cfg.task_kind != MGX_TASK_NONE;
     MgxCounters before, after;
@@ -500,7 +517,7 @@ extern "C" int mgx_get_state(mgx_handle h, uint8_t *grid, uint8_t *aux, int32_t 
     }
     PackParams p;
     memset(&p, 0, sizeof p);
-    p.cells = h->cells_d; p.rec = h->agent_d;
+    p.cells = h->cells_d; p.rec = h->agent_d; p.objaux = h->objaux_d;
     p.grid_out = (uint8_t *)t[0].dev; p.aux_out = (uint8_t *)t[1].dev; p.agent_out = (int32_t *)t[2].dev;
     p.carry_out = (uint8_t *)t[3].dev; p.steps_out = (int32_t *)t[4].dev;
     p.n = h->n; p.W = h->W; p.H = h->H; p.S = h->S; p.has_task = h->cfg.task_kind != MGX_TASK_NONE;
@@ -555,6 +572,47 @@ extern "C" int mgx_observe(mgx_handle h, uint8_t *obs)
     if (rc) return rc;
     if (!obs) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_observe: obs is required");
     return run_step(h, false, nullptr, obs, nullptr, nullptr);
+}
+
+static int objstate_io(mgx_handle h, const char *fn, const uint8_t *ci, const uint8_t *ai, const uint8_t *cci, uint8_t *co, uint8_t *ao, uint8_t *cco)
+{
+    int rc = check_handle(h, fn);
+    if (rc) return rc;
+    if (!h->objaux_d) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: the handle was not created with object_state = 1", fn);
+    const size_t n = (size_t)h->n, cells = (size_t)h->cells;
+    ObjStateParams p;
+    memset(&p, 0, sizeof p);
+    const void *d;
+    if ((rc = dev_in(h, 0, ci, n * cells * 3, &d))) return rc;
+    p.contains_in = (const uint8_t *)d;
+    if ((rc = dev_in(h, 1, ai, n, &d))) return rc;
+    p.carry_aux_in = (const uint8_t *)d;
+    if ((rc = dev_in(h, 2, cci, n * 3, &d))) return rc;
+    p.carry_contains_in = (const uint8_t *)d;
+    OutArg o[3];
+    if ((rc = dev_out(h, 0, co, n * cells * 3, &o[0]))) return rc;
+    if ((rc = dev_out(h, 1, ao, n, &o[1]))) return rc;
+    if ((rc = dev_out(h, 2, cco, n * 3, &o[2]))) return rc;
+    p.contains_out = (uint8_t *)o[0].dev; p.carry_aux_out = (uint8_t *)o[1].dev; p.carry_contains_out = (uint8_t *)o[2].dev;
+    p.objcont = h->objcont_d; p.objcont0 = h->objcont0_d; p.objcarry = h->objcarry_d; p.ctr = h->ctr_d;
+    p.n = h->n; p.W = h->W; p.H = h->H; p.S = h->S;
+    MgxCounters before, after;
+    if ((rc = read_counters(h, &before))) return rc;
+    HIP_TRY(mgx_launch_objstate(p, h->stream));
+    if ((rc = read_counters(h, &after))) return rc;
+    if (after.invalid_state != before.invalid_state)
+        return mgx_fail(MGX_ERR_INVALID_STATE, "%s: a contained object is not a (type, color, state) the reference can produce", fn);
+    return finish_out(h, o, 3);
+}
+
+extern "C" int mgx_set_object_state(mgx_handle h, const uint8_t *contains, const uint8_t *carry_aux, const uint8_t *carry_contains)
+{
+    return objstate_io(h, "mgx_set_object_state", contains, carry_aux, carry_contains, nullptr, nullptr, nullptr);
+}
+
+extern "C" int mgx_get_object_state(mgx_handle h, uint8_t *contains, uint8_t *carry_aux, uint8_t *carry_contains)
+{
+    return objstate_io(h, "mgx_get_object_state", nullptr, nullptr, nullptr, contains, carry_aux, carry_contains);
 }
 
 extern "C" int mgx_set_task(mgx_handle h, const uint32_t *task)

@@ -46,6 +46,10 @@ struct StepParams {
     float *reward;          // may be null
     uint8_t *done;          // may be null
     MgxCounters *ctr;
+    // hidden Goal/Box state (object_state handles, else null): planes, snapshots, carried object's pair
+    uint8_t *objaux, *objcont;
+    const uint8_t *objaux0, *objcont0;
+    uint16_t *objcarry;
     uint8_t *regen;        // stream mode: set to 1 for every env that consumed its next-level buffer (else null)
     int64_t n;
     int n_tiles;
@@ -59,6 +63,7 @@ struct PackParams {
     const uint8_t *mask;
     // internal state
     uint8_t *cells; uint8_t *cells0; uint2 *rec; uint2 *rec0;
+    uint8_t *objaux, *objaux0, *objcont, *objcont0; uint16_t *objcarry; // null unless object_state
     // outputs (unpack)
     uint8_t *grid_out; uint8_t *aux_out; int32_t *agent_out; uint8_t *carry_out; int32_t *steps_out;
     MgxCounters *ctr;
@@ -79,6 +84,16 @@ hipError_t mgx_launch_consume(const ConsumeParams &p, hipStream_t st);
 hipError_t mgx_launch_step(const StepParams &p, int mode, int waves_per_block, hipStream_t st);
 hipError_t mgx_raise_lds_limit(int W, int H, int mode, int bytes, int view, int alt_vis);
 hipError_t mgx_launch_onehot(const uint8_t *tri, uint8_t *out, int64_t n_cells, int nc, int ns, hipStream_t st);
+struct ObjStateParams {
+    const uint8_t *contains_in, *carry_aux_in, *carry_contains_in;
+    uint8_t *contains_out, *carry_aux_out, *carry_contains_out;
+    uint8_t *objcont, *objcont0;
+    uint16_t *objcarry;
+    MgxCounters *ctr;
+    int64_t n;
+    int W, H, S;
+};
+hipError_t mgx_launch_objstate(const ObjStateParams &p, hipStream_t st);
 hipError_t mgx_launch_task(uint2 *rec, uint2 *rec0, const uint32_t *set, uint32_t *get, int64_t n, hipStream_t st);
 hipError_t mgx_launch_direction(const uint2 *rec, uint8_t *out, int64_t n, hipStream_t st);
 hipError_t mgx_launch_pack(const PackParams &p, hipStream_t st);

@@ -185,9 +185,23 @@ __device__ __forceinline__ int transition_begin(const StepParams &p, Lane &L, ui
 // `cell_at(idx)` reads another cell of the env (only strafe_right onto a goal needs one: the reference tests
 // LEFT_cell.overlap there, minigrid.py:1310, and raises AttributeError unless the left cell is a goal as well;
 // that case is counted as a fault and treated as "not terminal").
+// Hidden Goal/Box state (object_state handles): per-cell byte `aux` = (toggletimes-1)&15 << 4 | (triage_color+1) << 1 and
+// per-cell contents code `cont` (Box.contains), plus the same pair for the carried object.  aux == nullptr: the handle
+// has no such planes and every Goal/Box is the default one (toggletimes 1, no triage colour, empty).
+struct ObjRef {
+    uint8_t *aux, *cont; // this env's planes
+    uint16_t *carry;     // aux | cont << 8 of the carried object
+};
+__device__ __forceinline__ bool box_overlappable(const ObjRef &o, int idx, uint32_t code)
+{ // Box.can_overlap: color == triage_color (minigrid.py:342-343)
+    if (!o.aux) return false;
+    const uint32_t tri = (o.aux[idx] >> 1) & 7u;
+    return tri != 0u && tri - 1u == ((code >> 4) & 7u);
+}
+
 template <int CH, class CellAt>
 __device__ __forceinline__ uint32_t transition_apply(const StepParams &p, Lane &L, uint32_t act, uint32_t fc, float &reward, bool &done,
-                                                     CellAt cell_at, bool &refbug)
+                                                     CellAt cell_at, bool &refbug, int tidx, const ObjRef &o)
 {
     const int dir = L.dir;
     if (act >= 7) { // strafe: only reachable with extended_actions
@@ -197,7 +211,7 @@ __device__ __forceinline__ uint32_t transition_apply(const StepParams &p, Lane &
         const uint32_t k = fc & 15u;
         const uint32_t OVERLAP = (1u << MGX_K_EMPTY) | (1u << MGX_K_FLOOR) | (1u << MGX_K_DOOR_OPEN) | (1u << MGX_K_GOAL) | (1u << MGX_K_LAVA);
         const int ax0 = L.ax, ay0 = L.ay;
-        if ((OVERLAP >> k) & 1u) { L.ax += tx; L.ay += ty; }
+        if (((OVERLAP >> k) & 1u) || (k == MGX_K_BOX && box_overlappable(o, tidx, fc))) { L.ax += tx; L.ay += ty; }
         if (k == MGX_K_GOAL) {
             bool ov;
             if (act == 7) ov = (fc & 0x80u) != 0;
@@ -220,7 +234,7 @@ __device__ __forceinline__ uint32_t transition_apply(const StepParams &p, Lane &
     else if (act == 2) {
         // None, Floor, open Door, Goal, Lava can be walked onto (minigrid.py:93,164-166,192,211,245-247)
         const uint32_t OVERLAP = (1u << MGX_K_EMPTY) | (1u << MGX_K_FLOOR) | (1u << MGX_K_DOOR_OPEN) | (1u << MGX_K_GOAL) | (1u << MGX_K_LAVA);
-        if ((OVERLAP >> k) & 1u) { L.ax += dx; L.ay += dy; }
+        if (((OVERLAP >> k) & 1u) || (k == MGX_K_BOX && box_overlappable(o, tidx, fc))) { L.ax += dx; L.ay += dy; }
         if (k == MGX_K_GOAL && (fc & 0x80u)) { // goal.overlap (minigrid.py:1259-1261)
             done = true;
             // _reward(): 1 - 0.9*(step_count/max_steps) in Python doubles (minigrid.py:933-937), then f32
@@ -232,9 +246,31 @@ __device__ __forceinline__ uint32_t transition_apply(const StepParams &p, Lane &
         }
     } else if (act == 3) {
         const uint32_t PICK = (1u << MGX_K_KEY) | (1u << MGX_K_BALL) | (1u << MGX_K_BOX);
-        if (((PICK >> k) & 1u) && L.carry == MGX_CODE_EMPTY) { L.carry = fc; nc = MGX_CODE_EMPTY; }
+        if (((PICK >> k) & 1u) && L.carry == MGX_CODE_EMPTY) {
+            L.carry = fc; nc = MGX_CODE_EMPTY;
+            if (o.aux) { *o.carry = (uint16_t)(o.aux[tidx] | (o.cont[tidx] << 8)); o.aux[tidx] = 0; o.cont[tidx] = MGX_CODE_EMPTY; }
+        }
     } else if (act == 4) {
-        if (k == MGX_K_EMPTY && L.carry != MGX_CODE_EMPTY) { nc = L.carry; L.carry = MGX_CODE_EMPTY; }
+        if (k == MGX_K_EMPTY && L.carry != MGX_CODE_EMPTY) {
+            nc = L.carry; L.carry = MGX_CODE_EMPTY;
+            if (o.aux) { o.aux[tidx] = (uint8_t)*o.carry; o.cont[tidx] = (uint8_t)(*o.carry >> 8); *o.carry = (uint16_t)(MGX_CODE_EMPTY << 8); }
+        }
+    } else if (act == 5 && o.aux && (k == MGX_K_GOAL || k == MGX_K_BOX)) {
+        // Goal.toggle / Box.toggle with their hidden state (minigrid.py:171-181,355-364)
+        uint32_t a = o.aux[tidx];
+        int tt = (int)(((a >> 4) + 1u) & 15u);
+        const uint32_t tri = (a >> 1) & 7u;
+        const bool goal = k == MGX_K_GOAL;
+        if (!goal || tt > 0) {
+            tt = tt > 0 ? tt - 1 : 0; // Box counts below zero in Python; every value <= 0 behaves the same
+            a = (a & 0x0Fu) | ((uint32_t)((tt - 1) & 15) << 4);
+            if (tt <= 0 && tri == 0u) { // Goal: removed; Box: replaced by its contents
+                nc = goal ? (uint32_t)MGX_CODE_EMPTY : (uint32_t)o.cont[tidx];
+                o.cont[tidx] = MGX_CODE_EMPTY;
+                a = 0;
+            } else if (tt <= 0) nc = (fc & 0x8Fu) | ((tri - 1u) << 4); // self.color = self.triage_color
+            o.aux[tidx] = (uint8_t)a;
+        }
     } else if (act == 5) {
         if (k == MGX_K_DOOR_LOCKED) { // Door.toggle (minigrid.py:252-262)
             if ((L.carry & 15u) == MGX_K_KEY && ((L.carry >> 4) & 7u) == ((fc >> 4) & 7u)) nc = (fc & 0xF0u) | MGX_K_DOOR_OPEN;
@@ -244,6 +280,16 @@ __device__ __forceinline__ uint32_t transition_apply(const StepParams &p, Lane &
         else if (k == MGX_K_BOX) nc = MGX_CODE_EMPTY;                         // Box.toggle, contains=None (minigrid.py:355-364)
     } // act == 6 ("done"): pass (minigrid.py:1291-1293)
     return nc;
+}
+
+// auto-reset of the hidden object state: planes back to the snapshot, nothing carried
+__device__ __forceinline__ void restore_objstate(const StepParams &p, int64_t env)
+{
+    if (!p.objaux) return;
+    const uint32_t *a0 = reinterpret_cast<const uint32_t *>(p.objaux0 + env * p.S), *c0 = reinterpret_cast<const uint32_t *>(p.objcont0 + env * p.S);
+    uint32_t *a = reinterpret_cast<uint32_t *>(p.objaux + env * p.S), *c = reinterpret_cast<uint32_t *>(p.objcont + env * p.S);
+    for (int i = 0; i < (p.S >> 2); i++) { a[i] = a0[i]; c[i] = c0[i]; }
+    p.objcarry[env] = (uint16_t)(MGX_CODE_EMPTY << 8);
 }
 
 // Restore this lane's env to its episode-start snapshot (LDS image + HBM).  Each done lane copies its own
@@ -706,7 +752,8 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
         const int fidx = transition_begin<CW, CH>(p, L, act, valid, bad_act, oob);
         if (fidx >= 0) {
             const uint32_t fc = g[fidx];
-            const uint32_t nc = transition_apply<CH>(p, L, act, fc, reward, done, [&](int i) -> uint32_t { return g[i]; }, oob);
+            const ObjRef obj = {p.objaux ? p.objaux + env * S : nullptr, p.objaux ? p.objcont + env * S : nullptr, p.objaux ? p.objcarry + env : nullptr};
+            const uint32_t nc = transition_apply<CH>(p, L, act, fc, reward, done, [&](int i) -> uint32_t { return g[i]; }, oob, fidx, obj);
             if (nc != fc) g[fidx] = (uint8_t)nc;
             if (valid && L.steps >= p.max_steps) done = true; // minigrid.py:1320-1321
             if (p.task) task_rule<CH>(p, L, act, reward, done, [&](int i) -> uint32_t { return g[i]; });
@@ -718,6 +765,7 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
         wave_stats(p, valid, done, reward, bad_act, oob, lane, tile);
         if (p.auto_reset && valid && done) {
             restore_own<CS>(p, env, g);
+            restore_objstate(p, env);
             L = unpack_rec(p.agent0[env], p.task);
             if (p.regen) p.regen[env] = 1; // the next-level buffer was consumed: k_levelgen refills it after this launch
         }
@@ -783,8 +831,9 @@ __global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
             const int fidx = transition_begin<CW, CH>(p, L, act, valid, bad_act, oob);
             if (fidx >= 0) {
                 const uint32_t fc = p.cells[env * S + fidx];
+                const ObjRef obj = {p.objaux ? p.objaux + env * S : nullptr, p.objaux ? p.objcont + env * S : nullptr, p.objaux ? p.objcarry + env : nullptr};
                 const uint32_t nc = transition_apply<CH>(p, L, act, fc, reward, done,
-                                                         [&](int i) -> uint32_t { return p.cells[env * S + i]; }, oob);
+                                                         [&](int i) -> uint32_t { return p.cells[env * S + i]; }, oob, fidx, obj);
                 if (valid && L.steps >= p.max_steps) done = true;
                 if (p.task) task_rule<CH>(p, L, act, reward, done, [&](int i) -> uint32_t { return (i == fidx) ? nc : (uint32_t)p.cells[env * S + i]; });
                 if (nc != fc && !(p.auto_reset && done)) {
@@ -798,6 +847,7 @@ __global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
             wave_stats(p, valid, done, reward, bad_act, oob, lane, tile);
             if (p.auto_reset && valid && done) {
                 L = unpack_rec(p.agent0[env], p.task);
+                restore_objstate(p, env);
                 reset = true;
                 if (p.regen) p.regen[env] = 1;
             }
@@ -1085,12 +1135,18 @@ __global__ __launch_bounds__(256) void k_pack_state(const PackParams p)
                 const uint32_t ty = tr[0], co = tr[1], st = tr[2];
                 const uint32_t ax = p.aux ? p.aux[e * cells + c] : 0u;
                 uint32_t k = ty;
-                if (ty < 1 || ty > 9 || co > 6 || ax > 1) bad = true;
+                if (ty < 1 || ty > 9 || co > 6) bad = true;
+                // aux: bit0 Goal.overlap | (triage_color+1) << 1 | ((toggletimes-1)&15) << 4.  Goals and boxes only; without
+                // object-state planes just the two goals the kernels know by themselves: default (0) and terminal (0xF1).
+                if (ax != 0 && ty != 8 && ty != 7) bad = true;
+                if ((ax & 1u) && ty != 8) bad = true;
+                if (!p.objaux && ax != 0 && !(ty == 8 && ax == 0xF1u)) bad = true;
                 if (ty == 4) { if (st > 2) bad = true; k = st == 0 ? MGX_K_DOOR_OPEN : (st == 1 ? MGX_K_DOOR_CLOSED : MGX_K_DOOR_LOCKED); }
                 else if (st != 0) bad = true;
                 if (ty == 1 && (co != 0 || ax != 0)) bad = true; // None encodes as exactly (1,0,0)
                 code = (k & 15u) | ((co & 7u) << 4) | ((ax & 1u) << 7);
-            }
+                if (p.objaux) { p.objaux[t] = (uint8_t)(ax & 0xFEu); p.objaux0[t] = (uint8_t)(ax & 0xFEu); p.objcont[t] = MGX_CODE_EMPTY; p.objcont0[t] = MGX_CODE_EMPTY; }
+            } else if (p.objaux) { p.objaux[t] = 0; p.objaux0[t] = 0; p.objcont[t] = MGX_CODE_EMPTY; p.objcont0[t] = MGX_CODE_EMPTY; }
             p.cells[t] = (uint8_t)code;
             p.cells0[t] = (uint8_t)code;
         }
@@ -1114,6 +1170,7 @@ __global__ __launch_bounds__(256) void k_pack_state(const PackParams p)
         }
         const uint2 rec = make_uint2((uint32_t)(x & 255) | ((uint32_t)(y & 255) << 8) | ((uint32_t)(d & 3) << 16) | (cc << 24), w1);
         p.rec[t] = rec;
+        if (p.objaux) p.objcarry[t] = (uint16_t)(MGX_CODE_EMPTY << 8);
         // the episode start always has nothing carried and step_count 0 (reset(), minigrid.py:851-854)
         p.rec0[t] = make_uint2((rec.x & 0x00FFFFFFu) | ((uint32_t)MGX_CODE_EMPTY << 24), p.has_task ? (w1 & 0xFFFF0000u) : 0u);
     }
@@ -1134,7 +1191,7 @@ __global__ __launch_bounds__(256) void k_unpack_state(const PackParams p)
             uint8_t *o = p.grid_out + t * 3;
             o[0] = (uint8_t)tr; o[1] = (uint8_t)(tr >> 8); o[2] = (uint8_t)(tr >> 16);
         }
-        if (p.aux_out) p.aux_out[t] = (uint8_t)(code >> 7);
+        if (p.aux_out) p.aux_out[t] = (uint8_t)((code >> 7) | (p.objaux ? p.objaux[e * p.S + c] : ((code & 15u) == MGX_K_GOAL && (code >> 7) ? 0xF0u : 0u)));
     }
     if (t < p.n) {
         const Lane L = unpack_rec(p.rec[t], p.has_task);
@@ -1288,6 +1345,58 @@ __global__ __launch_bounds__(256) void k_task(uint2 *rec, uint2 *rec0, const uin
     if (get) get[i] = rec[i].y >> 16;
 }
 } // namespace
+
+namespace {
+// Box.contains planes / carried object's hidden pair <-> reference encoding
+__global__ __launch_bounds__(256) void k_objstate(const ObjStateParams p)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int cells = p.W * p.H;
+    if (t < p.n * (int64_t)cells) {
+        const int64_t e = t / cells;
+        const int c = (int)(t - e * cells);
+        if (p.contains_in) {
+            const uint8_t *tr = p.contains_in + t * 3;
+            const uint32_t ty = tr[0], co = tr[1], st = tr[2];
+            uint32_t k = ty;
+            bool bad = ty < 1 || ty > 9 || co > 6 || (ty == 1 && (co || st));
+            if (ty == 4) { if (st > 2) bad = true; k = st == 0 ? MGX_K_DOOR_OPEN : (st == 1 ? MGX_K_DOOR_CLOSED : MGX_K_DOOR_LOCKED); }
+            else if (st != 0) bad = true;
+            if (bad) atomicAdd(&p.ctr->invalid_state, 1ull);
+            const uint8_t code = (uint8_t)((k & 15u) | ((co & 7u) << 4));
+            p.objcont[e * p.S + c] = code;
+            p.objcont0[e * p.S + c] = code;
+        }
+        if (p.contains_out) {
+            const uint32_t tr = decode_triple(p.objcont[e * p.S + c]);
+            uint8_t *o = p.contains_out + t * 3;
+            o[0] = (uint8_t)tr; o[1] = (uint8_t)(tr >> 8); o[2] = (uint8_t)(tr >> 16);
+        }
+    }
+    if (t < p.n) {
+        uint32_t w = p.objcarry[t];
+        if (p.carry_aux_in) w = (w & 0xFF00u) | (p.carry_aux_in[t] & 0xFEu);
+        if (p.carry_contains_in) {
+            const uint8_t *tr = p.carry_contains_in + t * 3;
+            const uint32_t k = tr[0] == 4 ? (tr[2] == 0 ? MGX_K_DOOR_OPEN : (tr[2] == 1 ? MGX_K_DOOR_CLOSED : MGX_K_DOOR_LOCKED)) : tr[0];
+            w = (w & 0x00FFu) | ((((k & 15u) | ((tr[1] & 7u) << 4))) << 8);
+        }
+        if (p.carry_aux_in || p.carry_contains_in) p.objcarry[t] = (uint16_t)w;
+        if (p.carry_aux_out) p.carry_aux_out[t] = (uint8_t)(w & 0xFEu);
+        if (p.carry_contains_out) {
+            const uint32_t tr = decode_triple(w >> 8);
+            p.carry_contains_out[t * 3] = (uint8_t)tr; p.carry_contains_out[t * 3 + 1] = (uint8_t)(tr >> 8); p.carry_contains_out[t * 3 + 2] = (uint8_t)(tr >> 16);
+        }
+    }
+}
+} // namespace
+
+hipError_t mgx_launch_objstate(const ObjStateParams &p, hipStream_t st)
+{
+    const int64_t total = p.n * (int64_t)p.W * p.H;
+    hipLaunchKernelGGL(k_objstate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
 
 hipError_t mgx_launch_task(uint2 *rec, uint2 *rec0, const uint32_t *set, uint32_t *get, int64_t n, hipStream_t st)
 {

@@ -33,7 +33,7 @@ class Config(ctypes.Structure):
                 ("auto_reset", ctypes.c_int32), ("level_kind", ctypes.c_int32), ("level_arg0", ctypes.c_int32),
                 ("level_arg1", ctypes.c_int32), ("new_level_each_episode", ctypes.c_int32), ("agent_view_size", ctypes.c_int32),
                 ("extended_actions", ctypes.c_int32), ("alt_visibility", ctypes.c_int32),
-                ("task_kind", ctypes.c_int32), ("reserved", ctypes.c_int32 * 1)]
+                ("task_kind", ctypes.c_int32), ("object_state", ctypes.c_int32)]
 
 
 class Stats(ctypes.Structure):
@@ -62,6 +62,8 @@ SIGNATURES = {
     "mgx_reset": (_int, [_vp, _vp, _vp, _vp]),
     "mgx_set_state": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "mgx_get_state": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "mgx_set_object_state": (_int, [_vp, _vp, _vp, _vp]),
+    "mgx_get_object_state": (_int, [_vp, _vp, _vp, _vp]),
     "mgx_observe": (_int, [_vp, _vp]),
     "mgx_get_direction": (_int, [_vp, _vp]),
     "mgx_step": (_int, [_vp, _vp, _vp, _vp, _vp]),

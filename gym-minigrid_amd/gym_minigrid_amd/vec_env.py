@@ -52,6 +52,8 @@ class VecMiniGrid:
     new_level_each_episode=True (with auto_reset): plain reference behaviour -- `seed(s_i)` once at reset(), then every
                      episode draws a NEW level from the env's own RNG stream (generated on the GPU); False: every
                      episode replays the level of reset() (ReseedWrapper(seeds=[s_i])).
+    object_state=True: keep the hidden Goal/Box state (toggletimes, triage_color, Box.contains; minigrid.py:156-181,332-364)
+                     per cell; injected with set_state(aux=...) + set_object_state(...).
     default_vis=False: the fork's alternative occlusion model (minigrid.py:649-709).
     extended_actions: ExtendedActions (minigrid.py:747-764): actions 7 / 8 strafe left / right.
     agent_view_size: ViewSizeWrapper (wrappers.py:579-608): 3, 5, 7 (default), 9 or 11.
@@ -60,7 +62,7 @@ class VecMiniGrid:
 
     def __init__(self, env_id=None, num_envs=1, device=0, seeds=0, obs_mode="partial", auto_reset=True,
                  config=None, backend="torch", env_offset=0, check_actions=False, new_level_each_episode=False,
-                 agent_view_size=7, extended_actions=False, default_vis=True):
+                 agent_view_size=7, extended_actions=False, default_vis=True, object_state=False):
         L = _lib.lib()
         if config is None:
             if env_id is None:
@@ -76,6 +78,7 @@ class VecMiniGrid:
         cfg.agent_view_size = int(agent_view_size)
         cfg.extended_actions = int(bool(extended_actions))
         cfg.alt_visibility = int(not default_vis)
+        cfg.object_state = int(bool(object_state))
         self.cfg = cfg
         self.num_envs = int(num_envs)
         self.device = int(device)
@@ -217,6 +220,19 @@ class VecMiniGrid:
             self._bind_stream()
         _lib.check(_lib.lib().mgx_get_state(self._h, _ptr(out["grid"]), _ptr(out["aux"]), _ptr(out["agent"]),
                                             _ptr(out["carry"]), _ptr(out["steps"])))
+        return out
+
+    def set_object_state(self, contains=None, carry_aux=None, carry_contains=None):
+        """object_state handles: Box.contains plane (N,W,H,3) and the carried object's hidden state (aux (N,), contains (N,3))."""
+        c = None if contains is None else np.ascontiguousarray(contains, np.uint8)
+        a = None if carry_aux is None else np.ascontiguousarray(carry_aux, np.uint8)
+        cc = None if carry_contains is None else np.ascontiguousarray(carry_contains, np.uint8)
+        _lib.check(_lib.lib().mgx_set_object_state(self._h, _ptr(c), _ptr(a), _ptr(cc)))
+
+    def get_object_state(self):
+        n, W, H = self.num_envs, self.width, self.height
+        out = dict(contains=np.empty((n, W, H, 3), np.uint8), carry_aux=np.empty(n, np.uint8), carry_contains=np.empty((n, 3), np.uint8))
+        _lib.check(_lib.lib().mgx_get_object_state(self._h, _ptr(out["contains"]), _ptr(out["carry_aux"]), _ptr(out["carry_contains"])))
         return out
 
     def set_task(self, task):

@@ -34,8 +34,10 @@
  *
  * Encodings (identical to the reference's):
  *   grid   uint8 [N][W][H][3]  Grid.encode(): index [x][y][channel] = (type, color, state); (1,0,0) = empty
- *   aux    uint8 [N][W][H]     bit0 = Goal.overlap, i.e. a goal built with toggletimes<=0 (terminal goal,
- *                              minigrid.py:156-162,1259-1261).  NULL = all zeros (the default objects).
+ *   aux    uint8 [N][W][H]     hidden Goal/Box state: bit0 = Goal.overlap (a goal built with toggletimes<=0: terminal,
+ *                              minigrid.py:156-162,1259-1261); bits 3:1 = triage_color + 1 (0 = None); bits 7:4 =
+ *                              (toggletimes - 1) & 15.  0 = the default Goal() / Box(color); 0xF1 = Goal(toggletimes=0).
+ *                              Anything else needs a handle created with object_state = 1.  NULL = all zeros.
  *   agent  int32 [N][3]        x, y, dir (0 right, 1 down, 2 left, 3 up; minigrid.py:64-73)
  *   carry  uint8 [N][3]        encode() of the carried object, (1,0,0) = nothing
  *   steps  int32 [N]           step_count
@@ -124,7 +126,9 @@ typedef struct {
     int32_t extended_actions;   /* 1 = ExtendedActions (minigrid.py:747-764): 7 = strafe_left, 8 = strafe_right */
     int32_t alt_visibility;     /* 1 = default_vis=False: the fork's alternative occlusion model (minigrid.py:649-709) */
     int32_t task_kind;          /* mgx_task_kind; needs max_steps <= 65535 (the step counter shares a word with the task) */
-    int32_t reserved[1];
+    int32_t object_state;       /* 1 = keep the hidden Goal/Box state per cell (toggletimes, triage_color, Box.contains;
+                                   minigrid.py:156-181,332-364) in extra planes; 0 = every Goal/Box is the default one
+                                   (toggletimes 1, or 0 for terminal goals; no triage colour; empty boxes) */
 } mgx_config;
 
 typedef struct mgx_env_s *mgx_handle;
@@ -176,6 +180,13 @@ int mgx_get_state(mgx_handle h, uint8_t *grid, uint8_t *aux, int32_t *agent, uin
  * set_task also records it for the episode-start snapshot. */
 int mgx_set_task(mgx_handle h, const uint32_t *task);
 int mgx_get_task(mgx_handle h, uint32_t *task);
+
+/* object_state handles: Box.contains of every cell (uint8 [N][W][H][3], encode() of the contents, (1,0,0) = None) and the
+ * hidden state of the carried object (carry_aux uint8 [N] in the aux format above, carry_contains uint8 [N][3]).
+ * Any pointer may be NULL (set: leave unchanged; get: skip).  mgx_set_state resets all of them to "empty / default";
+ * call this after it.  set also records the planes for the episode-start snapshot. */
+int mgx_set_object_state(mgx_handle h, const uint8_t *contains, const uint8_t *carry_aux, const uint8_t *carry_contains);
+int mgx_get_object_state(mgx_handle h, uint8_t *contains, uint8_t *carry_aux, uint8_t *carry_contains);
 
 /* gen_obs() of the current state, no transition. */
 int mgx_observe(mgx_handle h, uint8_t *obs);

@@ -56,15 +56,39 @@ OUT = os.path.join(REPO, "tests", "golden")
 
 
 # --------------------------------------------------------------------------- helpers
+def obj_aux(o):
+    """Hidden Goal/Box state as one byte: bit0 Goal.overlap, bits 3:1 triage_color+1 (0 = None), bits 7:4 (toggletimes-1)&15."""
+    if o is None or o.type not in ("goal", "box"):
+        return 0
+    a = 1 if (o.type == "goal" and o.overlap) else 0
+    if o.triage_color is not None:
+        a |= (M.COLOR_TO_IDX[o.triage_color] + 1) << 1
+    tt = max(int(o.toggletimes), 0)       # Box counts below zero; every value <= 0 behaves the same
+    assert tt <= 15
+    return a | (((tt - 1) & 15) << 4)
+
+
+def obj_contains(o):
+    c = getattr(o, "contains", None) if o is not None else None
+    return c.encode() if c is not None else (1, 0, 0)
+
+
 def aux_plane(env):
     W, H = env.grid.width, env.grid.height
     a = np.zeros((W, H), np.uint8)
     for x in range(W):
         for y in range(H):
-            o = env.grid.get(x, y)
-            if o is not None and o.type == "goal" and o.overlap:
-                a[x, y] = 1
+            a[x, y] = obj_aux(env.grid.get(x, y))
     return a
+
+
+def contains_plane(env):
+    W, H = env.grid.width, env.grid.height
+    c = np.zeros((W, H, 3), np.uint8)
+    for x in range(W):
+        for y in range(H):
+            c[x, y] = obj_contains(env.grid.get(x, y))
+    return c
 
 
 def task_word(env):
@@ -138,6 +162,27 @@ class SoupEnv(M.MiniGridEnv):
         self.agent_pos = np.array((x, y))
         self.agent_dir = rs.randint(0, 4)
         self.mission = "soup"
+
+
+class SoupAuxEnv(SoupEnv):
+    """Soup with the hidden Goal/Box state exercised: toggletimes 0..3, triage colours, boxes with contents."""
+
+    def _gen_grid(self, width, height):
+        super()._gen_grid(width, height)
+        rs = self.np_random
+        colors = list(M.COLOR_TO_IDX.keys())
+        for x in range(1, width - 1):
+            for y in range(1, height - 1):
+                o = self.grid.get(x, y)
+                if o is None or (x, y) == tuple(self.agent_pos):
+                    continue
+                tri = colors[rs.randint(0, 7)] if rs.randint(0, 2) else None
+                if o.type == "goal":
+                    self.grid.set(x, y, M.Goal(toggletimes=rs.randint(0, 4), triage_color=tri))
+                elif o.type == "box":
+                    inner = [None, M.Key, M.Ball][rs.randint(0, 3)]
+                    inner = inner(colors[rs.randint(0, 7)]) if inner else None
+                    self.grid.set(x, y, M.Box(o.color, contains=inner, toggletimes=rs.randint(1, 4), triage_color=tri))
 
 
 class SoupEnvv1(SoupEnv):
@@ -239,7 +284,7 @@ def doorkey_script(env):
 
 
 # --------------------------------------------------------------------------- recorder
-def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False, reseed=True, n_actions=7):
+def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False, reseed=True, n_actions=7, objstate=False):
     K = len(seeds)
     env0 = make_env()
     W, H = env0.width, env0.height
@@ -247,7 +292,8 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
     meta = dict(env_id=name, W=W, H=H, max_steps=int(env0.max_steps), view=V,
                 see_through=bool(env0.see_through_walls), lava_v1=bool(v1), full_obs=bool(full_obs),
                 reseed=bool(reseed), extended=bool(n_actions > 7), alt_vis=not bool(env0.default_vis),
-                task=1 if hasattr(env0, "targetType") else (2 if hasattr(env0, "target_pos") else 0))
+                task=1 if hasattr(env0, "targetType") else (2 if hasattr(env0, "target_pos") else 0),
+                objstate=bool(objstate))
     z = dict(
         seed=np.zeros(K, np.int64), init_grid=np.zeros((K, W, H, 3), np.uint8),
         init_aux=np.zeros((K, W, H), np.uint8), init_agent=np.zeros((K, 3), np.int32),
@@ -259,7 +305,13 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
     if full_obs:
         z["full"] = np.zeros((K, T, W, H, 3), np.uint8)
         z["init_full"] = np.zeros((K, W, H, 3), np.uint8)
-    rk, rt, rg, ra, rag, ro, rtask = [], [], [], [], [], [], []
+    if objstate:
+        z["init_contains"] = np.zeros((K, W, H, 3), np.uint8)
+        z["aux"] = np.zeros((K, T, W, H), np.uint8)
+        z["contains"] = np.zeros((K, T, W, H, 3), np.uint8)
+        z["carry_aux"] = np.zeros((K, T), np.uint8)
+        z["carry_contains"] = np.zeros((K, T, 3), np.uint8)
+    rk, rt, rg, ra, rag, ro, rtask, rcont = [], [], [], [], [], [], [], []
     for k, s in enumerate(seeds):
         env = make_env()
         env.seed(int(s))
@@ -270,6 +322,8 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
         z["init_agent"][k] = (env.agent_pos[0], env.agent_pos[1], env.agent_dir)
         z["init_obs"][k] = o["image"]
         z["init_task"][k] = task_word(env)
+        if objstate:
+            z["init_contains"][k] = contains_plane(env)
         if full_obs:
             z["init_full"][k] = full_image(env)
         # action stream: optional scripted prefix (computed on a scratch copy), then random
@@ -298,6 +352,11 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
             z["carry"][k, t] = carry_triple(env)
             z["steps"][k, t] = env.step_count
             z["grid"][k, t] = env.grid.encode()
+            if objstate:
+                z["aux"][k, t] = aux_plane(env)
+                z["contains"][k, t] = contains_plane(env)
+                z["carry_aux"][k, t] = obj_aux(env.carrying)
+                z["carry_contains"][k, t] = obj_contains(env.carrying)
             if full_obs:
                 z["full"][k, t] = full_image(env)
             if d:
@@ -311,6 +370,7 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
                 rag.append((env.agent_pos[0], env.agent_pos[1], env.agent_dir))
                 ro.append(o2["image"])
                 rtask.append(task_word(env))
+                rcont.append(contains_plane(env))
     R = len(rk)
     z["reset_k"] = np.asarray(rk, np.int32)
     z["reset_t"] = np.asarray(rt, np.int32)
@@ -319,6 +379,8 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
     z["reset_agent"] = np.asarray(rag, np.int32).reshape(R, 3)
     z["reset_obs"] = np.asarray(ro, np.uint8).reshape(R, V, V, 3)
     z["reset_task"] = np.asarray(rtask, np.uint32)
+    if objstate:
+        z["reset_contains"] = np.asarray(rcont, np.uint8).reshape(R, W, H, 3)
     z["meta"] = np.frombuffer(json.dumps(meta).encode(), np.uint8)
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **z)
@@ -488,6 +550,10 @@ def main():
     record_case("Soup-19x19-altvis", lambda: SoupEnv(19, 19, False, 150, 0.2, default_vis=False), list(range(4)), 300)
     record_case("Soup-7x11-altvis-view5", vs(lambda: SoupEnv(7, 11, False, 80, 0.3, default_vis=False), 5), list(range(6)), 170)
     record_case("Soup-9x9-altvis-view9-strafe", vs(lambda: SoupEnv(9, 9, False, 100, 0.3, extended=True, default_vis=False), 9), list(range(6)), 200, n_actions=9)
+    # hidden Goal/Box state: toggletimes, triage_color, Box.contains (minigrid.py:156-181,332-364)
+    record_case("SoupAux-8x8", lambda: SoupAuxEnv(8, 8, False, 96, 0.55), list(range(16)), 250, objstate=True)
+    record_case("SoupAux-9x9-strafe", lambda: SoupAuxEnv(9, 9, True, 100, 0.5, extended=True), list(range(8)), 250, n_actions=9, objstate=True)
+    record_case("SoupAux-7x11-full", lambda: SoupAuxEnv(7, 11, False, 80, 0.5), list(range(6)), 200, full_obs=True, objstate=True)
     # task rules layered on the base step: FetchEnv (envs/fetch.py:74-86), GoToDoorEnv (envs/gotodoor.py:71-93)
     def fetch_script(which):
         def f(env):

@@ -31,7 +31,9 @@
  *
  * State representation used here = the reference's own encoding:
  *   grid  u8[W][H][3]   Grid.encode() layout, index [x][y][channel]; (1,0,0) = None
- *   aux   u8[W][H]      bit0 = Goal.overlap (a goal built with toggletimes<=0)
+ *   aux   u8[W][H]      bit0 = Goal.overlap (a goal built with toggletimes<=0); bits 3:1 = triage_color + 1 (0 = None);
+ *                       bits 7:4 = (toggletimes - 1) & 15, so that 0 describes the default Goal() / Box(color)
+ *   contains u8[W][H][3] (optional, mgo_set_contains) encode() of Box.contains, (1,0,0) = None
  *   agent i32[3]        x, y, dir
  *   carry u8[3]         encode() of the carried object, (1,0,0) = nothing; carry_aux u8
  *   steps i32           step_count
@@ -65,6 +67,15 @@ typedef struct {
 static const int DIR_TO_VEC[4][2] = { {1, 0}, {0, 1}, {-1, 0}, {0, -1} }; /* minigrid.py:64-73 */
 
 static cell_t NONE(void) { cell_t c = { T_EMPTY, 0, 0, 0 }; return c; }
+
+/* aux byte accessors (Goal/Box hidden state, minigrid.py:157-161,333-337) */
+static int aux_tt(uint8_t a) { return ((a >> 4) + 1) & 15; }            /* toggletimes */
+static int aux_tri(uint8_t a) { return ((a >> 1) & 7) - 1; }            /* triage_color index, -1 = None */
+static uint8_t aux_with_tt(uint8_t a, int tt) { return (uint8_t)((a & 0x0F) | (((tt - 1) & 15) << 4)); }
+
+/* Box.contains planes of the batch being stepped (test-harness state, like the task words) */
+static uint8_t *g_contains = 0, *g_carry_contains = 0;
+void mgo_set_contains(uint8_t *contains, uint8_t *carry_contains) { g_contains = contains; g_carry_contains = carry_contains; }
 static int is_none(cell_t c) { return c.t == T_EMPTY; }
 
 static cell_t grid_get(const mgo_cfg *cf, const uint8_t *g, const uint8_t *aux, int i, int j)
@@ -89,6 +100,7 @@ static int can_overlap(cell_t c)
     switch (c.t) {
     case T_GOAL: case T_FLOOR: case T_LAVA: return 1;
     case T_DOOR: return c.s == ST_OPEN;
+    case T_BOX: return aux_tri(c.a) >= 0 && aux_tri(c.a) == c.c; /* Box.can_overlap: color == triage_color (minigrid.py:342-343) */
     default: return 0;
     }
 }
@@ -210,7 +222,8 @@ static void full_obs(const mgo_cfg *cf, const uint8_t *g, const int32_t *agent, 
 
 /* MiniGridEnv.step (minigrid.py:1227-1325) without the trailing gen_obs */
 static int step_state(const mgo_cfg *cf, uint8_t *g, uint8_t *aux, int32_t *agent, uint8_t *carry,
-                      uint8_t *carry_aux, int32_t *steps, int action, double *reward, uint8_t *done)
+                      uint8_t *carry_aux, int32_t *steps, int action, double *reward, uint8_t *done,
+                      uint8_t *cont /* [W][H][3] or NULL */, uint8_t *carry_cont /* [3] or NULL */)
 {
     int dir = agent[2];
     int fx, fy, lx, ly, rx, ry;
@@ -255,12 +268,22 @@ static int step_state(const mgo_cfg *cf, uint8_t *g, uint8_t *aux, int32_t *agen
             if (carry[0] == T_EMPTY) {
                 carry[0] = fwd.t; carry[1] = fwd.c; carry[2] = fwd.s; *carry_aux = fwd.a;
                 grid_set(cf, g, aux, fx, fy, NONE());
+                if (cont) {
+                    uint8_t *q = cont + ((size_t)fx * cf->H + fy) * 3;
+                    memcpy(carry_cont, q, 3);
+                    q[0] = T_EMPTY; q[1] = 0; q[2] = 0;
+                }
             }
         }
     } else if (action == A_DROP) {
         if (is_none(fwd) && carry[0] != T_EMPTY) {
             cell_t c = { carry[0], carry[1], carry[2], *carry_aux };
             grid_set(cf, g, aux, fx, fy, c);
+            if (cont) {
+                uint8_t *q = cont + ((size_t)fx * cf->H + fy) * 3;
+                memcpy(q, carry_cont, 3);
+                carry_cont[0] = T_EMPTY; carry_cont[1] = 0; carry_cont[2] = 0;
+            }
             carry[0] = T_EMPTY; carry[1] = 0; carry[2] = 0; *carry_aux = 0;
         }
     } else if (action == A_TOGGLE) {
@@ -272,10 +295,33 @@ static int step_state(const mgo_cfg *cf, uint8_t *g, uint8_t *aux, int32_t *agen
                     fwd.s = (fwd.s == ST_OPEN) ? ST_CLOSED : ST_OPEN;
                     grid_set(cf, g, aux, fx, fy, fwd);
                 }
-            } else if (fwd.t == T_GOAL) { /* Goal.toggle minigrid.py:171-181; default toggletimes=1 */
-                if (!(fwd.a & 1)) grid_set(cf, g, aux, fx, fy, NONE());
-            } else if (fwd.t == T_BOX) { /* Box.toggle minigrid.py:355-364; contains=None */
-                grid_set(cf, g, aux, fx, fy, NONE());
+            } else if (fwd.t == T_GOAL) { /* Goal.toggle minigrid.py:171-181 */
+                int tt = aux_tt(fwd.a);
+                if (tt > 0) {
+                    tt -= 1;
+                    fwd.a = aux_with_tt(fwd.a, tt);
+                    if (tt <= 0 && aux_tri(fwd.a) < 0) grid_set(cf, g, aux, fx, fy, NONE());
+                    else {
+                        if (tt <= 0) fwd.c = (uint8_t)aux_tri(fwd.a); /* self.color = self.triage_color */
+                        grid_set(cf, g, aux, fx, fy, fwd);
+                    }
+                }
+            } else if (fwd.t == T_BOX) { /* Box.toggle minigrid.py:355-364 */
+                int tt = aux_tt(fwd.a) - 1;
+                if (tt < 0) tt = 0; /* Python keeps counting down; every value <= 0 behaves the same */
+                fwd.a = aux_with_tt(fwd.a, tt);
+                if (tt <= 0 && aux_tri(fwd.a) < 0) { /* env.grid.set(*pos, self.contains) */
+                    cell_t c = NONE();
+                    if (cont) {
+                        uint8_t *q = cont + ((size_t)fx * cf->H + fy) * 3;
+                        c.t = q[0]; c.c = q[1]; c.s = q[2];
+                        q[0] = T_EMPTY; q[1] = 0; q[2] = 0;
+                    }
+                    grid_set(cf, g, aux, fx, fy, c);
+                } else {
+                    if (tt <= 0) fwd.c = (uint8_t)aux_tri(fwd.a);
+                    grid_set(cf, g, aux, fx, fy, fwd);
+                }
             }
         }
     } else if (action == A_STRAFE_LEFT || action == A_STRAFE_RIGHT) { /* minigrid.py:1295-1314 */
@@ -343,7 +389,8 @@ int mgo_step_batch(const mgo_cfg *cf, int64_t n, uint8_t *grid, uint8_t *aux, in
     for (int64_t e = 0; e < n; e++) {
         uint8_t *g = grid + e * cells * 3, *ax = aux + e * cells;
         int rc = step_state(cf, g, ax, agent + e * 3, carry + e * 3, carry_aux + e, steps + e,
-                            actions[e], reward + e, done + e);
+                            actions[e], reward + e, done + e,
+                            g_contains ? g_contains + e * cells * 3 : 0, g_carry_contains ? g_carry_contains + e * 3 : 0);
         if (cf->task && rc == MGO_OK)
             task_rule(cf, g, ax, agent + e * 3, carry + e * 3, steps[e], g_task ? g_task[e] : 0u, actions[e], reward + e, done + e);
         if (err) err[e] = rc;

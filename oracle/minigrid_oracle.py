@@ -37,6 +37,7 @@ def lib():
         _lib.mgo_rollout.restype = ctypes.c_int64
         _lib.mgo_obs_batch.restype = None
         _lib.mgo_set_task.restype = None
+        _lib.mgo_set_contains.restype = None
     return _lib
 
 
@@ -68,6 +69,16 @@ class OracleEnvs:
         self.carry_aux = np.zeros(n, np.uint8) if carry_aux is None else np.ascontiguousarray(carry_aux, np.uint8).copy()
         self.steps = np.zeros(n, np.int32) if steps is None else np.ascontiguousarray(steps, np.int32).copy()
         self.grid0, self.aux0, self.agent0 = self.grid.copy(), self.aux.copy(), self.agent.copy()
+        self.contains = None          # optional Box.contains plane (n, W, H, 3); set_contains() enables it
+        self.carry_contains = None
+
+    def set_contains(self, contains, carry_contains=None):
+        self.contains = np.ascontiguousarray(contains, np.uint8).copy()
+        assert self.contains.shape == (self.n, self.W, self.H, 3)
+        if carry_contains is None:
+            carry_contains = np.tile(np.array([1, 0, 0], np.uint8), (self.n, 1))
+        self.carry_contains = np.ascontiguousarray(carry_contains, np.uint8).reshape(self.n, 3).copy()
+        self.contains0 = self.contains.copy()
 
     def observe(self, full=False):
         obs = np.zeros((self.n, self.V, self.V, 3), np.uint8)
@@ -84,6 +95,7 @@ class OracleEnvs:
         reward = np.zeros(self.n, np.float64)
         done = np.zeros(self.n, np.uint8)
         err = np.zeros(self.n, np.int32)
+        lib().mgo_set_contains(_p(self.contains), _p(self.carry_contains))
         if self.cfg.task:
             self._task = np.ascontiguousarray(self.task if self.task is not None else np.zeros(self.n), np.uint32)
             lib().mgo_set_task(_p(self._task))
@@ -104,6 +116,9 @@ class OracleEnvs:
         self.carry[m] = (1, 0, 0)
         self.carry_aux[m] = 0
         self.steps[m] = 0
+        if self.contains is not None:
+            self.contains[m] = self.contains0[m]
+            self.carry_contains[m] = (1, 0, 0)
 
     def rollout(self, actions, with_obs=True, full=False):
         """actions u8[T][n]; restores the initial state on done.  Returns env-steps executed."""

@@ -19,7 +19,7 @@ def random_states(n, W, H, seed, density=0.4, interior_agent=True):
                    kind == 9, kind == 10, kind >= 11], [2, 3, 4, 5, 6, 7, 8, 8, 9])
     c = np.where(t == 9, 0, np.where(t == 8, 1, col))          # Lava() red, Goal() green
     s = np.where(t == 4, st, 0)
-    a = (kind == 10).astype(np.uint8)                           # Goal(toggletimes=0): terminal
+    a = np.where(kind == 10, 0xF1, 0).astype(np.uint8)          # Goal(toggletimes=0): terminal (aux format: include/mgx.h)
     grid[..., 0] = np.where(fill, t, 1)
     grid[..., 1] = np.where(fill, c, 0)
     grid[..., 2] = np.where(fill, s, 0)
@@ -43,6 +43,24 @@ def random_states(n, W, H, seed, density=0.4, interior_agent=True):
     carry[has, 1] = rs.randint(0, 7, size=n)[has]
     steps = rs.randint(0, 5, size=n).astype(np.int32)
     return grid, aux, agent, carry, steps
+
+
+def random_object_state(grid, seed):
+    """Random hidden Goal/Box state for `grid`: aux (toggletimes 0..3, triage_color None/0..2) and Box.contains."""
+    rs = np.random.RandomState(seed)
+    n, W, H, _ = grid.shape
+    tt = rs.randint(0, 4, size=(n, W, H))
+    tri = rs.randint(-1, 3, size=(n, W, H))
+    is_goal, is_box = grid[..., 0] == 8, grid[..., 0] == 7
+    aux = ((((tt - 1) & 15) << 4) | ((tri + 1) << 1)).astype(np.uint8)
+    aux = np.where(is_goal, aux | (tt == 0), np.where(is_box, aux, 0)).astype(np.uint8)
+    contains = np.zeros((n, W, H, 3), np.uint8)
+    contains[..., 0] = 1
+    what = rs.randint(0, 3, size=(n, W, H))
+    col = rs.randint(0, 7, size=(n, W, H))
+    contains[..., 0] = np.where(is_box & (what > 0), 4 + what, 1)
+    contains[..., 1] = np.where(is_box & (what > 0), col, 0)
+    return aux, contains
 
 
 def make_oracle(W, H, max_steps, see_through, lava_v1, grid, aux, agent, carry=None, steps=None):

@@ -17,6 +17,9 @@ def test_oracle_replays_reference_trace(name):
     env.set_state(z["init_grid"], z["init_agent"], aux=z["init_aux"])
     if meta.get("task", 0):
         env.task = z["init_task"].copy()
+    objstate = meta.get("objstate", False)
+    if objstate:
+        env.set_contains(z["init_contains"])
     if full:
         o, f = env.observe(full=True)
         assert np.array_equal(f, z["init_full"])
@@ -42,6 +45,11 @@ def test_oracle_replays_reference_trace(name):
         assert np.array_equal(env.carry, z["carry"][:, t]), (name, t)
         assert np.array_equal(env.steps, z["steps"][:, t]), (name, t)
         assert np.array_equal(env.grid, z["grid"][:, t]), (name, t)
+        if objstate:
+            assert np.array_equal(env.aux, z["aux"][:, t]), (name, t)
+            assert np.array_equal(env.contains, z["contains"][:, t]), (name, t)
+            assert np.array_equal(env.carry_aux, z["carry_aux"][:, t]), (name, t)
+            assert np.array_equal(env.carry_contains, z["carry_contains"][:, t]), (name, t)
         # caller-side reset on done, same seed -> the recorded reset state is the episode start
         assert sorted(k for k, _ in resets.get(t, [])) == sorted(np.flatnonzero(done).tolist())
         for k, r in resets.get(t, []):
@@ -54,6 +62,8 @@ def test_oracle_replays_reference_trace(name):
                 env.grid0[k], env.aux0[k], env.agent0[k] = z["reset_grid"][r], z["reset_aux"][r], z["reset_agent"][r]
                 if meta.get("task", 0):
                     env.task[k] = z["reset_task"][r]
+                if objstate:
+                    env.contains0[k] = z["reset_contains"][r]
         env.reset_where(done)
         if done.any():
             o = env.observe()
