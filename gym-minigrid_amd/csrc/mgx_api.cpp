@@ -269,7 +269,7 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     if (h->wpb > 4) h->wpb = 4;
     if (h->wpb < 1) {
         h->wpb = 1;
-        hipError_t e2 = mgx_raise_lds_limit(h->W, h->H, h->kernel_mode == 0 ? 0 : 1, h->wave_lds, h->view, h->cfg.alt_visibility ? 1 : 0);
+        hipError_t e2 = mgx_raise_lds_limit(h->W, h->H, h->kernel_mode == 0 ? 0 : 1, h->wave_lds, h->view, h->cfg.alt_visibility ? 1 : 0, h->cfg.object_state ? 1 : 0);
         if (e2 != hipSuccess) {
             int rc = mgx_fail(MGX_ERR_HIP, "mgx_create: cannot raise dynamic LDS to %d B: %s", h->wave_lds, hipGetErrorString(e2));
             delete h;

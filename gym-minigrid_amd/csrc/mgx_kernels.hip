@@ -752,7 +752,9 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
         const int fidx = transition_begin<CW, CH>(p, L, act, valid, bad_act, oob);
         if (fidx >= 0) {
             const uint32_t fc = g[fidx];
-            const ObjRef obj = {p.objaux ? p.objaux + env * S : nullptr, p.objaux ? p.objcont + env * S : nullptr, p.objaux ? p.objcarry + env : nullptr};
+            // hidden object state rides only on the run-time-size kernels (mgx_launch_step routes there): pruned from the sized ones
+            const bool has_obj = CW == 0 && p.objaux != nullptr;
+            const ObjRef obj = {has_obj ? p.objaux + env * S : nullptr, has_obj ? p.objcont + env * S : nullptr, has_obj ? p.objcarry + env : nullptr};
             const uint32_t nc = transition_apply<CH>(p, L, act, fc, reward, done, [&](int i) -> uint32_t { return g[i]; }, oob, fidx, obj);
             if (nc != fc) g[fidx] = (uint8_t)nc;
             if (valid && L.steps >= p.max_steps) done = true; // minigrid.py:1320-1321
@@ -765,7 +767,7 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
         wave_stats(p, valid, done, reward, bad_act, oob, lane, tile);
         if (p.auto_reset && valid && done) {
             restore_own<CS>(p, env, g);
-            restore_objstate(p, env);
+            if (CW == 0) restore_objstate(p, env);
             L = unpack_rec(p.agent0[env], p.task);
             if (p.regen) p.regen[env] = 1; // the next-level buffer was consumed: k_levelgen refills it after this launch
         }
@@ -831,7 +833,9 @@ __global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
             const int fidx = transition_begin<CW, CH>(p, L, act, valid, bad_act, oob);
             if (fidx >= 0) {
                 const uint32_t fc = p.cells[env * S + fidx];
-                const ObjRef obj = {p.objaux ? p.objaux + env * S : nullptr, p.objaux ? p.objcont + env * S : nullptr, p.objaux ? p.objcarry + env : nullptr};
+                // hidden object state rides only on the run-time-size kernels (mgx_launch_step routes there): pruned from the sized ones
+            const bool has_obj = CW == 0 && p.objaux != nullptr;
+            const ObjRef obj = {has_obj ? p.objaux + env * S : nullptr, has_obj ? p.objcont + env * S : nullptr, has_obj ? p.objcarry + env : nullptr};
                 const uint32_t nc = transition_apply<CH>(p, L, act, fc, reward, done,
                                                          [&](int i) -> uint32_t { return p.cells[env * S + i]; }, oob, fidx, obj);
                 if (valid && L.steps >= p.max_steps) done = true;
@@ -847,7 +851,7 @@ __global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
             wave_stats(p, valid, done, reward, bad_act, oob, lane, tile);
             if (p.auto_reset && valid && done) {
                 L = unpack_rec(p.agent0[env], p.task);
-                restore_objstate(p, env);
+                if (CW == 0) restore_objstate(p, env);
                 reset = true;
                 if (p.regen) p.regen[env] = 1;
             }
@@ -1269,14 +1273,16 @@ hipError_t mgx_launch_step(const StepParams &p, int mode, int waves_per_block, h
 #undef VCASE
         return hipErrorInvalidValue;
     }
+    if (p.objaux) return launch_sized<0, 0>(p, mode, grid, block, shmem, st);
 #define CASE(w, h) if (p.W == w && p.H == h) return launch_sized<w, h>(p, mode, grid, block, shmem, st);
     MGX_SIZED(CASE)
 #undef CASE
     return launch_sized<0, 0>(p, mode, grid, block, shmem, st);
 }
 
-hipError_t mgx_raise_lds_limit(int W, int H, int mode, int bytes, int view, int alt_vis)
+hipError_t mgx_raise_lds_limit(int W, int H, int mode, int bytes, int view, int alt_vis, int object_state)
 {
+    if (object_state) W = H = 0;
     if (mode == 0 && alt_vis) {
 #define VCASE(v) if (view == v) return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<0, 0, 0, v, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         MGX_VIEWS(VCASE) VCASE(7)
