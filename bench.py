@@ -36,11 +36,12 @@ for p in (ROOT, os.path.join(ROOT, "gym-minigrid_amd")):
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s is the measured streaming ceiling
 
 
-OBS_CHANNELS = {"partial": 3, "full": 3, "partial_onehot": 21, "full_onehot": 22, "full_onehot_nocolor": 15}
+OBS_CHANNELS = {"partial": 3, "full": 3, "partial_onehot": 21, "full_onehot": 22, "full_onehot_nocolor": 15, "flat": 3, "full_flat": 3}
+FLAT_MISSION = 27 * 96  # FlatObsWrapper: float32 image ++ one-hot mission string
 
 
 def obs_cells(W, H, obs_mode, view=7):
-    return view * view if obs_mode.startswith("partial") else W * H
+    return view * view if obs_mode.startswith("partial") or obs_mode == "flat" else W * H
 
 
 def survey_bytes_per_step(W, H, obs_mode, view=7):
@@ -48,6 +49,8 @@ def survey_bytes_per_step(W, H, obs_mode, view=7):
     + <=1 cell (3) wr + obs + reward 4 + done 1  ->  372 B for an 8x8 grid with the 7x7 view."""
     grid = W * H * 3
     obs = obs_cells(W, H, obs_mode, view) * OBS_CHANNELS[obs_mode]
+    if obs_mode.endswith("flat"):
+        obs = (obs + FLAT_MISSION) * 4
     return 1 + 12 + 12 + grid + 3 + obs + 4 + 1
 
 
@@ -60,6 +63,8 @@ def layout_bytes_per_step(W, H, obs_mode, view=7):
     obs = n * OBS_CHANNELS[obs_mode]
     if obs_mode.endswith("onehot") or obs_mode.endswith("nocolor"):
         obs += 2 * 3 * n  # the one-hot epilogue is a second kernel: triples written by k_step and read back
+    if obs_mode.endswith("flat"):
+        obs = (obs + FLAT_MISSION) * 4 + 2 * 3 * n
     return cells + 8 + 8 + 1 + obs + 4 + 1
 
 
@@ -204,14 +209,15 @@ def main():
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s, %d batched envs per GPU (%d total), obs %s, uniform random actions 0..6 "
                                    "(counter-based), auto-reset on done" % (args.env, n_local, n_total,
-                                                                            "uint8 (N,%d,%d,%d)" % (args.view, args.view, OBS_CHANNELS[args.obs_mode]) if args.obs_mode.startswith("partial")
+                                                                            "float32 (N,%d) FlatObs" % (obs_cells(cfg.width, cfg.height, args.obs_mode, args.view) * 3 + FLAT_MISSION) if args.obs_mode.endswith("flat")
+                                                                            else "uint8 (N,%d,%d,%d)" % (args.view, args.view, OBS_CHANNELS[args.obs_mode]) if args.obs_mode.startswith("partial")
                                                                             else "uint8 (N,W,H,%d) FullyObs" % OBS_CHANNELS[args.obs_mode]),
                        "env_id": args.env, "envs_per_gpu": n_local, "obs_mode": args.obs_mode, "parallelism": "env-shard x%d" % world,
                        "new_level_each_episode": bool(args.new_level_each_episode)},
             "episodes": episodes, "reward_sum": reward_sum,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_step" + ("+k_onehot" if "onehot" in args.obs_mode else "") + ("+k_levelgen" if args.new_level_each_episode else ""), "avg_kernel_us": avg_kernel_s * 1e6, "launches": launches,
+                         "kernel": "k_step" + ("+k_onehot" if "onehot" in args.obs_mode else "") + ("+k_flat" if args.obs_mode.endswith("flat") else "") + ("+k_levelgen" if args.new_level_each_episode else ""), "avg_kernel_us": avg_kernel_s * 1e6, "launches": launches,
                          "algorithmic_bytes_per_env_step": bps, "measured_streaming_ceiling": 6290.0,
                          "survey_bytes_per_env_step": sbps, "achieved_on_survey_bytes": sbps * n_local / avg_kernel_s / 1e9},
         }

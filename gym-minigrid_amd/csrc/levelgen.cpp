@@ -248,6 +248,38 @@ extern "C" int mgx_env_config(const char *env_id, mgx_config *cfg)
     return mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_env_config: unknown env id '%s'", env_id);
 }
 
+extern "C" int mgx_mission(const mgx_config *cfg, uint32_t task, char *out, int cap)
+{
+    if (!cfg || !out || cap < 1) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_mission: null argument");
+    static const char *const colors[7] = {"red", "green", "blue", "purple", "yellow", "grey", "white"}; // COLOR_TO_IDX (minigrid.py:27-35)
+    static const char *const fetch_tmpl[5] = {"get a %s %s", "go get a %s %s", "fetch a %s %s", "go fetch a %s %s", "you must fetch a %s %s"};
+    const bool lava = (cfg->level_arg1 & 15) == MGX_K_LAVA;
+    char buf[128];
+    const char *m = "";
+    switch (cfg->level_kind) {
+    case MGX_LEVEL_EMPTY: case MGX_LEVEL_DISTSHIFT: m = "get to the green goal square"; break;           // envs/empty.py:57, distshift.py:52
+    case MGX_LEVEL_DOORKEY: m = "use the key to open the door and then get to the goal"; break;          // envs/doorkey.py:44
+    case MGX_LEVEL_CROSSING: case MGX_LEVEL_LAVAGAP:                                                        // envs/crossing.py:88-92, lavagap.py:56-60
+        m = lava ? "avoid the lava and get to the green goal square" : "find the opening and get to the green goal square"; break;
+    case MGX_LEVEL_MULTIROOM: m = "traverse the rooms to get to the goal"; break;                           // envs/multiroom.py:117
+    case MGX_LEVEL_GOTODOOR: m = "go to the red door"; break;                                               // envs/gotodoor.py:70 (the fork's target is always red)
+    case MGX_LEVEL_FOURROOMS: m = "Reach the goal"; break;                                                  // envs/fourrooms.py:69
+    case MGX_LEVEL_FETCH: {                                                                                 // envs/fetch.py:57-71
+        const uint32_t kind = task & 15u, color = (task >> 4) & 7u, tmpl = task >> 8;
+        if ((kind != MGX_K_KEY && kind != MGX_K_BALL) || color > 6 || tmpl > 4 || (task & 0x80u))
+            return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_mission: 0x%x is not a Fetch task word", task);
+        snprintf(buf, sizeof buf, fetch_tmpl[tmpl], colors[color], kind == MGX_K_KEY ? "key" : "ball");
+        m = buf;
+        break;
+    }
+    default: break;
+    }
+    const int len = (int)strlen(m);
+    if (len + 1 > cap) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_mission: buffer of %d bytes for a %d-character mission", cap, len);
+    memcpy(out, m, (size_t)len + 1);
+    return len;
+}
+
 extern "C" const char *mgx_env_id(int i)
 {
     auto &R = registry();

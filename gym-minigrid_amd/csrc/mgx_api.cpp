@@ -50,7 +50,9 @@ struct mgx_env_s {
     int W = 0, H = 0, cells = 0, S = 0, LS = 0, wave_lds = 0, wpb = 4, view = 7;
     bool partial = true;   // the simulator emits the VxV view (else the full grid)
     int oh_nc = -1, oh_ns = 0; // one-hot epilogue channels (oh_nc < 0: none)
-    uint8_t *tri_d = nullptr;  // triples scratch feeding the one-hot epilogue
+    uint8_t *tri_d = nullptr;  // triples scratch feeding the one-hot / flat epilogue
+    bool flat = false;         // FlatObsWrapper epilogue (obs is float)
+    uint8_t *mission_d = nullptr; // [missions][96] character codes for k_flat
     int64_t tri_bytes = 0;     // per env
     int kernel_mode = 0; // 0 partial view, 1 full obs via the LDS tile image, 2 full obs direct (W*H % 4 == 0)
     int64_t obs_bytes = 0;
@@ -218,7 +220,7 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
         return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: bad task_kind %d", cfg->task_kind);
     if (cfg->task_kind != MGX_TASK_NONE && cfg->max_steps > 65535)
         return mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_create: task rules need max_steps <= 65535");
-    if (cfg->obs_mode < MGX_OBS_PARTIAL || cfg->obs_mode > MGX_OBS_FULL_ONEHOT_NOCOLOR)
+    if (cfg->obs_mode < MGX_OBS_PARTIAL || cfg->obs_mode > MGX_OBS_FULL_FLAT)
         return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: bad obs_mode %d", cfg->obs_mode);
     const int view = cfg->agent_view_size ? cfg->agent_view_size : MGX_VIEW;
     if (view != 3 && view != 5 && view != 7 && view != 9 && view != 11)
@@ -241,7 +243,8 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     h->S = (h->cells + 3) & ~3;
     h->LS = h->S + (((h->S >> 2) & 1) ? 0 : 4); // odd dword stride per env in LDS
     h->view = view;
-    h->partial = cfg->obs_mode == MGX_OBS_PARTIAL || cfg->obs_mode == MGX_OBS_PARTIAL_ONEHOT;
+    h->partial = cfg->obs_mode == MGX_OBS_PARTIAL || cfg->obs_mode == MGX_OBS_PARTIAL_ONEHOT || cfg->obs_mode == MGX_OBS_PARTIAL_FLAT;
+    h->flat = cfg->obs_mode == MGX_OBS_PARTIAL_FLAT || cfg->obs_mode == MGX_OBS_FULL_FLAT;
     if (cfg->obs_mode == MGX_OBS_PARTIAL_ONEHOT) { h->oh_nc = 7; h->oh_ns = 3; }
     else if (cfg->obs_mode == MGX_OBS_FULL_ONEHOT) { h->oh_nc = 7; h->oh_ns = 4; }
     else if (cfg->obs_mode == MGX_OBS_FULL_ONEHOT_NOCOLOR) { h->oh_nc = 0; h->oh_ns = 4; }
@@ -259,6 +262,7 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     h->stream_mode = cfg->new_level_each_episode && uses_rng;
     h->tri_bytes = h->partial ? view * view * 3 : (int64_t)h->cells * 3;
     h->obs_bytes = h->oh_nc < 0 ? h->tri_bytes : h->tri_bytes / 3 * (11 + h->oh_nc + h->oh_ns);
+    if (h->flat) h->obs_bytes = (h->tri_bytes + MGX_FLAT_MISSION) * (int64_t)sizeof(float);
     const int LDS_DEFAULT = 64 * 1024, LDS_MAX = 160 * 1024;
     if (h->wave_lds > LDS_MAX) {
         int rc = mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_create: a %dx%d tile (64 envs) needs %d B of LDS > %d", h->W, h->H, h->wave_lds, LDS_MAX);
@@ -309,7 +313,37 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     CREATE_TRY(hipMalloc((void **)&h->agent_d, ab));
     CREATE_TRY(hipMalloc((void **)&h->agent0_d, ab));
     CREATE_TRY(hipMalloc((void **)&h->ctr_d, sizeof(MgxCounters)));
-    if (h->oh_nc >= 0) CREATE_TRY(hipMalloc((void **)&h->tri_d, (size_t)h->n * h->tri_bytes + 16));
+    if (h->oh_nc >= 0 || h->flat) CREATE_TRY(hipMalloc((void **)&h->tri_d, (size_t)h->n * h->tri_bytes + 16));
+    if (h->flat) { // the family's mission strings as character codes (wrappers.py:563-571)
+        const int rows = cfg->level_kind == MGX_LEVEL_FETCH ? 80 : 1;
+        std::vector<uint8_t> tab((size_t)rows * 96, 255);
+        for (int r = 0; r < rows; r++) {
+            uint32_t task = 0;
+            if (cfg->level_kind == MGX_LEVEL_FETCH) {
+                const int color = r & 7, ball = (r >> 3) & 1, tmpl = r >> 4;
+                if (color > 6) continue;
+                task = (uint32_t)(ball ? MGX_K_BALL : MGX_K_KEY) | ((uint32_t)color << 4) | ((uint32_t)tmpl << 8);
+            }
+            char m[128];
+            const int len = mgx_mission(cfg, task, m, (int)sizeof m);
+            if (len < 0 || len > 96) { // assert len(mission) <= self.maxStrLen
+                int rc = len < 0 ? len : mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_create: mission string too long (%d chars)", len);
+                mgx_destroy(h);
+                return rc;
+            }
+            int code = -1;
+            for (int i = 0; i < len; i++) {
+                const char ch = (char)(m[i] >= 'A' && m[i] <= 'Z' ? m[i] - 'A' + 'a' : m[i]);
+                if (ch >= 'a' && ch <= 'z') code = ch - 'a';
+                else if (ch == ' ') code = 26;
+                // any other character re-uses the previous character's code (chNo keeps its value, wrappers.py:565-570)
+                if (code < 0) { int rc = mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_create: mission starts with a character the wrapper cannot encode"); mgx_destroy(h); return rc; }
+                tab[(size_t)r * 96 + i] = (uint8_t)code;
+            }
+        }
+        CREATE_TRY(hipMalloc((void **)&h->mission_d, tab.size()));
+        CREATE_TRY(hipMemcpy(h->mission_d, tab.data(), tab.size(), hipMemcpyHostToDevice));
+    }
     if (cfg->object_state) {
         for (uint8_t **pp : {&h->objaux_d, &h->objaux0_d}) { CREATE_TRY(hipMalloc((void **)pp, cb)); CREATE_TRY(hipMemsetAsync(*pp, 0, cb, h->stream)); }
         for (uint8_t **pp : {&h->objcont_d, &h->objcont0_d}) { CREATE_TRY(hipMalloc((void **)pp, cb)); CREATE_TRY(hipMemsetAsync(*pp, MGX_CODE_EMPTY, cb, h->stream)); }
@@ -348,7 +382,7 @@ extern "C" int mgx_destroy(mgx_handle h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->cells_d); (void)hipFree(h->cells0_d); (void)hipFree(h->agent_d); (void)hipFree(h->agent0_d);
-    (void)hipFree(h->ctr_d); (void)hipFree(h->tri_d);
+    (void)hipFree(h->ctr_d); (void)hipFree(h->tri_d); (void)hipFree(h->mission_d);
     (void)hipFree(h->objaux_d); (void)hipFree(h->objaux0_d); (void)hipFree(h->objcont_d); (void)hipFree(h->objcont0_d); (void)hipFree(h->objcarry_d);
     (void)hipFree(h->mt_d); (void)hipFree(h->mt_idx_d); (void)hipFree(h->regen_d); (void)hipFree(h->mt_init_d);
     for (auto &s : h->st_in) if (s.dev) (void)hipFree(s.dev);
@@ -547,10 +581,12 @@ static int run_step(mgx_handle h, bool do_step, const uint8_t *actions, uint8_t 
     if ((rc = dev_out(h, 1, reward, (size_t)h->n * sizeof(float), &o[1], 4))) return rc;
     if ((rc = dev_out(h, 2, done, (size_t)h->n, &o[2]))) return rc;
     p.obs = (uint8_t *)o[0].dev; p.reward = (float *)o[1].dev; p.done = (uint8_t *)o[2].dev;
-    if (h->oh_nc >= 0 && p.obs) p.obs = h->tri_d; // the simulator writes triples; the epilogue below expands them
+    if ((h->oh_nc >= 0 || h->flat) && p.obs) p.obs = h->tri_d; // the simulator writes triples; the epilogue below expands them
     HIP_TRY(mgx_launch_step(p, h->kernel_mode, h->wpb, h->stream));
     if (h->oh_nc >= 0 && o[0].dev)
         HIP_TRY(mgx_launch_onehot(h->tri_d, (uint8_t *)o[0].dev, h->n * (h->tri_bytes / 3), h->oh_nc, h->oh_ns, h->stream));
+    if (h->flat && o[0].dev)
+        HIP_TRY(mgx_launch_flat(h->tri_d, h->agent_d, h->mission_d, (float *)o[0].dev, h->n, (int)h->tri_bytes, h->cfg.level_kind == MGX_LEVEL_FETCH, h->stream));
     if (do_step) {
         h->steps_total += h->n;
         if (h->profiling) h->prof_launches++;

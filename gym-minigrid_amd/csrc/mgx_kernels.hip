@@ -1331,6 +1331,58 @@ hipError_t mgx_launch_onehot(const uint8_t *tri, uint8_t *out, int64_t n_cells, 
     return hipGetLastError();
 }
 
+// FlatObsWrapper.observation (wrappers.py:556-577): out[env] = f32(image bytes) ++ one-hot of the mission string
+// (96 positions x 27 codes).  `table` holds one row of 96 character codes (0..25 letters, 26 space, 255 past the end)
+// per mission of the family; only Fetch has more than one (row = (template*2 + is_ball)*8 + color of the task word).
+// A pure stream of 16-B stores over the flat [n][L] output: 4 consecutive floats per lane, one divide per lane.
+namespace {
+__global__ __launch_bounds__(256) void k_flat(const uint8_t *__restrict__ tri, const uint2 *__restrict__ rec, const uint8_t *__restrict__ table,
+                                               float *__restrict__ out, int64_t n, int img, int fetch)
+{
+    const int64_t L = (int64_t)img + MGX_FLAT_MISSION;
+    const int64_t total = n * L;
+    const int64_t g0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (g0 >= total) return;
+    int64_t env = g0 / L;
+    int off = (int)(g0 - env * L);
+    float v[4];
+    const uint8_t *row = nullptr;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        float x = 0.f;
+        if (g0 + j < total) {
+            if (off >= L) { off = 0; env++; row = nullptr; }
+            if (off < img) x = (float)tri[env * img + off];
+            else {
+                if (!row) {
+                    int mid = 0;
+                    if (fetch) {
+                        const uint32_t task = rec[env].y >> 16;
+                        mid = (int)((((task >> 8) & 7u) * 2u + ((task & 15u) == MGX_K_BALL ? 1u : 0u)) * 8u + ((task >> 4) & 7u));
+                    }
+                    row = table + mid * 96;
+                }
+                const int k = off - img, ch = k / 27, code = k - ch * 27;
+                x = row[ch] == code ? 1.f : 0.f;
+            }
+            off++;
+        }
+        v[j] = x;
+    }
+    if (g0 + 3 < total) nt_store16(reinterpret_cast<uint4 *>(out + g0), make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])));
+    else
+        for (int j = 0; j < 4 && g0 + j < total; j++) out[g0 + j] = v[j];
+}
+} // namespace
+
+hipError_t mgx_launch_flat(const uint8_t *tri, const uint2 *rec, const uint8_t *table, float *out, int64_t n, int img, int fetch, hipStream_t st)
+{
+    const int64_t quads = (n * ((int64_t)img + MGX_FLAT_MISSION) + 3) / 4;
+    if (quads == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_flat, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, tri, rec, table, out, n, img, fetch);
+    return hipGetLastError();
+}
+
 namespace {
 __global__ __launch_bounds__(256) void k_direction(const uint2 *__restrict__ rec, uint8_t *__restrict__ out, int64_t n)
 {

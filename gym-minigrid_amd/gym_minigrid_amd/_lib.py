@@ -10,7 +10,7 @@ SO_PATH = os.path.join(CSRC, "libmgx.so")
 MGX_OK = 0
 ERR_NAMES = {-1: "INVALID_ARG", -2: "INVALID_STATE", -3: "INVALID_ACTION", -4: "OUT_OF_BOUNDS",
              -5: "UNSUPPORTED", -6: "HIP", -7: "NO_LEVELGEN"}
-OBS_PARTIAL, OBS_FULL, OBS_PARTIAL_ONEHOT, OBS_FULL_ONEHOT, OBS_FULL_ONEHOT_NOCOLOR = 0, 1, 2, 3, 4
+OBS_PARTIAL, OBS_FULL, OBS_PARTIAL_ONEHOT, OBS_FULL_ONEHOT, OBS_FULL_ONEHOT_NOCOLOR, OBS_PARTIAL_FLAT, OBS_FULL_FLAT = 0, 1, 2, 3, 4, 5, 6
 
 
 class MgxError(RuntimeError):
@@ -47,6 +47,7 @@ SIGNATURES = {
     "mgx_version": (ctypes.c_char_p, []),
     "mgx_env_config": (_int, [ctypes.c_char_p, ctypes.POINTER(Config)]),
     "mgx_env_id": (ctypes.c_char_p, [_int]),
+    "mgx_mission": (_int, [ctypes.POINTER(Config), ctypes.c_uint32, ctypes.c_char_p, _int]),
     "mgx_create": (_int, [ctypes.POINTER(Config), _i64, _int, ctypes.POINTER(_vp)]),
     "mgx_destroy": (_int, [_vp]),
     "mgx_set_stream": (_int, [_vp, _vp]),

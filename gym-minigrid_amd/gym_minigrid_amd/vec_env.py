@@ -18,15 +18,6 @@ import numpy as np
 from . import _lib
 from .spaces import Box, Dict, Discrete
 
-MISSIONS = {1: "get to the green goal square",
-            2: "use the key to open the door and then get to the goal",
-            3: {9: "avoid the lava and get to the green goal square",
-                2: "find the opening and get to the green goal square"},
-            4: {9: "avoid the lava and get to the green goal square",
-                2: "find the opening and get to the green goal square"},
-            5: "get to the green goal square", 6: "traverse the rooms to get to the goal",
-            7: "fetch a <color> <type>: see get_task()", 8: "go to the red door", 9: "Reach the goal"}
-
 
 def _ptr(a):
     """numpy array / torch tensor / None -> c_void_p"""
@@ -72,7 +63,8 @@ class VecMiniGrid:
         cfg = _lib.Config()
         ctypes.memmove(ctypes.byref(cfg), ctypes.byref(config), ctypes.sizeof(cfg))
         cfg.obs_mode = {"partial": _lib.OBS_PARTIAL, "full": _lib.OBS_FULL, "partial_onehot": _lib.OBS_PARTIAL_ONEHOT,
-                        "full_onehot": _lib.OBS_FULL_ONEHOT, "full_onehot_nocolor": _lib.OBS_FULL_ONEHOT_NOCOLOR}[obs_mode]
+                        "full_onehot": _lib.OBS_FULL_ONEHOT, "full_onehot_nocolor": _lib.OBS_FULL_ONEHOT_NOCOLOR,
+                        "flat": _lib.OBS_PARTIAL_FLAT, "full_flat": _lib.OBS_FULL_FLAT}[obs_mode]
         cfg.auto_reset = int(bool(auto_reset))
         cfg.new_level_each_episode = int(bool(new_level_each_episode))
         cfg.agent_view_size = int(agent_view_size)
@@ -88,14 +80,19 @@ class VecMiniGrid:
         self.width, self.height, self.max_steps = cfg.width, cfg.height, cfg.max_steps
         self.obs_mode = obs_mode
         self.agent_view_size = int(agent_view_size)
-        chan = {"partial": 3, "full": 3, "partial_onehot": 21, "full_onehot": 22, "full_onehot_nocolor": 15}[obs_mode]
-        self.obs_shape = ((self.agent_view_size,) * 2 if obs_mode.startswith("partial") else (cfg.width, cfg.height)) + (chan,)
+        chan = {"partial": 3, "full": 3, "partial_onehot": 21, "full_onehot": 22, "full_onehot_nocolor": 15, "flat": 3, "full_flat": 3}[obs_mode]
+        self.obs_shape = ((self.agent_view_size,) * 2 if obs_mode in ("partial", "partial_onehot", "flat") else (cfg.width, cfg.height)) + (chan,)
+        self.obs_dtype = "uint8"
+        if obs_mode in ("flat", "full_flat"):  # FlatObsWrapper (wrappers.py:528-577): image ++ one-hot mission, float32
+            self.obs_shape = (int(np.prod(self.obs_shape)) + 27 * 96,)
+            self.obs_dtype = "float32"
         self.n_actions = 9 if extended_actions else 7
         self.action_space = Discrete(self.n_actions)  # minigrid.py:788-792
         self.observation_space = Dict({"image": Box(0, 255, self.obs_shape, "uint8")})
+        if self.obs_dtype == "float32":
+            self.observation_space = Box(0, 255, (1,) + self.obs_shape, "uint8")  # wrappers.py:543-548
         self.reward_range = (0, 1)
-        m = MISSIONS.get(cfg.level_kind, "")
-        self.mission = m.get(cfg.level_arg1 & 15, "") if isinstance(m, dict) else m
+        self.mission = self._mission_of(0) if cfg.level_kind != 7 else "fetch a <color> <type>: see missions()"
         self._h = ctypes.c_void_p()
         _lib.check(L.mgx_create(ctypes.byref(cfg), self.num_envs, self.device, ctypes.byref(self._h)))
         self._torch = None
@@ -106,7 +103,7 @@ class VecMiniGrid:
             self._bind_stream()
         elif backend != "numpy":
             raise ValueError("backend must be 'torch' or 'numpy'")
-        self._obs = self._new((self.num_envs,) + self.obs_shape, "uint8")
+        self._obs = self._new((self.num_envs,) + self.obs_shape, self.obs_dtype)
         self._reward = self._new((self.num_envs,), "float32")
         self._done = self._new((self.num_envs,), "uint8")
         self.seed(seeds)
@@ -234,6 +231,20 @@ class VecMiniGrid:
         out = dict(contains=np.empty((n, W, H, 3), np.uint8), carry_aux=np.empty(n, np.uint8), carry_contains=np.empty((n, 3), np.uint8))
         _lib.check(_lib.lib().mgx_get_object_state(self._h, _ptr(out["contains"]), _ptr(out["carry_aux"]), _ptr(out["carry_contains"])))
         return out
+
+    def _mission_of(self, task):
+        buf = ctypes.create_string_buffer(128)
+        n = _lib.lib().mgx_mission(ctypes.byref(self.cfg), int(task), buf, 128)
+        if n < 0:
+            _lib.check(n)
+        return buf.value.decode()
+
+    def missions(self):
+        """obs['mission'] of every env (minigrid.py:1373-1379); only Fetch missions differ between envs."""
+        if self.cfg.task_kind == 0:
+            return [self.mission] * self.num_envs
+        cache = {}
+        return [cache.setdefault(int(t), self._mission_of(int(t))) for t in self.get_task()]
 
     def set_task(self, task):
         """Per-env task word (Fetch: target cell code = type | color << 4), host uint32 array (N,)."""

@@ -75,7 +75,11 @@ typedef enum {
     MGX_OBS_FULL = 1,             /* uint8 [N][W][H][3]   FullyObsWrapper (wrappers.py:311-338)                          */
     MGX_OBS_PARTIAL_ONEHOT = 2,   /* uint8 [N][V][V][21]  OneHotPartialObsWrapper formula (wrappers.py:203-243)          */
     MGX_OBS_FULL_ONEHOT = 3,      /* uint8 [N][W][H][22]  FullyObsOneHotWrapper(flatten=False) (wrappers.py:340-415)     */
-    MGX_OBS_FULL_ONEHOT_NOCOLOR = 4 /* uint8 [N][W][H][15]  ... with drop_color=True                                    */
+    MGX_OBS_FULL_ONEHOT_NOCOLOR = 4, /* uint8 [N][W][H][15]  ... with drop_color=True                                   */
+    MGX_OBS_PARTIAL_FLAT = 5,     /* float [N][V*V*3 + 27*96]  FlatObsWrapper (wrappers.py:528-577): image bytes as f32, then
+                                     the mission string one-hot (96 chars x 27 codes); the `obs` arguments then point at
+                                     floats (np.concatenate of a uint8 and a float32 array is float32)                    */
+    MGX_OBS_FULL_FLAT = 6         /* float [N][W*H*3 + 27*96]  FlatObsWrapper(FullyObsWrapper(env))                        */
 } mgx_obs_mode;
 
 /* level families with a built-in seeded generator */
@@ -141,6 +145,10 @@ const char *mgx_version(void);
 int mgx_env_config(const char *env_id, mgx_config *cfg);
 /* i-th supported env id, or NULL past the end. */
 const char *mgx_env_id(int i);
+/* env.mission (the `mission` entry of gen_obs, minigrid.py:1373-1379) of a level of this family; `task` is the per-env
+ * task word (mgx_get_task; only Fetch missions depend on it: envs/fetch.py:60-71).  Writes a NUL-terminated string,
+ * returns its length, or a negative status (MGX_ERR_INVALID_ARG: cap too small / bad task word). */
+int mgx_mission(const mgx_config *cfg, uint32_t task, char *out, int cap);
 
 int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx_handle *out);
 int mgx_destroy(mgx_handle h);

@@ -449,6 +449,43 @@ def record_onehot():
     print("onehot.npz %6.1f KB  shapes %s %s" % (os.path.getsize(path) / 1024, np.asarray(full_oh).shape, np.asarray(full_oh_nc).shape))
 
 
+def record_flat():
+    """Known answers for the flat epilogue: FlatObsWrapper.observation (wrappers.py:528-577) on seeded episodes of
+    families with constant and per-episode (Fetch) missions, plus one FlatObsWrapper(FullyObsWrapper(env))."""
+    from gym_minigrid.wrappers import FlatObsWrapper
+    out = {}
+    cases = [("MiniGrid-Empty-8x8-v0", [0], False), ("MiniGrid-DoorKey-5x5-v0", [1, 2], False),
+             ("MiniGrid-Fetch-5x5-N2-v0", list(range(16)), False), ("MiniGrid-Fetch-8x8-N3-v0", list(range(8)), False),
+             ("MiniGrid-GoToDoor-5x5-v0", [0, 1], False), ("MiniGrid-FourRooms-v0", [0], False),
+             ("MiniGrid-LavaCrossingS9N1-v0", [0], False), ("MiniGrid-SimpleCrossingS9N1-v0", [0], False),
+             ("MiniGrid-MultiRoom-N2-S4-v0", [0], False), ("MiniGrid-Empty-5x5-v0", [0], True), ("MiniGrid-Fetch-5x5-N2-v0", [3, 4], True)]
+    ids, seeds, fulls, acts, flats, missions = [], [], [], [], [], []
+    T = 4
+    for env_id, ss, full in cases:
+        base = gym.make(env_id)
+        env = FlatObsWrapper(FullyObsWrapper(base) if full else base)
+        for sd in ss:
+            env.seed(int(sd))
+            rows = [env.reset()]
+            a = np.random.RandomState(sd + 77).randint(0, 3, size=T)   # turns/forward only: never ends the episode early
+            ms = [base.mission]
+            for t in range(T):
+                o, r, d, _ = env.step(int(a[t]))
+                assert not d
+                rows.append(o)
+                ms.append(base.mission)
+            assert all(r.dtype == np.float32 for r in rows)
+            ids.append(env_id); seeds.append(sd); fulls.append(full); acts.append(a); missions.append(ms[0])
+            assert len(set(ms)) == 1
+            flats.append(np.stack(rows))
+    for k, f in enumerate(flats):
+        out["flat_%d" % k] = f
+    path = os.path.join(OUT, "flat.npz")
+    np.savez_compressed(path, ids=np.array(ids), seeds=np.array(seeds, np.uint64), full=np.array(fulls), actions=np.array(acts, np.uint8),
+                        missions=np.array(missions), **out)
+    print("flat.npz %6.1f KB  %d episodes" % (os.path.getsize(path) / 1024, len(ids)))
+
+
 def record_levels():
     """Seeded level generation known answers: seed -> initial grid/agent."""
     out = {}
@@ -494,6 +531,10 @@ def record_levels():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 2 and sys.argv[1] == "--only":   # e.g. --only flat onehot: re-record just those fixture files
+        for what in sys.argv[2:]:
+            {"flat": record_flat, "onehot": record_onehot, "levels": record_levels, "level_streams": record_level_streams}[what]()
+        return
     mk = lambda i: (lambda: gym.make(i))  # noqa: E731
     record_case("Empty-8x8", mk("MiniGrid-Empty-8x8-v0"), [0, 1, 2, 3], 300)
     record_case("Empty-5x5", mk("MiniGrid-Empty-5x5-v0"), [0, 1], 120)
@@ -586,6 +627,7 @@ def main():
     record_levels()
     record_level_streams()
     record_onehot()
+    record_flat()
 
 
 if __name__ == "__main__":

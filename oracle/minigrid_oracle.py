@@ -135,3 +135,19 @@ class OracleEnvs:
                               _p(reward), _p(done))
         self.last = (obs, fo, reward, done)
         return int(r)
+
+
+def flat_obs(image, mission, max_str_len=96, num_char_codes=27):
+    """FlatObsWrapper.observation (wrappers.py:556-577) restated: image bytes followed by the one-hot mission string,
+    float32 (np.concatenate of uint8 and float32).  A character outside a-z/space re-uses the previous character's
+    code, as the reference's un-reset `chNo` does."""
+    assert len(mission) <= max_str_len
+    arr = np.zeros((max_str_len, num_char_codes), np.float32)
+    code = None
+    for i, ch in enumerate(mission.lower()):
+        if "a" <= ch <= "z":
+            code = ord(ch) - ord("a")
+        elif ch == " ":
+            code = 26
+        arr[i, code] = 1
+    return np.concatenate((np.asarray(image, np.uint8).flatten(), arr.flatten()))
