@@ -18,7 +18,7 @@ def pytest_configure(config):
 
 
 def golden_cases():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f not in ("levels.npz", "level_streams.npz", "onehot.npz"))
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f not in ("levels.npz", "level_streams.npz", "onehot.npz", "flat.npz"))
 
 
 def load_case(name):
