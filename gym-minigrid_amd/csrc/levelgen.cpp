@@ -159,6 +159,10 @@ int check_levelgen_cfg(const mgx_config *cfg, const char *fn)
         if ((W - 3) / 2 > MGX_LG_MAX_RIVERS || (H - 3) / 2 > MGX_LG_MAX_RIVERS)
             return mgx_fail(MGX_ERR_UNSUPPORTED, "%s: crossing grid %dx%d has more than %d candidate rivers per axis", fn, W, H, MGX_LG_MAX_RIVERS);
         break;
+    case MGX_LEVEL_DYNOBS:
+        if (W < 5 || H < 5 || W * H > 256) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: Dynamic-Obstacles grids are 5x5 .. 16x16", fn);
+        if (cfg->level_arg0 < 0 || cfg->level_arg0 > 8) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: n_obstacles %d (0..8)", fn, cfg->level_arg0);
+        break;
     default: return mgx_fail(MGX_ERR_NO_LEVELGEN, "%s: level_kind %d has no built-in generator", fn, cfg->level_kind);
     }
     return MGX_OK;
@@ -179,6 +183,13 @@ mgx_config mkt(int w, int h, int max_steps, int see, int kind, int a0, int task)
 {
     mgx_config c = mk(w, h, max_steps, see, 0, kind, a0, 0);
     c.task_kind = task;
+    return c;
+}
+
+mgx_config mkd(int size, int n_obst, int random_start)
+{
+    mgx_config c = mk(size, size, 4 * size * size, 1, 0, MGX_LEVEL_DYNOBS, n_obst, random_start);
+    c.task_kind = MGX_TASK_DYNOBS;
     return c;
 }
 
@@ -216,6 +227,14 @@ const std::vector<EnvId> &registry()
         {"MiniGrid-GoToDoor-5x5-v0", mkt(5, 5, 125, 1, MGX_LEVEL_GOTODOOR, 0, MGX_TASK_GOTODOOR)},
         {"MiniGrid-GoToDoor-6x6-v0", mkt(6, 6, 180, 1, MGX_LEVEL_GOTODOOR, 0, MGX_TASK_GOTODOOR)},
         {"MiniGrid-GoToDoor-8x8-v0", mkt(8, 8, 320, 1, MGX_LEVEL_GOTODOOR, 0, MGX_TASK_GOTODOOR)},
+        // DynamicObstaclesEnv: max_steps = 4*size^2, see_through_walls=True; n_obstacles after the clamp of
+        // envs/dynamicobstacles.py:22-26 (5x5: 2, 6x6: 3, 8x8: 4, 16x16: 8); '-Random-' = agent_start_pos=None
+        {"MiniGrid-Dynamic-Obstacles-5x5-v0", mkd(5, 2, 0)},
+        {"MiniGrid-Dynamic-Obstacles-Random-5x5-v0", mkd(5, 2, 1)},
+        {"MiniGrid-Dynamic-Obstacles-6x6-v0", mkd(6, 3, 0)},
+        {"MiniGrid-Dynamic-Obstacles-Random-6x6-v0", mkd(6, 3, 1)},
+        {"MiniGrid-Dynamic-Obstacles-8x8-v0", mkd(8, 4, 0)},
+        {"MiniGrid-Dynamic-Obstacles-16x16-v0", mkd(16, 8, 0)},
         // FourRoomsEnv: 19x19, max_steps=500 (envs/fourrooms.py:14-17)
         {"MiniGrid-FourRooms-v0", mk(19, 19, 500, 0, 0, MGX_LEVEL_FOURROOMS, 0, 0)},
         // MultiRoomEnv: 25x25, max_steps = maxNumRooms*20 (envs/multiroom.py:36-39,223-246)
@@ -263,6 +282,7 @@ extern "C" int mgx_mission(const mgx_config *cfg, uint32_t task, char *out, int 
         m = lava ? "avoid the lava and get to the green goal square" : "find the opening and get to the green goal square"; break;
     case MGX_LEVEL_MULTIROOM: m = "traverse the rooms to get to the goal"; break;                           // envs/multiroom.py:117
     case MGX_LEVEL_GOTODOOR: m = "go to the red door"; break;                                               // envs/gotodoor.py:70 (the fork's target is always red)
+    case MGX_LEVEL_DYNOBS: m = "get to the green goal square"; break;                                      // envs/dynamicobstacles.py:58
     case MGX_LEVEL_FOURROOMS: m = "Reach the goal"; break;                                                  // envs/fourrooms.py:69
     case MGX_LEVEL_FETCH: {                                                                                 // envs/fetch.py:57-71
         const uint32_t kind = task & 15u, color = (task >> 4) & 7u, tmpl = task >> 8;
@@ -307,6 +327,7 @@ extern "C" int mgx_generate_levels_ex(const mgx_config *cfg, int64_t n, const ui
         if (lg_uses_rng(*cfg)) rng.seed_gym(seeds[e]); // Empty with a fixed start consumes no randomness: skip the seeding
         lg_generate(*cfg, rng, L);
         lg_paint(L, codes.data());
+        for (auto &cd : codes) if (MGX_IS_OBSTACLE_MARK(cd)) cd = (uint8_t)MGX_CODE_BALL_BLUE; // DynObs order markers
         codes_to_triples(codes.data(), cells, grid + (size_t)e * cells * 3);
         agent[e * 3] = L.ax; agent[e * 3 + 1] = L.ay; agent[e * 3 + 2] = L.adir;
         if (task) task[e] = L.task;
@@ -332,6 +353,7 @@ extern "C" int mgx_generate_level_stream(const mgx_config *cfg, uint64_t seed, i
         L.cmds = cmds; L.ncmd = 0; L.W = cfg->width; L.H = cfg->height; L.ax = L.ay = -1; L.adir = 0; L.ws = ws;
         lg_generate(*cfg, rng, L);
         lg_paint(L, codes.data());
+        for (auto &cd : codes) if (MGX_IS_OBSTACLE_MARK(cd)) cd = (uint8_t)MGX_CODE_BALL_BLUE; // DynObs order markers
         codes_to_triples(codes.data(), cells, grid + (size_t)k * cells * 3);
         agent[k * 3] = L.ax; agent[k * 3 + 1] = L.ay; agent[k * 3 + 2] = L.adir;
     }

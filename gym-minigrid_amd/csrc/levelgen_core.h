@@ -450,6 +450,32 @@ LG_FN void lg_gen_fourrooms(const mgx_config &, R &r, LgLevel &L)
     lg_set(L, gx, gy, MGX_CODE_GOAL_GREEN);
 }
 
+// DynamicObstaclesEnv._gen_grid (envs/dynamicobstacles.py:35-58): room + goal, fixed or random agent, then n_obstacles
+// blue balls by place_obj(max_tries=100; the reference would raise after 101 failed tries -- with at most 8 balls in a
+// room that is a < 1e-12 event and is not restated).  Obstacle i is painted with a marker code (bit 7 | i << 4 | ball)
+// so that the reset path can recover the ORDER of the obstacles, which step() walks (k_dynobs_init turns the markers
+// into plain blue balls; the host generators do the same after painting).
+#define MGX_CODE_BALL_BLUE (MGX_K_BALL | (2u << 4))
+#define MGX_CODE_OBSTACLE(i) (0x80u | ((uint32_t)(i) << 4) | MGX_K_BALL)
+#define MGX_IS_OBSTACLE_MARK(code) (((code) & 0x8Fu) == (0x80u | MGX_K_BALL))
+template <class R>
+LG_FN void lg_gen_dynobs(const mgx_config &c, R &r, LgLevel &L)
+{
+    lg_room(L);
+    if (c.level_arg1 == 0) { L.ax = 1; L.ay = 1; L.adir = 0; }
+    else {
+        L.ax = -1; L.ay = -1;
+        lg_sample_free(r, L, L.W, L.H, false, &L.ax, &L.ay); // place_agent()
+        L.adir = lg_randint(r, 0, 4);
+    }
+    for (int i = 0; i < c.level_arg0; i++) {
+        int x, y;
+        lg_sample_free(r, L, L.W, L.H, true, &x, &y);
+        if (!r.alive()) return;
+        lg_set(L, x, y, MGX_CODE_OBSTACLE(i));
+    }
+}
+
 // true if the family draws random numbers (Empty with a fixed start does not)
 LG_FN bool lg_uses_rng(const mgx_config &c) { return !(c.level_kind == MGX_LEVEL_EMPTY && c.level_arg0 == 0) && c.level_kind != MGX_LEVEL_DISTSHIFT; }
 
@@ -465,6 +491,7 @@ LG_FN void lg_generate(const mgx_config &c, R &r, LgLevel &L)
     case MGX_LEVEL_FETCH: lg_gen_fetch(c, r, L); break;
     case MGX_LEVEL_GOTODOOR: lg_gen_gotodoor(c, r, L); break;
     case MGX_LEVEL_FOURROOMS: lg_gen_fourrooms(c, r, L); break;
+    case MGX_LEVEL_DYNOBS: lg_gen_dynobs(c, r, L); break;
     default: lg_gen_lavagap(c, r, L); break;
     }
 }

@@ -65,6 +65,10 @@ struct mgx_env_s {
     bool device_levels = false; // the family draws random numbers: mgx_reset seeds and generates on the GPU
     uint32_t *mt_d = nullptr, *mt_idx_d = nullptr, *mt_init_d = nullptr;
     uint8_t *regen_d = nullptr;
+    // Dynamic-Obstacles: obstacle order (+ episode-start copy), RNG block snapshot, folded actions
+    bool dynobs = false;
+    uint8_t *obst_d = nullptr, *obst0_d = nullptr, *act_d = nullptr;
+    uint32_t *mt0_d = nullptr, *pos0_d = nullptr;
     // object_state: hidden Goal/Box planes (+ episode-start snapshots) and the carried object's pair
     uint8_t *objaux_d = nullptr, *objaux0_d = nullptr, *objcont_d = nullptr, *objcont0_d = nullptr;
     uint16_t *objcarry_d = nullptr;
@@ -168,7 +172,7 @@ StepParams base_params(mgx_handle h)
     p.extended = h->cfg.extended_actions ? 1 : 0;
     p.alt_vis = h->cfg.alt_visibility ? 1 : 0;
     p.task = h->cfg.task_kind;
-    p.regen = h->stream_mode ? h->regen_d : nullptr;
+    p.regen = (h->stream_mode || h->dynobs) ? h->regen_d : nullptr;
     p.objaux = h->objaux_d; p.objcont = h->objcont_d; p.objaux0 = h->objaux0_d; p.objcont0 = h->objcont0_d; p.objcarry = h->objcarry_d;
     return p;
 }
@@ -182,6 +186,16 @@ LevelGenParams levelgen_params(mgx_handle h)
     g.ctr = h->ctr_d;
     g.n = h->n; g.n_tiles = (int)(h->n_pad / 64); g.S = h->S;
     return g;
+}
+
+DynObsParams dynobs_params(mgx_handle h)
+{
+    DynObsParams d;
+    memset(&d, 0, sizeof d);
+    d.cells = h->cells_d; d.cells0 = h->cells0_d; d.agent = h->agent_d; d.act_out = h->act_d; d.regen = h->regen_d;
+    d.obst = h->obst_d; d.obst0 = h->obst0_d; d.mt = h->mt_d; d.mt0 = h->mt0_d; d.pos = h->mt_idx_d; d.pos0 = h->pos0_d;
+    d.n = h->n; d.W = h->W; d.H = h->H; d.S = h->S; d.n_obst = h->cfg.level_arg0;
+    return d;
 }
 
 int launch_levelgen(mgx_handle h)
@@ -216,8 +230,16 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     if (cfg->width < 3 || cfg->height < 3 || cfg->width > 255 || cfg->height > 255)
         return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: grid %dx%d outside 3..255 (Grid.__init__ asserts >= 3)", cfg->width, cfg->height);
     if (cfg->max_steps <= 0) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: max_steps must be positive");
-    if (cfg->task_kind < MGX_TASK_NONE || cfg->task_kind > MGX_TASK_GOTODOOR)
+    if (cfg->task_kind < MGX_TASK_NONE || cfg->task_kind > MGX_TASK_DYNOBS)
         return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: bad task_kind %d", cfg->task_kind);
+    if ((cfg->task_kind == MGX_TASK_DYNOBS) != (cfg->level_kind == MGX_LEVEL_DYNOBS))
+        return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: MGX_TASK_DYNOBS and MGX_LEVEL_DYNOBS go together (the obstacle walk continues the level's RNG stream)");
+    if (cfg->task_kind == MGX_TASK_DYNOBS) {
+        if (cfg->new_level_each_episode || cfg->object_state || cfg->extended_actions)
+            return mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_create: Dynamic-Obstacles handles do not take new_level_each_episode / object_state / extended_actions");
+        if (cfg->width * cfg->height > 256 || cfg->level_arg0 < 0 || cfg->level_arg0 > 8)
+            return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: Dynamic-Obstacles needs W*H <= 256 and 0..8 obstacles");
+    }
     if (cfg->task_kind != MGX_TASK_NONE && cfg->max_steps > 65535)
         return mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_create: task rules need max_steps <= 65535");
     if (cfg->obs_mode < MGX_OBS_PARTIAL || cfg->obs_mode > MGX_OBS_FULL_FLAT)
@@ -368,6 +390,19 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
         CREATE_TRY(hipMemsetAsync(h->mt_idx_d, 0, (size_t)h->n_pad * sizeof(uint32_t), h->stream));
         CREATE_TRY(hipMemsetAsync(h->regen_d, 0, (size_t)h->n_pad, h->stream));
     }
+    if (cfg->task_kind == MGX_TASK_DYNOBS) {
+        if (!h->device_levels) { int rc = mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_create: Dynamic-Obstacles needs the on-device level generator"); mgx_destroy(h); return rc; }
+        h->dynobs = true;
+        CREATE_TRY(hipMalloc((void **)&h->obst_d, (size_t)h->n_pad * 8));
+        CREATE_TRY(hipMalloc((void **)&h->obst0_d, (size_t)h->n_pad * 8));
+        CREATE_TRY(hipMalloc((void **)&h->act_d, (size_t)h->n_pad));
+        CREATE_TRY(hipMalloc((void **)&h->mt0_d, (size_t)h->n_pad * 624 * sizeof(uint32_t)));
+        CREATE_TRY(hipMalloc((void **)&h->pos0_d, (size_t)h->n_pad * sizeof(uint32_t)));
+        CREATE_TRY(hipMemsetAsync(h->obst_d, 0, (size_t)h->n_pad * 8, h->stream));
+        CREATE_TRY(hipMemsetAsync(h->obst0_d, 0, (size_t)h->n_pad * 8, h->stream));
+        CREATE_TRY(hipMemsetAsync(h->mt0_d, 0, (size_t)h->n_pad * 624 * sizeof(uint32_t), h->stream));
+        CREATE_TRY(hipMemsetAsync(h->pos0_d, 0, (size_t)h->n_pad * sizeof(uint32_t), h->stream));
+    }
     CREATE_TRY(hipEventCreate(&h->ev0));
     CREATE_TRY(hipEventCreate(&h->ev1));
     CREATE_TRY(hipStreamSynchronize(h->stream));
@@ -385,6 +420,7 @@ extern "C" int mgx_destroy(mgx_handle h)
     (void)hipFree(h->ctr_d); (void)hipFree(h->tri_d); (void)hipFree(h->mission_d);
     (void)hipFree(h->objaux_d); (void)hipFree(h->objaux0_d); (void)hipFree(h->objcont_d); (void)hipFree(h->objcont0_d); (void)hipFree(h->objcarry_d);
     (void)hipFree(h->mt_d); (void)hipFree(h->mt_idx_d); (void)hipFree(h->regen_d); (void)hipFree(h->mt_init_d);
+    (void)hipFree(h->obst_d); (void)hipFree(h->obst0_d); (void)hipFree(h->act_d); (void)hipFree(h->mt0_d); (void)hipFree(h->pos0_d);
     for (auto &s : h->st_in) if (s.dev) (void)hipFree(s.dev);
     for (auto &s : h->st_out) if (s.dev) (void)hipFree(s.dev);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -525,6 +561,8 @@ extern "C" int mgx_set_state(mgx_handle h, const uint8_t *grid, const uint8_t *a
 {
     int rc = check_handle(h, "mgx_set_state");
     if (rc) return rc;
+    if (h->dynobs)
+        return mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_set_state: a Dynamic-Obstacles state includes the env's RNG stream and the obstacle order; use mgx_reset(seeds, mask)");
     return set_state_impl(h, grid, aux, agent, carry, steps, nullptr);
 }
 
@@ -575,6 +613,12 @@ static int run_step(mgx_handle h, bool do_step, const uint8_t *actions, uint8_t 
         if (!actions) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_step: actions is required");
         if ((rc = dev_in(h, 0, actions, (size_t)h->n, &d))) return rc;
         p.actions = (const uint8_t *)d;
+        if (h->dynobs) { // the obstacle walk precedes the base step and folds the actions (envs/dynamicobstacles.py:60-80)
+            DynObsParams dp = dynobs_params(h);
+            dp.actions = p.actions;
+            HIP_TRY(mgx_launch_dynobs(dp, h->stream));
+            p.actions = h->act_d;
+        }
     }
     OutArg o[3];
     if ((rc = dev_out(h, 0, obs, (size_t)h->n * h->obs_bytes, &o[0], 16))) return rc;
@@ -711,6 +755,11 @@ extern "C" int mgx_reset(mgx_handle h, const uint64_t *seeds, const uint8_t *mas
         c.n = h->n; c.S = h->S; c.flag_regen = h->stream_mode ? 1 : 0;
         HIP_TRY(mgx_launch_consume(c, h->stream));
         if (h->stream_mode && (rc = launch_levelgen(h))) return rc;
+        if (h->dynobs) { // obstacle order out of the generator's markers + snapshot of the RNG right after reset()
+            DynObsParams dp = dynobs_params(h);
+            dp.mask = (const uint8_t *)dm;
+            HIP_TRY(mgx_launch_dynobs_init(dp, h->stream));
+        }
         if (obs) return run_step(h, false, nullptr, obs, nullptr, nullptr);
         return MGX_OK;
     }

@@ -77,6 +77,22 @@ struct ConsumeParams {
     int64_t n;
     int S, flag_regen;
 };
+// Dynamic-Obstacles (MGX_TASK_DYNOBS): the obstacle walk that precedes the base step, and its reset-time setup
+struct DynObsParams {
+    uint8_t *cells, *cells0;
+    const uint2 *agent;
+    const uint8_t *actions; // caller's actions (k_dynobs) ...
+    uint8_t *act_out;       // ... folded to 0..2, bit 7 = "moved forward while the front cell was not clear"
+    const uint8_t *mask;    // k_dynobs_init: envs being reset (null = all)
+    uint8_t *regen;         // set by the step kernels' in-kernel reset: restore obstacle order + RNG position first
+    uint8_t *obst, *obst0;  // u8[n_pad][8] cell index of obstacle i (placement order), and at episode start
+    uint32_t *mt, *mt0;     // u32[n_pad][624] MT19937 words (lazily regenerated in place past the first block) + snapshot
+    uint32_t *pos, *pos0;   // u32[n_pad] words drawn since the block in `mt0` was generated (= mt_idx right after reset)
+    int64_t n;
+    int W, H, S, n_obst;
+};
+hipError_t mgx_launch_dynobs_init(const DynObsParams &p, hipStream_t st);
+hipError_t mgx_launch_dynobs(const DynObsParams &p, hipStream_t st);
 hipError_t mgx_launch_levelgen(const LevelGenParams &p, hipStream_t st);
 hipError_t mgx_launch_seed(const uint64_t *seeds, const uint8_t *mask, const uint32_t *init, uint32_t *mt, uint32_t *mt_idx,
                            uint8_t *regen, int64_t n, hipStream_t st);

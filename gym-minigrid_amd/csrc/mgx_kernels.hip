@@ -741,6 +741,8 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
     const uint2 rec = p.agent[env]; // agent/cells arrays are padded to whole tiles
     uint32_t act = 6;
     if (p.do_step && valid) act = __builtin_nontemporal_load(&p.actions[env]);
+    const bool crash = p.task == MGX_TASK_DYNOBS && (act & 0x80u); // k_dynobs' verdict rides on the folded action
+    if (p.task == MGX_TASK_DYNOBS) act &= 0x7Fu;
     stage_tile<CS>(p.cells, env0, S, LS, lds, lane);
     wave_sync();
 
@@ -762,6 +764,7 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
             // the one cell a transition can change; skipped when the env is about to be restored anyway
             if (nc != fc && !(p.auto_reset && done)) p.cells[env * S + fidx] = (uint8_t)nc;
         } else if (valid && L.steps >= p.max_steps) done = true;
+        if (crash) { reward = -1.f; done = true; } // envs/dynamicobstacles.py:83-86
         if (p.reward && valid) __builtin_nontemporal_store(reward, &p.reward[env]);
         if (p.done && valid) __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), &p.done[env]);
         wave_stats(p, valid, done, reward, bad_act, oob, lane, tile);
@@ -826,6 +829,8 @@ __global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
         Lane L = unpack_rec(p.agent[env], p.task);
         uint32_t act = 6;
         if (p.do_step && valid) act = __builtin_nontemporal_load(&p.actions[env]);
+        const bool crash = p.task == MGX_TASK_DYNOBS && (act & 0x80u);
+        if (p.task == MGX_TASK_DYNOBS) act &= 0x7Fu;
         float reward = 0.f;
         bool done = false, bad_act = false, oob = false, reset = false;
         uint32_t wr = 0, changed = 0;
@@ -846,6 +851,7 @@ __global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
                     changed = 1;
                 }
             } else if (valid && L.steps >= p.max_steps) done = true;
+            if (crash) { reward = -1.f; done = true; }
             if (p.reward && valid) __builtin_nontemporal_store(reward, &p.reward[env]);
             if (p.done && valid) __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), &p.done[env]);
             wave_stats(p, valid, done, reward, bad_act, oob, lane, tile);
@@ -1328,6 +1334,134 @@ hipError_t mgx_launch_onehot(const uint8_t *tri, uint8_t *out, int64_t n_cells, 
     else if (nc == 7 && ns == 4) hipLaunchKernelGGL((k_onehot<7, 4>), grid, block, 0, st, tri, out, n_cells);
     else if (nc == 0 && ns == 4) hipLaunchKernelGGL((k_onehot<0, 4>), grid, block, 0, st, tri, out, n_cells);
     else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dynamic-Obstacles (envs/dynamicobstacles.py:60-89).  The obstacle walk draws from the env's own MT19937 stream
+// inside step(), so it cannot live in the streaming step kernel: k_dynobs runs before it, one lane per env.
+//   RNG   : the per-env block `mt` is the one k_seed/k_levelgen left behind (words [pos, 624) not drawn yet).  Past
+//           the block the next words are produced ONE AT A TIME in place -- new[k] = f(old[k], old[k+1], old[k+397] or
+//           new[k-227]) is exactly the order genrand's bulk twist uses, so the stream is numpy's -- which costs three
+//           loads and a store per draw instead of a 2.5 KB twist per lane.
+//   reset : the in-kernel auto-reset of the step kernels raises regen[env]; the walk then first restores the obstacle
+//           order and the RNG position of the episode start (ReseedWrapper: seed(s) + reset()), and the block itself
+//           only if the episode ran past it (pos > 624), which random-action episodes (~6 steps) never do.
+namespace {
+struct LaneRng {
+    uint32_t *A;
+    uint32_t p;
+    __device__ __forceinline__ uint32_t next32()
+    {
+        uint32_t y;
+        if (p < 624u) y = A[p];
+        else {
+            const uint32_t k = p % 624u, k1 = k + 1u == 624u ? 0u : k + 1u, km = k + 397u >= 624u ? k + 397u - 624u : k + 397u;
+            y = lg_twist_word(A[k], A[k1], A[km]);
+            A[k] = y;
+        }
+        p++;
+        return lg_temper(y);
+    }
+    __device__ __forceinline__ bool alive() const { return true; }
+};
+
+__global__ __launch_bounds__(256) void k_dynobs_init(const DynObsParams p)
+{
+    // snapshot of the RNG block (coalesced: 156 uint4 per env)
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < p.n * 156) {
+        const int64_t e = t / 156;
+        if (!p.mask || p.mask[e]) reinterpret_cast<uint4 *>(p.mt0)[t] = reinterpret_cast<const uint4 *>(p.mt)[t];
+    }
+    if (t >= p.n || (p.mask && !p.mask[t])) return;
+    // obstacle order from the generator's marker codes; the cells become plain blue balls
+    uint8_t ob[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int cells = p.W * p.H;
+    for (int c = 0; c < cells; c++) {
+        const uint32_t code = p.cells0[t * p.S + c];
+        if (MGX_IS_OBSTACLE_MARK(code)) {
+            ob[(code >> 4) & 7u] = (uint8_t)c;
+            p.cells0[t * p.S + c] = (uint8_t)MGX_CODE_BALL_BLUE;
+            p.cells[t * p.S + c] = (uint8_t)MGX_CODE_BALL_BLUE;
+        }
+    }
+    uint2 w;
+    w.x = ob[0] | (ob[1] << 8) | (ob[2] << 16) | ((uint32_t)ob[3] << 24);
+    w.y = ob[4] | (ob[5] << 8) | (ob[6] << 16) | ((uint32_t)ob[7] << 24);
+    reinterpret_cast<uint2 *>(p.obst0)[t] = w;
+    reinterpret_cast<uint2 *>(p.obst)[t] = w;
+    p.pos0[t] = p.pos[t];
+    p.regen[t] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_dynobs(const DynObsParams p)
+{
+    const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= p.n) return;
+    const int W = p.W, H = p.H;
+    uint8_t *g = p.cells + env * p.S;
+    uint2 ow = reinterpret_cast<const uint2 *>(p.obst)[env];
+    uint32_t pos = p.pos[env];
+    if (p.regen[env]) { // the previous step ended the episode: cells/agent are already the episode start
+        ow = reinterpret_cast<const uint2 *>(p.obst0)[env];
+        if (pos > 624u) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(p.mt0) + env * 156;
+            uint4 *dst = reinterpret_cast<uint4 *>(p.mt) + env * 156;
+            for (int i = 0; i < 156; i++) dst[i] = src[i];
+        }
+        pos = p.pos0[env];
+        p.regen[env] = 0;
+    }
+    uint32_t a = p.actions[env];
+    if (a >= 3u) a = 0u; // `if action >= self.action_space.n: action = 0`
+    const uint32_t rec = p.agent[env].x;
+    const int ax = (int)(rec & 255u), ay = (int)((rec >> 8) & 255u), dir = (int)((rec >> 16) & 3u);
+    const int fx = ax + (dir == 0) - (dir == 2), fy = ay + (dir == 1) - (dir == 3);
+    bool not_clear = false; // front_cell and front_cell.type != 'goal', BEFORE the obstacles move
+    if (fx >= 0 && fx < W && fy >= 0 && fy < H) {
+        const uint32_t k = g[fx * H + fy] & 15u;
+        not_clear = k != MGX_K_EMPTY && k != MGX_K_GOAL;
+    }
+    LaneRng r = {p.mt + env * 624, pos};
+    for (int i = 0; i < p.n_obst; i++) {
+        const uint32_t o = (i < 4 ? ow.x >> (8 * i) : ow.y >> (8 * (i - 4))) & 255u;
+        const int ox = (int)o / H, oy = (int)o - ox * H;
+        const int tx = ox > 0 ? ox - 1 : 0, ty = oy > 0 ? oy - 1 : 0;
+        const int xh = tx + 3 < W ? tx + 3 : W, yh = ty + 3 < H ? ty + 3 : H;
+        int nx = -1, ny = -1;
+        for (int tries = 0; tries <= 100; tries++) { // num_tries > max_tries raises: 101 samples at most
+            const int x = lg_randint(r, tx, xh), y = lg_randint(r, ty, yh);
+            if (g[x * H + y] != MGX_CODE_EMPTY) continue;
+            if (x == ax && y == ay) continue;
+            nx = x; ny = y;
+            break;
+        }
+        if (nx < 0) continue; // RecursionError swallowed by the bare except: the obstacle stays
+        g[nx * H + ny] = (uint8_t)MGX_CODE_BALL_BLUE;
+        g[o] = (uint8_t)MGX_CODE_EMPTY;
+        const uint32_t n8 = (uint32_t)(nx * H + ny);
+        if (i < 4) ow.x = (ow.x & ~(255u << (8 * i))) | (n8 << (8 * i));
+        else ow.y = (ow.y & ~(255u << (8 * (i - 4)))) | (n8 << (8 * (i - 4)));
+    }
+    reinterpret_cast<uint2 *>(p.obst)[env] = ow;
+    p.pos[env] = r.p;
+    p.act_out[env] = (uint8_t)(a | ((a == 2u && not_clear) ? 0x80u : 0u));
+}
+} // namespace
+
+hipError_t mgx_launch_dynobs_init(const DynObsParams &p, hipStream_t st)
+{
+    const int64_t total = p.n * 156;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_dynobs_init, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+hipError_t mgx_launch_dynobs(const DynObsParams &p, hipStream_t st)
+{
+    if (p.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_dynobs, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, st, p);
     return hipGetLastError();
 }
 

@@ -88,10 +88,13 @@ class VecMiniGrid:
             self.obs_dtype = "float32"
         self.n_actions = 9 if extended_actions else 7
         self.action_space = Discrete(self.n_actions)  # minigrid.py:788-792
+        if cfg.task_kind == 3:  # Dynamic-Obstacles: Discrete(3), larger actions fold to 0 (envs/dynamicobstacles.py:32-33,61-63)
+            self.action_space = Discrete(3)
+            self.n_actions = 256
         self.observation_space = Dict({"image": Box(0, 255, self.obs_shape, "uint8")})
         if self.obs_dtype == "float32":
             self.observation_space = Box(0, 255, (1,) + self.obs_shape, "uint8")  # wrappers.py:543-548
-        self.reward_range = (0, 1)
+        self.reward_range = (-1, 1) if cfg.task_kind == 3 else (0, 1)
         self.mission = self._mission_of(0) if cfg.level_kind != 7 else "fetch a <color> <type>: see missions()"
         self._h = ctypes.c_void_p()
         _lib.check(L.mgx_create(ctypes.byref(cfg), self.num_envs, self.device, ctypes.byref(self._h)))

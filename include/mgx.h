@@ -94,8 +94,12 @@ typedef enum {
     MGX_LEVEL_FETCH = 7,     /* FetchEnv (envs/fetch.py): level_arg0 = numObjs; use with task_kind = MGX_TASK_FETCH */
     MGX_LEVEL_GOTODOOR = 8,  /* GoToDoorEnv (envs/gotodoor.py); use with task_kind = MGX_TASK_GOTODOOR */
     MGX_LEVEL_FOURROOMS = 9, /* FourRoomsEnv (envs/fourrooms.py:8-70), random agent and goal */
-    MGX_LEVEL_MULTIROOM = 6  /* MultiRoomEnv (envs/multiroom.py): level_arg0 = minNumRooms | maxNumRooms << 8 (<= 8),
+    MGX_LEVEL_DYNOBS = 10,   /* DynamicObstaclesEnv (envs/dynamicobstacles.py): level_arg0 = n_obstacles after the
+                                constructor's clamp (<= 8), level_arg1 = 1 for a random agent start; use with
+                                task_kind = MGX_TASK_DYNOBS */
+    MGX_LEVEL_MULTIROOM = 6, /* MultiRoomEnv (envs/multiroom.py): level_arg0 = minNumRooms | maxNumRooms << 8 (<= 8),
                                 level_arg1 = maxRoomSize */
+    MGX_LEVEL_KIND_END = 11
 } mgx_level_kind;
 
 /* task rules layered on MiniGridEnv.step by env subclasses (`step` overrides that only reshape reward/done) */
@@ -103,8 +107,13 @@ typedef enum {
     MGX_TASK_NONE = 0,
     MGX_TASK_FETCH = 1,    /* envs/fetch.py:74-86: once something is carried the episode ends; reward = _reward() iff it is
                               the target object.  Per-env task word = target cell code | mission template << 8. */
-    MGX_TASK_GOTODOOR = 2  /* envs/gotodoor.py:71-93: the `done` action next to any door ends the episode, next to the
+    MGX_TASK_GOTODOOR = 2, /* envs/gotodoor.py:71-93: the `done` action next to any door ends the episode, next to the
                               target (red) door it also pays _reward(). */
+    MGX_TASK_DYNOBS = 3    /* envs/dynamicobstacles.py:60-89 (with level_kind = MGX_LEVEL_DYNOBS): actions >= 3 fold to 0;
+                              before the base step every obstacle (blue ball) is re-placed in its 3x3 neighbourhood with
+                              draws from the env's own RNG stream (place_obj, max_tries=100); moving forward while the
+                              front cell was occupied by anything but the goal gives reward -1 and done.  State enters
+                              through mgx_reset only (the RNG stream is part of it): mgx_set_state is refused. */
 } mgx_task_kind;
 
 typedef struct {

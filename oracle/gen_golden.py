@@ -284,7 +284,7 @@ def doorkey_script(env):
 
 
 # --------------------------------------------------------------------------- recorder
-def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False, reseed=True, n_actions=7, objstate=False):
+def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False, reseed=True, n_actions=7, objstate=False, gym_id=None):
     K = len(seeds)
     env0 = make_env()
     W, H = env0.width, env0.height
@@ -293,7 +293,7 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
                 see_through=bool(env0.see_through_walls), lava_v1=bool(v1), full_obs=bool(full_obs),
                 reseed=bool(reseed), extended=bool(n_actions > 7), alt_vis=not bool(env0.default_vis),
                 task=1 if hasattr(env0, "targetType") else (2 if hasattr(env0, "target_pos") else 0),
-                objstate=bool(objstate))
+                objstate=bool(objstate), dynobs=int(getattr(env0, "n_obstacles", 0)), gym_id=gym_id or "")
     z = dict(
         seed=np.zeros(K, np.int64), init_grid=np.zeros((K, W, H, 3), np.uint8),
         init_aux=np.zeros((K, W, H), np.uint8), init_agent=np.zeros((K, 3), np.int32),
@@ -531,10 +531,15 @@ def record_levels():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    if len(sys.argv) > 2 and sys.argv[1] == "--only":   # e.g. --only flat onehot: re-record just those fixture files
-        for what in sys.argv[2:]:
+    only = sys.argv[2:] if len(sys.argv) > 2 and sys.argv[1] == "--only" else None
+    if only and not any(w.startswith("case:") for w in only):   # e.g. --only flat onehot: re-record just those fixture files
+        for what in only:
             {"flat": record_flat, "onehot": record_onehot, "levels": record_levels, "level_streams": record_level_streams}[what]()
         return
+    if only:                                                     # e.g. --only case:DynObs  (prefix of the case names)
+        global record_case
+        full_record, prefixes = record_case, tuple(w[5:] for w in only)
+        record_case = lambda name, *a, **k: full_record(name, *a, **k) if name.startswith(prefixes) else None  # noqa: E731
     mk = lambda i: (lambda: gym.make(i))  # noqa: E731
     record_case("Empty-8x8", mk("MiniGrid-Empty-8x8-v0"), [0, 1, 2, 3], 300)
     record_case("Empty-5x5", mk("MiniGrid-Empty-5x5-v0"), [0, 1], 120)
@@ -595,6 +600,12 @@ def main():
     record_case("SoupAux-8x8", lambda: SoupAuxEnv(8, 8, False, 96, 0.55), list(range(16)), 250, objstate=True)
     record_case("SoupAux-9x9-strafe", lambda: SoupAuxEnv(9, 9, True, 100, 0.5, extended=True), list(range(8)), 250, n_actions=9, objstate=True)
     record_case("SoupAux-7x11-full", lambda: SoupAuxEnv(7, 11, False, 80, 0.5), list(range(6)), 200, full_obs=True, objstate=True)
+    # moving obstacles drawn from the env's RNG inside step() (envs/dynamicobstacles.py:60-89); actions 3.. fold to 0
+    for short, gid, seeds, T in [("DynObs-5x5", "MiniGrid-Dynamic-Obstacles-5x5-v0", range(8), 200),
+                                 ("DynObs-Random-6x6", "MiniGrid-Dynamic-Obstacles-Random-6x6-v0", range(12), 300),
+                                 ("DynObs-8x8", "MiniGrid-Dynamic-Obstacles-8x8-v0", range(12), 400),
+                                 ("DynObs-16x16", "MiniGrid-Dynamic-Obstacles-16x16-v0", range(4), 400)]:
+        record_case(short, mk(gid), list(seeds), T, n_actions=4, gym_id=gid)
     # task rules layered on the base step: FetchEnv (envs/fetch.py:74-86), GoToDoorEnv (envs/gotodoor.py:71-93)
     def fetch_script(which):
         def f(env):
@@ -624,6 +635,8 @@ def main():
     record_case("DoorKey-5x5-stream", mk("MiniGrid-DoorKey-5x5-v0"), [0, 1, 2], 800, reseed=False)
     record_case("LavaGapS6-stream", mk("MiniGrid-LavaGapS6-v0"), [0, 1, 2, 3], 400, reseed=False)
     record_case("Empty-Random-6x6-stream", mk("MiniGrid-Empty-Random-6x6-v0"), [0, 1], 450, reseed=False)
+    if only:
+        return
     record_levels()
     record_level_streams()
     record_onehot()

@@ -18,7 +18,9 @@ def pytest_configure(config):
 
 
 def golden_cases():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f not in ("levels.npz", "level_streams.npz", "onehot.npz", "flat.npz"))
+    """Trace cases whose state can be injected with set_state (DynObs-* carry an RNG stream: tests/test_dynobs.py)."""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and not f.startswith("DynObs-")
+                  and f not in ("levels.npz", "level_streams.npz", "onehot.npz", "flat.npz"))
 
 
 def load_case(name):

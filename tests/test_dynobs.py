@@ -1,0 +1,142 @@
+"""Dynamic-Obstacles (envs/dynamicobstacles.py:60-89): obstacles re-placed with draws from the env's
+own RNG stream inside step().  CPU: the restatement (oracle/dynobs_oracle.py: numpy RandomState + the C base step) is
+pinned to traces recorded from the reference.  GPU: k_dynobs + the step kernels against the traces (same seeds,
+same actions, auto-reset with ReseedWrapper semantics) and against the restatement on larger seeded batches."""
+import numpy as np
+import pytest
+
+import gym_minigrid_amd as mg
+from conftest import load_case
+from oracle.dynobs_oracle import DynObsOracle, n_obstacles_of
+
+CASES = [("DynObs-5x5", 5, 2, False), ("DynObs-Random-6x6", 6, 3, True), ("DynObs-8x8", 8, 4, False), ("DynObs-16x16", 16, 8, False)]
+
+
+@pytest.mark.parametrize("name,size,n_obst,rnd", CASES)
+def test_restatement_matches_reference_trace(name, size, n_obst, rnd):
+    meta, z = load_case(name)
+    assert meta["dynobs"] == n_obst and meta["max_steps"] == 4 * size * size and meta["see_through"]
+    K, T = z["actions"].shape
+    o = DynObsOracle(size, n_obst, rnd, z["seed"])
+    assert np.array_equal(o.base.grid, z["init_grid"]) and np.array_equal(o.base.agent, z["init_agent"])
+    assert np.array_equal(o.observe(), z["init_obs"])
+    dones = 0
+    for t in range(T):
+        obs, r, d = o.step(z["actions"][:, t])
+        assert np.array_equal(obs, z["obs"][:, t]), (name, t)
+        assert np.array_equal(r, z["reward"][:, t]) and np.array_equal(d, z["done"][:, t]), (name, t)
+        assert np.array_equal(o.base.grid, z["grid"][:, t]) and np.array_equal(o.base.agent, z["agent"][:, t]), (name, t)
+        o.reset_where(d)                                  # env.seed(s); env.reset() as the recorder did
+        dones += int(d.sum())
+    assert dones > 20
+
+
+def test_registry_matches_constructor_clamp():
+    for env_id, size, n in [("MiniGrid-Dynamic-Obstacles-5x5-v0", 5, 2), ("MiniGrid-Dynamic-Obstacles-Random-5x5-v0", 5, 2),
+                            ("MiniGrid-Dynamic-Obstacles-6x6-v0", 6, 3), ("MiniGrid-Dynamic-Obstacles-Random-6x6-v0", 6, 3),
+                            ("MiniGrid-Dynamic-Obstacles-8x8-v0", 8, 4), ("MiniGrid-Dynamic-Obstacles-16x16-v0", 16, 8)]:
+        c = mg.env_config(env_id)
+        assert (c.width, c.height, c.max_steps, c.see_through_walls) == (size, size, 4 * size * size, 1)
+        assert c.level_arg0 == n_obstacles_of(size, n) and c.level_arg1 == int("Random" in env_id) and c.task_kind == 3
+        # host-side generator: same level as the restatement (markers cleaned to plain blue balls)
+        seeds = np.arange(40, dtype=np.uint64)
+        grid, agent = mg.generate_levels(env_id, seeds)
+        o = DynObsOracle(size, n, "Random" in env_id, seeds)
+        assert np.array_equal(grid, o.base.grid) and np.array_equal(agent, o.base.agent), env_id
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,size,n_obst,rnd", CASES)
+@pytest.mark.parametrize("mode", ["partial", "full"])
+def test_gpu_matches_reference_trace(name, size, n_obst, rnd, mode):
+    meta, z = load_case(name)
+    K, T = z["actions"].shape
+    N = 64 + K                                              # more than one tile; env i replays trace i % K
+    sel = np.arange(N) % K
+    env = mg.VecMiniGrid(meta["gym_id"], num_envs=N, seeds=z["seed"][sel].astype(np.uint64), obs_mode=mode, auto_reset=True, backend="numpy")
+    assert env.action_space.n == 3 and env.max_steps == meta["max_steps"]
+    obs = env.reset()
+    st = env.get_state()
+    assert np.array_equal(st["grid"], z["init_grid"][sel]) and np.array_equal(st["agent"], z["init_agent"][sel])
+    if mode == "partial":
+        assert np.array_equal(obs, z["init_obs"][sel])
+    for t in range(T):
+        obs, rew, done, _ = env.step(z["actions"][sel, t])
+        d = z["done"][sel, t].astype(bool)
+        assert np.array_equal(done, z["done"][sel, t]), (name, t)
+        assert np.array_equal(rew, z["reward"][sel, t].astype(np.float32)), (name, t)
+        st = env.get_state()
+        want_grid = np.where(d[:, None, None, None], z["init_grid"][sel], z["grid"][sel, t])
+        assert np.array_equal(st["grid"], want_grid), (name, t)
+        assert np.array_equal(st["agent"], np.where(d[:, None], z["init_agent"][sel], z["agent"][sel, t])), (name, t)
+        if mode == "partial":
+            want = np.where(d[:, None, None, None], z["init_obs"][sel], z["obs"][sel, t])
+            assert np.array_equal(obs, want), (name, t)
+    s = env.stats()
+    assert s["episodes"] == int(z["done"][sel].sum()) and s["invalid_actions"] == 0
+    env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_id,size,n_obst", [("MiniGrid-Dynamic-Obstacles-Random-5x5-v0", 5, 2), ("MiniGrid-Dynamic-Obstacles-8x8-v0", 8, 4),
+                                                 ("MiniGrid-Dynamic-Obstacles-16x16-v0", 16, 8)])
+@pytest.mark.parametrize("auto_reset", [True, False])
+def test_gpu_vs_restatement_random_batch(env_id, size, n_obst, auto_reset):
+    N, T = 64 * 3 + 9, 60
+    seeds = (np.arange(N, dtype=np.uint64) * 7919 + 5) % 100003
+    orc = DynObsOracle(size, n_obst, "Random" in env_id, seeds)
+    env = mg.VecMiniGrid(env_id, num_envs=N, seeds=seeds, auto_reset=auto_reset, backend="torch")
+    assert np.array_equal(env.reset().cpu().numpy(), orc.observe())
+    rs = np.random.RandomState(3)
+    for t in range(T):
+        a = rs.randint(0, 3, size=N).astype(np.uint8)
+        turn = rs.uniform(size=N) < 0.55                    # mostly turns (incl. folded 3..255): episodes live longer
+        a[turn] = rs.choice([0, 1, 4, 6, 255], size=N)[turn]
+        obs, rew, done, _ = env.step(a)
+        oo, orew, odone = orc.step(a)
+        assert np.array_equal(done.cpu().numpy(), odone), t
+        assert np.array_equal(rew.cpu().numpy(), orew.astype(np.float32)), t
+        if auto_reset:
+            orc.reset_where(odone)
+            oo = np.where(odone.astype(bool)[:, None, None, None], orc.observe(), oo)
+        assert np.array_equal(obs.cpu().numpy(), oo), t
+        assert np.array_equal(env.get_state()["grid"], orc.base.grid), t
+        if not auto_reset and odone.any() and t % 7 == 3:   # caller-side reset of the finished envs: seed(s); reset()
+            env.reset(mask=odone)
+            orc.reset_where(odone)
+    env.close()
+
+
+@pytest.mark.gpu
+def test_long_episodes_cross_the_first_rng_block():
+    """Turn-only actions: nobody crashes, every step draws ~11 words, the 624-word block is crossed many times before
+    max_steps (lazy in-place regeneration), then the time-out reset must restore the block."""
+    env_id, size, n_obst, N = "MiniGrid-Dynamic-Obstacles-6x6-v0", 6, 3, 70
+    seeds = np.arange(N, dtype=np.uint64) + 1000
+    orc = DynObsOracle(size, n_obst, False, seeds)
+    env = mg.VecMiniGrid(env_id, num_envs=N, seeds=seeds, auto_reset=True, backend="numpy")
+    env.reset()
+    rs = np.random.RandomState(0)
+    T = 144 * 2 + 20
+    for t in range(T):
+        a = rs.randint(0, 2, size=N).astype(np.uint8)
+        obs, rew, done, _ = env.step(a)
+        oo, orew, odone = orc.step(a)
+        orc.reset_where(odone)
+        oo = np.where(odone.astype(bool)[:, None, None, None], orc.observe(), oo)
+        assert np.array_equal(done, odone) and np.array_equal(obs, oo), t
+        assert (t + 1) % 144 != 0 or odone.all()
+    assert env.stats()["episodes"] == 2 * N
+    env.close()
+
+
+@pytest.mark.gpu
+def test_set_state_is_refused():
+    env = mg.VecMiniGrid("MiniGrid-Dynamic-Obstacles-5x5-v0", num_envs=3, backend="numpy")
+    env.reset()
+    st = env.get_state()
+    with pytest.raises(mg.MgxError):
+        env.set_state(st["grid"], st["agent"])
+    with pytest.raises(mg.MgxError):
+        mg.VecMiniGrid("MiniGrid-Dynamic-Obstacles-5x5-v0", num_envs=3, backend="numpy", new_level_each_episode=True)
+    env.close()
