@@ -160,7 +160,7 @@ int check_levelgen_cfg(const mgx_config *cfg, const char *fn)
             return mgx_fail(MGX_ERR_UNSUPPORTED, "%s: crossing grid %dx%d has more than %d candidate rivers per axis", fn, W, H, MGX_LG_MAX_RIVERS);
         break;
     case MGX_LEVEL_DYNOBS:
-        if (W < 5 || H < 5 || W * H > 256) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: Dynamic-Obstacles grids are 5x5 .. 16x16", fn);
+        if (W < 5 || H < 5 || W > 16 || H > 16) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: Dynamic-Obstacles grids are 5x5 .. 16x16", fn);
         if (cfg->level_arg0 < 0 || cfg->level_arg0 > 8) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: n_obstacles %d (0..8)", fn, cfg->level_arg0);
         break;
     default: return mgx_fail(MGX_ERR_NO_LEVELGEN, "%s: level_kind %d has no built-in generator", fn, cfg->level_kind);

@@ -195,6 +195,7 @@ DynObsParams dynobs_params(mgx_handle h)
     d.cells = h->cells_d; d.cells0 = h->cells0_d; d.agent = h->agent_d; d.act_out = h->act_d; d.regen = h->regen_d;
     d.obst = h->obst_d; d.obst0 = h->obst0_d; d.mt = h->mt_d; d.mt0 = h->mt0_d; d.pos = h->mt_idx_d; d.pos0 = h->pos0_d;
     d.n = h->n; d.W = h->W; d.H = h->H; d.S = h->S; d.n_obst = h->cfg.level_arg0;
+    d.n_tiles = (int)(h->n_pad / 64); d.LS = h->LS; d.wave_lds = mgx_dynobs_wave_lds(h->LS);
     return d;
 }
 
@@ -237,8 +238,8 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     if (cfg->task_kind == MGX_TASK_DYNOBS) {
         if (cfg->new_level_each_episode || cfg->object_state || cfg->extended_actions)
             return mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_create: Dynamic-Obstacles handles do not take new_level_each_episode / object_state / extended_actions");
-        if (cfg->width * cfg->height > 256 || cfg->level_arg0 < 0 || cfg->level_arg0 > 8)
-            return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: Dynamic-Obstacles needs W*H <= 256 and 0..8 obstacles");
+        if (cfg->width > 16 || cfg->height > 16 || cfg->level_arg0 < 0 || cfg->level_arg0 > 8)
+            return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: Dynamic-Obstacles needs W, H <= 16 and 0..8 obstacles");
     }
     if (cfg->task_kind != MGX_TASK_NONE && cfg->max_steps > 65535)
         return mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_create: task rules need max_steps <= 65535");

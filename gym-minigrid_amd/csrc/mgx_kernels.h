@@ -85,12 +85,14 @@ struct DynObsParams {
     uint8_t *act_out;       // ... folded to 0..2, bit 7 = "moved forward while the front cell was not clear"
     const uint8_t *mask;    // k_dynobs_init: envs being reset (null = all)
     uint8_t *regen;         // set by the step kernels' in-kernel reset: restore obstacle order + RNG position first
-    uint8_t *obst, *obst0;  // u8[n_pad][8] cell index of obstacle i (placement order), and at episode start
+    uint8_t *obst, *obst0;  // u8[n_pad][8] position x << 4 | y of obstacle i (placement order), and at episode start
     uint32_t *mt, *mt0;     // u32[n_pad][624] MT19937 words (lazily regenerated in place past the first block) + snapshot
     uint32_t *pos, *pos0;   // u32[n_pad] words drawn since the block in `mt0` was generated (= mt_idx right after reset)
     int64_t n;
     int W, H, S, n_obst;
+    int n_tiles, LS, wave_lds; // k_dynobs: one wave per 64-env tile, cells + RNG windows staged in LDS
 };
+int mgx_dynobs_wave_lds(int LS);
 hipError_t mgx_launch_dynobs_init(const DynObsParams &p, hipStream_t st);
 hipError_t mgx_launch_dynobs(const DynObsParams &p, hipStream_t st);
 hipError_t mgx_launch_levelgen(const LevelGenParams &p, hipStream_t st);
