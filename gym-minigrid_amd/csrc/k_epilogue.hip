@@ -1,0 +1,133 @@
+// k_epilogue.hip -- observation epilogues behind k_step: one-hot wrappers (k_onehot) and FlatObsWrapper (k_flat).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mgx_internal.h"
+#include "mgx_kernels.h"
+#include "mgx_device.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// One-hot epilogue: (type, color, state) triples -> NB = 11 + NC + NS bytes per cell with three ones
+//   OneHotPartialObsWrapper  wrappers.py:203-243  (NC 7, NS 3 -> 21 channels: out[type] = out[11+color] = out[18+state] = 1)
+//   FullyObsOneHotWrapper    wrappers.py:340-415  (NS 4 because the agent cell carries its direction; NC 7 or 0 = drop_color)
+// The observation batch is one flat array of cells.  A lane takes 4 consecutive cells (12 input bytes, one
+// dwordx3 load) and produces their 4*NB output bytes = NB whole dwords; every output byte is ONE compare because
+// its (cell, channel) is known at compile time.  The wave's 64*NB dwords are contiguous in the output, so they are
+// transposed through LDS and leave as 16-B/lane coalesced stores.
+template <int NC, int NS>
+__global__ __launch_bounds__(256) void k_onehot(const uint8_t *__restrict__ tri, uint8_t *__restrict__ out, int64_t n_cells)
+{
+    constexpr int NB = 11 + NC + NS;
+    __shared__ __attribute__((aligned(16))) uint32_t s_x[4][64 * NB];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + wv;
+    const int64_t cell0 = wave * 256; // first cell of this wave
+    if (cell0 >= n_cells) return;
+    const int64_t c = cell0 + 4 * (int64_t)lane;
+    uint32_t ty[4], co[4], st[4];
+    if (c + 3 < n_cells) {
+        struct __attribute__((packed, aligned(4))) In12 { uint32_t a, b, c; };
+        const In12 v = *reinterpret_cast<const In12 *>(tri + c * 3);
+        ty[0] = v.a & 255u; co[0] = (v.a >> 8) & 255u; st[0] = (v.a >> 16) & 255u;
+        ty[1] = v.a >> 24;  co[1] = v.b & 255u;        st[1] = (v.b >> 8) & 255u;
+        ty[2] = (v.b >> 16) & 255u; co[2] = v.b >> 24; st[2] = v.c & 255u;
+        ty[3] = (v.c >> 8) & 255u; co[3] = (v.c >> 16) & 255u; st[3] = v.c >> 24;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const bool ok = c + k < n_cells;
+            ty[k] = ok ? tri[(c + k) * 3] : 255u; co[k] = ok ? tri[(c + k) * 3 + 1] : 255u; st[k] = ok ? tri[(c + k) * 3 + 2] : 255u;
+        }
+    }
+    uint32_t *x = s_x[wv] + lane * NB;
+#pragma unroll
+    for (int d = 0; d < NB; d++) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int q = 4 * d + b, k = q / NB, ch = q % NB; // compile-time
+            const bool one = ch < 11 ? ty[k] == (uint32_t)ch : (ch < 11 + NC ? co[k] == (uint32_t)(ch - 11) : st[k] == (uint32_t)(ch - 11 - NC));
+            w |= (uint32_t)one << (8 * b);
+        }
+        x[d] = w;
+    }
+    wave_sync();
+    const int64_t wave_cells = n_cells - cell0 < 256 ? n_cells - cell0 : 256;
+    const int n_bytes = (int)wave_cells * NB;
+    uint8_t *dst = out + cell0 * NB; // 256*NB bytes per wave: 16-B aligned
+    const uint4 *x4 = reinterpret_cast<const uint4 *>(s_x[wv]);
+    for (int i = lane; i < (n_bytes + 15) / 16; i += 64) {
+        if (16 * i + 16 <= n_bytes) nt_store16(reinterpret_cast<uint4 *>(dst) + i, x4[i]);
+        else
+            for (int b = 16 * i; b < n_bytes; b++) dst[b] = reinterpret_cast<const uint8_t *>(s_x[wv])[b];
+    }
+}
+
+
+} // namespace
+
+hipError_t mgx_launch_onehot(const uint8_t *tri, uint8_t *out, int64_t n_cells, int nc, int ns, hipStream_t st)
+{
+    const dim3 grid((unsigned)((n_cells + 1023) / 1024)), block(256);
+    if (nc == 7 && ns == 3) hipLaunchKernelGGL((k_onehot<7, 3>), grid, block, 0, st, tri, out, n_cells);
+    else if (nc == 7 && ns == 4) hipLaunchKernelGGL((k_onehot<7, 4>), grid, block, 0, st, tri, out, n_cells);
+    else if (nc == 0 && ns == 4) hipLaunchKernelGGL((k_onehot<0, 4>), grid, block, 0, st, tri, out, n_cells);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+
+// FlatObsWrapper.observation (wrappers.py:556-577): out[env] = f32(image bytes) ++ one-hot of the mission string
+// (96 positions x 27 codes).  `table` holds one row of 96 character codes (0..25 letters, 26 space, 255 past the end)
+// per mission of the family; only Fetch has more than one (row = (template*2 + is_ball)*8 + color of the task word).
+// A pure stream of 16-B stores over the flat [n][L] output: 4 consecutive floats per lane, one divide per lane.
+namespace {
+__global__ __launch_bounds__(256) void k_flat(const uint8_t *__restrict__ tri, const uint2 *__restrict__ rec, const uint8_t *__restrict__ table,
+                                               float *__restrict__ out, int64_t n, int img, int fetch)
+{
+    const int64_t L = (int64_t)img + MGX_FLAT_MISSION;
+    const int64_t total = n * L;
+    const int64_t g0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (g0 >= total) return;
+    int64_t env = g0 / L;
+    int off = (int)(g0 - env * L);
+    float v[4];
+    const uint8_t *row = nullptr;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        float x = 0.f;
+        if (g0 + j < total) {
+            if (off >= L) { off = 0; env++; row = nullptr; }
+            if (off < img) x = (float)tri[env * img + off];
+            else {
+                if (!row) {
+                    int mid = 0;
+                    if (fetch) {
+                        const uint32_t task = rec[env].y >> 16;
+                        mid = (int)((((task >> 8) & 7u) * 2u + ((task & 15u) == MGX_K_BALL ? 1u : 0u)) * 8u + ((task >> 4) & 7u));
+                    }
+                    row = table + mid * 96;
+                }
+                const int k = off - img, ch = k / 27, code = k - ch * 27;
+                x = row[ch] == code ? 1.f : 0.f;
+            }
+            off++;
+        }
+        v[j] = x;
+    }
+    if (g0 + 3 < total) nt_store16(reinterpret_cast<uint4 *>(out + g0), make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])));
+    else
+        for (int j = 0; j < 4 && g0 + j < total; j++) out[g0 + j] = v[j];
+}
+} // namespace
+
+hipError_t mgx_launch_flat(const uint8_t *tri, const uint2 *rec, const uint8_t *table, float *out, int64_t n, int img, int fetch, hipStream_t st)
+{
+    const int64_t quads = (n * ((int64_t)img + MGX_FLAT_MISSION) + 3) / 4;
+    if (quads == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_flat, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, tri, rec, table, out, n, img, fetch);
+    return hipGetLastError();
+}
+

@@ -1,0 +1,757 @@
+// k_step.hip -- the hot path of libmgx.so for gfx950 (MI355X / CDNA4): k_step, k_step_fulldirect.
+//
+// One launch = one lockstep `env.step(a)` (or `gen_obs()`) for every env of the handle:
+//   MiniGridEnv.step       /root/reference/gym_minigrid/minigrid.py:1227-1325
+//   gen_obs_grid / gen_obs minigrid.py:1327-1381  (slice :453, rotate_left :439, process_vis :617, encode :571)
+//   FullyObsWrapper        /root/reference/gym_minigrid/wrappers.py:326-338
+//
+// Mapping (wave64, no MFMA -- this is integer gather/scan work, bounded by HBM):
+//   * one wavefront owns a TILE of 64 consecutive envs; lane e simulates env e of the tile.
+//   * state in HBM is SoA: cells u8[N][S] (1-byte cell codes, x-major like Grid.encode, S = W*H rounded
+//     up to 4) and one 8-byte agent record per env.  A tile's cells are one contiguous 64*S-byte run, so the
+//     wave streams it with 16-B/lane loads and parks it in LDS with an ODD dword stride per env, which makes
+//     the per-lane dynamic gathers (forward cell, 7x7 view) conflict-free up to the agents' own offsets.
+//   * the transition touches the forward cell only (one LDS byte read, at most one byte written back).
+//   * view: closed form  world = pos + f*(6-vy) + r*(vx-3)  (spec O1) -> 49 LDS byte reads.
+//   * occlusion (process_vis) is BIT-SLICED ACROSS THE WAVE: transparency of view cell (vx,vy) for all 64
+//     envs is one 64-bit ballot; the reference's two-sweep row flood becomes s_and/s_or on SGPR pairs
+//     (scalar unit, off the VALU), and the result is applied with v_cndmask on the inverse ballot.
+//   * the 147-byte observation is not dword aligned per env: each lane packs its 49 triples into 37 dwords,
+//     funnel-shifts them by its byte phase (3*lane mod 4), merges the boundary dword with its neighbour by
+//     DPP row_shr:1 and stores to the wave's LDS image of the tile's 9408 contiguous output bytes, which then
+//     leaves as 16-B/lane coalesced global stores.
+//   * done / fault flags reduce with wave ballots: one atomic per wave and only when something happened.
+//   * auto-reset restores the episode-start snapshot for the (rare) done lanes inside the same launch.
+#include <hip/hip_runtime.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mgx_internal.h"
+#include "mgx_kernels.h"
+#include "mgx_device.h"
+
+namespace {
+
+// Task rules that env subclasses layer on MiniGridEnv.step (they run after the base step, time-out included).
+template <int CH, class CellAt>
+__device__ __forceinline__ void task_rule(const StepParams &p, const Lane &L, uint32_t act, float &reward, bool &done, CellAt cell_at)
+{
+    if (p.task == MGX_TASK_FETCH) { // envs/fetch.py:74-86
+        if (L.carry != MGX_CODE_EMPTY) {
+            done = true;
+            reward = ((L.carry & 0x7Fu) == (L.task & 0x7Fu)) ? (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps)) : 0.f;
+        }
+    } else if (p.task == MGX_TASK_GOTODOOR) { // envs/gotodoor.py:71-93: `done` next to a door; the target door is the red one
+        if (act == 6) {
+            const int H = CH ? CH : p.H;
+            const int base = L.ax * H + L.ay;
+            const uint32_t n4[4] = {cell_at(base + H), cell_at(base - H), cell_at(base + 1), cell_at(base - 1)};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t k = n4[i] & 15u;
+                const bool door = k == MGX_K_DOOR_OPEN || k == MGX_K_DOOR_CLOSED || k == MGX_K_DOOR_LOCKED;
+                if (door) done = true;
+                if (door && ((n4[i] >> 4) & 7u) == 0u) reward = (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps));
+            }
+        }
+    }
+}
+
+// MiniGridEnv.step without the observation (spec S1-S8), in two halves so that the forward cell can come from
+// the LDS tile image (partial-view kernel) or straight from HBM (full-obs kernel).
+// Half 1: step_count += 1, fault checks, index of the forward cell (-1: nothing to read, no transition).
+// With extended_actions the target of strafe_left (7) / strafe_right (8) is the left / right cell (minigrid.py:1295-1314).
+template <int CW, int CH>
+__device__ __forceinline__ int transition_begin(const StepParams &p, Lane &L, uint32_t act, bool valid, bool &bad_act, bool &oob)
+{
+    const int W = CW ? CW : p.W, H = CH ? CH : p.H;
+    L.steps += 1;
+    const int dir = L.dir;
+    const int td = act == 7 ? (dir + 3) & 3 : (act == 8 ? (dir + 1) & 3 : dir);
+    const int dx = (td == 0) - (td == 2), dy = (td == 1) - (td == 3); // DIR_TO_VEC (minigrid.py:64-73)
+    // front/left/right are all read by the reference (minigrid.py:1239-1243): any of them outside -> assert
+    const uint32_t okm = (uint32_t)(L.ax + 1 < W) | ((uint32_t)(L.ay + 1 < H) << 1) | ((uint32_t)(L.ax >= 1) << 2) |
+                         ((uint32_t)(L.ay >= 1) << 3);
+    const uint32_t need = 0xFu & ~(1u << ((dir + 2) & 3));
+    oob = valid && ((okm & need) != need);
+    bad_act = valid && act >= (p.extended ? 9u : MGX_NUM_ACTIONS_K);
+    if (!valid || oob || bad_act) return -1;
+    return (L.ax + dx) * H + (L.ay + dy);
+}
+
+// Half 2: the action switch on the target cell code `fc`; returns the cell's new code (== fc: unchanged).
+// `cell_at(idx)` reads another cell of the env (only strafe_right onto a goal needs one: the reference tests
+// LEFT_cell.overlap there, minigrid.py:1310, and raises AttributeError unless the left cell is a goal as well;
+// that case is counted as a fault and treated as "not terminal").
+// Hidden Goal/Box state (object_state handles): per-cell byte `aux` = (toggletimes-1)&15 << 4 | (triage_color+1) << 1 and
+// per-cell contents code `cont` (Box.contains), plus the same pair for the carried object.  aux == nullptr: the handle
+// has no such planes and every Goal/Box is the default one (toggletimes 1, no triage colour, empty).
+struct ObjRef {
+    uint8_t *aux, *cont; // this env's planes
+    uint16_t *carry;     // aux | cont << 8 of the carried object
+};
+__device__ __forceinline__ bool box_overlappable(const ObjRef &o, int idx, uint32_t code)
+{ // Box.can_overlap: color == triage_color (minigrid.py:342-343)
+    if (!o.aux) return false;
+    const uint32_t tri = (o.aux[idx] >> 1) & 7u;
+    return tri != 0u && tri - 1u == ((code >> 4) & 7u);
+}
+
+template <int CH, class CellAt>
+__device__ __forceinline__ uint32_t transition_apply(const StepParams &p, Lane &L, uint32_t act, uint32_t fc, float &reward, bool &done,
+                                                     CellAt cell_at, bool &refbug, int tidx, const ObjRef &o)
+{
+    const int dir = L.dir;
+    if (act >= 7) { // strafe: only reachable with extended_actions
+        const int H = CH ? CH : p.H;
+        const int td = act == 7 ? (dir + 3) & 3 : (dir + 1) & 3;
+        const int tx = (td == 0) - (td == 2), ty = (td == 1) - (td == 3);
+        const uint32_t k = fc & 15u;
+        const uint32_t OVERLAP = (1u << MGX_K_EMPTY) | (1u << MGX_K_FLOOR) | (1u << MGX_K_DOOR_OPEN) | (1u << MGX_K_GOAL) | (1u << MGX_K_LAVA);
+        const int ax0 = L.ax, ay0 = L.ay;
+        if (((OVERLAP >> k) & 1u) || (k == MGX_K_BOX && box_overlappable(o, tidx, fc))) { L.ax += tx; L.ay += ty; }
+        if (k == MGX_K_GOAL) {
+            bool ov;
+            if (act == 7) ov = (fc & 0x80u) != 0;
+            else {
+                const int ld = (dir + 3) & 3;
+                const uint32_t lc = cell_at((ax0 + (ld == 0) - (ld == 2)) * H + ay0 + (ld == 1) - (ld == 3));
+                if ((lc & 15u) == MGX_K_GOAL) ov = (lc & 0x80u) != 0;
+                else { ov = false; refbug = true; }
+            }
+            if (ov) { done = true; reward = (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps)); }
+        }
+        if (k == MGX_K_LAVA) done = true; // no 'v1' special case on the strafe path (minigrid.py:1304-1305,1313-1314)
+        return fc;
+    }
+    const int dx = (dir == 0) - (dir == 2), dy = (dir == 1) - (dir == 3);
+    const uint32_t k = fc & 15u;
+    uint32_t nc = fc;
+    if (act == 0) L.dir = (dir + 3) & 3;
+    else if (act == 1) L.dir = (dir + 1) & 3;
+    else if (act == 2) {
+        // None, Floor, open Door, Goal, Lava can be walked onto (minigrid.py:93,164-166,192,211,245-247)
+        const uint32_t OVERLAP = (1u << MGX_K_EMPTY) | (1u << MGX_K_FLOOR) | (1u << MGX_K_DOOR_OPEN) | (1u << MGX_K_GOAL) | (1u << MGX_K_LAVA);
+        if (((OVERLAP >> k) & 1u) || (k == MGX_K_BOX && box_overlappable(o, tidx, fc))) { L.ax += dx; L.ay += dy; }
+        if (k == MGX_K_GOAL && (fc & 0x80u)) { // goal.overlap (minigrid.py:1259-1261)
+            done = true;
+            // _reward(): 1 - 0.9*(step_count/max_steps) in Python doubles (minigrid.py:933-937), then f32
+            reward = (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps));
+        }
+        if (k == MGX_K_LAVA) { // minigrid.py:1262-1268
+            if (p.lava_v1) { done = false; reward = -1.f; }
+            else done = true;
+        }
+    } else if (act == 3) {
+        const uint32_t PICK = (1u << MGX_K_KEY) | (1u << MGX_K_BALL) | (1u << MGX_K_BOX);
+        if (((PICK >> k) & 1u) && L.carry == MGX_CODE_EMPTY) {
+            L.carry = fc; nc = MGX_CODE_EMPTY;
+            if (o.aux) { *o.carry = (uint16_t)(o.aux[tidx] | (o.cont[tidx] << 8)); o.aux[tidx] = 0; o.cont[tidx] = MGX_CODE_EMPTY; }
+        }
+    } else if (act == 4) {
+        if (k == MGX_K_EMPTY && L.carry != MGX_CODE_EMPTY) {
+            nc = L.carry; L.carry = MGX_CODE_EMPTY;
+            if (o.aux) { o.aux[tidx] = (uint8_t)*o.carry; o.cont[tidx] = (uint8_t)(*o.carry >> 8); *o.carry = (uint16_t)(MGX_CODE_EMPTY << 8); }
+        }
+    } else if (act == 5 && o.aux && (k == MGX_K_GOAL || k == MGX_K_BOX)) {
+        // Goal.toggle / Box.toggle with their hidden state (minigrid.py:171-181,355-364)
+        uint32_t a = o.aux[tidx];
+        int tt = (int)(((a >> 4) + 1u) & 15u);
+        const uint32_t tri = (a >> 1) & 7u;
+        const bool goal = k == MGX_K_GOAL;
+        if (!goal || tt > 0) {
+            tt = tt > 0 ? tt - 1 : 0; // Box counts below zero in Python; every value <= 0 behaves the same
+            a = (a & 0x0Fu) | ((uint32_t)((tt - 1) & 15) << 4);
+            if (tt <= 0 && tri == 0u) { // Goal: removed; Box: replaced by its contents
+                nc = goal ? (uint32_t)MGX_CODE_EMPTY : (uint32_t)o.cont[tidx];
+                o.cont[tidx] = MGX_CODE_EMPTY;
+                a = 0;
+            } else if (tt <= 0) nc = (fc & 0x8Fu) | ((tri - 1u) << 4); // self.color = self.triage_color
+            o.aux[tidx] = (uint8_t)a;
+        }
+    } else if (act == 5) {
+        if (k == MGX_K_DOOR_LOCKED) { // Door.toggle (minigrid.py:252-262)
+            if ((L.carry & 15u) == MGX_K_KEY && ((L.carry >> 4) & 7u) == ((fc >> 4) & 7u)) nc = (fc & 0xF0u) | MGX_K_DOOR_OPEN;
+        } else if (k == MGX_K_DOOR_OPEN) nc = (fc & 0xF0u) | MGX_K_DOOR_CLOSED;
+        else if (k == MGX_K_DOOR_CLOSED) nc = (fc & 0xF0u) | MGX_K_DOOR_OPEN;
+        else if (k == MGX_K_GOAL) { if (!(fc & 0x80u)) nc = MGX_CODE_EMPTY; } // Goal.toggle, toggletimes=1 (minigrid.py:171-181)
+        else if (k == MGX_K_BOX) nc = MGX_CODE_EMPTY;                         // Box.toggle, contains=None (minigrid.py:355-364)
+    } // act == 6 ("done"): pass (minigrid.py:1291-1293)
+    return nc;
+}
+
+// auto-reset of the hidden object state: planes back to the snapshot, nothing carried
+__device__ __forceinline__ void restore_objstate(const StepParams &p, int64_t env)
+{
+    if (!p.objaux) return;
+    const uint32_t *a0 = reinterpret_cast<const uint32_t *>(p.objaux0 + env * p.S), *c0 = reinterpret_cast<const uint32_t *>(p.objcont0 + env * p.S);
+    uint32_t *a = reinterpret_cast<uint32_t *>(p.objaux + env * p.S), *c = reinterpret_cast<uint32_t *>(p.objcont + env * p.S);
+    for (int i = 0; i < (p.S >> 2); i++) { a[i] = a0[i]; c[i] = c0[i]; }
+    p.objcarry[env] = (uint16_t)(MGX_CODE_EMPTY << 8);
+}
+
+// Restore this lane's env to its episode-start snapshot (LDS image + HBM).  Each done lane copies its own
+// S bytes with all loads issued back to back, so a wave pays ONE memory latency however many of its envs
+// finished (a wave-cooperative loop over done envs would pay one per env: measured 2x slower end to end on
+// LavaCrossing, where 40% of the waves see a reset every step).
+template <int CS>
+__device__ __forceinline__ void restore_own(const StepParams &p, int64_t env, uint8_t *g)
+{
+    const int S = CS ? CS : p.S;
+    uint32_t *l32 = reinterpret_cast<uint32_t *>(g);
+    if constexpr (CS != 0 && (CS % 16) == 0) {
+        const uint4 *s = reinterpret_cast<const uint4 *>(p.cells0 + env * S);
+        uint4 *d = reinterpret_cast<uint4 *>(p.cells + env * S);
+#pragma unroll
+        for (int i = 0; i < CS / 16; i++) {
+            const uint4 v = s[i];
+            l32[4 * i + 0] = v.x; l32[4 * i + 1] = v.y; l32[4 * i + 2] = v.z; l32[4 * i + 3] = v.w;
+            d[i] = v;
+        }
+    } else {
+        const uint32_t *s = reinterpret_cast<const uint32_t *>(p.cells0 + env * S);
+        uint32_t *d = reinterpret_cast<uint32_t *>(p.cells + env * S);
+        if constexpr (CS != 0) { // e.g. 9x9: 21 dword loads, all in flight before the first use
+            uint32_t v[CS / 4];
+#pragma unroll
+            for (int i = 0; i < CS / 4; i++) v[i] = s[i];
+#pragma unroll
+            for (int i = 0; i < CS / 4; i++) { l32[i] = v[i]; d[i] = v[i]; }
+        } else {
+            const int SD = S >> 2;
+#pragma unroll 8
+            for (int i = 0; i < SD; i++) {
+                const uint32_t v = s[i];
+                l32[i] = v;
+                d[i] = v;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void wave_stats(const StepParams &p, bool valid, bool done, float reward, bool bad_act, bool oob, int lane, int tile)
+{
+    MgxCounterShard *sh = &p.ctr->shard[tile & (MGX_CTR_SHARDS - 1)];
+    const u64 md = __ballot(valid && done), mr = __ballot(valid && reward != 0.f);
+    const u64 ma = __ballot(bad_act), mo = __ballot(oob);
+    if (md && lane == 0) atomicAdd(&sh->episodes, (u64)__popcll(md));
+    if (ma && lane == 0) atomicAdd(&p.ctr->invalid_actions, (u64)__popcll(ma));
+    if (mo && lane == 0) atomicAdd(&p.ctr->out_of_bounds, (u64)__popcll(mo));
+    if (mr) { // rare: wave-reduce the rewards in f64, one atomic
+        double r = valid ? (double)reward : 0.0;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) r += __shfl_xor(r, o, 64);
+        if (lane == 0) atomicAdd(&sh->reward_sum, r);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Partial (VxVx3, V = agent_view_size, odd) observation of lane's env -> wave's LDS image of the tile's output -> HBM.
+// B = 3*V*V bytes per env is always 3 mod 4 for odd V, so the byte-phase logic below is the same for every V.
+template <int CW, int CH, int V, bool ALT>
+__device__ __forceinline__ void emit_partial_obs(const StepParams &p, const Lane &L, uint8_t *lds, const uint8_t *g,
+                                                 int64_t env0, int lane)
+{
+    constexpr int B = V * V * 3;       // bytes per observation (147 for V = 7)
+    constexpr int NDW = (B + 1) / 4;   // dwords holding one observation, the last with 3 valid bytes (37)
+    constexpr int NQ = (V * V) / 4;    // groups of 4 cells = 3 dwords (12), plus one last cell
+    const int W = CW ? CW : p.W, H = CH ? CH : p.H;
+    const int dir = L.dir;
+    const int dx = (dir == 0) - (dir == 2), dy = (dir == 1) - (dir == 3);
+    const int rx = -dy, ry = dx; // right_vec (minigrid.py:1102-1109)
+    const int base = L.ax * H + L.ay;
+    const int sf = dx * H + dy, sr = rx * H + ry;
+
+    // in-bounds is separable: the forward coordinate depends on d = 6-vy only, the lateral one on l = vx-3 only
+    bool vf[V], vl[V];
+#pragma unroll
+    for (int d = 0; d < V; d++) vf[d] = (unsigned)(L.ax + dx * d) < (unsigned)W && (unsigned)(L.ay + dy * d) < (unsigned)H;
+#pragma unroll
+    for (int k = 0; k < V; k++) vl[k] = (unsigned)(L.ax + rx * (k - V / 2)) < (unsigned)W && (unsigned)(L.ay + ry * (k - V / 2)) < (unsigned)H;
+
+    // gather: code[vx][vy]; outside the grid -> grey wall (Grid.slice, minigrid.py:465-469)
+    uint32_t code[V][V];
+#pragma unroll
+    for (int vy = V - 1; vy >= 0; vy--) {
+        const int rowbase = base + (V - 1 - vy) * sf;
+#pragma unroll
+        for (int vx = 0; vx < V; vx++) {
+            const bool inb = vf[V - 1 - vy] && vl[vx];
+            const int idx = inb ? rowbase + (vx - V / 2) * sr : base;
+            const uint32_t c = g[idx];
+            code[vx][vy] = inb ? c : (uint32_t)MGX_CODE_WALL_GREY;
+        }
+    }
+
+    if (ALT && !p.see_through) {
+        // the fork's alternative visibility model, default_vis=False (minigrid.py:649-709), per lane on column bit
+        // masks (bit j of m[i] = view cell (i, j) visible): its data-dependent `break`s become per-lane alive flags.
+        constexpr int PX = V / 2, PY = V - 1;
+        uint32_t m[V], oq[V];
+#pragma unroll
+        for (int i = 0; i < V; i++) {
+            m[i] = 0u;
+            uint32_t o = 0u;
+#pragma unroll
+            for (int j = 0; j < V; j++) o |= (uint32_t)is_opaque(code[i][j]) << j;
+            oq[i] = o;
+        }
+        m[PX] = 1u << PY;
+        bool alive = true;
+#pragma unroll
+        for (int i = PX + 1; i < V; i++) { if (alive) m[i] |= 1u << PY; alive = alive && !((oq[i] >> PY) & 1u); }
+        alive = true;
+#pragma unroll
+        for (int i = PX - 1; i >= 0; i--) { if (alive) m[i] |= 1u << PY; alive = alive && !((oq[i] >> PY) & 1u); }
+        alive = true;
+#pragma unroll
+        for (int j = V - 2; j >= 0; j--) { if (alive) m[PX] |= 1u << j; alive = alive && !((oq[PX] >> j) & 1u); }
+#pragma unroll
+        for (int i = PX + 1; i < V; i++) { // right side; hideside = True
+            alive = true;
+#pragma unroll
+            for (int j = V - 2; j >= 0; j--) {
+                const bool cond = alive && ((m[i] >> (j + 1)) & 1u) && ((m[i - 1] >> j) & 1u);
+                const bool c = (oq[i] >> j) & 1u, ca = (oq[i] >> (j + 1)) & 1u, cb = (oq[i - 1] >> j) & 1u;
+                const bool brk = cond && !c && (ca || cb);
+                alive = alive && !brk;
+                if (cond && !brk) m[i] |= 1u << j;
+            }
+        }
+#pragma unroll
+        for (int i = PX - 1; i >= 0; i--) { // left side
+            alive = true;
+#pragma unroll
+            for (int j = V - 2; j >= 0; j--) {
+                const bool cond = alive && ((m[i] >> (j + 1)) & 1u) && ((m[i + 1] >> j) & 1u);
+                const bool c = (oq[i] >> j) & 1u, ca = (oq[i] >> (j + 1)) & 1u, cb = (oq[i + 1] >> j) & 1u;
+                const bool brk = cond && !c && (ca || cb);
+                alive = alive && !brk;
+                if (cond && !brk) m[i] |= 1u << j;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < V; i++)
+#pragma unroll
+            for (int j = 0; j < V; j++) code[i][j] = ((m[i] >> j) & 1u) ? code[i][j] : 0u;
+    }
+    // occlusion, bit-sliced over the wave (process_vis default branch, minigrid.py:617-648; spec O4)
+    if (!ALT && !p.see_through) {
+        u64 vis[V];
+#pragma unroll
+        for (int i = 0; i < V; i++) vis[i] = (i == V / 2) ? ~0ull : 0ull;
+#pragma unroll
+        for (int vy = V - 1; vy >= 0; vy--) {
+            u64 T[V];
+#pragma unroll
+            for (int i = 0; i < V; i++) T[i] = __ballot(!is_opaque(code[i][vy]));
+#pragma unroll
+            for (int i = 0; i < V - 1; i++) vis[i + 1] |= vis[i] & T[i]; // left-to-right sweep (:624-635)
+#pragma unroll
+            for (int i = V - 1; i >= 1; i--) vis[i - 1] |= vis[i] & T[i]; // right-to-left sweep (:637-648)
+#pragma unroll
+            for (int i = 0; i < V; i++) code[i][vy] = lane_bit(vis[i]) ? code[i][vy] : 0u; // unseen -> (0,0,0)
+            if (vy > 0) {
+                u64 s[V], nx[V];
+#pragma unroll
+                for (int i = 0; i < V; i++) s[i] = vis[i] & T[i]; // visible and transparent: lights the row above
+#pragma unroll
+                for (int i = 0; i < V; i++) nx[i] = s[i] | (i > 0 ? s[i - 1] : 0ull) | (i < V - 1 ? s[i + 1] : 0ull);
+#pragma unroll
+                for (int i = 0; i < V; i++) vis[i] = nx[i];
+            }
+        }
+    }
+    // the agent's own cell shows what it carries, after occlusion; always visible (minigrid.py:1349-1356)
+    code[V / 2][V - 1] = L.carry;
+
+    // pack 49 triples (image[vx][vy][c], vx-major) into 37 dwords; v_perm_b32 picks 4 of the 8 bytes {S0,S1}
+    uint32_t D[NDW];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const uint32_t c0 = decode_triple(code[(4 * q) / V][(4 * q) % V]);
+        const uint32_t c1 = decode_triple(code[(4 * q + 1) / V][(4 * q + 1) % V]);
+        const uint32_t c2 = decode_triple(code[(4 * q + 2) / V][(4 * q + 2) % V]);
+        const uint32_t c3 = decode_triple(code[(4 * q + 3) / V][(4 * q + 3) % V]);
+        D[3 * q + 0] = __builtin_amdgcn_perm(c1, c0, 0x04020100u); // c0.b0 c0.b1 c0.b2 c1.b0
+        D[3 * q + 1] = __builtin_amdgcn_perm(c2, c1, 0x05040201u); // c1.b1 c1.b2 c2.b0 c2.b1
+        D[3 * q + 2] = __builtin_amdgcn_perm(c3, c2, 0x06050402u); // c2.b2 c3.b0 c3.b1 c3.b2
+    }
+    D[NDW - 1] = decode_triple(code[V - 1][V - 1]); // 3 bytes
+
+    // byte phase of this env inside the tile's contiguous output: B*lane = 4*P + s.  Q = D delayed by s bytes:
+    // Q[k] = bytes (4-s)..(7-s) of {D[k], D[k-1]}  -> one v_perm_b32 with a per-lane selector
+    const uint32_t s = (3u * (uint32_t)lane) & 3u;
+    const uint32_t sel = 0x07060504u - s * 0x01010101u;
+    uint32_t Q[NDW + 1];
+    Q[0] = __builtin_amdgcn_perm(D[0], 0u, sel);
+#pragma unroll
+    for (int k = 1; k < NDW; k++) Q[k] = __builtin_amdgcn_perm(D[k], D[k - 1], sel);
+    Q[NDW] = __builtin_amdgcn_perm(0u, D[NDW - 1], sel);
+    // the last, partial dword belongs to the next lane's first dword
+    const uint32_t tail = (s == 0u) ? Q[NDW - 1] : Q[NDW];
+    const uint32_t prev_tail = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)tail, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
+    if (s != 0u) Q[0] |= prev_tail;
+
+    // The tile's 64*B output bytes (9408 for V = 7) go through LDS in two halves of 32 envs (32*B = 16 * 2B bytes): the
+    // LDS image is then no larger than the grid image it overlays, which doubles the resident waves per CU.
+    constexpr int HALF = 32 * B, CHUNKS = 2 * B; // bytes and 16-B chunks per half
+    const int64_t nv = p.n - env0; // valid envs in this tile (>= 1)
+    const int lim_all = nv >= 64 ? 64 * B : (int)nv * B;
+    uint32_t *o32 = reinterpret_cast<uint32_t *>(lds) + (((uint32_t)B * (uint32_t)(lane & 31)) >> 2);
+    const uint4 *l128 = reinterpret_cast<const uint4 *>(lds);
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        wave_sync(); // every lane is done reading what this image overlays (grid image / previous half)
+        if ((lane >> 5) == h) {
+#pragma unroll
+            for (int k = 0; k < NDW - 1; k++) o32[k] = Q[k];
+            if (s != 0u) o32[NDW - 1] = Q[NDW - 1];
+        }
+        wave_sync();
+        uint8_t *dst = p.obs + env0 * B + h * HALF;
+        const int lim = lim_all - h * HALF; // valid bytes of this half (may be <= 0 in a tail tile)
+        if (lim >= HALF) {
+#pragma unroll
+            for (int i = 0; i < (CHUNKS + 63) / 64; i++) {
+                const int c = lane + 64 * i;
+                if (c < CHUNKS) nt_store16(reinterpret_cast<uint4 *>(dst) + c, l128[c]);
+            }
+        } else if (lim > 0) {
+            for (int c = lane; c < CHUNKS; c += 64) {
+                if (16 * c + 16 <= lim) reinterpret_cast<uint4 *>(dst)[c] = l128[c];
+                else
+                    for (int b = 16 * c; b < lim; b++) dst[b] = lds[b];
+            }
+        }
+    }
+}
+
+// Full-grid observation: Grid.encode() + agent marker (wrappers.py:326-338).  The wave decodes its tile's
+// 64*W*H cells cooperatively: lane handles output dwords lane, lane+64, ... (coalesced 4-B stores).
+template <int CW, int CH>
+__device__ __forceinline__ void emit_full_obs(const StepParams &p, const Lane &L, bool valid, uint8_t *lds, uint8_t *g,
+                                              int LS, int64_t env0, int lane)
+{
+    const int W = CW ? CW : p.W, H = CH ? CH : p.H;
+    const int cells = W * H;
+    if (valid) g[L.ax * H + L.ay] = (uint8_t)(MGX_K_AGENT | (L.dir << 4)); // LDS copy only
+    wave_sync();
+    const int64_t nv = p.n - env0;
+    const int n_env = nv >= 64 ? 64 : (int)nv;
+    uint8_t *dst = p.obs + env0 * cells * 3;
+    if constexpr (CW != 0 && ((CW * CH) % 16) == 0) {
+        // fast path: a lane decodes 16 consecutive cells of one env (4 LDS dwords) into 48 output bytes = 3 x 16-B stores
+        constexpr int UPE = (CW * CH) / 16; // units per env
+        const int n_units = n_env * UPE;
+        const uint32_t *l32 = reinterpret_cast<const uint32_t *>(lds);
+        uint8_t *xpose = lds + 64 * LS; // 3 KiB scratch behind the grid image (sized by the host: wave_lds)
+        for (int u0 = 0; u0 < n_units; u0 += 64) { // wave-uniform trip count
+            const int u = u0 + lane;
+            const int uc = u < n_units ? u : n_units - 1;
+            const int e = uc / UPE, o = uc - e * UPE;
+            const uint32_t *src = l32 + e * (LS >> 2) + o * 4;
+            uint32_t t[16];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t w = src[i];
+#pragma unroll
+                for (int j = 0; j < 4; j++) t[4 * i + j] = decode_triple_full((w >> (8 * j)) & 255u);
+            }
+            uint32_t D[12];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                D[3 * q + 0] = __builtin_amdgcn_perm(t[4 * q + 1], t[4 * q + 0], 0x04020100u);
+                D[3 * q + 1] = __builtin_amdgcn_perm(t[4 * q + 2], t[4 * q + 1], 0x05040201u);
+                D[3 * q + 2] = __builtin_amdgcn_perm(t[4 * q + 3], t[4 * q + 2], 0x06050402u);
+            }
+            if (u0 + 64 <= n_units) {
+                // 64 lanes x 48 B = 3 KiB contiguous: transpose through LDS so each store instruction is 1 KiB contiguous
+                uint4 *x4 = reinterpret_cast<uint4 *>(xpose);
+                x4[3 * lane + 0] = make_uint4(D[0], D[1], D[2], D[3]);
+                x4[3 * lane + 1] = make_uint4(D[4], D[5], D[6], D[7]);
+                x4[3 * lane + 2] = make_uint4(D[8], D[9], D[10], D[11]);
+                wave_sync();
+                uint4 *o4 = reinterpret_cast<uint4 *>(dst + (size_t)u0 * 48);
+                const uint4 a = x4[lane], b = x4[64 + lane], c = x4[128 + lane];
+                o4[lane] = a; o4[64 + lane] = b; o4[128 + lane] = c;
+                wave_sync();
+            } else if (u < n_units) {
+                uint4 *o4 = reinterpret_cast<uint4 *>(dst + (size_t)u * 48);
+                o4[0] = make_uint4(D[0], D[1], D[2], D[3]);
+                o4[1] = make_uint4(D[4], D[5], D[6], D[7]);
+                o4[2] = make_uint4(D[8], D[9], D[10], D[11]);
+            }
+        }
+        return;
+    }
+
+    const int n_dw = n_env * cells * 3 / 4;      // whole dwords
+    const int n_bytes = n_env * cells * 3;
+    for (int j = lane; j < n_dw; j += 64) {
+        const int b = 4 * j;
+        const int q = b / 3, r = b - 3 * q; // first cell of the tile's cell stream touched by this dword, byte phase
+        const int e0 = q / cells, c0 = q - e0 * cells;
+        int e1 = e0, c1 = c0 + 1;
+        if (c1 == cells) { c1 = 0; e1 = e0 + 1; }
+        const uint32_t t0 = decode_triple_full(lds[e0 * LS + c0]);
+        const uint32_t t1 = (e1 < 64) ? decode_triple_full(lds[e1 * LS + c1]) : 0u;
+        const u64 both = (u64)t0 | ((u64)t1 << 24);
+        reinterpret_cast<uint32_t *>(dst)[j] = (uint32_t)(both >> (8 * r));
+    }
+    // (n_env*cells*3 is a multiple of 4 unless the tail tile has an odd cell count: finish by bytes)
+    for (int b = 4 * n_dw + lane; b < n_bytes; b += 64) {
+        const int q = b / 3, r = b - 3 * q;
+        const int e0 = q / cells, c0 = q - e0 * cells;
+        dst[b] = (uint8_t)(decode_triple_full(lds[e0 * LS + c0]) >> (8 * r));
+    }
+}
+
+
+
+template <int CW, int CH, int MODE, int V, bool ALT = false>
+__global__ __launch_bounds__(256) void k_step(const StepParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int tile = blockIdx.x * (blockDim.x >> 6) + wv;
+    if (tile >= p.n_tiles) return; // wave-uniform
+    constexpr int CS = (CW && CH) ? ((CW * CH + 3) & ~3) : 0;
+    const int S = CS ? CS : p.S;
+    const int LS = p.LS;
+    uint8_t *lds = smem + (size_t)wv * p.wave_lds;
+    const int64_t env0 = (int64_t)tile * 64;
+    const int64_t env = env0 + lane;
+    const bool valid = env < p.n;
+
+    const uint2 rec = p.agent[env]; // agent/cells arrays are padded to whole tiles
+    uint32_t act = 6;
+    if (p.do_step && valid) act = __builtin_nontemporal_load(&p.actions[env]);
+    const bool crash = p.task == MGX_TASK_DYNOBS && (act & 0x80u); // k_dynobs' verdict rides on the folded action
+    if (p.task == MGX_TASK_DYNOBS) act &= 0x7Fu;
+    stage_tile<CS>(p.cells, env0, S, LS, lds, lane);
+    wave_sync();
+
+    Lane L = unpack_rec(rec, p.task);
+    uint8_t *g = lds + lane * LS;
+    float reward = 0.f;
+    bool done = false, bad_act = false, oob = false;
+    if (p.do_step) {
+        const int fidx = transition_begin<CW, CH>(p, L, act, valid, bad_act, oob);
+        if (fidx >= 0) {
+            const uint32_t fc = g[fidx];
+            // hidden object state rides only on the run-time-size kernels (mgx_launch_step routes there): pruned from the sized ones
+            const bool has_obj = CW == 0 && p.objaux != nullptr;
+            const ObjRef obj = {has_obj ? p.objaux + env * S : nullptr, has_obj ? p.objcont + env * S : nullptr, has_obj ? p.objcarry + env : nullptr};
+            const uint32_t nc = transition_apply<CH>(p, L, act, fc, reward, done, [&](int i) -> uint32_t { return g[i]; }, oob, fidx, obj);
+            if (nc != fc) g[fidx] = (uint8_t)nc;
+            if (valid && L.steps >= p.max_steps) done = true; // minigrid.py:1320-1321
+            if (p.task) task_rule<CH>(p, L, act, reward, done, [&](int i) -> uint32_t { return g[i]; });
+            // the one cell a transition can change; skipped when the env is about to be restored anyway
+            if (nc != fc && !(p.auto_reset && done)) p.cells[env * S + fidx] = (uint8_t)nc;
+        } else if (valid && L.steps >= p.max_steps) done = true;
+        if (crash) { reward = -1.f; done = true; } // envs/dynamicobstacles.py:83-86
+        if (p.reward && valid) __builtin_nontemporal_store(reward, &p.reward[env]);
+        if (p.done && valid) __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), &p.done[env]);
+        wave_stats(p, valid, done, reward, bad_act, oob, lane, tile);
+        if (p.auto_reset && valid && done) {
+            restore_own<CS>(p, env, g);
+            if (CW == 0) restore_objstate(p, env);
+            L = unpack_rec(p.agent0[env], p.task);
+            if (p.regen) p.regen[env] = 1; // the next-level buffer was consumed: k_levelgen refills it after this launch
+        }
+        if (valid) p.agent[env] = pack_rec(L, p.task);
+    }
+    if (p.obs) {
+        if (MODE == 0) emit_partial_obs<CW, CH, V, ALT>(p, L, lds, g, env0, lane);
+        else emit_full_obs<CW, CH>(p, L, valid, lds, g, LS, env0, lane);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// FullyObs, direct form (W*H a multiple of 4): no tile image in LDS, and a tile of 64 envs belongs to a whole
+// 256-thread BLOCK so that the cooperative decode has 4x the waves (a wave walking a 16x16 tile alone needs 16
+// dependent load->decode->store rounds and the kernel becomes latency-bound: measured 48 us wave lifetime).
+//   prefetch : every thread issues the coalesced loads of the cell units it will decode, before anything else;
+//   phase A  : wave 0, lane-per-env: transition with the forward cell gathered straight from HBM (its line is part
+//              of the prefetch, so no extra HBM bytes), results handed over through LDS;
+//   phase B  : all 4 waves: unit = 4 consecutive cells (one dword) -> 12 output bytes, stored with ONE
+//              global_store_dwordx3 per lane: consecutive lanes write consecutive 12-byte records, so every store
+//              instruction covers 768 contiguous, line-aligned bytes (16-cell units + 3 dwordx4 stores at a 48-byte
+//              lane stride measured ~20% slower: each lane's 16 bytes was its own L1 transaction).
+//              Envs that finished re-read the episode-start snapshot and write it back (a coalesced restore); the
+//              one cell phase A changed and the agent marker are patched in registers, so phase B never depends
+//              on phase A's global stores being visible.
+template <int CW, int CH>
+__global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
+{
+    __shared__ uint32_t s_info[64]; // per env: agent idx | dir<<16 | reset<<18 | (1<<19 if a cell changed)
+    __shared__ uint32_t s_wr[64];   // changed cell: idx | code<<16
+    __shared__ uint32_t s_lut[256]; // cell code -> (type | color<<8 | state<<16)
+    constexpr int CS = CW * CH;
+    constexpr int KPF = CS ? (CS / 4 * 64 + 255) / 256 : 0; // prefetched units per thread (compile-time sizes only)
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x;
+    const int H = CH ? CH : p.H;
+    const int S = CS ? CS : p.S;
+    const int UPE = S >> 2; // 4-cell units per env
+    const int64_t env0 = (int64_t)tile * 64;
+    const int64_t nv = p.n - env0;
+    const int n_units = (nv >= 64 ? 64 : (int)nv) * UPE;
+    const uint32_t *cells32 = reinterpret_cast<const uint32_t *>(p.cells + env0 * S);
+
+    uint32_t pf[KPF ? KPF : 1];
+#pragma unroll
+    for (int k = 0; k < KPF; k++) {
+        const int u = tid + 256 * k;
+        pf[k] = cells32[u < n_units ? u : 0];
+    }
+    s_lut[tid] = decode_triple_full(tid);
+
+    if (tid < 64) { // phase A: wave 0
+        const int lane = tid;
+        const int64_t env = env0 + lane;
+        const bool valid = env < p.n;
+        Lane L = unpack_rec(p.agent[env], p.task);
+        uint32_t act = 6;
+        if (p.do_step && valid) act = __builtin_nontemporal_load(&p.actions[env]);
+        const bool crash = p.task == MGX_TASK_DYNOBS && (act & 0x80u);
+        if (p.task == MGX_TASK_DYNOBS) act &= 0x7Fu;
+        float reward = 0.f;
+        bool done = false, bad_act = false, oob = false, reset = false;
+        uint32_t wr = 0, changed = 0;
+        if (p.do_step) {
+            const int fidx = transition_begin<CW, CH>(p, L, act, valid, bad_act, oob);
+            if (fidx >= 0) {
+                const uint32_t fc = p.cells[env * S + fidx];
+                // hidden object state rides only on the run-time-size kernels (mgx_launch_step routes there): pruned from the sized ones
+            const bool has_obj = CW == 0 && p.objaux != nullptr;
+            const ObjRef obj = {has_obj ? p.objaux + env * S : nullptr, has_obj ? p.objcont + env * S : nullptr, has_obj ? p.objcarry + env : nullptr};
+                const uint32_t nc = transition_apply<CH>(p, L, act, fc, reward, done,
+                                                         [&](int i) -> uint32_t { return p.cells[env * S + i]; }, oob, fidx, obj);
+                if (valid && L.steps >= p.max_steps) done = true;
+                if (p.task) task_rule<CH>(p, L, act, reward, done, [&](int i) -> uint32_t { return (i == fidx) ? nc : (uint32_t)p.cells[env * S + i]; });
+                if (nc != fc && !(p.auto_reset && done)) {
+                    p.cells[env * S + fidx] = (uint8_t)nc;
+                    wr = (uint32_t)fidx | (nc << 16);
+                    changed = 1;
+                }
+            } else if (valid && L.steps >= p.max_steps) done = true;
+            if (crash) { reward = -1.f; done = true; }
+            if (p.reward && valid) __builtin_nontemporal_store(reward, &p.reward[env]);
+            if (p.done && valid) __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), &p.done[env]);
+            wave_stats(p, valid, done, reward, bad_act, oob, lane, tile);
+            if (p.auto_reset && valid && done) {
+                L = unpack_rec(p.agent0[env], p.task);
+                if (CW == 0) restore_objstate(p, env);
+                reset = true;
+                if (p.regen) p.regen[env] = 1;
+            }
+            if (valid) p.agent[env] = pack_rec(L, p.task);
+        }
+        s_info[lane] = (uint32_t)(L.ax * H + L.ay) | ((uint32_t)L.dir << 16) | ((uint32_t)reset << 18) | (changed << 19);
+        s_wr[lane] = wr;
+    }
+    __syncthreads();
+
+    struct __attribute__((packed, aligned(4))) Out12 { uint32_t a, b, c; };
+    Out12 *dst = p.obs ? reinterpret_cast<Out12 *>(p.obs + env0 * (int64_t)S * 3) : nullptr;
+    constexpr int NIT = KPF ? KPF : 1;
+    const int n_iter = KPF ? KPF : (n_units + 255) / 256;
+#pragma unroll
+    for (int kk = 0; kk < NIT; kk++)
+    for (int k = kk; k < (KPF ? kk + 1 : n_iter); k++) { // compile-time sizes: fully unrolled (pf[] stays in registers)
+        const int u = tid + 256 * k;
+        if (u >= n_units) break;
+        const int e = u / UPE, o = u - e * UPE;
+        const uint32_t info = s_info[e];
+        const bool rst = (info >> 18) & 1u;
+        uint32_t w;
+        if (KPF != 0 && !rst) w = pf[kk];
+        else w = reinterpret_cast<const uint32_t *>(rst ? p.cells0 + env0 * S : p.cells + env0 * S)[u];
+        if (rst) reinterpret_cast<uint32_t *>(p.cells + env0 * S)[u] = w; // restore, coalesced
+        if (!dst) continue;
+        if ((info >> 19) & 1u) { // the cell the transition changed (whether or not the load already saw it)
+            const uint32_t x = s_wr[e], idx = x & 0xFFFFu, code = x >> 16, sh = 8u * (idx & 3u);
+            if ((int)(idx >> 2) == o) w = (w & ~(0xFFu << sh)) | (code << sh);
+        }
+        { // agent marker (10, 0, dir): wrappers.py:329-333
+            const uint32_t idx = info & 0xFFFFu, code = MGX_K_AGENT | (((info >> 16) & 3u) << 4), sh = 8u * (idx & 3u);
+            if ((int)(idx >> 2) == o) w = (w & ~(0xFFu << sh)) | (code << sh);
+        }
+        const uint32_t t0 = s_lut[w & 255u], t1 = s_lut[(w >> 8) & 255u], t2 = s_lut[(w >> 16) & 255u], t3 = s_lut[w >> 24];
+        Out12 r;
+        r.a = __builtin_amdgcn_perm(t1, t0, 0x04020100u);
+        r.b = __builtin_amdgcn_perm(t2, t1, 0x05040201u);
+        r.c = __builtin_amdgcn_perm(t3, t2, 0x06050402u);
+        nt_store12(&dst[u].a, r.a, r.b, r.c);
+    }
+}
+
+
+template <int CW, int CH>
+hipError_t launch_sized(const StepParams &p, int mode, dim3 grid, dim3 block, size_t shmem, hipStream_t st)
+{
+    if (mode == 0) hipLaunchKernelGGL((k_step<CW, CH, 0, 7>), grid, block, shmem, st, p);
+    else if (mode == 1) hipLaunchKernelGGL((k_step<CW, CH, 1, 7>), grid, block, shmem, st, p);
+    else hipLaunchKernelGGL((k_step_fulldirect<CW, CH>), dim3(p.n_tiles), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+template <int CW, int CH>
+hipError_t raise_lds_limit(int mode, int bytes)
+{
+    if (mode == 0) return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<CW, CH, 0, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<CW, CH, 1, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+} // namespace
+
+#define MGX_SIZED(X) X(5, 5) X(6, 6) X(7, 7) X(8, 8) X(9, 9) X(11, 11) X(16, 16)
+#define MGX_VIEWS(X) X(3) X(5) X(9) X(11)  /* agent_view_size other than 7: run-time grid size only */
+
+hipError_t mgx_launch_step(const StepParams &p, int mode, int waves_per_block, hipStream_t st)
+{
+    const dim3 block(64 * waves_per_block);
+    const dim3 grid((p.n_tiles + waves_per_block - 1) / waves_per_block);
+    const size_t shmem = (size_t)waves_per_block * p.wave_lds;
+    if (mode == 0 && p.alt_vis) { // default_vis=False: run-time grid size only
+#define VCASE(v) if (p.view == v) { hipLaunchKernelGGL((k_step<0, 0, 0, v, true>), grid, block, shmem, st, p); return hipGetLastError(); }
+        MGX_VIEWS(VCASE) VCASE(7)
+#undef VCASE
+        return hipErrorInvalidValue;
+    }
+    if (mode == 0 && p.view != 7) {
+#define VCASE(v) if (p.view == v) { hipLaunchKernelGGL((k_step<0, 0, 0, v>), grid, block, shmem, st, p); return hipGetLastError(); }
+        MGX_VIEWS(VCASE)
+#undef VCASE
+        return hipErrorInvalidValue;
+    }
+    if (p.objaux) return launch_sized<0, 0>(p, mode, grid, block, shmem, st);
+#define CASE(w, h) if (p.W == w && p.H == h) return launch_sized<w, h>(p, mode, grid, block, shmem, st);
+    MGX_SIZED(CASE)
+#undef CASE
+    return launch_sized<0, 0>(p, mode, grid, block, shmem, st);
+}
+
+hipError_t mgx_raise_lds_limit(int W, int H, int mode, int bytes, int view, int alt_vis, int object_state)
+{
+    if (object_state) W = H = 0;
+    if (mode == 0 && alt_vis) {
+#define VCASE(v) if (view == v) return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<0, 0, 0, v, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        MGX_VIEWS(VCASE) VCASE(7)
+#undef VCASE
+        return hipErrorInvalidValue;
+    }
+    if (mode == 0 && view != 7) {
+#define VCASE(v) if (view == v) return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<0, 0, 0, v>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        MGX_VIEWS(VCASE)
+#undef VCASE
+        return hipErrorInvalidValue;
+    }
+#define CASE(w, h) if (W == w && H == h) return raise_lds_limit<w, h>(mode, bytes);
+    MGX_SIZED(CASE)
+#undef CASE
+    return raise_lds_limit<0, 0>(mode, bytes);
+}
+

@@ -1,5 +1,5 @@
 // levelgen_core.h -- the seeded level generators, written once for host (levelgen.cpp) and device (k_levelgen in
-// mgx_kernels.hip).  Everything here is `__host__ __device__`, allocation-free and works on 1-byte cell codes
+// k_levelgen.hip).  Everything here is `__host__ __device__`, allocation-free and works on 1-byte cell codes
 // (mgx_internal.h), x-major like Grid.encode().
 //
 // Reference: EmptyEnv._gen_grid     /root/reference/gym_minigrid/envs/empty.py:30-57

@@ -1,7 +1,7 @@
 // mgx_api.cpp -- host side of libmgx.so: the C ABI declared in include/mgx.h.
 //
 // Owns the per-GPU handle (SoA state in HBM, episode-start snapshot, counters, staging buffers for
-// host-pointer callers, HIP stream/events) and enqueues the kernels of mgx_kernels.hip.  There is NO CPU
+// host-pointer callers, HIP stream/events) and enqueues the kernels of k_*.hip.  There is NO CPU
 // fallback for any compute entry point: without a usable HIP device mgx_create fails loudly.
 #include <hip/hip_runtime.h>
 

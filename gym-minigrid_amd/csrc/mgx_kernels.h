@@ -1,4 +1,4 @@
-// mgx_kernels.h -- launch interface between mgx_api.cpp (host) and mgx_kernels.hip (device).
+// mgx_kernels.h -- launch interface between mgx_api.cpp (host) and the kernel files k_*.hip (device).
 #ifndef MGX_KERNELS_H
 #define MGX_KERNELS_H
 
@@ -8,7 +8,7 @@
 #include "mgx.h"
 
 #define MGX_NUM_ACTIONS_K 7u
-#define MGX_LG_LDS_PER_WAVE_BYTES (2 * 624 * 4 + 16 + 2 * (6 * 32) + 8 * (8 + 4 * 32)) /* == MGX_LG_LDS_PER_WAVE in mgx_kernels.hip */
+#define MGX_LG_LDS_PER_WAVE_BYTES (2 * 624 * 4 + 16 + 2 * (6 * 32) + 8 * (8 + 4 * 32)) /* == MGX_LG_LDS_PER_WAVE in k_levelgen.hip */
 
 // Running totals.  The per-step counters are SHARDED over 256 cache lines (shard = tile & 255): with one word,
 // LavaCrossing (40% of the waves see a done every step) spent >half of the step serialising ~3,300 same-address

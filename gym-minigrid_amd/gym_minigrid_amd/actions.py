@@ -1,6 +1,6 @@
 """The counter-based synthetic action stream used by bench.py and the parity tests:
 a(seed, env, t) = mix64(seed + env*PHI + t*C) mapped to 0..6.  NumPy replica of
-`action_of` in csrc/mgx_kernels.hip (device) so CPU-side checkers see the same actions."""
+`action_of` in csrc/k_state.hip (device) so CPU-side checkers see the same actions."""
 import numpy as np
 
 _M = (1 << 64) - 1
