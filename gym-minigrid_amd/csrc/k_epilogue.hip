@@ -80,54 +80,69 @@ hipError_t mgx_launch_onehot(const uint8_t *tri, uint8_t *out, int64_t n_cells, 
 
 
 // FlatObsWrapper.observation (wrappers.py:556-577): out[env] = f32(image bytes) ++ one-hot of the mission string
-// (96 positions x 27 codes).  `table` holds one row of 96 character codes (0..25 letters, 26 space, 255 past the end)
-// per mission of the family; only Fetch has more than one (row = (template*2 + is_ball)*8 + color of the task word).
-// A pure stream of 16-B stores over the flat [n][L] output: 4 consecutive floats per lane, one divide per lane.
+// (96 positions x 27 codes, 95 % of the row).  `pattern` holds that one-hot block as floats, one row of 2592 per
+// mission of the family (built by the host at create; only Fetch has more than one: row = (template*2 + is_ball)*8 +
+// color of the task word), so the kernel is a copy: a block owns a group of 4 envs (4*L floats is a whole number of
+// 16-B quads, L itself is not), a lane one quad; inside the mission block a quad is one 4-byte-aligned dwordx4 read
+// of the L2-resident pattern and one non-temporal 16-B store.
 namespace {
-__global__ __launch_bounds__(256) void k_flat(const uint8_t *__restrict__ tri, const uint2 *__restrict__ rec, const uint8_t *__restrict__ table,
+struct __attribute__((packed, aligned(4))) FlatQuad { uint32_t a, b, c, d; };
+
+__device__ __forceinline__ int flat_row(const uint2 *rec, int64_t env, int fetch)
+{
+    if (!fetch) return 0;
+    const uint32_t task = rec[env].y >> 16;
+    return (int)((((task >> 8) & 7u) * 2u + ((task & 15u) == MGX_K_BALL ? 1u : 0u)) * 8u + ((task >> 4) & 7u));
+}
+
+__global__ __launch_bounds__(256) void k_flat(const uint8_t *__restrict__ tri, const uint2 *__restrict__ rec, const float *__restrict__ pattern,
                                                float *__restrict__ out, int64_t n, int img, int fetch)
 {
-    const int64_t L = (int64_t)img + MGX_FLAT_MISSION;
-    const int64_t total = n * L;
-    const int64_t g0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (g0 >= total) return;
-    int64_t env = g0 / L;
-    int off = (int)(g0 - env * L);
+    const int L = img + MGX_FLAT_MISSION;
+    const int64_t env_base = (int64_t)blockIdx.y * 4;
+    const int n_here = n - env_base < 4 ? (int)(n - env_base) : 4;
+    const int q = blockIdx.x * 256 + threadIdx.x; // quad of this group's n_here*L floats
+    const int g0 = 4 * q;
+    if (g0 >= n_here * L) return;
+    float *dst = out + env_base * L + g0;
+    const int e = (g0 >= L) + (g0 >= 2 * L) + (g0 >= 3 * L);
+    const int off = g0 - e * L;
+    if (off >= img && off + 4 <= L) { // the whole quad lies in one env's mission block
+        const int row = flat_row(rec, env_base + e, fetch);
+        const FlatQuad v = *reinterpret_cast<const FlatQuad *>(pattern + (size_t)row * MGX_FLAT_MISSION + (off - img));
+        nt_store16(reinterpret_cast<uint4 *>(dst), make_uint4(v.a, v.b, v.c, v.d));
+        return;
+    }
     float v[4];
-    const uint8_t *row = nullptr;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < 4; j++) { // image bytes, or a quad that straddles two envs
+        const int g = g0 + j;
+        const int ej = (g >= L) + (g >= 2 * L) + (g >= 3 * L), oj = g - ej * L;
         float x = 0.f;
-        if (g0 + j < total) {
-            if (off >= L) { off = 0; env++; row = nullptr; }
-            if (off < img) x = (float)tri[env * img + off];
-            else {
-                if (!row) {
-                    int mid = 0;
-                    if (fetch) {
-                        const uint32_t task = rec[env].y >> 16;
-                        mid = (int)((((task >> 8) & 7u) * 2u + ((task & 15u) == MGX_K_BALL ? 1u : 0u)) * 8u + ((task >> 4) & 7u));
-                    }
-                    row = table + mid * 96;
-                }
-                const int k = off - img, ch = k / 27, code = k - ch * 27;
-                x = row[ch] == code ? 1.f : 0.f;
-            }
-            off++;
+        if (g < n_here * L) {
+            if (oj < img) x = (float)tri[(env_base + ej) * img + oj];
+            else x = pattern[(size_t)flat_row(rec, env_base + ej, fetch) * MGX_FLAT_MISSION + (oj - img)];
         }
         v[j] = x;
     }
-    if (g0 + 3 < total) nt_store16(reinterpret_cast<uint4 *>(out + g0), make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])));
+    if (g0 + 3 < n_here * L) nt_store16(reinterpret_cast<uint4 *>(dst), make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])));
     else
-        for (int j = 0; j < 4 && g0 + j < total; j++) out[g0 + j] = v[j];
+        for (int j = 0; j < 4 && g0 + j < n_here * L; j++) dst[j] = v[j];
 }
 } // namespace
 
-hipError_t mgx_launch_flat(const uint8_t *tri, const uint2 *rec, const uint8_t *table, float *out, int64_t n, int img, int fetch, hipStream_t st)
+hipError_t mgx_launch_flat(const uint8_t *tri, const uint2 *rec, const float *pattern, float *out, int64_t n, int img, int fetch, hipStream_t st)
 {
-    const int64_t quads = (n * ((int64_t)img + MGX_FLAT_MISSION) + 3) / 4;
-    if (quads == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_flat, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, tri, rec, table, out, n, img, fetch);
+    if (n == 0) return hipSuccess;
+    const int quads = (4 * (img + MGX_FLAT_MISSION) + 3) / 4;
+    const int64_t groups = (n + 3) / 4;
+    if (groups > 65535 * 1024ll) return hipErrorInvalidValue;
+    // grid.y is limited to 65535: fold larger batches into several launches
+    for (int64_t g0 = 0; g0 < groups; g0 += 65535) {
+        const int64_t gy = groups - g0 < 65535 ? groups - g0 : 65535;
+        const int64_t e0 = g0 * 4;
+        hipLaunchKernelGGL(k_flat, dim3((unsigned)((quads + 255) / 256), (unsigned)gy), dim3(256), 0, st, tri + e0 * img, rec + e0, pattern,
+                           out + e0 * (img + MGX_FLAT_MISSION), n - e0 < gy * 4 ? n - e0 : gy * 4, img, fetch);
+    }
     return hipGetLastError();
 }
-

@@ -52,7 +52,7 @@ struct mgx_env_s {
     int oh_nc = -1, oh_ns = 0; // one-hot epilogue channels (oh_nc < 0: none)
     uint8_t *tri_d = nullptr;  // triples scratch feeding the one-hot / flat epilogue
     bool flat = false;         // FlatObsWrapper epilogue (obs is float)
-    uint8_t *mission_d = nullptr; // [missions][96] character codes for k_flat
+    float *mission_d = nullptr;   // [missions][96*27] one-hot mission blocks for k_flat
     int64_t tri_bytes = 0;     // per env
     int kernel_mode = 0; // 0 partial view, 1 full obs via the LDS tile image, 2 full obs direct (W*H % 4 == 0)
     int64_t obs_bytes = 0;
@@ -339,7 +339,7 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     if (h->oh_nc >= 0 || h->flat) CREATE_TRY(hipMalloc((void **)&h->tri_d, (size_t)h->n * h->tri_bytes + 16));
     if (h->flat) { // the family's mission strings as character codes (wrappers.py:563-571)
         const int rows = cfg->level_kind == MGX_LEVEL_FETCH ? 80 : 1;
-        std::vector<uint8_t> tab((size_t)rows * 96, 255);
+        std::vector<float> tab((size_t)rows * MGX_FLAT_MISSION, 0.f);
         for (int r = 0; r < rows; r++) {
             uint32_t task = 0;
             if (cfg->level_kind == MGX_LEVEL_FETCH) {
@@ -361,11 +361,11 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
                 else if (ch == ' ') code = 26;
                 // any other character re-uses the previous character's code (chNo keeps its value, wrappers.py:565-570)
                 if (code < 0) { int rc = mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_create: mission starts with a character the wrapper cannot encode"); mgx_destroy(h); return rc; }
-                tab[(size_t)r * 96 + i] = (uint8_t)code;
+                tab[(size_t)r * MGX_FLAT_MISSION + (size_t)i * 27 + code] = 1.f; // strArray[idx, chNo] = 1
             }
         }
-        CREATE_TRY(hipMalloc((void **)&h->mission_d, tab.size()));
-        CREATE_TRY(hipMemcpy(h->mission_d, tab.data(), tab.size(), hipMemcpyHostToDevice));
+        CREATE_TRY(hipMalloc((void **)&h->mission_d, tab.size() * sizeof(float)));
+        CREATE_TRY(hipMemcpy(h->mission_d, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     if (cfg->object_state) {
         for (uint8_t **pp : {&h->objaux_d, &h->objaux0_d}) { CREATE_TRY(hipMalloc((void **)pp, cb)); CREATE_TRY(hipMemsetAsync(*pp, 0, cb, h->stream)); }

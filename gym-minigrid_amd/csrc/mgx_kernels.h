@@ -102,7 +102,7 @@ hipError_t mgx_launch_consume(const ConsumeParams &p, hipStream_t st);
 hipError_t mgx_launch_step(const StepParams &p, int mode, int waves_per_block, hipStream_t st);
 hipError_t mgx_raise_lds_limit(int W, int H, int mode, int bytes, int view, int alt_vis, int object_state);
 #define MGX_FLAT_MISSION (96 * 27) /* FlatObsWrapper: maxStrLen x numCharCodes (wrappers.py:534-537) */
-hipError_t mgx_launch_flat(const uint8_t *tri, const uint2 *rec, const uint8_t *table, float *out, int64_t n, int img, int fetch, hipStream_t st);
+hipError_t mgx_launch_flat(const uint8_t *tri, const uint2 *rec, const float *pattern, float *out, int64_t n, int img, int fetch, hipStream_t st);
 hipError_t mgx_launch_onehot(const uint8_t *tri, uint8_t *out, int64_t n_cells, int nc, int ns, hipStream_t st);
 struct ObjStateParams {
     const uint8_t *contains_in, *carry_aux_in, *carry_contains_in;
