@@ -248,9 +248,9 @@ __device__ __forceinline__ void wave_stats(const StepParams &p, bool valid, bool
 // ------------------------------------------------------------------------------------------------
 // Partial (VxVx3, V = agent_view_size, odd) observation of lane's env -> wave's LDS image of the tile's output -> HBM.
 // B = 3*V*V bytes per env is always 3 mod 4 for odd V, so the byte-phase logic below is the same for every V.
-template <int CW, int CH, int V, bool ALT>
+template <int CW, int CH, int V, bool ALT, bool GATHER = false>
 __device__ __forceinline__ void emit_partial_obs(const StepParams &p, const Lane &L, uint8_t *lds, const uint8_t *g,
-                                                 int64_t env0, int lane)
+                                                 int64_t env0, int lane, int pidx = -1, uint32_t pcode = 0)
 {
     constexpr int B = V * V * 3;       // bytes per observation (147 for V = 7)
     constexpr int NDW = (B + 1) / 4;   // dwords holding one observation, the last with 3 valid bytes (37)
@@ -278,7 +278,8 @@ __device__ __forceinline__ void emit_partial_obs(const StepParams &p, const Lane
         for (int vx = 0; vx < V; vx++) {
             const bool inb = vf[V - 1 - vy] && vl[vx];
             const int idx = inb ? rowbase + (vx - V / 2) * sr : base;
-            const uint32_t c = g[idx];
+            uint32_t c = g[idx];
+            if constexpr (GATHER) c = idx == pidx ? pcode : c; // the cell this step changed is not in HBM yet for this lane's reads
             code[vx][vy] = inb ? c : (uint32_t)MGX_CODE_WALL_GREY;
         }
     }
@@ -529,33 +530,48 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
     if (p.do_step && valid) act = __builtin_nontemporal_load(&p.actions[env]);
     const bool crash = p.task == MGX_TASK_DYNOBS && (act & 0x80u); // k_dynobs' verdict rides on the folded action
     if (p.task == MGX_TASK_DYNOBS) act &= 0x7Fu;
-    stage_tile<CS>(p.cells, env0, S, LS, lds, lane);
-    wave_sync();
+    // MODE 3 (large grids): no tile image in LDS -- at 25x25 it would be 40 KB per wave and leave 4 waves per CU; each
+    // lane gathers its forward cell and its VxV view straight from its row in HBM/L2 instead (50 byte loads).
+    constexpr bool GATHER = MODE == 3;
+    if constexpr (!GATHER) {
+        stage_tile<CS>(p.cells, env0, S, LS, lds, lane);
+        wave_sync();
+    }
 
     Lane L = unpack_rec(rec, p.task);
-    uint8_t *g = lds + lane * LS;
+    uint8_t *g = lds + lane * LS;                       // (staged modes) this env's cells in LDS
+    const uint8_t *row = GATHER ? p.cells + env * S : g; // where cells are read from
     float reward = 0.f;
     bool done = false, bad_act = false, oob = false;
+    int pidx = -1;
+    uint32_t pcode = 0;
     if (p.do_step) {
         const int fidx = transition_begin<CW, CH>(p, L, act, valid, bad_act, oob);
         if (fidx >= 0) {
-            const uint32_t fc = g[fidx];
+            const uint32_t fc = row[fidx];
             // hidden object state rides only on the run-time-size kernels (mgx_launch_step routes there): pruned from the sized ones
             const bool has_obj = CW == 0 && p.objaux != nullptr;
             const ObjRef obj = {has_obj ? p.objaux + env * S : nullptr, has_obj ? p.objcont + env * S : nullptr, has_obj ? p.objcarry + env : nullptr};
-            const uint32_t nc = transition_apply<CH>(p, L, act, fc, reward, done, [&](int i) -> uint32_t { return g[i]; }, oob, fidx, obj);
-            if (nc != fc) g[fidx] = (uint8_t)nc;
+            const uint32_t nc = transition_apply<CH>(p, L, act, fc, reward, done, [&](int i) -> uint32_t { return row[i]; }, oob, fidx, obj);
+            if constexpr (!GATHER) { if (nc != fc) g[fidx] = (uint8_t)nc; }
             if (valid && L.steps >= p.max_steps) done = true; // minigrid.py:1320-1321
-            if (p.task) task_rule<CH>(p, L, act, reward, done, [&](int i) -> uint32_t { return g[i]; });
+            if (p.task) task_rule<CH>(p, L, act, reward, done, [&](int i) -> uint32_t { return (GATHER && i == fidx) ? nc : (uint32_t)row[i]; });
             // the one cell a transition can change; skipped when the env is about to be restored anyway
-            if (nc != fc && !(p.auto_reset && done)) p.cells[env * S + fidx] = (uint8_t)nc;
+            if (nc != fc && !(p.auto_reset && done)) { p.cells[env * S + fidx] = (uint8_t)nc; pidx = fidx; pcode = nc; }
         } else if (valid && L.steps >= p.max_steps) done = true;
         if (crash) { reward = -1.f; done = true; } // envs/dynamicobstacles.py:83-86
         if (p.reward && valid) __builtin_nontemporal_store(reward, &p.reward[env]);
         if (p.done && valid) __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), &p.done[env]);
         wave_stats(p, valid, done, reward, bad_act, oob, lane, tile);
         if (p.auto_reset && valid && done) {
-            restore_own<CS>(p, env, g);
+            if constexpr (GATHER) { // global -> global; the observation below reads the snapshot itself
+                const uint32_t *s = reinterpret_cast<const uint32_t *>(p.cells0 + env * S);
+                uint32_t *d = reinterpret_cast<uint32_t *>(p.cells + env * S);
+#pragma unroll 8
+                for (int i = 0; i < (S >> 2); i++) d[i] = s[i];
+                row = p.cells0 + env * S;
+                pidx = -1;
+            } else restore_own<CS>(p, env, g);
             if (CW == 0) restore_objstate(p, env);
             L = unpack_rec(p.agent0[env], p.task);
             if (p.regen) p.regen[env] = 1; // the next-level buffer was consumed: k_levelgen refills it after this launch
@@ -563,7 +579,8 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
         if (valid) p.agent[env] = pack_rec(L, p.task);
     }
     if (p.obs) {
-        if (MODE == 0) emit_partial_obs<CW, CH, V, ALT>(p, L, lds, g, env0, lane);
+        if constexpr (GATHER) emit_partial_obs<CW, CH, V, ALT, true>(p, L, lds, row, env0, lane, pidx, pcode);
+        else if (MODE == 0) emit_partial_obs<CW, CH, V, ALT>(p, L, lds, g, env0, lane);
         else emit_full_obs<CW, CH>(p, L, valid, lds, g, LS, env0, lane);
     }
 }
@@ -715,6 +732,10 @@ hipError_t mgx_launch_step(const StepParams &p, int mode, int waves_per_block, h
     const dim3 block(64 * waves_per_block);
     const dim3 grid((p.n_tiles + waves_per_block - 1) / waves_per_block);
     const size_t shmem = (size_t)waves_per_block * p.wave_lds;
+    if (mode == 3) { // large grids, default view and visibility: gather form
+        hipLaunchKernelGGL((k_step<0, 0, 3, 7>), grid, block, shmem, st, p);
+        return hipGetLastError();
+    }
     if (mode == 0 && p.alt_vis) { // default_vis=False: run-time grid size only
 #define VCASE(v) if (p.view == v) { hipLaunchKernelGGL((k_step<0, 0, 0, v, true>), grid, block, shmem, st, p); return hipGetLastError(); }
         MGX_VIEWS(VCASE) VCASE(7)

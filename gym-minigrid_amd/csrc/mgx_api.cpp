@@ -54,7 +54,8 @@ struct mgx_env_s {
     bool flat = false;         // FlatObsWrapper epilogue (obs is float)
     float *mission_d = nullptr;   // [missions][96*27] one-hot mission blocks for k_flat
     int64_t tri_bytes = 0;     // per env
-    int kernel_mode = 0; // 0 partial view, 1 full obs via the LDS tile image, 2 full obs direct (W*H % 4 == 0)
+    int kernel_mode = 0; // 0 partial view, 1 full obs via the LDS tile image, 2 full obs direct (W*H % 4 == 0),
+                         // 3 partial view gathered straight from HBM (grids beyond 16x16)
     int64_t obs_bytes = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     uint8_t *cells_d = nullptr, *cells0_d = nullptr;
@@ -277,6 +278,9 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     if (!h->partial) need = ((need + 15) & ~15) + 3072; // + transpose scratch of emit_full_obs
     h->kernel_mode = h->partial ? 0 : ((h->cells % 4 == 0 && h->cells <= 65535) ? 2 : 1);
     if (h->kernel_mode == 2) need = 16; // k_step_fulldirect keeps no tile image in LDS
+    const char *force = getenv("MGX_PARTIAL_KERNEL"); // "staged" / "gather": override the size rule (tests, tuning)
+    const bool gather_ok = h->partial && view == 7 && !cfg->alt_visibility && !cfg->object_state;
+    if (gather_ok && (force ? !strcmp(force, "gather") : h->S > 256)) { h->kernel_mode = 3; need = obs_img; }
     h->wave_lds = (need + 15) & ~15;
     // a family that draws no random numbers (Empty with a fixed start) has only one level: nothing to generate
     const bool uses_rng = cfg->level_kind != MGX_LEVEL_NONE && cfg->level_kind != MGX_LEVEL_DISTSHIFT &&

@@ -143,6 +143,20 @@ SHAPES = [(8, 8), (9, 9), (16, 16), (5, 5), (6, 6), (7, 7), (11, 11), (7, 11), (
 @pytest.mark.parametrize("W,H", SHAPES)
 def test_random_batch_vs_oracle(W, H, auto_reset, mode):
     """Seeded random states + uniform random actions, HIP vs CPU oracle, every step, every byte."""
+    _random_batch_vs_oracle(W, H, auto_reset, mode)
+
+
+@pytest.mark.parametrize("form,W,H", [("gather", 8, 8), ("gather", 9, 9), ("gather", 7, 11), ("gather", 16, 16), ("gather", 5, 5),
+                                      ("staged", 19, 19), ("staged", 25, 25), ("staged", 40, 33)])
+@pytest.mark.parametrize("auto_reset", [False, True])
+def test_partial_kernel_forms(monkeypatch, form, W, H, auto_reset):
+    """Both forms of the partial-view kernel (tile staged in LDS / view gathered from HBM) on both sides of the size
+    rule that normally picks one (MGX_PARTIAL_KERNEL overrides it at mgx_create)."""
+    monkeypatch.setenv("MGX_PARTIAL_KERNEL", form)
+    _random_batch_vs_oracle(W, H, auto_reset, "partial")
+
+
+def _random_batch_vs_oracle(W, H, auto_reset, mode):
     N = 64 * 9 + 17 if W * H <= 400 else 64 * 2 + 3
     T = 48
     max_steps = 23  # several time-outs inside T
@@ -363,8 +377,10 @@ def test_ragged_batch_sizes(N):
 
 
 def test_largest_grids():
-    """50x50 is about the largest tile (64 envs x 2,504 B) that fits one wave's 160 KiB of LDS; beyond that the partial
-    view is refused loudly, while FullyObs (no LDS image when W*H % 4 == 0) still works."""
+    """Beyond 16x16 the default partial view is gathered straight from HBM (no LDS tile image), so the grid size is
+    bounded by the 255 of the record's coordinate bytes only.  The staged forms (other view sizes, default_vis=False)
+    still need the 64-env tile in one wave's 160 KiB of LDS and are refused loudly past ~50x50; FullyObs keeps no LDS
+    image when W*H % 4 == 0."""
     W = H = 50
     N = 70
     grid, aux, agent, carry, steps = random_states(N, W, H, seed=5, density=0.2)
@@ -381,7 +397,21 @@ def test_largest_grids():
         assert np.array_equal(to_np(obs), want)
     env.close()
     with pytest.raises(mg.MgxError):
-        mg.VecMiniGrid(config=cfg_from(60, 60, 9, False), num_envs=4, backend="numpy")
+        mg.VecMiniGrid(config=cfg_from(60, 60, 9, False), num_envs=4, backend="numpy", agent_view_size=5)
+    for (W, H) in [(60, 60), (200, 150)]:
+        N = 67
+        grid, aux, agent, carry, steps = random_states(N, W, H, seed=6, density=0.3)
+        orc = make_oracle(W, H, 9, False, False, grid, aux, agent, carry, steps)
+        env = mg.VecMiniGrid(config=cfg_from(W, H, 9, False), num_envs=N, auto_reset=True, backend="numpy")
+        env.set_state(grid, agent, aux=aux, carry=carry, steps=steps)
+        for t in range(12):
+            a = rs.randint(0, 7, size=N).astype(np.uint8)
+            obs, rew, done, _ = env.step(a)
+            oo, orew, odone = orc.step(a)
+            orc.reset_where(odone)
+            assert np.array_equal(obs, np.where(odone.astype(bool)[:, None, None, None], orc.observe(), oo)), (W, H, t)
+        assert np.array_equal(env.get_state()["grid"], orc.grid)
+        env.close()
     big = mg.VecMiniGrid(config=cfg_from(60, 60, 9, False), num_envs=5, obs_mode="full", auto_reset=False, backend="numpy")
     g2, x2, ag2, c2, s2 = random_states(5, 60, 60, seed=1, density=0.1)
     big.set_state(g2, ag2, aux=x2)
