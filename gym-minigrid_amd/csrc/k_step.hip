@@ -599,14 +599,20 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
 //              Envs that finished re-read the episode-start snapshot and write it back (a coalesced restore); the
 //              one cell phase A changed and the agent marker are patched in registers, so phase B never depends
 //              on phase A's global stores being visible.
-template <int CW, int CH>
+//   RAGGED   : W*H not a multiple of 4 (5x5, 7x7, 9x9, 11x11, 19x19, 25x25 ...): an env's 3*W*H output bytes are then
+//              not dword aligned, but the TILE's are, so the units run over the tile's flat cell sequence instead
+//              (cell f -> env f / cells, cell f % cells; the padded rows in HBM are read with one unaligned dword
+//              load per unit, byte-wise only for the one unit per env that straddles two envs).  The output side is
+//              the same stream of 12-byte records.  (Before this form these sizes went through the LDS tile image:
+//              3.0-3.7 TB/s for the sized kernels, 0.8-1.2 for 19x19 / 25x25.)
+template <int CW, int CH, bool RAGGED = false>
 __global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
 {
     __shared__ uint32_t s_info[64]; // per env: agent idx | dir<<16 | reset<<18 | (1<<19 if a cell changed)
     __shared__ uint32_t s_wr[64];   // changed cell: idx | code<<16
     __shared__ uint32_t s_lut[256]; // cell code -> (type | color<<8 | state<<16)
-    constexpr int CS = CW * CH;
-    constexpr int KPF = CS ? (CS / 4 * 64 + 255) / 256 : 0; // prefetched units per thread (compile-time sizes only)
+    constexpr int CS = (CW * CH + 3) & ~3;
+    constexpr int KPF = (CS && !RAGGED) ? (CS / 4 * 64 + 255) / 256 : 0; // prefetched units per thread (compile-time sizes only)
     const int tid = threadIdx.x;
     const int tile = blockIdx.x;
     const int H = CH ? CH : p.H;
@@ -672,6 +678,60 @@ __global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
     __syncthreads();
 
     struct __attribute__((packed, aligned(4))) Out12 { uint32_t a, b, c; };
+    if constexpr (RAGGED) {
+        const int cells = (CW && CH) ? CW * CH : p.W * p.H;
+        const int nenv = nv >= 64 ? 64 : (int)nv;
+        for (int e = 0; e < nenv; e++) { // restore the (few) envs that finished: block-uniform test, coalesced copy
+            if (!((s_info[e] >> 18) & 1u)) continue;
+            const uint32_t *s0 = reinterpret_cast<const uint32_t *>(p.cells0 + (env0 + e) * S);
+            uint32_t *d0 = reinterpret_cast<uint32_t *>(p.cells + (env0 + e) * S);
+            for (int i = tid; i < UPE; i += 256) d0[i] = s0[i];
+        }
+        if (!p.obs) return;
+        uint8_t *out = p.obs + env0 * (int64_t)cells * 3;
+        const int n_flat = nenv * cells, n_u = (n_flat + 3) >> 2;
+        struct __attribute__((packed)) U4 { uint32_t v; };
+        for (int u = tid; u < n_u; u += 256) {
+            const int f0 = 4 * u;
+            int e = f0 / cells, c = f0 - e * cells;
+            uint32_t tr[4];
+            if (c + 3 < cells) { // the whole unit inside one env: one unaligned dword
+                const uint32_t info = s_info[e];
+                const uint8_t *rowp = (((info >> 18) & 1u) ? p.cells0 : p.cells) + (env0 + e) * S;
+                uint32_t w = reinterpret_cast<const U4 *>(rowp + c)->v;
+                if ((info >> 19) & 1u) {
+                    const uint32_t x = s_wr[e], d = (x & 0xFFFFu) - (uint32_t)c;
+                    if (d < 4u) w = (w & ~(0xFFu << (8u * d))) | ((x >> 16) << (8u * d));
+                }
+                {
+                    const uint32_t d = (info & 0xFFFFu) - (uint32_t)c, code = MGX_K_AGENT | (((info >> 16) & 3u) << 4);
+                    if (d < 4u) w = (w & ~(0xFFu << (8u * d))) | (code << (8u * d));
+                }
+                tr[0] = s_lut[w & 255u]; tr[1] = s_lut[(w >> 8) & 255u]; tr[2] = s_lut[(w >> 16) & 255u]; tr[3] = s_lut[w >> 24];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    uint32_t code = MGX_CODE_EMPTY;
+                    if (f0 + j < n_flat) {
+                        const uint32_t info = s_info[e];
+                        code = ((((info >> 18) & 1u) ? p.cells0 : p.cells) + (env0 + e) * S)[c];
+                        if (((info >> 19) & 1u) && (s_wr[e] & 0xFFFFu) == (uint32_t)c) code = s_wr[e] >> 16;
+                        if ((info & 0xFFFFu) == (uint32_t)c) code = MGX_K_AGENT | (((info >> 16) & 3u) << 4);
+                    }
+                    tr[j] = s_lut[code];
+                    if (++c == cells) { c = 0; e++; }
+                }
+            }
+            const uint32_t a = __builtin_amdgcn_perm(tr[1], tr[0], 0x04020100u), b = __builtin_amdgcn_perm(tr[2], tr[1], 0x05040201u),
+                           cc = __builtin_amdgcn_perm(tr[3], tr[2], 0x06050402u);
+            if (f0 + 4 <= n_flat) nt_store12(reinterpret_cast<uint32_t *>(out + 12 * (int64_t)u), a, b, cc);
+            else { // tail tile whose cell count is not a multiple of 4: the last unit is short
+                const uint32_t wds[3] = {a, b, cc};
+                for (int b8 = 0; b8 < 3 * (n_flat - f0); b8++) out[12 * (int64_t)u + b8] = (uint8_t)(wds[b8 >> 2] >> (8 * (b8 & 3)));
+            }
+        }
+        return;
+    }
     Out12 *dst = p.obs ? reinterpret_cast<Out12 *>(p.obs + env0 * (int64_t)S * 3) : nullptr;
     constexpr int NIT = KPF ? KPF : 1;
     const int n_iter = KPF ? KPF : (n_units + 255) / 256;
@@ -711,7 +771,8 @@ hipError_t launch_sized(const StepParams &p, int mode, dim3 grid, dim3 block, si
 {
     if (mode == 0) hipLaunchKernelGGL((k_step<CW, CH, 0, 7>), grid, block, shmem, st, p);
     else if (mode == 1) hipLaunchKernelGGL((k_step<CW, CH, 1, 7>), grid, block, shmem, st, p);
-    else hipLaunchKernelGGL((k_step_fulldirect<CW, CH>), dim3(p.n_tiles), dim3(256), 0, st, p);
+    else if (((CW && CH) ? CW * CH : p.W * p.H) % 4 == 0) hipLaunchKernelGGL((k_step_fulldirect<CW, CH>), dim3(p.n_tiles), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_step_fulldirect<CW, CH, true>), dim3(p.n_tiles), dim3(256), 0, st, p);
     return hipGetLastError();
 }
 

@@ -276,7 +276,13 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     int need = 64 * h->LS;
     if (obs_img > need) need = obs_img;
     if (!h->partial) need = ((need + 15) & ~15) + 3072; // + transpose scratch of emit_full_obs
-    h->kernel_mode = h->partial ? 0 : ((h->cells % 4 == 0 && h->cells <= 65535) ? 2 : 1);
+    // FullyObs: the direct kernels unless W*H is small AND not a multiple of 4 (5x5, 7x7, 9x9, 11x11: a block per tile
+    // has too little to do there and the wave-per-tile LDS form measures faster: 110 vs 138 us at 1 Mi 9x9 envs).
+    // MGX_FULL_KERNEL=lds / direct overrides the rule (tests, tuning).
+    const char *ff = getenv("MGX_FULL_KERNEL");
+    const bool direct_ok = h->cells <= 65535;
+    const bool direct = direct_ok && (ff ? !strcmp(ff, "direct") : (h->cells % 4 == 0 || h->cells > 128));
+    h->kernel_mode = h->partial ? 0 : (direct ? 2 : 1);
     if (h->kernel_mode == 2) need = 16; // k_step_fulldirect keeps no tile image in LDS
     const char *force = getenv("MGX_PARTIAL_KERNEL"); // "staged" / "gather": override the size rule (tests, tuning)
     const bool gather_ok = h->partial && view == 7 && !cfg->alt_visibility && !cfg->object_state;

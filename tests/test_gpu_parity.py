@@ -156,6 +156,15 @@ def test_partial_kernel_forms(monkeypatch, form, W, H, auto_reset):
     _random_batch_vs_oracle(W, H, auto_reset, "partial")
 
 
+@pytest.mark.parametrize("form,W,H", [("lds", 9, 9), ("lds", 8, 8), ("lds", 19, 19), ("lds", 16, 16),
+                                      ("direct", 9, 9), ("direct", 5, 5), ("direct", 7, 11), ("direct", 3, 3)])
+def test_full_obs_kernel_forms(monkeypatch, form, W, H):
+    """Both FullyObs forms (tile image in LDS / direct, incl. the ragged direct form for W*H % 4 != 0) on both sides of
+    the size rule that normally picks one (MGX_FULL_KERNEL overrides it at mgx_create)."""
+    monkeypatch.setenv("MGX_FULL_KERNEL", form)
+    _random_batch_vs_oracle(W, H, True, "full")
+
+
 def _random_batch_vs_oracle(W, H, auto_reset, mode):
     N = 64 * 9 + 17 if W * H <= 400 else 64 * 2 + 3
     T = 48
