@@ -1,0 +1,40 @@
+#!/bin/bash
+# Usage (GPU box, repo root): tools/profile_round.sh r01   -- regenerates the rocprofv3 evidence kept under profiles/
+# Writes gpurun_out/profiles_<tag>/ ; copy what should be judged into profiles/ afterwards.
+set -e
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/profiles_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+stats() { # name, bench args...
+  local name=$1; shift
+  rm -rf $OUT/tmp_$name
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tmp_$name -- python3 $R/bench.py --no-cpu-baseline "$@" > $OUT/$name.log 2>&1 || { echo "stats $name failed"; return 0; }
+  local f=$(find $OUT/tmp_$name -name "*kernel_stats.csv" | head -n 1)
+  [ -n "$f" ] && cp $f $OUT/${TAG}_kernel_stats_$name.csv
+  tail -n 1 $OUT/$name.log > $OUT/${TAG}_bench_$name.json
+  rm -rf $OUT/tmp_$name
+  echo "stats $name ok"
+}
+stats empty8x8_1M --steps 1024 --warmup 64
+stats doorkey8x8_1M --env MiniGrid-DoorKey-8x8-v0 --steps 1024 --warmup 64
+stats lavacrossing_512k --env MiniGrid-LavaCrossingS9N1-v0 --envs-per-gpu 524288 --steps 1024 --warmup 64
+stats empty16x16_full_256k --env MiniGrid-Empty-16x16-v0 --envs-per-gpu 262144 --obs-mode full --steps 1024 --warmup 64
+stats lavacrossing_1M_newlevel --env MiniGrid-LavaCrossingS9N1-v0 --new-level-each-episode --steps 256
+stats dynobs8x8_1M --env MiniGrid-Dynamic-Obstacles-8x8-v0 --steps 512 --warmup 64
+stats empty8x8_1M_partial_onehot --obs-mode partial_onehot --steps 256
+stats empty8x8_128k_flat --obs-mode flat --envs-per-gpu 131072 --steps 256
+stats multiroom_n6_256k --env MiniGrid-MultiRoom-N6-v0 --envs-per-gpu 262144 --steps 256
+stats fourrooms_full_128k --env MiniGrid-FourRooms-v0 --envs-per-gpu 131072 --obs-mode full --steps 256
+# HBM traffic of the headline kernel: one counter per pass, kernel-trace only
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $OUT/tmp_pmc
+  timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/tmp_pmc -- python3 $R/bench.py --steps 48 --warmup 8 --no-cpu-baseline > $OUT/pmc_$c.log 2>&1 || { echo "pmc $c failed"; continue; }
+  f=$(find $OUT/tmp_pmc -name "*counter_collection.csv" | head -n 1)
+  [ -n "$f" ] && cp $f $OUT/$(echo $c | tr A-Z a-z)_counter_collection.csv
+  rm -rf $OUT/tmp_pmc
+  echo "pmc $c ok"
+done
+cd $R && timeout -k 10 400 python3 bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/bench_default.err || echo "default bench failed"
+echo "done $TAG"
