@@ -48,60 +48,80 @@ __global__ __launch_bounds__(256) void k_dynobs_init(const DynObsParams p)
 }
 
 // One wave per tile of 64 envs, lane per env, like k_step.  The walk is a chain of draw -> look at a cell -> maybe draw
-// again, every link depending on the one before and diverging between lanes; taken straight from HBM each link costs a
-// memory round trip for the whole wave (measured 0.55 - 1.9 ms per step at 1 Mi 8x8 envs).  So the wave first brings
-// what the chain will touch into LDS with coalesced loads -- the tile's cells (as k_step stages them) and, per env, the
-// next MGX_DYN_WIN words of its RNG block (two envs per 256-B load) -- and the chain then runs on LDS.
+// again, every link depending on the one before and diverging between lanes.  Three forms were measured at 1 Mi 8x8 envs:
+// lane-per-env straight from HBM 0.55-1.9 ms per step (a memory round trip per link); cells + a byte-wide window of
+// tempered words staged in LDS 0.28 ms (bound by VALU issue: the per-draw rejection loops and the try loops run for the
+// slowest lane of the wave, ~4.5 k instructions per wave); this one:
+//   * every draw of the walk is `bounded(2)` (a 3-wide range: obstacles live in the interior, so the 3x3 box never
+//     clips): masked rejection on the low two bits of the tempered word.  The accepted draws are therefore simply the
+//     words whose two bits are not 3, in order.  The wave loads the next 64 words of env e with ONE coalesced 256-B
+//     load (lane = word), computes the two bits (a 6-op shortcut of the tempering) and takes three BALLOTS -- valid,
+//     bit 0, bit 1 -- which are exactly env e's window as three 64-bit masks; lane e keeps them in registers.  A draw is
+//     then `ctz(valid >> cursor)` + two bit extracts: no loop, no memory access.
+//   * the tile's cells are staged in LDS as k_step stages them; moved obstacles are written through to HBM.
 // RNG bookkeeping: `pos` counts the words drawn since the block in memory was complete (bit 31: the block is no longer
-// the episode-start block).  A lane that draws past its window reads the global words, and past the block it produces
-// the next block's words one at a time in place (new[k] from old[k], old[k+1], old[k+397] or new[k-227]: the order of
-// genrand's bulk twist, so the stream is numpy's).  At the start of the next step the whole wave finishes such a
-// half-regenerated block (words k..623, in LDS, in chunks of <= 227 independent words) so that the env is back on the
+// the episode-start block).  A lane that exhausts its 64-word window reads the global words, and past the block it
+// produces the next block's words one at a time in place (new[k] from old[k], old[k+1], old[k+397] or new[k-227]: the
+// order of genrand's bulk twist, so the stream is numpy's).  At the start of the next step the whole wave finishes such
+// a half-regenerated block (words k..623, in LDS, in chunks of <= 227 independent words) so that the env is back on the
 // window path; the in-kernel auto-reset of the step kernels raises regen[env], upon which the wave restores the
 // obstacle order, the RNG position and -- if it was touched -- the block from the episode-start snapshot
 // (ReseedWrapper: seed(s) + reset()).
-#define MGX_DYN_WIN 48
-#define MGX_DYN_WSTRIDE 52 /* bytes per lane: 13 dwords, odd */
-// Every draw of the walk is `bounded(2)` (a 3-wide range: obstacles live in the interior, so the 3x3 box never clips):
-// only the low two bits of the tempered word matter.  The window therefore keeps ONE BYTE per word (tempered at fill
-// time): 3 KB per wave instead of 12, which is what bounds the occupancy of this latency-bound kernel.
+typedef unsigned long long dyn_u64;
+
+// low two bits of genrand's tempering of y (checked against the full tempering on 1e6 random words)
+__device__ __forceinline__ uint32_t temper2(uint32_t y)
+{
+    const uint32_t y1 = y ^ (y >> 11);
+    return (y1 ^ (y1 >> 18) ^ (y1 >> 11) ^ ((y1 >> 3) & 1u)) & 3u;
+}
+
 struct DynRng {
-    const uint8_t *win; // LDS: low byte of the tempered words [p0, lim) of the block
-    uint32_t *A;
-    uint32_t p, p0, lim;
-    __device__ __forceinline__ uint32_t next8()
+    dyn_u64 valid, lo, hi; // window: word pos+i is an accepted draw / its bit 0 / its bit 1
+    uint32_t *A;           // the env's block in HBM
+    uint32_t pos, c;       // window start, words of it consumed
+    uint32_t p;            // absolute position once the window is used up (0xFFFFFFFF while inside it)
+    __device__ __forceinline__ int draw3() // _rand_int(t, t + 3) - t
     {
-        if (p < lim) return win[p++ - p0];
-        uint32_t y;
-        if (p < 624u) y = A[p];
-        else {
-            const uint32_t k = p % 624u, k1 = k + 1u == 624u ? 0u : k + 1u, km = k + 397u >= 624u ? k + 397u - 624u : k + 397u;
-            y = lg_twist_word(A[k], A[k1], A[km]);
-            A[k] = y;
+        if (p == 0xFFFFFFFFu) {
+            const dyn_u64 m = c < 64u ? valid >> c : 0ull;
+            if (m) {
+                const uint32_t idx = c + (uint32_t)__builtin_ctzll(m);
+                c = idx + 1u;
+                return (int)(((lo >> idx) & 1ull) | (((hi >> idx) & 1ull) << 1));
+            }
+            p = pos + 64u < 624u || pos >= 624u ? pos + 64u : 624u; // first word behind the window
+            if (pos >= 624u) p = pos;                                 // (no window at all)
         }
-        p++;
-        return lg_temper(y) & 255u;
+        for (;;) {
+            uint32_t y;
+            if (p < 624u) y = A[p];
+            else {
+                const uint32_t k = p % 624u, k1 = k + 1u == 624u ? 0u : k + 1u, km = k + 397u >= 624u ? k + 397u - 624u : k + 397u;
+                y = lg_twist_word(A[k], A[k1], A[km]);
+                A[k] = y;
+            }
+            p++;
+            const uint32_t v = temper2(y);
+            if (v != 3u) return (int)v;
+        }
     }
-    __device__ __forceinline__ int draw3() // _rand_int(t, t + 3) - t: masked rejection on two bits
-    {
-        uint32_t v;
-        do { v = next8() & 3u; } while (v > 2u);
-        return (int)v;
-    }
+    __device__ __forceinline__ uint32_t end_pos() const { return p == 0xFFFFFFFFu ? pos + c : p; }
 };
 
+template <int CW, int CH>
 __global__ __launch_bounds__(256) void k_dynobs(const DynObsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int tile = blockIdx.x * (blockDim.x >> 6) + wv;
     if (tile >= p.n_tiles) return; // wave-uniform
-    const int W = p.W, H = p.H, S = p.S, LS = p.LS;
+    constexpr int CS = (CW && CH) ? ((CW * CH + 3) & ~3) : 0;
+    const int H = CH ? CH : p.H, S = CS ? CS : p.S, LS = p.LS;
     uint8_t *lds = smem + (size_t)wv * p.wave_lds;
     const int cells_bytes = 64 * LS > 2496 ? ((64 * LS + 15) & ~15) : 2496;
     uint32_t *blk = reinterpret_cast<uint32_t *>(lds); // 624 words: a block being restored / finished (before the cells arrive)
-    uint8_t *win = lds + cells_bytes;
-    uint32_t *ps = reinterpret_cast<uint32_t *>(win + 64 * MGX_DYN_WSTRIDE);
+    uint32_t *ps = reinterpret_cast<uint32_t *>(lds + cells_bytes);
     const int64_t env0 = (int64_t)tile * 64, env = env0 + lane;
     const bool valid = env < p.n;
 
@@ -119,15 +139,21 @@ __global__ __launch_bounds__(256) void k_dynobs(const DynObsParams p)
         dirty = false;
         p.regen[env] = 0;
     }
-    ps[lane] = valid ? pos : 0xFFFFFFFFu;
+    ps[lane] = pos;
     wave_sync();
 
-    const unsigned long long m_restore = __ballot(need_restore);
-    unsigned long long m_service = m_restore | __ballot(need_finish);
-    const bool any_service = m_service != 0ull;
-    while (m_service) { // wave-uniform: one env at a time, all 64 lanes on its block
-        const int e = __builtin_ctzll(m_service);
-        m_service &= m_service - 1;
+    dyn_u64 w_valid = 0, w_lo = 0, w_hi = 0;
+    // env e's window out of 64 consecutive words (this lane holds word `lane`, inb = it exists): three ballots
+    auto take = [&](int e, uint32_t y, bool inb) {
+        const uint32_t v = temper2(y);
+        const dyn_u64 mv = __ballot(inb && v != 3u), ml = __ballot((v & 1u) != 0u), mh = __ballot((v & 2u) != 0u);
+        if (lane == e) { w_valid = mv; w_lo = ml; w_hi = mh; }
+    };
+
+    const dyn_u64 m_restore = __ballot(need_restore);
+    const dyn_u64 m_serviced = m_restore | __ballot(need_finish);
+    for (dyn_u64 m = m_serviced; m; m &= m - 1) { // wave-uniform: one env at a time, all 64 lanes on its block
+        const int e = __builtin_ctzll(m);
         uint4 *dst4 = reinterpret_cast<uint4 *>(p.mt) + (env0 + e) * 156;
         uint4 *blk4 = reinterpret_cast<uint4 *>(blk);
         uint32_t pe;
@@ -164,49 +190,40 @@ __global__ __launch_bounds__(256) void k_dynobs(const DynObsParams p)
             for (int i = lane; i < 156; i += 64) dst4[i] = blk4[i];
         }
         wave_sync();
-        if (lane < MGX_DYN_WIN) win[e * MGX_DYN_WSTRIDE + lane] = (uint8_t)(pe + (uint32_t)lane < 624u ? lg_temper(blk[pe + lane]) : 0u);
-        if (lane == 0) ps[e] = pe | 0x40000000u; // window already filled (from LDS: the global words were just written)
+        const bool inb = pe + (uint32_t)lane < 624u; // the window comes from LDS: the global words were only just written
+        take(e, inb ? blk[pe + lane] : 0u, inb);
         wave_sync();
     }
     if (need_finish) { pos %= 624u; dirty = true; }
-    if (any_service) { // blocks rewritten by the whole wave may be read word-wise by single lanes below: same CU, same
-                       // L1, so the stores only have to be complete (an agent-scope fence would write back the XCD's L2)
+    if (m_serviced) { // blocks rewritten by the whole wave may be read word-wise by single lanes below: same CU, same L1,
+                      // so the stores only have to be complete (an agent-scope fence would write back the XCD's L2)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
-    { // RNG windows: quad q = it*64 + lane of the tile's 64 x 12 quads -> each env's 48 words are 12 consecutive
-      // (4-byte aligned) dwordx4 loads; every load is issued before the first is consumed
-        struct __attribute__((packed, aligned(4))) Q { uint32_t a, b, c, d; };
-        Q v[MGX_DYN_WIN / 4];
+    const uint32_t pos_w = valid ? pos : 0xFFFFFFFFu;
+    { // all 64 loads (one 256-B run per env) are issued before the first is consumed: one memory round trip, not 64
+        uint32_t y[64];
 #pragma unroll
-        for (int it = 0; it < MGX_DYN_WIN / 4; it++) {
-            const int q = it * 64 + lane, e = q / (MGX_DYN_WIN / 4), j = q - e * (MGX_DYN_WIN / 4);
-            const uint32_t pe = ps[e];
-            v[it] = Q{0u, 0u, 0u, 0u};
-            if (pe < 624u && pe + 4u * j + 4u <= 624u) v[it] = *reinterpret_cast<const Q *>(p.mt + (env0 + e) * 624 + pe + 4 * j);
-            else if (pe < 624u) { // the block ends inside this quad
-                const uint32_t *src = p.mt + (env0 + e) * 624;
-                const uint32_t b = pe + 4u * j;
-                if (b < 624u) v[it].a = src[b];
-                if (b + 1u < 624u) v[it].b = src[b + 1u];
-                if (b + 2u < 624u) v[it].c = src[b + 2u];
-            }
+        for (int e = 0; e < 64; e++) {
+            const uint32_t pe = (uint32_t)__builtin_amdgcn_readlane((int)pos_w, e);
+            const bool inb = pe < 624u && pe + (uint32_t)lane < 624u && !((m_serviced >> e) & 1ull);
+            y[e] = inb ? p.mt[(env0 + e) * 624 + pe + lane] : 0u;
         }
-        stage_tile<0>(p.cells, env0, S, LS, lds, lane);
 #pragma unroll
-        for (int it = 0; it < MGX_DYN_WIN / 4; it++) {
-            const int q = it * 64 + lane, e = q / (MGX_DYN_WIN / 4), j = q - e * (MGX_DYN_WIN / 4);
-            if (ps[e] < 624u)
-                *reinterpret_cast<uint32_t *>(win + e * MGX_DYN_WSTRIDE + 4 * j) =
-                    (lg_temper(v[it].a) & 255u) | ((lg_temper(v[it].b) & 255u) << 8) | ((lg_temper(v[it].c) & 255u) << 16) | (lg_temper(v[it].d) << 24);
+        for (int e = 0; e < 64; e++) {
+            const uint32_t pe = (uint32_t)__builtin_amdgcn_readlane((int)pos_w, e);
+            const bool inb = pe < 624u && pe + (uint32_t)lane < 624u;
+            if (!((m_serviced >> e) & 1ull)) take(e, y[e], inb);
         }
     }
+    stage_tile<CS>(p.cells, env0, S, LS, lds, lane);
     wave_sync();
     if (!valid) return;
 
     uint8_t *g = lds + lane * LS;
     uint8_t *gg = p.cells + env * S;
     if (a >= 3u) a = 0u; // `if action >= self.action_space.n: action = 0`
+    const int W = CW ? CW : p.W;
     const int ax = (int)(rec & 255u), ay = (int)((rec >> 8) & 255u), dir = (int)((rec >> 16) & 3u);
     const int fx = ax + (dir == 0) - (dir == 2), fy = ay + (dir == 1) - (dir == 3);
     bool not_clear = false; // front_cell and front_cell.type != 'goal', BEFORE the obstacles move
@@ -214,8 +231,7 @@ __global__ __launch_bounds__(256) void k_dynobs(const DynObsParams p)
         const uint32_t k = g[fx * H + fy] & 15u;
         not_clear = k != MGX_K_EMPTY && k != MGX_K_GOAL;
     }
-    const uint32_t have = pos < 624u ? ((624u - pos) < MGX_DYN_WIN ? 624u - pos : (uint32_t)MGX_DYN_WIN) : 0u;
-    DynRng r = {win + lane * MGX_DYN_WSTRIDE, p.mt + env * 624, pos, pos, pos + have};
+    DynRng r = {w_valid, w_lo, w_hi, p.mt + env * 624, pos, 0u, 0xFFFFFFFFu};
     for (int i = 0; i < p.n_obst; i++) {
         const uint32_t o = (i < 4 ? ow.x >> (8 * i) : ow.y >> (8 * (i - 4))) & 255u; // x << 4 | y
         const int tx = (int)(o >> 4) - 1, ty = (int)(o & 15u) - 1; // top = old_pos + (-1, -1): interior, never clipped
@@ -236,7 +252,8 @@ __global__ __launch_bounds__(256) void k_dynobs(const DynObsParams p)
         else ow.y = (ow.y & ~(255u << (8 * (i - 4)))) | (nb << (8 * (i - 4)));
     }
     reinterpret_cast<uint2 *>(p.obst)[env] = ow;
-    p.pos[env] = r.p | ((dirty || r.p > 624u) ? 0x80000000u : 0u);
+    const uint32_t pe = r.end_pos();
+    p.pos[env] = pe | ((dirty || pe > 624u) ? 0x80000000u : 0u);
     p.act_out[env] = (uint8_t)(a | ((a == 2u && not_clear) ? 0x80u : 0u));
 }
 } // namespace
@@ -249,14 +266,19 @@ hipError_t mgx_launch_dynobs_init(const DynObsParams &p, hipStream_t st)
     return hipGetLastError();
 }
 
-int mgx_dynobs_wave_lds(int LS) { return (64 * LS > 2496 ? ((64 * LS + 15) & ~15) : 2496) + 64 * MGX_DYN_WSTRIDE + 64 * 4; }
+int mgx_dynobs_wave_lds(int LS) { return (64 * LS > 2496 ? ((64 * LS + 15) & ~15) : 2496) + 64 * 4; }
 
 hipError_t mgx_launch_dynobs(const DynObsParams &p, hipStream_t st)
 {
     if (p.n_tiles == 0) return hipSuccess;
     if (p.wave_lds > 65536) return hipErrorInvalidValue;
-    const int wpb = 1; // one wave per block: the LDS footprint, not the wave slots, bounds the occupancy
-    hipLaunchKernelGGL(k_dynobs, dim3((unsigned)((p.n_tiles + wpb - 1) / wpb)), dim3(64 * wpb), (size_t)wpb * p.wave_lds, st, p);
+    int wpb = 65536 / p.wave_lds;
+    if (wpb > 4) wpb = 4;
+    const dim3 grid((unsigned)((p.n_tiles + wpb - 1) / wpb)), block(64 * wpb);
+    const size_t shmem = (size_t)wpb * p.wave_lds;
+#define CASE(w, h) if (p.W == w && p.H == h) { hipLaunchKernelGGL((k_dynobs<w, h>), grid, block, shmem, st, p); return hipGetLastError(); }
+    CASE(5, 5) CASE(6, 6) CASE(8, 8) CASE(16, 16) // the registered Dynamic-Obstacles sizes
+#undef CASE
+    hipLaunchKernelGGL((k_dynobs<0, 0>), grid, block, shmem, st, p);
     return hipGetLastError();
 }
-
