@@ -66,6 +66,12 @@ struct mgx_env_s {
     bool device_levels = false; // the family draws random numbers: mgx_reset seeds and generates on the GPU
     uint32_t *mt_d = nullptr, *mt_idx_d = nullptr, *mt_init_d = nullptr;
     uint8_t *regen_d = nullptr;
+    // mgx_rollout: the captured T-step graph and the arguments it was captured for
+    hipGraphExec_t roll_exec = nullptr;
+    hipStream_t cap_stream = nullptr; // capture happens here (the caller's stream may be the null stream, which cannot capture)
+    int64_t roll_T = 0;
+    const void *roll_args[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool assume_device = false; // inside the capture: arguments were classified up front
     // Dynamic-Obstacles: obstacle order (+ episode-start copy), RNG block snapshot, folded actions
     bool dynobs = false;
     uint8_t *obst_d = nullptr, *obst0_d = nullptr, *act_d = nullptr;
@@ -117,7 +123,7 @@ bool is_device_ptr_query(const void *p)
 int dev_in(mgx_handle h, int slot, const void *src, size_t bytes, const void **out, unsigned align = 1)
 {
     if (!src) { *out = nullptr; return MGX_OK; }
-    if (is_device_ptr(src)) {
+    if (h->assume_device || is_device_ptr(src)) {
         if ((uintptr_t)src & (align - 1)) return mgx_fail(MGX_ERR_INVALID_ARG, "device pointer %p is not %u-byte aligned", src, align);
         *out = src;
         return MGX_OK;
@@ -135,7 +141,7 @@ int dev_out(mgx_handle h, int slot, void *dst, size_t bytes, OutArg *o, unsigned
 {
     o->user = dst; o->bytes = bytes; o->staged = false; o->dev = nullptr;
     if (!dst) return MGX_OK;
-    if (is_device_ptr(dst)) {
+    if (h->assume_device || is_device_ptr(dst)) {
         if ((uintptr_t)dst & (align - 1)) return mgx_fail(MGX_ERR_INVALID_ARG, "device pointer %p is not %u-byte aligned", dst, align);
         o->dev = dst;
         return MGX_OK;
@@ -431,6 +437,8 @@ extern "C" int mgx_destroy(mgx_handle h)
     (void)hipFree(h->ctr_d); (void)hipFree(h->tri_d); (void)hipFree(h->mission_d);
     (void)hipFree(h->objaux_d); (void)hipFree(h->objaux0_d); (void)hipFree(h->objcont_d); (void)hipFree(h->objcont0_d); (void)hipFree(h->objcarry_d);
     (void)hipFree(h->mt_d); (void)hipFree(h->mt_idx_d); (void)hipFree(h->regen_d); (void)hipFree(h->mt_init_d);
+    if (h->roll_exec) (void)hipGraphExecDestroy(h->roll_exec);
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     (void)hipFree(h->obst_d); (void)hipFree(h->obst0_d); (void)hipFree(h->act_d); (void)hipFree(h->mt0_d); (void)hipFree(h->pos0_d);
     for (auto &s : h->st_in) if (s.dev) (void)hipFree(s.dev);
     for (auto &s : h->st_out) if (s.dev) (void)hipFree(s.dev);
@@ -663,6 +671,51 @@ extern "C" int mgx_observe(mgx_handle h, uint8_t *obs)
     if (rc) return rc;
     if (!obs) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_observe: obs is required");
     return run_step(h, false, nullptr, obs, nullptr, nullptr);
+}
+
+// T consecutive mgx_step calls in one host call: step t reads actions[t][N] and writes obs[t], reward[t], done[t].
+// The T x (k_dynobs, k_step, epilogue, k_levelgen) launches are captured into a hipGraph the first time and replayed
+// afterwards (same T and buffers), so small batches are not bound by one host launch per kernel.
+extern "C" int mgx_rollout(mgx_handle h, int64_t T, const uint8_t *actions, uint8_t *obs, float *reward, uint8_t *done)
+{
+    int rc = check_handle(h, "mgx_rollout");
+    if (rc) return rc;
+    if (T <= 0 || !actions) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_rollout: T > 0 and actions are required");
+    const void *args[4] = {actions, obs, reward, done};
+    for (const void *a : args)
+        if (a && !is_device_ptr(a)) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_rollout: buffers must be device memory (host buffers: call mgx_step per step)");
+    if (obs && (((uintptr_t)obs | (uintptr_t)((size_t)h->n * h->obs_bytes)) & 15u))
+        return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_rollout: obs slices must stay 16-byte aligned (n_envs * obs_bytes = %lld)", (long long)(h->n * h->obs_bytes));
+    if ((reward && ((uintptr_t)reward & 3u))) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_rollout: reward is not 4-byte aligned");
+    const bool cached = h->roll_exec && h->roll_T == T && !memcmp(h->roll_args, args, sizeof args);
+    if (!cached) {
+        if (h->roll_exec) { (void)hipGraphExecDestroy(h->roll_exec); h->roll_exec = nullptr; }
+        const int64_t steps_before = h->steps_total, launches_before = h->prof_launches;
+        if (!h->cap_stream) HIP_TRY(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+        hipStream_t user_stream = h->stream;
+        HIP_TRY(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+        h->stream = h->cap_stream; // run_step enqueues on h->stream: recorded, not executed
+        h->assume_device = true;
+        for (int64_t t = 0; t < T && !rc; t++)
+            rc = run_step(h, true, actions + t * h->n, obs ? obs + t * h->n * h->obs_bytes : nullptr,
+                          reward ? reward + t * h->n : nullptr, done ? done + t * h->n : nullptr);
+        h->assume_device = false;
+        h->stream = user_stream;
+        hipGraph_t graph = nullptr;
+        hipError_t e = hipStreamEndCapture(h->cap_stream, &graph);
+        h->steps_total = steps_before; h->prof_launches = launches_before; // nothing ran yet
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess) return mgx_fail(MGX_ERR_HIP, "mgx_rollout: stream capture failed: %s", hipGetErrorString(e));
+        e = hipGraphInstantiate(&h->roll_exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) { h->roll_exec = nullptr; return mgx_fail(MGX_ERR_HIP, "mgx_rollout: hipGraphInstantiate: %s", hipGetErrorString(e)); }
+        h->roll_T = T;
+        memcpy(h->roll_args, args, sizeof args);
+    }
+    HIP_TRY(hipGraphLaunch(h->roll_exec, h->stream));
+    h->steps_total += T * h->n;
+    if (h->profiling) h->prof_launches += T;
+    return MGX_OK;
 }
 
 static int objstate_io(mgx_handle h, const char *fn, const uint8_t *ci, const uint8_t *ai, const uint8_t *cci, uint8_t *co, uint8_t *ao, uint8_t *cco)

@@ -181,6 +181,26 @@ class VecMiniGrid:
         self._last_actions = a  # keep alive until the async kernel has consumed it
         return self._obs, self._reward, self._done, {}
 
+    def rollout(self, actions, with_obs=True):
+        """T steps in one call: actions uint8 (T, N) on the device -> obs (T, N, ...), reward (T, N), done (T, N).
+        One hipGraph launch per call once (T, buffers) repeat: the output buffers are cached per T for that reason and
+        are overwritten by the next rollout of the same length (torch backend only)."""
+        if self._torch is None:
+            raise ValueError("rollout needs the torch backend (device buffers)")
+        torch = self._torch
+        self._bind_stream()
+        T = int(actions.shape[0])
+        if actions.dtype != torch.uint8 or tuple(actions.shape) != (T, self.num_envs) or not actions.is_contiguous() or not actions.is_cuda:
+            raise ValueError("actions must be a contiguous uint8 cuda tensor of shape (T, num_envs)")
+        cache = self.__dict__.setdefault("_roll", {})
+        if T not in cache:
+            cache[T] = (torch.empty((T, self.num_envs) + self.obs_shape, dtype=getattr(torch, self.obs_dtype), device=self._dev),
+                        torch.empty((T, self.num_envs), dtype=torch.float32, device=self._dev),
+                        torch.empty((T, self.num_envs), dtype=torch.uint8, device=self._dev))
+        obs, reward, done = cache[T]
+        _lib.check(_lib.lib().mgx_rollout(self._h, T, _ptr(actions), _ptr(obs) if with_obs else None, _ptr(reward), _ptr(done)))
+        return (obs if with_obs else None), reward, done
+
     def observe(self):
         if self._torch is not None:
             self._bind_stream()

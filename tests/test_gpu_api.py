@@ -96,3 +96,31 @@ def test_two_handles_two_streams_and_stats():
     torch.cuda.synchronize()
     assert out2.tolist() == [float(dones), st["reward_sum"]]
     e1.close(); e2.close()
+
+
+@pytest.mark.parametrize("env_id,N,T", [("MiniGrid-DoorKey-8x8-v0", 4096, 16), ("MiniGrid-LavaCrossingS9N1-v0", 1024, 24),
+                                        ("MiniGrid-Dynamic-Obstacles-6x6-v0", 512, 12)])
+def test_rollout_graph_equals_stepping(env_id, N, T):
+    """mgx_rollout (T steps captured into one hipGraph, replayed) == T mgx_step calls, on every output byte; the replay
+    of the cached graph continues the episodes."""
+    seeds = np.arange(N, dtype=np.uint64)
+    a_env = mg.VecMiniGrid(env_id, num_envs=N, seeds=seeds, backend="torch", new_level_each_episode=("Lava" in env_id))
+    b_env = mg.VecMiniGrid(env_id, num_envs=N, seeds=seeds, backend="torch", new_level_each_episode=("Lava" in env_id))
+    a_env.reset(); b_env.reset()
+    for rep in range(3):                                     # rep 0 captures, 1 and 2 replay the same graph
+        acts = a_env.fill_actions(11, rep * T, T)            # (T, N) uint8 on the device
+        acts_keep = acts if rep == 0 else acts_keep
+        if rep:                                              # same buffer as the captured one: copy the new actions in
+            acts_keep.copy_(acts)
+        obs, rew, done = a_env.rollout(acts_keep)
+        torch.cuda.synchronize()
+        for t in range(T):
+            o, r, d, _ = b_env.step(acts_keep[t])
+            assert torch.equal(obs[t], o), (rep, t)
+            assert torch.equal(rew[t], r) and torch.equal(done[t], d), (rep, t)
+    sa, sb = a_env.stats(), b_env.stats()
+    assert sa == sb and sa["steps"] == 3 * T * N
+    with pytest.raises(mg.MgxError):
+        host = np.zeros((T, N), np.uint8)
+        _lib.check(_lib.lib().mgx_rollout(a_env._h, T, host.ctypes.data, None, None, None))
+    a_env.close(); b_env.close()
