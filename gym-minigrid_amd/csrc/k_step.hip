@@ -523,7 +523,8 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
     if (tile >= p.n_tiles) return; // wave-uniform
     constexpr int CS = (CW && CH) ? ((CW * CH + 3) & ~3) : 0;
     const int S = CS ? CS : p.S;
-    const int LS = p.LS;
+    constexpr int CLS = CS + (((CS >> 2) & 1) ? 0 : 4); // the host's rule (mgx_create): odd dword stride per env in LDS
+    const int LS = CS ? CLS : p.LS;
     uint8_t *lds = smem + (size_t)wv * p.wave_lds;
     const int64_t env0 = (int64_t)tile * 64;
     const int64_t env = env0 + lane;

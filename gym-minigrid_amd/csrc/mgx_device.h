@@ -76,6 +76,13 @@ __device__ __forceinline__ void stage_tile(const uint8_t *__restrict__ cells, in
     const uint4 *src = reinterpret_cast<const uint4 *>(cells + env0 * S);
     uint32_t *l32 = reinterpret_cast<uint32_t *>(lds);
     const int n_chunks = 4 * S; // 64*S/16
+    if constexpr (CS != 0 && ((CS >> 2) & 1)) {
+        // S/4 already odd (5x5, 6x6, 7x7, 9x9, 11x11): the LDS image has the layout of the HBM run, a straight 16-B copy
+        uint4 *l128 = reinterpret_cast<uint4 *>(lds);
+#pragma unroll
+        for (int c = lane; c < n_chunks; c += 64) l128[c] = src[c];
+        return;
+    }
 #pragma unroll 4
     for (int c = lane; c < n_chunks; c += 64) {
         const uint4 v = src[c]; // default cache policy on purpose: the state is re-read every step and non-temporal
