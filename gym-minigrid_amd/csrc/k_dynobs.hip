@@ -20,13 +20,17 @@
 namespace {
 __global__ __launch_bounds__(256) void k_dynobs_init(const DynObsParams p)
 {
-    // snapshot of the RNG block (coalesced: 156 uint4 per env)
+    // snapshot of the RNG block (coalesced: 156 uint4 per env) of the envs this reset really re-seeded
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < p.n * 156) {
         const int64_t e = t / 156;
-        if (!p.mask || p.mask[e]) reinterpret_cast<uint4 *>(p.mt0)[t] = reinterpret_cast<const uint4 *>(p.mt)[t];
+        if ((!p.mask_reset || p.mask_reset[e]) && (!p.mask || p.mask[e])) reinterpret_cast<uint4 *>(p.mt0)[t] = reinterpret_cast<const uint4 *>(p.mt)[t];
     }
-    if (t >= p.n || (p.mask && !p.mask[t])) return;
+    if (t >= p.n || (p.mask_reset && !p.mask_reset[t])) return;
+    if (p.mask && !p.mask[t]) { // reset with the seed it already has: the next k_dynobs restores order, RNG position and block
+        p.regen[t] = 1;
+        return;
+    }
     // obstacle order from the generator's marker codes; the cells become plain blue balls
     uint8_t ob[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int cells = p.W * p.H;

@@ -530,6 +530,7 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
     const int64_t env = env0 + lane;
     const bool valid = env < p.n;
 
+    if (p.obs_mask && !__ballot(valid && p.obs_mask[env])) return; // wave-uniform: nothing in this tile was reset
     const uint2 rec = p.agent[env]; // agent/cells arrays are padded to whole tiles
     uint32_t act = 6;
     if (p.do_step && valid) act = __builtin_nontemporal_load(&p.actions[env]);
@@ -627,6 +628,7 @@ __global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
     const int64_t nv = p.n - env0;
     const int n_units = (nv >= 64 ? 64 : (int)nv) * UPE;
     const uint32_t *cells32 = reinterpret_cast<const uint32_t *>(p.cells + env0 * S);
+    if (p.obs_mask && !__syncthreads_or((tid < 64 && env0 + tid < p.n) ? (int)p.obs_mask[env0 + tid] : 0)) return; // block-uniform
 
     uint32_t pf[KPF ? KPF : 1];
 #pragma unroll

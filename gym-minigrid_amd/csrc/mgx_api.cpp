@@ -66,6 +66,8 @@ struct mgx_env_s {
     bool device_levels = false; // the family draws random numbers: mgx_reset seeds and generates on the GPU
     uint32_t *mt_d = nullptr, *mt_idx_d = nullptr, *mt_init_d = nullptr;
     uint8_t *regen_d = nullptr;
+    uint64_t *seed0_d = nullptr;                  // seed of the level the episode-start snapshot holds ...
+    uint8_t *has_seed_d = nullptr, *reseeded_d = nullptr; // ... if any; envs the last mgx_reset really re-seeded
     // mgx_rollout: the captured T-step graph and the arguments it was captured for
     hipGraphExec_t roll_exec = nullptr;
     hipStream_t cap_stream = nullptr; // capture happens here (the caller's stream may be the null stream, which cannot capture)
@@ -406,6 +408,11 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
         CREATE_TRY(hipMemsetAsync(h->mt_d, 0, (size_t)h->n_pad * 624 * sizeof(uint32_t), h->stream));
         CREATE_TRY(hipMemsetAsync(h->mt_idx_d, 0, (size_t)h->n_pad * sizeof(uint32_t), h->stream));
         CREATE_TRY(hipMemsetAsync(h->regen_d, 0, (size_t)h->n_pad, h->stream));
+        CREATE_TRY(hipMalloc((void **)&h->seed0_d, (size_t)h->n_pad * sizeof(uint64_t)));
+        CREATE_TRY(hipMalloc((void **)&h->has_seed_d, (size_t)h->n_pad));
+        CREATE_TRY(hipMalloc((void **)&h->reseeded_d, (size_t)h->n_pad));
+        CREATE_TRY(hipMemsetAsync(h->has_seed_d, 0, (size_t)h->n_pad, h->stream));
+        CREATE_TRY(hipMemsetAsync(h->reseeded_d, 0, (size_t)h->n_pad, h->stream));
     }
     if (cfg->task_kind == MGX_TASK_DYNOBS) {
         if (!h->device_levels) { int rc = mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_create: Dynamic-Obstacles needs the on-device level generator"); mgx_destroy(h); return rc; }
@@ -437,6 +444,7 @@ extern "C" int mgx_destroy(mgx_handle h)
     (void)hipFree(h->ctr_d); (void)hipFree(h->tri_d); (void)hipFree(h->mission_d);
     (void)hipFree(h->objaux_d); (void)hipFree(h->objaux0_d); (void)hipFree(h->objcont_d); (void)hipFree(h->objcont0_d); (void)hipFree(h->objcarry_d);
     (void)hipFree(h->mt_d); (void)hipFree(h->mt_idx_d); (void)hipFree(h->regen_d); (void)hipFree(h->mt_init_d);
+    (void)hipFree(h->seed0_d); (void)hipFree(h->has_seed_d); (void)hipFree(h->reseeded_d);
     if (h->roll_exec) (void)hipGraphExecDestroy(h->roll_exec);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     (void)hipFree(h->obst_d); (void)hipFree(h->obst0_d); (void)hipFree(h->act_d); (void)hipFree(h->mt0_d); (void)hipFree(h->pos0_d);
@@ -563,6 +571,7 @@ static int set_state_impl(mgx_handle h, const uint8_t *grid, const uint8_t *aux,
     MgxCounters before, after;
     if ((rc = read_counters(h, &before))) return rc;
     HIP_TRY(mgx_launch_pack(p, h->stream));
+    if (h->has_seed_d) HIP_TRY(hipMemsetAsync(h->has_seed_d, 0, (size_t)h->n_pad, h->stream)); // the snapshots no longer belong to seeds
     if ((rc = read_counters(h, &after))) return rc;
     if (h->stream_mode) { // the injected state is the CURRENT episode; the next one comes from the env's RNG stream
         if (mask_host) HIP_TRY(hipMemcpyAsync(h->regen_d, p.mask, n, hipMemcpyDeviceToDevice, h->stream));
@@ -622,10 +631,11 @@ extern "C" int mgx_get_state(mgx_handle h, uint8_t *grid, uint8_t *aux, int32_t 
 }
 
 // ------------------------------------------------------------------------------------------------ step / observe
-static int run_step(mgx_handle h, bool do_step, const uint8_t *actions, uint8_t *obs, float *reward, uint8_t *done)
+static int run_step(mgx_handle h, bool do_step, const uint8_t *actions, uint8_t *obs, float *reward, uint8_t *done, const uint8_t *obs_mask_dev = nullptr)
 {
     StepParams p = base_params(h);
     p.do_step = do_step ? 1 : 0;
+    p.obs_mask = do_step ? nullptr : obs_mask_dev;
     const void *d = nullptr;
     int rc;
     if (do_step) {
@@ -768,6 +778,7 @@ extern "C" int mgx_set_task(mgx_handle h, const uint32_t *task)
     const void *d;
     if ((rc = dev_in(h, 4, task, (size_t)h->n * sizeof(uint32_t), &d, 4))) return rc;
     HIP_TRY(mgx_launch_task(h->agent_d, h->agent0_d, (const uint32_t *)d, nullptr, h->n, h->stream));
+    if (h->has_seed_d) HIP_TRY(hipMemsetAsync(h->has_seed_d, 0, (size_t)h->n_pad, h->stream)); // the snapshot's task word changed
     return MGX_OK;
 }
 
@@ -810,21 +821,27 @@ extern "C" int mgx_reset(mgx_handle h, const uint64_t *seeds, const uint8_t *mas
         if ((rc = dev_in(h, 4, seeds, n * sizeof(uint64_t), &ds, 8))) return rc;
         if ((rc = dev_in(h, 5, mask, n, &dm))) return rc;
         HIP_TRY(hipMemsetAsync(h->regen_d, 0, n, h->stream));
-        HIP_TRY(mgx_launch_seed((const uint64_t *)ds, (const uint8_t *)dm, h->mt_init_d, h->mt_d, h->mt_idx_d, h->regen_d, h->n, h->stream));
+        // (an env that keeps its seed keeps its level: with the snapshot still holding it -- not in stream mode, where the
+        // buffer holds the NEXT level -- seeding and generation are skipped for it and k_consume alone restores it)
+        HIP_TRY(mgx_launch_seed((const uint64_t *)ds, (const uint8_t *)dm, h->mt_init_d, h->mt_d, h->mt_idx_d, h->regen_d, h->seed0_d, h->has_seed_d,
+                                h->reseeded_d, h->stream_mode ? 0 : 1, h->n, h->stream));
         if ((rc = launch_levelgen(h))) return rc;
         ConsumeParams c;
         memset(&c, 0, sizeof c);
         c.mask = (const uint8_t *)dm;
         c.cells = h->cells_d; c.cells0 = h->cells0_d; c.agent = h->agent_d; c.agent0 = h->agent0_d; c.regen = h->regen_d;
+        c.objaux = h->objaux_d; c.objaux0 = h->objaux0_d; c.objcont = h->objcont_d; c.objcont0 = h->objcont0_d; c.objcarry = h->objcarry_d;
         c.n = h->n; c.S = h->S; c.flag_regen = h->stream_mode ? 1 : 0;
         HIP_TRY(mgx_launch_consume(c, h->stream));
         if (h->stream_mode && (rc = launch_levelgen(h))) return rc;
         if (h->dynobs) { // obstacle order out of the generator's markers + snapshot of the RNG right after reset()
             DynObsParams dp = dynobs_params(h);
-            dp.mask = (const uint8_t *)dm;
+            dp.mask = h->reseeded_d;
+            dp.mask_reset = (const uint8_t *)dm;
             HIP_TRY(mgx_launch_dynobs_init(dp, h->stream));
         }
-        if (obs) return run_step(h, false, nullptr, obs, nullptr, nullptr);
+        // (with a mask only the 64-env tiles that hold a reset env are re-observed; the rest of `obs` is left as it is)
+        if (obs) return run_step(h, false, nullptr, obs, nullptr, nullptr, is_device_ptr(obs) ? (const uint8_t *)dm : nullptr);
         return MGX_OK;
     }
     std::vector<uint8_t> grid(n * cells * 3);

@@ -51,6 +51,7 @@ struct StepParams {
     const uint8_t *objaux0, *objcont0;
     uint16_t *objcarry;
     uint8_t *regen;        // stream mode: set to 1 for every env that consumed its next-level buffer (else null)
+    const uint8_t *obs_mask; // observe after a masked reset: 64-env tiles without a masked env are skipped (else null)
     int64_t n;
     int n_tiles;
     int W, H, S, LS, wave_lds, view;
@@ -74,6 +75,7 @@ struct PackParams {
 struct ConsumeParams {
     const uint8_t *mask; // u8[n] or null
     uint8_t *cells; const uint8_t *cells0; uint2 *agent; const uint2 *agent0; uint8_t *regen;
+    uint8_t *objaux, *objaux0, *objcont, *objcont0; uint16_t *objcarry; // object_state handles (else null): back to defaults
     int64_t n;
     int S, flag_regen;
 };
@@ -83,7 +85,8 @@ struct DynObsParams {
     const uint2 *agent;
     const uint8_t *actions; // caller's actions (k_dynobs) ...
     uint8_t *act_out;       // ... folded to 0..2, bit 7 = "moved forward while the front cell was not clear"
-    const uint8_t *mask;    // k_dynobs_init: envs being reset (null = all)
+    const uint8_t *mask;    // k_dynobs_init: envs that were re-seeded and get a new snapshot (null = all)
+    const uint8_t *mask_reset; // k_dynobs_init: envs being reset (null = all); those not re-seeded only raise regen
     uint8_t *regen;         // set by the step kernels' in-kernel reset: restore obstacle order + RNG position first
     uint8_t *obst, *obst0;  // u8[n_pad][8] position x << 4 | y of obstacle i (placement order), and at episode start
     uint32_t *mt, *mt0;     // u32[n_pad][624] MT19937 words (lazily regenerated in place past the first block) + snapshot
@@ -97,7 +100,7 @@ hipError_t mgx_launch_dynobs_init(const DynObsParams &p, hipStream_t st);
 hipError_t mgx_launch_dynobs(const DynObsParams &p, hipStream_t st);
 hipError_t mgx_launch_levelgen(const LevelGenParams &p, hipStream_t st);
 hipError_t mgx_launch_seed(const uint64_t *seeds, const uint8_t *mask, const uint32_t *init, uint32_t *mt, uint32_t *mt_idx,
-                           uint8_t *regen, int64_t n, hipStream_t st);
+                           uint8_t *regen, uint64_t *seed0, uint8_t *has_seed, uint8_t *reseeded, int skip_same, int64_t n, hipStream_t st);
 hipError_t mgx_launch_consume(const ConsumeParams &p, hipStream_t st);
 hipError_t mgx_launch_step(const StepParams &p, int mode, int waves_per_block, hipStream_t st);
 hipError_t mgx_raise_lds_limit(int W, int H, int mode, int bytes, int view, int alt_vis, int object_state);

@@ -166,7 +166,8 @@ class VecMiniGrid:
         return [seed]
 
     def reset(self, mask=None):
-        """seed(seed_i); reset() for every env (or those with mask[i] != 0).  Returns obs of ALL envs."""
+        """seed(seed_i); reset() for every env (or those with mask[i] != 0).  Returns the obs buffer of ALL envs (the one
+        step() returns: with a mask only the tiles holding a reset env are rewritten, the rest still hold the last step)."""
         if self._torch is not None:
             self._bind_stream()
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)

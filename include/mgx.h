@@ -183,7 +183,11 @@ int mgx_generate_level_stream(const mgx_config *cfg, uint64_t seed, int64_t K, u
 
 /* env.seed(seeds[i]); env.reset() for every env with mask[i] != 0 (mask NULL = all).
  * For the families that draw random numbers the whole reset runs on the GPU (k_seed: SHA-512 key + MT19937
- * init_by_array per env, then k_levelgen).  obs (optional) receives the reset observation of ALL envs. */
+ * init_by_array per env, then k_levelgen); an env whose seed is the one it already has is restored from its
+ * episode-start snapshot instead (same result: the level and the RNG state are functions of the seed).
+ * obs (optional) receives the current observation of all envs; with a mask and a DEVICE obs buffer only the 64-env
+ * tiles that contain a reset env are rewritten (pass the buffer the last mgx_step wrote, as the reference's
+ * `if done: obs = env.reset()` loop does, and the other entries are already right). */
 int mgx_reset(mgx_handle h, const uint64_t *seeds, const uint8_t *mask, uint8_t *obs);
 
 /* Inject / read back the full simulator state.  set_state also records the state as the

@@ -124,3 +124,65 @@ def test_rollout_graph_equals_stepping(env_id, N, T):
         host = np.zeros((T, N), np.uint8)
         _lib.check(_lib.lib().mgx_rollout(a_env._h, T, host.ctypes.data, None, None, None))
     a_env.close(); b_env.close()
+
+
+@pytest.mark.parametrize("env_id", ["MiniGrid-DoorKey-8x8-v0", "MiniGrid-LavaCrossingS9N1-v0", "MiniGrid-Fetch-8x8-N3-v0"])
+def test_masked_reset_same_and_changed_seeds(env_id):
+    """reset(mask): an env that keeps its seed is restored from the episode-start snapshot (no re-seeding), one whose
+    seed changed is re-seeded and regenerated; either way the state equals `seed(s); reset()` of the reference."""
+    N = 300
+    seeds = np.arange(N, dtype=np.uint64) + 7
+    env = mg.VecMiniGrid(env_id, num_envs=N, seeds=seeds, auto_reset=False, backend="numpy")
+    env.reset()
+    rs = np.random.RandomState(0)
+    for t in range(30):
+        env.step(rs.randint(0, 7, size=N).astype(np.uint8))
+    mask = (rs.uniform(size=N) < 0.5).astype(np.uint8)
+    changed = (rs.uniform(size=N) < 0.5)
+    new_seeds = np.where(changed, seeds + 1000, seeds).astype(np.uint64)
+    before = env.get_state()
+    env.seed(new_seeds)
+    env.reset(mask=mask)
+    st = env.get_state()
+    grid, agent, task = mg.generate_levels(env_id, new_seeds, with_task=True)
+    m = mask.astype(bool)
+    assert np.array_equal(st["grid"][m], grid[m]) and np.array_equal(st["agent"][m], agent[m])
+    assert (st["steps"][m] == 0).all() and (st["carry"][m] == (1, 0, 0)).all()
+    for k in ("grid", "agent", "steps", "carry"):
+        assert np.array_equal(st[k][~m], before[k][~m]), k
+    if env.cfg.task_kind:
+        assert np.array_equal(env.get_task()[m], task[m])
+    # and once more with everything unchanged (pure snapshot restore), after more steps
+    for t in range(10):
+        env.step(rs.randint(0, 7, size=N).astype(np.uint8))
+    env.reset(mask=mask)
+    st = env.get_state()
+    assert np.array_equal(st["grid"][m], grid[m]) and np.array_equal(st["agent"][m], agent[m])
+    env.close()
+    # device buffers: the masked reset rewrites only the tiles that hold a reset env; together with what the last
+    # step left in the buffer that is the observation of every env
+    tenv = mg.VecMiniGrid(env_id, num_envs=N, seeds=seeds, auto_reset=False, backend="torch")
+    tenv.reset()
+    for t in range(12):
+        tenv.step(torch.from_numpy(rs.randint(0, 7, size=N).astype(np.uint8)).cuda())
+    sparse = np.zeros(N, np.uint8)
+    sparse[[3, 200]] = 1                                     # tiles 0 and 3 of 5
+    got = tenv.reset(mask=sparse).clone()
+    assert torch.equal(got, tenv.observe())
+    tenv.close()
+
+
+def test_reset_restores_default_object_state():
+    """object_state handles of a built-in family: mgx_reset puts the hidden Goal/Box state back to the defaults."""
+    N = 130
+    env = mg.VecMiniGrid("MiniGrid-Empty-6x6-v0", num_envs=N, seeds=0, auto_reset=False, backend="numpy", object_state=True)
+    env.reset()
+    a = np.tile(np.array([2, 2, 2, 1, 2, 2, 5, 5], np.uint8), 4)   # walk to the goal (6x6: (4,4)) and toggle it away
+    for t in range(len(a)):
+        env.step(np.full(N, a[t], np.uint8))
+    env.reset()
+    st, os_ = env.get_state(), env.get_object_state()
+    grid, agent = mg.generate_levels("MiniGrid-Empty-6x6-v0", np.arange(N, dtype=np.uint64))
+    assert np.array_equal(st["grid"], grid) and (st["aux"] == 0).all()
+    assert (os_["contains"] == np.array([1, 0, 0], np.uint8)).all() and (os_["carry_aux"] == 0).all()
+    env.close()
