@@ -163,15 +163,25 @@ class VecMiniGrid:
             if s.shape != (self.num_envs,):
                 raise ValueError("seeds must have shape (%d,)" % self.num_envs)
         self.seeds = s
+        self._seeds_dev = None  # device copy (torch backend), made on first use
         return [seed]
 
     def reset(self, mask=None):
         """seed(seed_i); reset() for every env (or those with mask[i] != 0).  Returns the obs buffer of ALL envs (the one
         step() returns: with a mask only the tiles holding a reset env are rewritten, the rest still hold the last step)."""
+        seeds = self.seeds
         if self._torch is not None:
             self._bind_stream()
-        m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
-        _lib.check(_lib.lib().mgx_reset(self._h, _ptr(self.seeds), _ptr(m), _ptr(self._obs)))
+            if self._seeds_dev is None:  # keep the seeds on the GPU: a masked reset per step must not upload 8 B per env
+                self._seeds_dev = self._torch.from_numpy(self.seeds.view(np.int64)).to(self._dev)
+            seeds = self._seeds_dev
+        if mask is None or isinstance(mask, np.ndarray) or self._torch is None or not isinstance(mask, self._torch.Tensor):
+            m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
+        else:                            # e.g. the `done` tensor step() returned: used in place
+            m = mask if mask.dtype == self._torch.uint8 else mask.to(self._torch.uint8)
+            if m.shape != (self.num_envs,) or not m.is_contiguous():
+                raise ValueError("mask must be a contiguous tensor of shape (num_envs,)")
+        _lib.check(_lib.lib().mgx_reset(self._h, _ptr(seeds), _ptr(m), _ptr(self._obs)))
         return self._obs
 
     def step(self, actions):
