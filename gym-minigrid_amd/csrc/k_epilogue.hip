@@ -81,8 +81,8 @@ hipError_t mgx_launch_onehot(const uint8_t *tri, uint8_t *out, int64_t n_cells, 
 
 // FlatObsWrapper.observation (wrappers.py:556-577): out[env] = f32(image bytes) ++ one-hot of the mission string
 // (96 positions x 27 codes, 95 % of the row).  `pattern` holds that one-hot block as floats, one row of 2592 per
-// mission of the family (built by the host at create; only Fetch has more than one: row = (template*2 + is_ball)*8 +
-// color of the task word), so the kernel is a copy: a block owns a group of 4 envs (4*L floats is a whole number of
+// mission of the family (built by the host at create; Fetch: row = (template*2 + is_ball)*8 + color of the task word,
+// GoToObject: row = type*8 + color), so the kernel is a copy: a block owns a group of 4 envs (4*L floats is a whole number of
 // 16-B quads, L itself is not), a lane one quad; inside the mission block a quad is one 4-byte-aligned dwordx4 read
 // of the L2-resident pattern and one non-temporal 16-B store.
 namespace {
@@ -92,6 +92,7 @@ __device__ __forceinline__ int flat_row(const uint2 *rec, int64_t env, int fetch
 {
     if (!fetch) return 0;
     const uint32_t task = rec[env].y >> 16;
+    if (fetch == 2) return (int)(((task >> 8) & 3u) * 8u + ((task >> 10) & 7u)); // GoToObject: type, color
     return (int)((((task >> 8) & 7u) * 2u + ((task & 15u) == MGX_K_BALL ? 1u : 0u)) * 8u + ((task >> 4) & 7u));
 }
 

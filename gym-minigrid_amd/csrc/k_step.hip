@@ -54,6 +54,13 @@ __device__ __forceinline__ void task_rule(const StepParams &p, const Lane &L, ui
                 if (door && ((n4[i] >> 4) & 7u) == 0u) reward = (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps));
             }
         }
+    } else if (p.task == MGX_TASK_GOTOOBJECT) { // envs/gotoobject.py:68-84
+        if (act == 5) done = true;              // "Toggle/pickup action terminates the episode"
+        if (act == 6) {
+            const int dx = L.ax - (int)(L.task & 15u), dy = L.ay - (int)((L.task >> 4) & 15u);
+            if (dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1) reward = (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps));
+            done = true;
+        }
     }
 }
 

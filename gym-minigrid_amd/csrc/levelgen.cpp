@@ -159,6 +159,10 @@ int check_levelgen_cfg(const mgx_config *cfg, const char *fn)
         if ((W - 3) / 2 > MGX_LG_MAX_RIVERS || (H - 3) / 2 > MGX_LG_MAX_RIVERS)
             return mgx_fail(MGX_ERR_UNSUPPORTED, "%s: crossing grid %dx%d has more than %d candidate rivers per axis", fn, W, H, MGX_LG_MAX_RIVERS);
         break;
+    case MGX_LEVEL_GOTOOBJECT:
+        if (W > 16 || H > 16 || cfg->level_arg0 < 1 || cfg->level_arg0 > 8)
+            return mgx_fail(MGX_ERR_INVALID_ARG, "%s: GoToObject needs W, H <= 16 and 1..8 objects", fn);
+        break;
     case MGX_LEVEL_DYNOBS:
         if (W < 5 || H < 5 || W > 16 || H > 16) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: Dynamic-Obstacles grids are 5x5 .. 16x16", fn);
         if (cfg->level_arg0 < 0 || cfg->level_arg0 > 8) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: n_obstacles %d (0..8)", fn, cfg->level_arg0);
@@ -235,6 +239,9 @@ const std::vector<EnvId> &registry()
         {"MiniGrid-Dynamic-Obstacles-Random-6x6-v0", mkd(6, 3, 1)},
         {"MiniGrid-Dynamic-Obstacles-8x8-v0", mkd(8, 4, 0)},
         {"MiniGrid-Dynamic-Obstacles-16x16-v0", mkd(16, 8, 0)},
+        // GoToObjectEnv: max_steps = 5*size^2, see_through_walls=True (envs/gotoobject.py:10-22)
+        {"MiniGrid-GoToObject-6x6-N2-v0", mkt(6, 6, 180, 1, MGX_LEVEL_GOTOOBJECT, 2, MGX_TASK_GOTOOBJECT)},
+        {"MiniGrid-GoToObject-8x8-N2-v0", mkt(8, 8, 320, 1, MGX_LEVEL_GOTOOBJECT, 2, MGX_TASK_GOTOOBJECT)},
         // FourRoomsEnv: 19x19, max_steps=500 (envs/fourrooms.py:14-17)
         {"MiniGrid-FourRooms-v0", mk(19, 19, 500, 0, 0, MGX_LEVEL_FOURROOMS, 0, 0)},
         // MultiRoomEnv: 25x25, max_steps = maxNumRooms*20 (envs/multiroom.py:36-39,223-246)
@@ -284,6 +291,14 @@ extern "C" int mgx_mission(const mgx_config *cfg, uint32_t task, char *out, int 
     case MGX_LEVEL_GOTODOOR: m = "go to the red door"; break;                                               // envs/gotodoor.py:70 (the fork's target is always red)
     case MGX_LEVEL_DYNOBS: m = "get to the green goal square"; break;                                      // envs/dynamicobstacles.py:58
     case MGX_LEVEL_FOURROOMS: m = "Reach the goal"; break;                                                  // envs/fourrooms.py:69
+    case MGX_LEVEL_GOTOOBJECT: {                                                                            // envs/gotoobject.py:63-64
+        static const char *const types[3] = {"key", "ball", "box"};
+        const uint32_t ty = (task >> 8) & 3u, color = (task >> 10) & 7u;
+        if (ty > 2 || color > 6) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_mission: 0x%x is not a GoToObject task word", task);
+        snprintf(buf, sizeof buf, "go to the %s %s", colors[color], types[ty]);
+        m = buf;
+        break;
+    }
     case MGX_LEVEL_FETCH: {                                                                                 // envs/fetch.py:57-71
         const uint32_t kind = task & 15u, color = (task >> 4) & 7u, tmpl = task >> 8;
         if ((kind != MGX_K_KEY && kind != MGX_K_BALL) || color > 6 || tmpl > 4 || (task & 0x80u))

@@ -383,6 +383,42 @@ LG_FN void lg_gen_fetch(const mgx_config &c, R &r, LgLevel &L)
     L.task = (uint32_t)L.cmds[first_obj + t].code | ((uint32_t)tmpl << 8);
 }
 
+// GoToObjectEnv._gen_grid (envs/gotoobject.py:24-66): numObjs (level_arg0) distinct (type, color) objects out of
+// key / ball / box x 7 colours anywhere in the room (a duplicate pair costs its two draws and is drawn again), random
+// agent, random target among them.  task = tx | ty << 4 | (type - key) << 8 | color << 10 (the rule needs the position).
+template <class R>
+LG_FN void lg_gen_gotoobject(const mgx_config &c, R &r, LgLevel &L)
+{
+    L.ncmd = 0;
+    lg_rect(L, 0, 0, L.W - 1, 0, MGX_CODE_WALL_GREY);
+    lg_rect(L, 0, L.H - 1, L.W - 1, L.H - 1, MGX_CODE_WALL_GREY);
+    lg_rect(L, 0, 0, 0, L.H - 1, MGX_CODE_WALL_GREY);
+    lg_rect(L, L.W - 1, 0, L.W - 1, L.H - 1, MGX_CODE_WALL_GREY);
+    const int first_obj = L.ncmd, n = c.level_arg0;
+    L.ax = -1; L.ay = -1;
+    int have = 0;
+    while (have < n) {
+        const int type = lg_randint(r, 0, 3);                   // _rand_elem(['key', 'ball', 'box'])
+        const int color = lg_sorted_color(lg_randint(r, 0, 7)); // _rand_elem(COLOR_NAMES)
+        if (!r.alive()) return;
+        const uint32_t code = (uint32_t)(MGX_K_KEY + type) | ((uint32_t)color << 4);
+        bool dup = false;
+        for (int k = 0; k < have; k++) dup = dup || L.cmds[first_obj + k].code == code;
+        if (dup) continue;
+        int x, y;
+        lg_sample_free(r, L, L.W, L.H, false, &x, &y);          // place_obj(obj): anywhere empty
+        if (!r.alive() || L.too_big) return;
+        lg_set(L, x, y, code);
+        have++;
+    }
+    lg_sample_free(r, L, L.W, L.H, false, &L.ax, &L.ay);        // place_agent()
+    L.adir = lg_randint(r, 0, 4);
+    const int t = lg_randint(r, 0, n);                          // objIdx = _rand_int(0, len(objs))
+    if (L.too_big || !r.alive()) return;
+    const LgCmd tc = L.cmds[first_obj + t];
+    L.task = (uint32_t)tc.x0 | ((uint32_t)tc.y0 << 4) | ((uint32_t)((tc.code & 15u) - MGX_K_KEY) << 8) | ((uint32_t)((tc.code >> 4) & 7u) << 10);
+}
+
 // GoToDoorEnv._gen_grid (envs/gotodoor.py:23-69, as modified by the fork): four locked doors on the four walls in four
 // distinct colours, redrawn until one of them is red (the target); random agent.
 template <class R>
@@ -492,6 +528,7 @@ LG_FN void lg_generate(const mgx_config &c, R &r, LgLevel &L)
     case MGX_LEVEL_GOTODOOR: lg_gen_gotodoor(c, r, L); break;
     case MGX_LEVEL_FOURROOMS: lg_gen_fourrooms(c, r, L); break;
     case MGX_LEVEL_DYNOBS: lg_gen_dynobs(c, r, L); break;
+    case MGX_LEVEL_GOTOOBJECT: lg_gen_gotoobject(c, r, L); break;
     default: lg_gen_lavagap(c, r, L); break;
     }
 }

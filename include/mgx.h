@@ -99,7 +99,8 @@ typedef enum {
                                 task_kind = MGX_TASK_DYNOBS */
     MGX_LEVEL_MULTIROOM = 6, /* MultiRoomEnv (envs/multiroom.py): level_arg0 = minNumRooms | maxNumRooms << 8 (<= 8),
                                 level_arg1 = maxRoomSize */
-    MGX_LEVEL_KIND_END = 11
+    MGX_LEVEL_GOTOOBJECT = 11, /* GoToObjectEnv (envs/gotoobject.py): level_arg0 = numObjs; use with task_kind = MGX_TASK_GOTOOBJECT */
+    MGX_LEVEL_KIND_END = 12
 } mgx_level_kind;
 
 /* task rules layered on MiniGridEnv.step by env subclasses (`step` overrides that only reshape reward/done) */
@@ -109,7 +110,10 @@ typedef enum {
                               the target object.  Per-env task word = target cell code | mission template << 8. */
     MGX_TASK_GOTODOOR = 2, /* envs/gotodoor.py:71-93: the `done` action next to any door ends the episode, next to the
                               target (red) door it also pays _reward(). */
-    MGX_TASK_DYNOBS = 3    /* envs/dynamicobstacles.py:60-89 (with level_kind = MGX_LEVEL_DYNOBS): actions >= 3 fold to 0;
+    MGX_TASK_GOTOOBJECT = 4, /* envs/gotoobject.py:68-84: `toggle` ends the episode; `done` ends it and pays _reward() when the agent
+                              is within one cell (Chebyshev) of the target's INITIAL position.  Per-env task word =
+                              tx | ty << 4 | (type - key) << 8 | color << 10. */
+    MGX_TASK_DYNOBS = 3,   /* envs/dynamicobstacles.py:60-89 (with level_kind = MGX_LEVEL_DYNOBS): actions >= 3 fold to 0;
                               before the base step every obstacle (blue ball) is re-placed in its 3x3 neighbourhood with
                               draws from the env's own RNG stream (place_obj, max_tries=100); moving forward while the
                               front cell was occupied by anything but the goal gives reward -1 and done.  State enters

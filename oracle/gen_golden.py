@@ -92,7 +92,10 @@ def contains_plane(env):
 
 
 def task_word(env):
-    """Fetch: target object as a cell code (type | color << 4)."""
+    """Fetch: target object as a cell code (type | color << 4).  GoToObject: tx | ty << 4 | (type - key) << 8 | color << 10."""
+    if type(env).__name__.startswith(("GoToObject", "GotoEnv")):
+        tx, ty = env.target_pos
+        return int(tx) | (int(ty) << 4) | ((M.OBJECT_TO_IDX[env.targetType] - 5) << 8) | (M.COLOR_TO_IDX[env.target_color] << 10)
     if hasattr(env, "targetType"):
         return M.OBJECT_TO_IDX[env.targetType] | (M.COLOR_TO_IDX[env.targetColor] << 4)
     return 0
@@ -292,7 +295,7 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
     meta = dict(env_id=name, W=W, H=H, max_steps=int(env0.max_steps), view=V,
                 see_through=bool(env0.see_through_walls), lava_v1=bool(v1), full_obs=bool(full_obs),
                 reseed=bool(reseed), extended=bool(n_actions > 7), alt_vis=not bool(env0.default_vis),
-                task=1 if hasattr(env0, "targetType") else (2 if hasattr(env0, "target_pos") else 0),
+                task=4 if type(env0).__name__.startswith(("GoToObject", "GotoEnv")) else (1 if hasattr(env0, "targetType") else (2 if hasattr(env0, "target_pos") else 0)),
                 objstate=bool(objstate), dynobs=int(getattr(env0, "n_obstacles", 0)), gym_id=gym_id or "")
     z = dict(
         seed=np.zeros(K, np.int64), init_grid=np.zeros((K, W, H, 3), np.uint8),
@@ -457,6 +460,7 @@ def record_flat():
     cases = [("MiniGrid-Empty-8x8-v0", [0], False), ("MiniGrid-DoorKey-5x5-v0", [1, 2], False),
              ("MiniGrid-Fetch-5x5-N2-v0", list(range(16)), False), ("MiniGrid-Fetch-8x8-N3-v0", list(range(8)), False),
              ("MiniGrid-GoToDoor-5x5-v0", [0, 1], False), ("MiniGrid-FourRooms-v0", [0], False),
+             ("MiniGrid-GoToObject-6x6-N2-v0", list(range(8)), False), ("MiniGrid-Dynamic-Obstacles-6x6-v0", [0, 1], False),
              ("MiniGrid-LavaCrossingS9N1-v0", [0], False), ("MiniGrid-SimpleCrossingS9N1-v0", [0], False),
              ("MiniGrid-MultiRoom-N2-S4-v0", [0], False), ("MiniGrid-Empty-5x5-v0", [0], True), ("MiniGrid-Fetch-5x5-N2-v0", [3, 4], True)]
     ids, seeds, fulls, acts, flats, missions = [], [], [], [], [], []
@@ -498,6 +502,7 @@ def record_levels():
                           ("MiniGrid-FourRooms-v0", range(128)), ("MiniGrid-Fetch-5x5-N2-v0", range(64)), ("MiniGrid-Fetch-6x6-N2-v0", range(64)),
                           ("MiniGrid-Fetch-8x8-N3-v0", range(128)), ("MiniGrid-GoToDoor-5x5-v0", range(64)),
                           ("MiniGrid-GoToDoor-6x6-v0", range(64)), ("MiniGrid-GoToDoor-8x8-v0", range(128)),
+                          ("MiniGrid-GoToObject-6x6-N2-v0", range(128)), ("MiniGrid-GoToObject-8x8-N2-v0", range(128)),
                           ("MiniGrid-MultiRoom-N4-S5-v0", range(128)), ("MiniGrid-MultiRoom-N6-v0", range(128)), ("MiniGrid-DistShift1-v0", range(2)),
                           ("MiniGrid-DistShift1-v1", range(2)), ("MiniGrid-DistShift2-v0", range(2)),
                           ("MiniGrid-LavaGapS5-v0", range(32)), ("MiniGrid-LavaGapS7-v0", range(64)),
@@ -630,6 +635,18 @@ def main():
     record_case("Fetch-5x5-N2", mk("MiniGrid-Fetch-5x5-N2-v0"), list(range(4)), 300, scripts=[fetch_script(1), fetch_script(0), None, None], reseed=False)
     record_case("GoToDoor-8x8", mk("MiniGrid-GoToDoor-8x8-v0"), list(range(8)), 400, scripts=[gotodoor_script(0), gotodoor_script(1)] * 2 + [None] * 4, reseed=False)
     record_case("GoToDoor-5x5", mk("MiniGrid-GoToDoor-5x5-v0"), list(range(4)), 300, scripts=[gotodoor_script(1), gotodoor_script(0), None, None], reseed=False)
+    def gotoobject_script(which):
+        def f(env):
+            # walk next to the target (which=0) or next to another object (which=1) and say `done`
+            objs = [(x, y) for x in range(env.width) for y in range(env.height)
+                    if env.grid.get(x, y) is not None and env.grid.get(x, y).type in ("key", "ball", "box")]
+            oth = [p for p in objs if tuple(p) != tuple(env.target_pos)]
+            pick = tuple(env.target_pos) if which == 0 or not oth else oth[0]
+            acts = plan_face(env, pick) or []
+            return acts + [6]
+        return f
+    record_case("GoToObject-8x8-N2", mk("MiniGrid-GoToObject-8x8-N2-v0"), list(range(8)), 400, scripts=[gotoobject_script(0), gotoobject_script(1)] * 2 + [None] * 4, reseed=False)
+    record_case("GoToObject-6x6-N2", mk("MiniGrid-GoToObject-6x6-N2-v0"), list(range(6)), 300, scripts=[gotoobject_script(1), gotoobject_script(0)] + [None] * 4, reseed=False)
     # plain reference semantics at the episode boundary: reset() WITHOUT re-seeding (a new level every episode)
     record_case("LavaCrossingS9N1-stream", mk("MiniGrid-LavaCrossingS9N1-v0"), list(range(6)), 500, reseed=False)
     record_case("DoorKey-5x5-stream", mk("MiniGrid-DoorKey-5x5-v0"), [0, 1, 2], 800, reseed=False)

@@ -369,6 +369,13 @@ static void task_rule(const mgo_cfg *cf, const uint8_t *g, const uint8_t *aux, c
                 if (c.c == 0) *reward = 1 - 0.9 * ((double)steps / (double)cf->max_steps); /* the target door is the red one */
             }
         }
+    } else if (cf->task == 4) { /* GoToObjectEnv.step envs/gotoobject.py:68-84; task = tx | ty << 4 | ... */
+        if (action == A_TOGGLE) *done = 1;
+        if (action == A_DONE) {
+            int dx = agent[0] - (int)(task & 15u), dy = agent[1] - (int)((task >> 4) & 15u);
+            if (dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1) *reward = 1 - 0.9 * ((double)steps / (double)cf->max_steps);
+            *done = 1;
+        }
     }
 }
 
