@@ -34,7 +34,8 @@ namespace {
 
 // Task rules that env subclasses layer on MiniGridEnv.step (they run after the base step, time-out included).
 template <int CH, class CellAt>
-__device__ __forceinline__ void task_rule(const StepParams &p, const Lane &L, uint32_t act, float &reward, bool &done, CellAt cell_at)
+__device__ __forceinline__ void task_rule(const StepParams &p, const Lane &L, uint32_t act, float &reward, bool &done, CellAt cell_at,
+                                          int fidx = -1, uint32_t fc = 0)
 {
     if (p.task == MGX_TASK_FETCH) { // envs/fetch.py:74-86
         if (L.carry != MGX_CODE_EMPTY) {
@@ -54,6 +55,14 @@ __device__ __forceinline__ void task_rule(const StepParams &p, const Lane &L, ui
                 if (door && ((n4[i] >> 4) & 7u) == 0u) reward = (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps));
             }
         }
+    } else if (p.task == MGX_TASK_REDBLUEDOORS) { // envs/redbluedoors.py:44-66; cell_at() is the state AFTER the step
+        const int H = CH ? CH : p.H;
+        const int ri = (H / 2) * H + (int)(L.task & 15u), bi = (H / 2 + H - 1) * H + (int)((L.task >> 4) & 15u);
+        const bool red_after = (cell_at(ri) & 15u) == MGX_K_DOOR_OPEN, blue_after = (cell_at(bi) & 15u) == MGX_K_DOOR_OPEN;
+        const bool red_before = ((ri == fidx ? fc : cell_at(ri)) & 15u) == MGX_K_DOOR_OPEN;
+        const bool blue_before = ((bi == fidx ? fc : cell_at(bi)) & 15u) == MGX_K_DOOR_OPEN;
+        if (blue_after) { reward = red_before ? (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps)) : 0.f; done = true; }
+        else if (red_after && blue_before) { reward = 0.f; done = true; }
     } else if (p.task == MGX_TASK_GOTOOBJECT) { // envs/gotoobject.py:68-84
         if (act == 5) done = true;              // "Toggle/pickup action terminates the episode"
         if (act == 6) {
@@ -568,7 +577,7 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
             const uint32_t nc = transition_apply<CH>(p, L, act, fc, reward, done, [&](int i) -> uint32_t { return row[i]; }, oob, fidx, obj);
             if constexpr (!GATHER) { if (nc != fc) g[fidx] = (uint8_t)nc; }
             if (valid && L.steps >= p.max_steps) done = true; // minigrid.py:1320-1321
-            if (p.task) task_rule<CH>(p, L, act, reward, done, [&](int i) -> uint32_t { return (GATHER && i == fidx) ? nc : (uint32_t)row[i]; });
+            if (p.task) task_rule<CH>(p, L, act, reward, done, [&](int i) -> uint32_t { return (GATHER && i == fidx) ? nc : (uint32_t)row[i]; }, fidx, fc);
             // the one cell a transition can change; skipped when the env is about to be restored anyway
             if (nc != fc && !(p.auto_reset && done)) { p.cells[env * S + fidx] = (uint8_t)nc; pidx = fidx; pcode = nc; }
         } else if (valid && L.steps >= p.max_steps) done = true;
@@ -667,7 +676,7 @@ __global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
                 const uint32_t nc = transition_apply<CH>(p, L, act, fc, reward, done,
                                                          [&](int i) -> uint32_t { return p.cells[env * S + i]; }, oob, fidx, obj);
                 if (valid && L.steps >= p.max_steps) done = true;
-                if (p.task) task_rule<CH>(p, L, act, reward, done, [&](int i) -> uint32_t { return (i == fidx) ? nc : (uint32_t)p.cells[env * S + i]; });
+                if (p.task) task_rule<CH>(p, L, act, reward, done, [&](int i) -> uint32_t { return (i == fidx) ? nc : (uint32_t)p.cells[env * S + i]; }, fidx, fc);
                 if (nc != fc && !(p.auto_reset && done)) {
                     p.cells[env * S + fidx] = (uint8_t)nc;
                     wr = (uint32_t)fidx | (nc << 16);

@@ -419,6 +419,35 @@ LG_FN void lg_gen_gotoobject(const mgx_config &c, R &r, LgLevel &L)
     L.task = (uint32_t)tc.x0 | ((uint32_t)tc.y0 << 4) | ((uint32_t)((tc.code & 15u) - MGX_K_KEY) << 8) | ((uint32_t)((tc.code >> 4) & 7u) << 10);
 }
 
+// RedBlueDoorEnv._gen_grid (envs/redbluedoors.py:20-42): a size x size room in the middle of a 2*size x size grid, random
+// agent inside it, a closed red door in its left wall and a closed blue one in its right wall.
+// task = red door y | blue door y << 4.
+template <class R>
+LG_FN void lg_gen_redbluedoors(const mgx_config &, R &r, LgLevel &L)
+{
+    const int s = L.H, x0 = s / 2, x1 = s / 2 + s - 1;
+    L.ncmd = 0;
+    lg_rect(L, 0, 0, L.W - 1, 0, MGX_CODE_WALL_GREY);            // wall_rect(0, 0, 2*size, size)
+    lg_rect(L, 0, L.H - 1, L.W - 1, L.H - 1, MGX_CODE_WALL_GREY);
+    lg_rect(L, 0, 0, 0, L.H - 1, MGX_CODE_WALL_GREY);
+    lg_rect(L, L.W - 1, 0, L.W - 1, L.H - 1, MGX_CODE_WALL_GREY);
+    lg_rect(L, x0, 0, x0, L.H - 1, MGX_CODE_WALL_GREY);          // wall_rect(size//2, 0, size, size): its two vertical walls
+    lg_rect(L, x1, 0, x1, L.H - 1, MGX_CODE_WALL_GREY);
+    L.ax = -1; L.ay = -1;
+    for (;;) { // place_agent(top=(size//2, 0), size=(size, size))
+        const int x = lg_randint(r, x0, x0 + s < L.W ? x0 + s : L.W), y = lg_randint(r, 0, s < L.H ? s : L.H);
+        if (!r.alive()) return;
+        if (!lg_empty(L, x, y)) continue;
+        L.ax = x; L.ay = y;
+        break;
+    }
+    L.adir = lg_randint(r, 0, 4);
+    const int ry = lg_randint(r, 1, s - 1), by = lg_randint(r, 1, s - 1);
+    lg_set(L, x0, ry, MGX_K_DOOR_CLOSED | (0u << 4));            // Door("red")
+    lg_set(L, x1, by, MGX_K_DOOR_CLOSED | (2u << 4));            // Door("blue")
+    L.task = (uint32_t)ry | ((uint32_t)by << 4);
+}
+
 // GoToDoorEnv._gen_grid (envs/gotodoor.py:23-69, as modified by the fork): four locked doors on the four walls in four
 // distinct colours, redrawn until one of them is red (the target); random agent.
 template <class R>
@@ -529,6 +558,7 @@ LG_FN void lg_generate(const mgx_config &c, R &r, LgLevel &L)
     case MGX_LEVEL_FOURROOMS: lg_gen_fourrooms(c, r, L); break;
     case MGX_LEVEL_DYNOBS: lg_gen_dynobs(c, r, L); break;
     case MGX_LEVEL_GOTOOBJECT: lg_gen_gotoobject(c, r, L); break;
+    case MGX_LEVEL_REDBLUEDOORS: lg_gen_redbluedoors(c, r, L); break;
     default: lg_gen_lavagap(c, r, L); break;
     }
 }

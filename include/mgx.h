@@ -100,7 +100,8 @@ typedef enum {
     MGX_LEVEL_MULTIROOM = 6, /* MultiRoomEnv (envs/multiroom.py): level_arg0 = minNumRooms | maxNumRooms << 8 (<= 8),
                                 level_arg1 = maxRoomSize */
     MGX_LEVEL_GOTOOBJECT = 11, /* GoToObjectEnv (envs/gotoobject.py): level_arg0 = numObjs; use with task_kind = MGX_TASK_GOTOOBJECT */
-    MGX_LEVEL_KIND_END = 12
+    MGX_LEVEL_REDBLUEDOORS = 12, /* RedBlueDoorEnv (envs/redbluedoors.py): width = 2*height; use with task_kind = MGX_TASK_REDBLUEDOORS */
+    MGX_LEVEL_KIND_END = 13
 } mgx_level_kind;
 
 /* task rules layered on MiniGridEnv.step by env subclasses (`step` overrides that only reshape reward/done) */
@@ -113,6 +114,9 @@ typedef enum {
     MGX_TASK_GOTOOBJECT = 4, /* envs/gotoobject.py:68-84: `toggle` ends the episode; `done` ends it and pays _reward() when the agent
                               is within one cell (Chebyshev) of the target's INITIAL position.  Per-env task word =
                               tx | ty << 4 | (type - key) << 8 | color << 10. */
+    MGX_TASK_REDBLUEDOORS = 5, /* envs/redbluedoors.py:44-66: the episode ends when the blue door is open after a step (reward
+                              _reward() iff the red one was open before it) or when the red one is open after a step that
+                              closed an open blue one.  Per-env task word = red door y | blue door y << 4. */
     MGX_TASK_DYNOBS = 3,   /* envs/dynamicobstacles.py:60-89 (with level_kind = MGX_LEVEL_DYNOBS): actions >= 3 fold to 0;
                               before the base step every obstacle (blue ball) is re-placed in its 3x3 neighbourhood with
                               draws from the env's own RNG stream (place_obj, max_tries=100); moving forward while the

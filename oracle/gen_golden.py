@@ -93,6 +93,10 @@ def contains_plane(env):
 
 def task_word(env):
     """Fetch: target object as a cell code (type | color << 4).  GoToObject: tx | ty << 4 | (type - key) << 8 | color << 10."""
+    if type(env).__name__.startswith("RedBlueDoor"):
+        ry = [y for y in range(env.height) if env.grid.get(env.size // 2, y) is env.red_door][0]
+        by = [y for y in range(env.height) if env.grid.get(env.size // 2 + env.size - 1, y) is env.blue_door][0]
+        return ry | (by << 4)
     if type(env).__name__.startswith(("GoToObject", "GotoEnv")):
         tx, ty = env.target_pos
         return int(tx) | (int(ty) << 4) | ((M.OBJECT_TO_IDX[env.targetType] - 5) << 8) | (M.COLOR_TO_IDX[env.target_color] << 10)
@@ -295,7 +299,7 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
     meta = dict(env_id=name, W=W, H=H, max_steps=int(env0.max_steps), view=V,
                 see_through=bool(env0.see_through_walls), lava_v1=bool(v1), full_obs=bool(full_obs),
                 reseed=bool(reseed), extended=bool(n_actions > 7), alt_vis=not bool(env0.default_vis),
-                task=4 if type(env0).__name__.startswith(("GoToObject", "GotoEnv")) else (1 if hasattr(env0, "targetType") else (2 if hasattr(env0, "target_pos") else 0)),
+                task=5 if type(env0).__name__.startswith("RedBlueDoor") else 4 if type(env0).__name__.startswith(("GoToObject", "GotoEnv")) else (1 if hasattr(env0, "targetType") else (2 if hasattr(env0, "target_pos") else 0)),
                 objstate=bool(objstate), dynobs=int(getattr(env0, "n_obstacles", 0)), gym_id=gym_id or "")
     z = dict(
         seed=np.zeros(K, np.int64), init_grid=np.zeros((K, W, H, 3), np.uint8),
@@ -503,6 +507,7 @@ def record_levels():
                           ("MiniGrid-Fetch-8x8-N3-v0", range(128)), ("MiniGrid-GoToDoor-5x5-v0", range(64)),
                           ("MiniGrid-GoToDoor-6x6-v0", range(64)), ("MiniGrid-GoToDoor-8x8-v0", range(128)),
                           ("MiniGrid-GoToObject-6x6-N2-v0", range(128)), ("MiniGrid-GoToObject-8x8-N2-v0", range(128)),
+                          ("MiniGrid-RedBlueDoors-6x6-v0", range(128)), ("MiniGrid-RedBlueDoors-8x8-v0", range(128)),
                           ("MiniGrid-MultiRoom-N4-S5-v0", range(128)), ("MiniGrid-MultiRoom-N6-v0", range(128)), ("MiniGrid-DistShift1-v0", range(2)),
                           ("MiniGrid-DistShift1-v1", range(2)), ("MiniGrid-DistShift2-v0", range(2)),
                           ("MiniGrid-LavaGapS5-v0", range(32)), ("MiniGrid-LavaGapS7-v0", range(64)),
@@ -645,6 +650,22 @@ def main():
             acts = plan_face(env, pick) or []
             return acts + [6]
         return f
+    def redblue_script(order):
+        def f(env):
+            # open the doors in the given order ("rb" pays, "br" does not), closing nothing
+            acts = []
+            scratch = env
+            for ch in order:
+                door = scratch.red_door if ch == "r" else scratch.blue_door
+                pos = [(x, y) for x in range(scratch.width) for y in range(scratch.height) if scratch.grid.get(x, y) is door][0]
+                a = plan_face(scratch, pos) or []
+                for k in a + [5]:
+                    scratch.step(k)
+                acts += a + [5]
+            return acts
+        return f
+    record_case("RedBlueDoors-8x8", mk("MiniGrid-RedBlueDoors-8x8-v0"), list(range(8)), 500, scripts=[redblue_script("rb"), redblue_script("br"), redblue_script("rrb"), redblue_script("b")] + [None] * 4, reseed=False)
+    record_case("RedBlueDoors-6x6", mk("MiniGrid-RedBlueDoors-6x6-v0"), list(range(6)), 400, scripts=[redblue_script("br"), redblue_script("rb")] + [None] * 4, reseed=False)
     record_case("GoToObject-8x8-N2", mk("MiniGrid-GoToObject-8x8-N2-v0"), list(range(8)), 400, scripts=[gotoobject_script(0), gotoobject_script(1)] * 2 + [None] * 4, reseed=False)
     record_case("GoToObject-6x6-N2", mk("MiniGrid-GoToObject-6x6-N2-v0"), list(range(6)), 300, scripts=[gotoobject_script(1), gotoobject_script(0)] + [None] * 4, reseed=False)
     # plain reference semantics at the episode boundary: reset() WITHOUT re-seeding (a new level every episode)

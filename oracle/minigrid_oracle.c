@@ -346,8 +346,15 @@ static int step_state(const mgo_cfg *cf, uint8_t *g, uint8_t *aux, int32_t *agen
 }
 
 /* step() overrides that only reshape reward/done after MiniGridEnv.step.  task word: Fetch = target (type | color<<4). */
+/* RedBlueDoors: is the door at (x, y) open?  (Door.encode: state 0 = open, minigrid.py:264-275) */
+static int door_open(const mgo_cfg *cf, const uint8_t *g, int x, int y)
+{
+    const uint8_t *t = g + ((size_t)x * cf->H + y) * 3;
+    return t[0] == T_DOOR && t[2] == ST_OPEN;
+}
+
 static void task_rule(const mgo_cfg *cf, const uint8_t *g, const uint8_t *aux, const int32_t *agent, const uint8_t *carry,
-                      int32_t steps, uint32_t task, int action, double *reward, uint8_t *done)
+                      int32_t steps, uint32_t task, int action, double *reward, uint8_t *done, int pre)
 {
     if (cf->task == 1) {
         if (carry[0] != T_EMPTY) { /* if self.carrying: */
@@ -369,6 +376,11 @@ static void task_rule(const mgo_cfg *cf, const uint8_t *g, const uint8_t *aux, c
                 if (c.c == 0) *reward = 1 - 0.9 * ((double)steps / (double)cf->max_steps); /* the target door is the red one */
             }
         }
+    } else if (cf->task == 5) { /* RedBlueDoorEnv.step envs/redbluedoors.py:44-66; pre = red | blue << 1 before the step */
+        const int rx = cf->H / 2, bx = cf->H / 2 + cf->H - 1;
+        const int red_after = door_open(cf, g, rx, (int)(task & 15u)), blue_after = door_open(cf, g, bx, (int)((task >> 4) & 15u));
+        if (blue_after) { *reward = (pre & 1) ? 1 - 0.9 * ((double)steps / (double)cf->max_steps) : 0; *done = 1; }
+        else if (red_after && (pre & 2)) { *reward = 0; *done = 1; }
     } else if (cf->task == 4) { /* GoToObjectEnv.step envs/gotoobject.py:68-84; task = tx | ty << 4 | ... */
         if (action == A_TOGGLE) *done = 1;
         if (action == A_DONE) {
@@ -395,11 +407,14 @@ int mgo_step_batch(const mgo_cfg *cf, int64_t n, uint8_t *grid, uint8_t *aux, in
     int first = 0;
     for (int64_t e = 0; e < n; e++) {
         uint8_t *g = grid + e * cells * 3, *ax = aux + e * cells;
+        int pre = 0;
+        if (cf->task == 5 && g_task)
+            pre = door_open(cf, g, cf->H / 2, (int)(g_task[e] & 15u)) | (door_open(cf, g, cf->H / 2 + cf->H - 1, (int)((g_task[e] >> 4) & 15u)) << 1);
         int rc = step_state(cf, g, ax, agent + e * 3, carry + e * 3, carry_aux + e, steps + e,
                             actions[e], reward + e, done + e,
                             g_contains ? g_contains + e * cells * 3 : 0, g_carry_contains ? g_carry_contains + e * 3 : 0);
         if (cf->task && rc == MGO_OK)
-            task_rule(cf, g, ax, agent + e * 3, carry + e * 3, steps[e], g_task ? g_task[e] : 0u, actions[e], reward + e, done + e);
+            task_rule(cf, g, ax, agent + e * 3, carry + e * 3, steps[e], g_task ? g_task[e] : 0u, actions[e], reward + e, done + e, pre);
         if (err) err[e] = rc;
         if (rc && !first) first = rc;
         if (obs) gen_obs(cf, g, ax, agent + e * 3, carry + e * 3, obs + e * (cf->view * cf->view * 3));
