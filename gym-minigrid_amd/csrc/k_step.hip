@@ -63,6 +63,11 @@ __device__ __forceinline__ void task_rule(const StepParams &p, const Lane &L, ui
         const bool blue_before = ((bi == fidx ? fc : cell_at(bi)) & 15u) == MGX_K_DOOR_OPEN;
         if (blue_after) { reward = red_before ? (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps)) : 0.f; done = true; }
         else if (red_after && blue_before) { reward = 0.f; done = true; }
+    } else if (p.task == MGX_TASK_MEMORY) { // envs/memory.py:92-99 (the pickup -> toggle remap happens where the action is loaded)
+        const int H = CH ? CH : p.H;
+        const int tx = (int)(L.task & 15u), sy = ((L.task >> 4) & 1u) ? H / 2 - 1 : H / 2 + 1, fy = ((L.task >> 4) & 1u) ? H / 2 + 1 : H / 2 - 1;
+        if (L.ax == tx && L.ay == sy) { reward = (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps)); done = true; }
+        if (L.ax == tx && L.ay == fy) { reward = 0.f; done = true; }
     } else if (p.task == MGX_TASK_GOTOOBJECT) { // envs/gotoobject.py:68-84
         if (act == 5) done = true;              // "Toggle/pickup action terminates the episode"
         if (act == 6) {
@@ -552,6 +557,7 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
     if (p.do_step && valid) act = __builtin_nontemporal_load(&p.actions[env]);
     const bool crash = p.task == MGX_TASK_DYNOBS && (act & 0x80u); // k_dynobs' verdict rides on the folded action
     if (p.task == MGX_TASK_DYNOBS) act &= 0x7Fu;
+    if (p.task == MGX_TASK_MEMORY && act == 3u) act = 5u; // `if action == pickup: action = toggle` (envs/memory.py:89-90)
     // MODE 3 (large grids): no tile image in LDS -- at 25x25 it would be 40 KB per wave and leave 4 waves per CU; each
     // lane gathers its forward cell and its VxV view straight from its row in HBM/L2 instead (50 byte loads).
     constexpr bool GATHER = MODE == 3;
@@ -663,6 +669,7 @@ __global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
         if (p.do_step && valid) act = __builtin_nontemporal_load(&p.actions[env]);
         const bool crash = p.task == MGX_TASK_DYNOBS && (act & 0x80u);
         if (p.task == MGX_TASK_DYNOBS) act &= 0x7Fu;
+        if (p.task == MGX_TASK_MEMORY && act == 3u) act = 5u;
         float reward = 0.f;
         bool done = false, bad_act = false, oob = false, reset = false;
         uint32_t wr = 0, changed = 0;

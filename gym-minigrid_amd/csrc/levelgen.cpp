@@ -159,6 +159,9 @@ int check_levelgen_cfg(const mgx_config *cfg, const char *fn)
         if ((W - 3) / 2 > MGX_LG_MAX_RIVERS || (H - 3) / 2 > MGX_LG_MAX_RIVERS)
             return mgx_fail(MGX_ERR_UNSUPPORTED, "%s: crossing grid %dx%d has more than %d candidate rivers per axis", fn, W, H, MGX_LG_MAX_RIVERS);
         break;
+    case MGX_LEVEL_MEMORY:
+        if (W != H || !(H & 1) || H < 7 || H > 17) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: Memory grids are odd squares of 7..17", fn);
+        break;
     case MGX_LEVEL_REDBLUEDOORS:
         if (W != 2 * H || H < 4 || H > 16 || (H & 1))
             return mgx_fail(MGX_ERR_INVALID_ARG, "%s: RedBlueDoors grids are 2*size x size with an even size of 4..16", fn);
@@ -249,6 +252,13 @@ const std::vector<EnvId> &registry()
         // RedBlueDoorEnv: 2*size x size, max_steps = 20*size^2 (envs/redbluedoors.py:11-18)
         {"MiniGrid-RedBlueDoors-6x6-v0", mkt(12, 6, 720, 0, MGX_LEVEL_REDBLUEDOORS, 0, MGX_TASK_REDBLUEDOORS)},
         {"MiniGrid-RedBlueDoors-8x8-v0", mkt(16, 8, 1280, 0, MGX_LEVEL_REDBLUEDOORS, 0, MGX_TASK_REDBLUEDOORS)},
+        // MemoryEnv: max_steps = 5*size^2 (envs/memory.py:14-27,103-154)
+        {"MiniGrid-MemoryS7-v0", mkt(7, 7, 245, 0, MGX_LEVEL_MEMORY, 0, MGX_TASK_MEMORY)},
+        {"MiniGrid-MemoryS9-v0", mkt(9, 9, 405, 0, MGX_LEVEL_MEMORY, 0, MGX_TASK_MEMORY)},
+        {"MiniGrid-MemoryS11-v0", mkt(11, 11, 605, 0, MGX_LEVEL_MEMORY, 0, MGX_TASK_MEMORY)},
+        {"MiniGrid-MemoryS13-v0", mkt(13, 13, 845, 0, MGX_LEVEL_MEMORY, 0, MGX_TASK_MEMORY)},
+        {"MiniGrid-MemoryS13Random-v0", mkt(13, 13, 845, 0, MGX_LEVEL_MEMORY, 1, MGX_TASK_MEMORY)},
+        {"MiniGrid-MemoryS17Random-v0", mkt(17, 17, 1445, 0, MGX_LEVEL_MEMORY, 1, MGX_TASK_MEMORY)},
         // FourRoomsEnv: 19x19, max_steps=500 (envs/fourrooms.py:14-17)
         {"MiniGrid-FourRooms-v0", mk(19, 19, 500, 0, 0, MGX_LEVEL_FOURROOMS, 0, 0)},
         // MultiRoomEnv: 25x25, max_steps = maxNumRooms*20 (envs/multiroom.py:36-39,223-246)
@@ -298,6 +308,7 @@ extern "C" int mgx_mission(const mgx_config *cfg, uint32_t task, char *out, int 
     case MGX_LEVEL_GOTODOOR: m = "go to the red door"; break;                                               // envs/gotodoor.py:70 (the fork's target is always red)
     case MGX_LEVEL_DYNOBS: m = "get to the green goal square"; break;                                      // envs/dynamicobstacles.py:58
     case MGX_LEVEL_REDBLUEDOORS: m = "open the red door then the blue door"; break;                        // envs/redbluedoors.py:42
+    case MGX_LEVEL_MEMORY: m = "go to the matching object at the end of the hallway"; break;              // envs/memory.py:86
     case MGX_LEVEL_FOURROOMS: m = "Reach the goal"; break;                                                  // envs/fourrooms.py:69
     case MGX_LEVEL_GOTOOBJECT: {                                                                            // envs/gotoobject.py:63-64
         static const char *const types[3] = {"key", "ball", "box"};

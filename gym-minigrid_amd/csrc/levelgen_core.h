@@ -448,6 +448,42 @@ LG_FN void lg_gen_redbluedoors(const mgx_config &, R &r, LgLevel &L)
     L.task = (uint32_t)ry | ((uint32_t)by << 4);
 }
 
+// MemoryEnv._gen_grid (envs/memory.py:29-86): start room on the left with a green key or ball, a hallway to a split with a
+// green key and a green ball; the matching one marks the success cell.  Draw order: hallway_end (random_length only),
+// agent x, start object, order of the two objects at the split.  task = x of the success/failure cells | upper << 4.
+#define MGX_CODE_KEY_GREEN (MGX_K_KEY | (1u << 4))
+#define MGX_CODE_BALL_GREEN (MGX_K_BALL | (1u << 4))
+template <class R>
+LG_FN void lg_gen_memory(const mgx_config &c, R &r, LgLevel &L)
+{
+    const int W = L.W, H = L.H, mid = H / 2, up = mid - 2, lo = mid + 2;
+    L.ncmd = 0;
+    lg_rect(L, 0, 0, W - 1, 0, MGX_CODE_WALL_GREY);
+    lg_rect(L, 0, H - 1, W - 1, H - 1, MGX_CODE_WALL_GREY);
+    lg_rect(L, 0, 0, 0, H - 1, MGX_CODE_WALL_GREY);
+    lg_rect(L, W - 1, 0, W - 1, H - 1, MGX_CODE_WALL_GREY);
+    const int he = c.level_arg0 ? lg_randint(r, 4, W - 2) : W - 3; // hallway_end
+    lg_rect(L, 1, up, 4, up, MGX_CODE_WALL_GREY);                  // start room
+    lg_rect(L, 1, lo, 4, lo, MGX_CODE_WALL_GREY);
+    lg_set(L, 4, up + 1, MGX_CODE_WALL_GREY);
+    lg_set(L, 4, lo - 1, MGX_CODE_WALL_GREY);
+    if (he > 5) {                                                  // horizontal hallway: i in range(5, hallway_end)
+        lg_rect(L, 5, up + 1, he - 1, up + 1, MGX_CODE_WALL_GREY);
+        lg_rect(L, 5, lo - 1, he - 1, lo - 1, MGX_CODE_WALL_GREY);
+    }
+    lg_rect(L, he, 0, he, mid - 1, MGX_CODE_WALL_GREY);            // vertical hallway, open at mid
+    lg_rect(L, he, mid + 1, he, H - 1, MGX_CODE_WALL_GREY);
+    lg_rect(L, he + 2, 0, he + 2, H - 1, MGX_CODE_WALL_GREY);
+    L.ax = lg_randint(r, 1, he + 1); L.ay = mid; L.adir = 0;
+    const int start_ball = lg_randint(r, 0, 2);                    // _rand_elem([Key, Ball])
+    lg_set(L, 1, mid - 1, start_ball ? MGX_CODE_BALL_GREEN : MGX_CODE_KEY_GREEN);
+    const int key_first = lg_randint(r, 0, 2);                     // _rand_elem([[Ball, Key], [Key, Ball]])
+    lg_set(L, he + 1, mid - 2, key_first ? MGX_CODE_KEY_GREEN : MGX_CODE_BALL_GREEN);
+    lg_set(L, he + 1, mid + 2, key_first ? MGX_CODE_BALL_GREEN : MGX_CODE_KEY_GREEN);
+    const bool upper = (start_ball != 0) == (key_first == 0);      // start_room_obj == other_objs[0]
+    L.task = (uint32_t)(he + 1) | ((uint32_t)upper << 4);
+}
+
 // GoToDoorEnv._gen_grid (envs/gotodoor.py:23-69, as modified by the fork): four locked doors on the four walls in four
 // distinct colours, redrawn until one of them is red (the target); random agent.
 template <class R>
@@ -559,6 +595,7 @@ LG_FN void lg_generate(const mgx_config &c, R &r, LgLevel &L)
     case MGX_LEVEL_DYNOBS: lg_gen_dynobs(c, r, L); break;
     case MGX_LEVEL_GOTOOBJECT: lg_gen_gotoobject(c, r, L); break;
     case MGX_LEVEL_REDBLUEDOORS: lg_gen_redbluedoors(c, r, L); break;
+    case MGX_LEVEL_MEMORY: lg_gen_memory(c, r, L); break;
     default: lg_gen_lavagap(c, r, L); break;
     }
 }

@@ -240,7 +240,7 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     if (cfg->width < 3 || cfg->height < 3 || cfg->width > 255 || cfg->height > 255)
         return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: grid %dx%d outside 3..255 (Grid.__init__ asserts >= 3)", cfg->width, cfg->height);
     if (cfg->max_steps <= 0) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: max_steps must be positive");
-    if (cfg->task_kind < MGX_TASK_NONE || cfg->task_kind > MGX_TASK_REDBLUEDOORS)
+    if (cfg->task_kind < MGX_TASK_NONE || cfg->task_kind > MGX_TASK_MEMORY)
         return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: bad task_kind %d", cfg->task_kind);
     if ((cfg->task_kind == MGX_TASK_DYNOBS) != (cfg->level_kind == MGX_LEVEL_DYNOBS))
         return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: MGX_TASK_DYNOBS and MGX_LEVEL_DYNOBS go together (the obstacle walk continues the level's RNG stream)");

@@ -101,7 +101,9 @@ typedef enum {
                                 level_arg1 = maxRoomSize */
     MGX_LEVEL_GOTOOBJECT = 11, /* GoToObjectEnv (envs/gotoobject.py): level_arg0 = numObjs; use with task_kind = MGX_TASK_GOTOOBJECT */
     MGX_LEVEL_REDBLUEDOORS = 12, /* RedBlueDoorEnv (envs/redbluedoors.py): width = 2*height; use with task_kind = MGX_TASK_REDBLUEDOORS */
-    MGX_LEVEL_KIND_END = 13
+    MGX_LEVEL_MEMORY = 13,   /* MemoryEnv (envs/memory.py): odd square grids 7..17, level_arg0 = random_length; use with
+                                task_kind = MGX_TASK_MEMORY */
+    MGX_LEVEL_KIND_END = 14
 } mgx_level_kind;
 
 /* task rules layered on MiniGridEnv.step by env subclasses (`step` overrides that only reshape reward/done) */
@@ -117,6 +119,9 @@ typedef enum {
     MGX_TASK_REDBLUEDOORS = 5, /* envs/redbluedoors.py:44-66: the episode ends when the blue door is open after a step (reward
                               _reward() iff the red one was open before it) or when the red one is open after a step that
                               closed an open blue one.  Per-env task word = red door y | blue door y << 4. */
+    MGX_TASK_MEMORY = 6,   /* envs/memory.py:88-101: `pickup` acts as `toggle`; standing on the success / failure cell at the
+                              end of the hallway ends the episode (reward _reward() / 0).  Per-env task word = x of those
+                              cells | (success is the upper one) << 4. */
     MGX_TASK_DYNOBS = 3,   /* envs/dynamicobstacles.py:60-89 (with level_kind = MGX_LEVEL_DYNOBS): actions >= 3 fold to 0;
                               before the base step every obstacle (blue ball) is re-placed in its 3x3 neighbourhood with
                               draws from the env's own RNG stream (place_obj, max_tries=100); moving forward while the

@@ -93,6 +93,8 @@ def contains_plane(env):
 
 def task_word(env):
     """Fetch: target object as a cell code (type | color << 4).  GoToObject: tx | ty << 4 | (type - key) << 8 | color << 10."""
+    if type(env).__name__.startswith("Memory"):
+        return int(env.success_pos[0]) | (int(env.success_pos[1] < env.height // 2) << 4)
     if type(env).__name__.startswith("RedBlueDoor"):
         ry = [y for y in range(env.height) if env.grid.get(env.size // 2, y) is env.red_door][0]
         by = [y for y in range(env.height) if env.grid.get(env.size // 2 + env.size - 1, y) is env.blue_door][0]
@@ -299,7 +301,7 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
     meta = dict(env_id=name, W=W, H=H, max_steps=int(env0.max_steps), view=V,
                 see_through=bool(env0.see_through_walls), lava_v1=bool(v1), full_obs=bool(full_obs),
                 reseed=bool(reseed), extended=bool(n_actions > 7), alt_vis=not bool(env0.default_vis),
-                task=5 if type(env0).__name__.startswith("RedBlueDoor") else 4 if type(env0).__name__.startswith(("GoToObject", "GotoEnv")) else (1 if hasattr(env0, "targetType") else (2 if hasattr(env0, "target_pos") else 0)),
+                task=6 if type(env0).__name__.startswith("Memory") else 5 if type(env0).__name__.startswith("RedBlueDoor") else 4 if type(env0).__name__.startswith(("GoToObject", "GotoEnv")) else (1 if hasattr(env0, "targetType") else (2 if hasattr(env0, "target_pos") else 0)),
                 objstate=bool(objstate), dynobs=int(getattr(env0, "n_obstacles", 0)), gym_id=gym_id or "")
     z = dict(
         seed=np.zeros(K, np.int64), init_grid=np.zeros((K, W, H, 3), np.uint8),
@@ -508,6 +510,8 @@ def record_levels():
                           ("MiniGrid-GoToDoor-6x6-v0", range(64)), ("MiniGrid-GoToDoor-8x8-v0", range(128)),
                           ("MiniGrid-GoToObject-6x6-N2-v0", range(128)), ("MiniGrid-GoToObject-8x8-N2-v0", range(128)),
                           ("MiniGrid-RedBlueDoors-6x6-v0", range(128)), ("MiniGrid-RedBlueDoors-8x8-v0", range(128)),
+                          ("MiniGrid-MemoryS7-v0", range(64)), ("MiniGrid-MemoryS9-v0", range(64)), ("MiniGrid-MemoryS11-v0", range(64)),
+                          ("MiniGrid-MemoryS13-v0", range(64)), ("MiniGrid-MemoryS13Random-v0", range(128)), ("MiniGrid-MemoryS17Random-v0", range(128)),
                           ("MiniGrid-MultiRoom-N4-S5-v0", range(128)), ("MiniGrid-MultiRoom-N6-v0", range(128)), ("MiniGrid-DistShift1-v0", range(2)),
                           ("MiniGrid-DistShift1-v1", range(2)), ("MiniGrid-DistShift2-v0", range(2)),
                           ("MiniGrid-LavaGapS5-v0", range(32)), ("MiniGrid-LavaGapS7-v0", range(64)),
@@ -666,6 +670,16 @@ def main():
         return f
     record_case("RedBlueDoors-8x8", mk("MiniGrid-RedBlueDoors-8x8-v0"), list(range(8)), 500, scripts=[redblue_script("rb"), redblue_script("br"), redblue_script("rrb"), redblue_script("b")] + [None] * 4, reseed=False)
     record_case("RedBlueDoors-6x6", mk("MiniGrid-RedBlueDoors-6x6-v0"), list(range(6)), 400, scripts=[redblue_script("br"), redblue_script("rb")] + [None] * 4, reseed=False)
+    def memory_script(which):
+        def f(env):
+            # walk down the hallway to the success (0) or failure (1) cell
+            tgt = tuple(env.success_pos if which == 0 else env.failure_pos)
+            acts = plan_face(env, tgt) or []
+            return acts + [3, 2]   # a pickup (= toggle here) at the wall of objects, then step onto the cell
+        return f
+    record_case("MemoryS7", mk("MiniGrid-MemoryS7-v0"), list(range(6)), 300, scripts=[memory_script(0), memory_script(1)] + [None] * 4, reseed=False)
+    record_case("MemoryS13Random", mk("MiniGrid-MemoryS13Random-v0"), list(range(8)), 500, scripts=[memory_script(0), memory_script(1)] * 2 + [None] * 4, reseed=False)
+    record_case("MemoryS17Random", mk("MiniGrid-MemoryS17Random-v0"), list(range(4)), 400, scripts=[memory_script(1), memory_script(0), None, None], reseed=False)
     record_case("GoToObject-8x8-N2", mk("MiniGrid-GoToObject-8x8-N2-v0"), list(range(8)), 400, scripts=[gotoobject_script(0), gotoobject_script(1)] * 2 + [None] * 4, reseed=False)
     record_case("GoToObject-6x6-N2", mk("MiniGrid-GoToObject-6x6-N2-v0"), list(range(6)), 300, scripts=[gotoobject_script(1), gotoobject_script(0)] + [None] * 4, reseed=False)
     # plain reference semantics at the episode boundary: reset() WITHOUT re-seeding (a new level every episode)

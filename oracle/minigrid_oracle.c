@@ -376,6 +376,11 @@ static void task_rule(const mgo_cfg *cf, const uint8_t *g, const uint8_t *aux, c
                 if (c.c == 0) *reward = 1 - 0.9 * ((double)steps / (double)cf->max_steps); /* the target door is the red one */
             }
         }
+    } else if (cf->task == 6) { /* MemoryEnv.step envs/memory.py:92-99; task = x of the two end cells | (success is the upper one) << 4 */
+        const int tx = (int)(task & 15u), up = (int)((task >> 4) & 1u);
+        const int sy = up ? cf->H / 2 - 1 : cf->H / 2 + 1, fy = up ? cf->H / 2 + 1 : cf->H / 2 - 1;
+        if (agent[0] == tx && agent[1] == sy) { *reward = 1 - 0.9 * ((double)steps / (double)cf->max_steps); *done = 1; }
+        if (agent[0] == tx && agent[1] == fy) { *reward = 0; *done = 1; }
     } else if (cf->task == 5) { /* RedBlueDoorEnv.step envs/redbluedoors.py:44-66; pre = red | blue << 1 before the step */
         const int rx = cf->H / 2, bx = cf->H / 2 + cf->H - 1;
         const int red_after = door_open(cf, g, rx, (int)(task & 15u)), blue_after = door_open(cf, g, bx, (int)((task >> 4) & 15u));
@@ -410,11 +415,12 @@ int mgo_step_batch(const mgo_cfg *cf, int64_t n, uint8_t *grid, uint8_t *aux, in
         int pre = 0;
         if (cf->task == 5 && g_task)
             pre = door_open(cf, g, cf->H / 2, (int)(g_task[e] & 15u)) | (door_open(cf, g, cf->H / 2 + cf->H - 1, (int)((g_task[e] >> 4) & 15u)) << 1);
+        const int act_e = (cf->task == 6 && actions[e] == A_PICKUP) ? A_TOGGLE : actions[e]; /* envs/memory.py:89-90 */
         int rc = step_state(cf, g, ax, agent + e * 3, carry + e * 3, carry_aux + e, steps + e,
-                            actions[e], reward + e, done + e,
+                            act_e, reward + e, done + e,
                             g_contains ? g_contains + e * cells * 3 : 0, g_carry_contains ? g_carry_contains + e * 3 : 0);
         if (cf->task && rc == MGO_OK)
-            task_rule(cf, g, ax, agent + e * 3, carry + e * 3, steps[e], g_task ? g_task[e] : 0u, actions[e], reward + e, done + e, pre);
+            task_rule(cf, g, ax, agent + e * 3, carry + e * 3, steps[e], g_task ? g_task[e] : 0u, act_e, reward + e, done + e, pre);
         if (err) err[e] = rc;
         if (rc && !first) first = rc;
         if (obs) gen_obs(cf, g, ax, agent + e * 3, carry + e * 3, obs + e * (cf->view * cf->view * 3));
