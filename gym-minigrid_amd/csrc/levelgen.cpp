@@ -159,6 +159,9 @@ int check_levelgen_cfg(const mgx_config *cfg, const char *fn)
         if ((W - 3) / 2 > MGX_LG_MAX_RIVERS || (H - 3) / 2 > MGX_LG_MAX_RIVERS)
             return mgx_fail(MGX_ERR_UNSUPPORTED, "%s: crossing grid %dx%d has more than %d candidate rivers per axis", fn, W, H, MGX_LG_MAX_RIVERS);
         break;
+    case MGX_LEVEL_UNLOCK:
+        if (W != 11 || H != 6 || cfg->level_arg0 < 0 || cfg->level_arg0 > 2) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: the Unlock family is 11x6 with variant 0..2", fn);
+        break;
     case MGX_LEVEL_MEMORY:
         if (W != H || !(H & 1) || H < 7 || H > 17) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: Memory grids are odd squares of 7..17", fn);
         break;
@@ -259,6 +262,10 @@ const std::vector<EnvId> &registry()
         {"MiniGrid-MemoryS13-v0", mkt(13, 13, 845, 0, MGX_LEVEL_MEMORY, 0, MGX_TASK_MEMORY)},
         {"MiniGrid-MemoryS13Random-v0", mkt(13, 13, 845, 0, MGX_LEVEL_MEMORY, 1, MGX_TASK_MEMORY)},
         {"MiniGrid-MemoryS17Random-v0", mkt(17, 17, 1445, 0, MGX_LEVEL_MEMORY, 1, MGX_TASK_MEMORY)},
+        // Unlock / UnlockPickup / BlockedUnlockPickup: RoomGrid 1x2 of 6x6 rooms, max_steps = 8 (16) * room_size^2
+        {"MiniGrid-Unlock-v0", mkt(11, 6, 288, 0, MGX_LEVEL_UNLOCK, 0, MGX_TASK_UNLOCK)},
+        {"MiniGrid-UnlockPickup-v0", mkt(11, 6, 288, 0, MGX_LEVEL_UNLOCK, 1, MGX_TASK_PICKUPBOX)},
+        {"MiniGrid-BlockedUnlockPickup-v0", mkt(11, 6, 576, 0, MGX_LEVEL_UNLOCK, 2, MGX_TASK_PICKUPBOX)},
         // FourRoomsEnv: 19x19, max_steps=500 (envs/fourrooms.py:14-17)
         {"MiniGrid-FourRooms-v0", mk(19, 19, 500, 0, 0, MGX_LEVEL_FOURROOMS, 0, 0)},
         // MultiRoomEnv: 25x25, max_steps = maxNumRooms*20 (envs/multiroom.py:36-39,223-246)
@@ -309,6 +316,14 @@ extern "C" int mgx_mission(const mgx_config *cfg, uint32_t task, char *out, int 
     case MGX_LEVEL_DYNOBS: m = "get to the green goal square"; break;                                      // envs/dynamicobstacles.py:58
     case MGX_LEVEL_REDBLUEDOORS: m = "open the red door then the blue door"; break;                        // envs/redbluedoors.py:42
     case MGX_LEVEL_MEMORY: m = "go to the matching object at the end of the hallway"; break;              // envs/memory.py:86
+    case MGX_LEVEL_UNLOCK:                                                                                  // envs/unlock.py:31, unlockpickup.py:33
+        if (cfg->level_arg0 == 0) m = "open the door";
+        else {
+            if ((task & 7u) > 6) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_mission: 0x%x is not a box colour", task);
+            snprintf(buf, sizeof buf, "pick up the %s box", colors[task & 7u]);
+            m = buf;
+        }
+        break;
     case MGX_LEVEL_FOURROOMS: m = "Reach the goal"; break;                                                  // envs/fourrooms.py:69
     case MGX_LEVEL_GOTOOBJECT: {                                                                            // envs/gotoobject.py:63-64
         static const char *const types[3] = {"key", "ball", "box"};

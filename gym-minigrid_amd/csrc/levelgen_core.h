@@ -484,6 +484,64 @@ LG_FN void lg_gen_memory(const mgx_config &c, R &r, LgLevel &L)
     L.task = (uint32_t)(he + 1) | ((uint32_t)upper << 4);
 }
 
+// RoomGrid(num_rows=1, num_cols=2, room_size=6) (roomgrid.py:118-166) with the _gen_grid of Unlock / UnlockPickup /
+// BlockedUnlockPickup (envs/unlock.py:21-31, unlockpickup.py:21-33, blockedunlockpickup.py:22-37).  variant = level_arg0.
+// RoomGrid parks the agent in the middle of the grid, (8, 3), while the objects are placed: place_obj rejects that cell
+// and reject_next_to (roomgrid.py:3-12) every cell at Manhattan distance < 2 of it.
+template <class R>
+LG_FN bool lg_roomgrid_place(R &r, LgLevel &L, int tx, int ty, int *ox, int *oy)
+{
+    for (;;) { // place_obj(obj, room.top, room.size, reject_fn=reject_next_to)
+        const int x = lg_randint(r, tx, tx + 6 < L.W ? tx + 6 : L.W), y = lg_randint(r, ty, ty + 6 < L.H ? ty + 6 : L.H);
+        if (!r.alive()) return false;
+        if (!lg_empty(L, x, y)) continue;
+        const int dx = x > 8 ? x - 8 : 8 - x, dy = y > 3 ? y - 3 : 3 - y;
+        if (dx + dy < 2) continue; // (covers pos == agent_pos as well)
+        *ox = x; *oy = y;
+        return true;
+    }
+}
+
+template <class R>
+LG_FN void lg_gen_unlock(const mgx_config &c, R &r, LgLevel &L)
+{
+    const int variant = c.level_arg0;
+    L.ncmd = 0;
+    for (int i = 0; i < 2; i++) { // wall_rect of room (i, 0): top (5 i, 0), size 6 x 6
+        const int x0 = 5 * i;
+        lg_rect(L, x0, 0, x0 + 5, 0, MGX_CODE_WALL_GREY);
+        lg_rect(L, x0, 5, x0 + 5, 5, MGX_CODE_WALL_GREY);
+        lg_rect(L, x0, 0, x0, 5, MGX_CODE_WALL_GREY);
+        lg_rect(L, x0 + 5, 0, x0 + 5, 5, MGX_CODE_WALL_GREY);
+    }
+    const int door_y = lg_randint(r, 1, 5); // room(0,0).door_pos[0] = (x_m, _rand_int(y_l, y_m))
+    int x, y, box_color = 0;
+    if (variant >= 1) { // add_object(1, 0, kind="box"): colour, then a place in the right room
+        box_color = lg_sorted_color(lg_randint(r, 0, 7));
+        if (!lg_roomgrid_place(r, L, 5, 0, &x, &y)) return;
+        lg_set(L, x, y, MGX_K_BOX | ((uint32_t)box_color << 4));
+    }
+    const int door_color = lg_sorted_color(lg_randint(r, 0, 7)); // add_door(0, 0, 0, locked=True): colour
+    lg_set(L, 5, door_y, MGX_K_DOOR_LOCKED | ((uint32_t)door_color << 4));
+    if (variant == 2) { // the ball that blocks the door
+        const int ball_color = lg_sorted_color(lg_randint(r, 0, 7));
+        lg_set(L, 4, door_y, MGX_K_BALL | ((uint32_t)ball_color << 4));
+    }
+    if (!lg_roomgrid_place(r, L, 0, 0, &x, &y)) return;          // add_object(0, 0, 'key', door.color)
+    lg_set(L, x, y, MGX_K_KEY | ((uint32_t)door_color << 4));
+    for (;;) { // RoomGrid.place_agent(0, 0): a free cell of the left room whose front cell is empty or a wall
+        const int ax = lg_randint(r, 0, 6), ay = lg_randint(r, 0, 6);
+        if (!r.alive()) return;
+        if (!lg_empty(L, ax, ay)) continue;
+        const int d = lg_randint(r, 0, 4);
+        const int fx = ax + (d == 0) - (d == 2), fy = ay + (d == 1) - (d == 3);
+        const uint32_t fc = lg_cell_code(L.cmds, L.ncmd, fx, fy);
+        L.ax = ax; L.ay = ay; L.adir = d;
+        if (fc == MGX_CODE_EMPTY || (fc & 15u) == MGX_K_WALL) break;
+    }
+    L.task = variant == 0 ? (uint32_t)door_y : (uint32_t)box_color;
+}
+
 // GoToDoorEnv._gen_grid (envs/gotodoor.py:23-69, as modified by the fork): four locked doors on the four walls in four
 // distinct colours, redrawn until one of them is red (the target); random agent.
 template <class R>
@@ -596,6 +654,7 @@ LG_FN void lg_generate(const mgx_config &c, R &r, LgLevel &L)
     case MGX_LEVEL_GOTOOBJECT: lg_gen_gotoobject(c, r, L); break;
     case MGX_LEVEL_REDBLUEDOORS: lg_gen_redbluedoors(c, r, L); break;
     case MGX_LEVEL_MEMORY: lg_gen_memory(c, r, L); break;
+    case MGX_LEVEL_UNLOCK: lg_gen_unlock(c, r, L); break;
     default: lg_gen_lavagap(c, r, L); break;
     }
 }

@@ -93,6 +93,10 @@ def contains_plane(env):
 
 def task_word(env):
     """Fetch: target object as a cell code (type | color << 4).  GoToObject: tx | ty << 4 | (type - key) << 8 | color << 10."""
+    if type(env).__name__ == "Unlock":
+        return int(env.door.cur_pos[1])
+    if type(env).__name__ in ("UnlockPickup", "BlockedUnlockPickup"):
+        return M.COLOR_TO_IDX[env.obj.color]
     if type(env).__name__.startswith("Memory"):
         return int(env.success_pos[0]) | (int(env.success_pos[1] < env.height // 2) << 4)
     if type(env).__name__.startswith("RedBlueDoor"):
@@ -301,7 +305,7 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
     meta = dict(env_id=name, W=W, H=H, max_steps=int(env0.max_steps), view=V,
                 see_through=bool(env0.see_through_walls), lava_v1=bool(v1), full_obs=bool(full_obs),
                 reseed=bool(reseed), extended=bool(n_actions > 7), alt_vis=not bool(env0.default_vis),
-                task=6 if type(env0).__name__.startswith("Memory") else 5 if type(env0).__name__.startswith("RedBlueDoor") else 4 if type(env0).__name__.startswith(("GoToObject", "GotoEnv")) else (1 if hasattr(env0, "targetType") else (2 if hasattr(env0, "target_pos") else 0)),
+                task=7 if type(env0).__name__ == "Unlock" else 8 if type(env0).__name__ in ("UnlockPickup", "BlockedUnlockPickup") else 6 if type(env0).__name__.startswith("Memory") else 5 if type(env0).__name__.startswith("RedBlueDoor") else 4 if type(env0).__name__.startswith(("GoToObject", "GotoEnv")) else (1 if hasattr(env0, "targetType") else (2 if hasattr(env0, "target_pos") else 0)),
                 objstate=bool(objstate), dynobs=int(getattr(env0, "n_obstacles", 0)), gym_id=gym_id or "")
     z = dict(
         seed=np.zeros(K, np.int64), init_grid=np.zeros((K, W, H, 3), np.uint8),
@@ -510,6 +514,7 @@ def record_levels():
                           ("MiniGrid-GoToDoor-6x6-v0", range(64)), ("MiniGrid-GoToDoor-8x8-v0", range(128)),
                           ("MiniGrid-GoToObject-6x6-N2-v0", range(128)), ("MiniGrid-GoToObject-8x8-N2-v0", range(128)),
                           ("MiniGrid-RedBlueDoors-6x6-v0", range(128)), ("MiniGrid-RedBlueDoors-8x8-v0", range(128)),
+                          ("MiniGrid-Unlock-v0", range(256)), ("MiniGrid-UnlockPickup-v0", range(256)), ("MiniGrid-BlockedUnlockPickup-v0", range(256)),
                           ("MiniGrid-MemoryS7-v0", range(64)), ("MiniGrid-MemoryS9-v0", range(64)), ("MiniGrid-MemoryS11-v0", range(64)),
                           ("MiniGrid-MemoryS13-v0", range(64)), ("MiniGrid-MemoryS13Random-v0", range(128)), ("MiniGrid-MemoryS17Random-v0", range(128)),
                           ("MiniGrid-MultiRoom-N4-S5-v0", range(128)), ("MiniGrid-MultiRoom-N6-v0", range(128)), ("MiniGrid-DistShift1-v0", range(2)),
@@ -670,6 +675,42 @@ def main():
         return f
     record_case("RedBlueDoors-8x8", mk("MiniGrid-RedBlueDoors-8x8-v0"), list(range(8)), 500, scripts=[redblue_script("rb"), redblue_script("br"), redblue_script("rrb"), redblue_script("b")] + [None] * 4, reseed=False)
     record_case("RedBlueDoors-6x6", mk("MiniGrid-RedBlueDoors-6x6-v0"), list(range(6)), 400, scripts=[redblue_script("br"), redblue_script("rb")] + [None] * 4, reseed=False)
+    def unlock_script(pick_box):
+        def f(env):
+            # (move the blocking ball away,) fetch the key, open the door (, fetch the box): stepping the scratch env as we plan
+            acts = []
+
+            def do(seq):
+                for k in seq:
+                    env.step(k)
+                    acts.append(k)
+
+            def find(kind):
+                return [(x, y) for x in range(env.width) for y in range(env.height)
+                        if env.grid.get(x, y) is not None and env.grid.get(x, y).type == kind]
+            door = find("door")[0]
+            if env.grid.get(door[0] - 1, door[1]) is not None:          # BlockedUnlockPickup: the ball in front of the door
+                do((plan_face(env, (door[0] - 1, door[1])) or []) + [3])
+                for _ in range(4):                                     # drop it on the first free side
+                    if env.carrying is None:
+                        break
+                    do([0, 4])
+            do((plan_face(env, find("key")[0]) or []) + [3])
+            do((plan_face(env, door) or []) + [5])
+            if pick_box and find("box"):
+                do([4] if False else [])
+                # the key is still carried: drop it first (pickup needs empty hands)
+                for _ in range(4):
+                    if env.carrying is None:
+                        break
+                    do([0, 4])
+                do((plan_face(env, find("box")[0]) or []) + [3, 3])
+            return acts
+        return f
+    record_case("Unlock", mk("MiniGrid-Unlock-v0"), list(range(8)), 400, scripts=[unlock_script(False)] * 3 + [None] * 5, reseed=False)
+    record_case("UnlockPickup", mk("MiniGrid-UnlockPickup-v0"), list(range(8)), 400, scripts=[unlock_script(True)] * 3 + [None] * 5, reseed=False)
+    record_case("BlockedUnlockPickup", mk("MiniGrid-BlockedUnlockPickup-v0"), list(range(8)), 500, scripts=[unlock_script(True)] * 4 + [None] * 4, reseed=False)
+
     def memory_script(which):
         def f(env):
             # walk down the hallway to the success (0) or failure (1) cell
