@@ -66,8 +66,8 @@ __device__ __forceinline__ void task_rule(const StepParams &p, const Lane &L, ui
     } else if (p.task == MGX_TASK_UNLOCK) { // envs/unlock.py:33-41: the door is at (5, task)
         const int H = CH ? CH : p.H;
         if (act == 5 && (cell_at(5 * H + (int)(L.task & 15u)) & 15u) == MGX_K_DOOR_OPEN) { reward = (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps)); done = true; }
-    } else if (p.task == MGX_TASK_PICKUPBOX) { // envs/unlockpickup.py:35-43: `self.carrying == self.obj`, the only box of the level
-        if (act == 3 && (L.carry & 15u) == MGX_K_BOX) { reward = (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps)); done = true; }
+    } else if (p.task == MGX_TASK_PICKUPBOX) { // envs/unlockpickup.py:35-43, keycorridor.py:51-59: `self.carrying == self.obj`
+        if (act == 3 && (L.carry & 0x7Fu) == (L.task & 0x7Fu)) { reward = (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps)); done = true; }
     } else if (p.task == MGX_TASK_MEMORY) { // envs/memory.py:92-99 (the pickup -> toggle remap happens where the action is loaded)
         const int H = CH ? CH : p.H;
         const int tx = (int)(L.task & 15u), sy = ((L.task >> 4) & 1u) ? H / 2 - 1 : H / 2 + 1, fy = ((L.task >> 4) & 1u) ? H / 2 + 1 : H / 2 - 1;

@@ -159,6 +159,12 @@ int check_levelgen_cfg(const mgx_config *cfg, const char *fn)
         if ((W - 3) / 2 > MGX_LG_MAX_RIVERS || (H - 3) / 2 > MGX_LG_MAX_RIVERS)
             return mgx_fail(MGX_ERR_UNSUPPORTED, "%s: crossing grid %dx%d has more than %d candidate rivers per axis", fn, W, H, MGX_LG_MAX_RIVERS);
         break;
+    case MGX_LEVEL_KEYCORRIDOR: {
+        const int S = cfg->level_arg0;
+        if (S < 3 || S > 6 || W != 3 * (S - 1) + 1 || (H - 1) % (S - 1) != 0 || (H - 1) / (S - 1) < 1 || (H - 1) / (S - 1) > 3)
+            return mgx_fail(MGX_ERR_INVALID_ARG, "%s: KeyCorridor is a RoomGrid of 3 x (1..3) rooms of size 3..6", fn);
+        break;
+    }
     case MGX_LEVEL_UNLOCK:
         if (W != 11 || H != 6 || cfg->level_arg0 < 0 || cfg->level_arg0 > 2) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: the Unlock family is 11x6 with variant 0..2", fn);
         break;
@@ -266,6 +272,13 @@ const std::vector<EnvId> &registry()
         {"MiniGrid-Unlock-v0", mkt(11, 6, 288, 0, MGX_LEVEL_UNLOCK, 0, MGX_TASK_UNLOCK)},
         {"MiniGrid-UnlockPickup-v0", mkt(11, 6, 288, 0, MGX_LEVEL_UNLOCK, 1, MGX_TASK_PICKUPBOX)},
         {"MiniGrid-BlockedUnlockPickup-v0", mkt(11, 6, 576, 0, MGX_LEVEL_UNLOCK, 2, MGX_TASK_PICKUPBOX)},
+        // KeyCorridor: RoomGrid 3 x rows of room_size S, max_steps = 30*S^2 (envs/keycorridor.py:10-24,61-106)
+        {"MiniGrid-KeyCorridorS3R1-v0", mkt(7, 3, 270, 0, MGX_LEVEL_KEYCORRIDOR, 3, MGX_TASK_PICKUPBOX)},
+        {"MiniGrid-KeyCorridorS3R2-v0", mkt(7, 5, 270, 0, MGX_LEVEL_KEYCORRIDOR, 3, MGX_TASK_PICKUPBOX)},
+        {"MiniGrid-KeyCorridorS3R3-v0", mkt(7, 7, 270, 0, MGX_LEVEL_KEYCORRIDOR, 3, MGX_TASK_PICKUPBOX)},
+        {"MiniGrid-KeyCorridorS4R3-v0", mkt(10, 10, 480, 0, MGX_LEVEL_KEYCORRIDOR, 4, MGX_TASK_PICKUPBOX)},
+        {"MiniGrid-KeyCorridorS5R3-v0", mkt(13, 13, 750, 0, MGX_LEVEL_KEYCORRIDOR, 5, MGX_TASK_PICKUPBOX)},
+        {"MiniGrid-KeyCorridorS6R3-v0", mkt(16, 16, 1080, 0, MGX_LEVEL_KEYCORRIDOR, 6, MGX_TASK_PICKUPBOX)},
         // FourRoomsEnv: 19x19, max_steps=500 (envs/fourrooms.py:14-17)
         {"MiniGrid-FourRooms-v0", mk(19, 19, 500, 0, 0, MGX_LEVEL_FOURROOMS, 0, 0)},
         // MultiRoomEnv: 25x25, max_steps = maxNumRooms*20 (envs/multiroom.py:36-39,223-246)
@@ -317,10 +330,13 @@ extern "C" int mgx_mission(const mgx_config *cfg, uint32_t task, char *out, int 
     case MGX_LEVEL_REDBLUEDOORS: m = "open the red door then the blue door"; break;                        // envs/redbluedoors.py:42
     case MGX_LEVEL_MEMORY: m = "go to the matching object at the end of the hallway"; break;              // envs/memory.py:86
     case MGX_LEVEL_UNLOCK:                                                                                  // envs/unlock.py:31, unlockpickup.py:33
-        if (cfg->level_arg0 == 0) m = "open the door";
+    case MGX_LEVEL_KEYCORRIDOR:                                                                             // keycorridor.py:49
+        if (cfg->level_kind == MGX_LEVEL_UNLOCK && cfg->level_arg0 == 0) m = "open the door";
         else {
-            if ((task & 7u) > 6) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_mission: 0x%x is not a box colour", task);
-            snprintf(buf, sizeof buf, "pick up the %s box", colors[task & 7u]);
+            const uint32_t kind = task & 15u, color = (task >> 4) & 7u;
+            if ((kind != MGX_K_BOX && kind != MGX_K_BALL && kind != MGX_K_KEY) || color > 6)
+                return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_mission: 0x%x is not a pick-up target", task);
+            snprintf(buf, sizeof buf, "pick up the %s %s", colors[color], kind == MGX_K_BOX ? "box" : (kind == MGX_K_BALL ? "ball" : "key"));
             m = buf;
         }
         break;

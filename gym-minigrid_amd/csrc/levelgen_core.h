@@ -81,6 +81,8 @@ LG_FN void lg_paint(const LgLevel &L, uint8_t *g)
         for (int y = 0; y < L.H; y++) g[x * L.H + y] = (uint8_t)lg_cell_code(L.cmds, L.ncmd, x, y);
 }
 
+LG_FN int lg_ctz32(uint32_t x) { int n = 0; while (!(x & 1u)) { x >>= 1; n++; } return n; } // (x != 0)
+
 // uniform integer in [0, max] by masked rejection (numpy legacy bounded_uint32)
 template <class R>
 LG_FN uint32_t lg_bounded(R &r, uint32_t max)
@@ -539,7 +541,108 @@ LG_FN void lg_gen_unlock(const mgx_config &c, R &r, LgLevel &L)
         L.ax = ax; L.ay = ay; L.adir = d;
         if (fc == MGX_CODE_EMPTY || (fc & 15u) == MGX_K_WALL) break;
     }
-    L.task = variant == 0 ? (uint32_t)door_y : (uint32_t)box_color;
+    L.task = variant == 0 ? (uint32_t)door_y : ((uint32_t)MGX_K_BOX | ((uint32_t)box_color << 4)); // door row / the target's cell code
+}
+
+// KeyCorridor._gen_grid (envs/keycorridor.py:26-52) on RoomGrid(num_cols=3, num_rows=R, room_size=S) (roomgrid.py:118-166):
+// door positions drawn room by room, the middle column opened into a hallway, a locked door into a random right-hand
+// room with the ball behind it, the key in a random left-hand room, the agent in the middle, then connect_all
+// (roomgrid.py:306-352): random (room, side) picks until every room is reachable.  level_arg0 = S, rows = (H-1)/(S-1).
+// Room bookkeeping lives in L.ws: [r] y of the right door, [9+r] x of the down door, [18+r] bits 0-3 = sides already
+// connected (right, down, left, up), bit 4 = locked; r = 3*j + i.
+template <class R>
+LG_FN void lg_gen_keycorridor(const mgx_config &c, R &r, LgLevel &L)
+{
+    const int S = c.level_arg0, T = S - 1, rows = (L.H - 1) / T, W = L.W, H = L.H;
+    int16_t *dr = L.ws, *dd = L.ws + 9, *fl = L.ws + 18;
+    L.ncmd = 0;
+    for (int k = 0; k <= 3; k++) lg_rect(L, k * T, 0, k * T, H - 1, MGX_CODE_WALL_GREY);
+    for (int k = 0; k <= rows; k++) lg_rect(L, 0, k * T, W - 1, k * T, MGX_CODE_WALL_GREY);
+    for (int j = 0; j < rows; j++)
+        for (int i = 0; i < 3; i++) {
+            const int q = 3 * j + i, xl = i * T + 1, yl = j * T + 1, xm = i * T + S - 1, ym = j * T + S - 1;
+            dr[q] = 0; dd[q] = 0; fl[q] = 0;
+            if (i < 2) dr[q] = (int16_t)lg_randint(r, yl, ym);
+            if (j < rows - 1) dd[q] = (int16_t)lg_randint(r, xl, xm);
+        }
+    if (!r.alive()) return;
+    const int ax0 = T + S / 2, ay0 = (rows / 2) * T + S / 2; // RoomGrid parks the agent here while the objects are placed
+    auto mark = [&](int i, int j, int k) { // both sides of wall k of room (i, j) are now connected
+        fl[3 * j + i] |= (int16_t)(1 << k);
+        const int ni = i + (k == 0) - (k == 2), nj = j + (k == 1) - (k == 3);
+        fl[3 * nj + ni] |= (int16_t)(1 << ((k + 2) & 3));
+    };
+    auto door_xy = [&](int i, int j, int k, int *x, int *y) { // room.door_pos[k]
+        if (k == 0) { *x = i * T + S - 1; *y = dr[3 * j + i]; }
+        else if (k == 1) { *x = dd[3 * j + i]; *y = j * T + S - 1; }
+        else if (k == 2) { *x = i * T; *y = dr[3 * j + i - 1]; }
+        else { *x = dd[3 * (j - 1) + i]; *y = j * T; }
+    };
+    auto place = [&](int i, int j, int *ox, int *oy) -> bool { // place_in_room: place_obj(top, size, reject_next_to)
+        for (;;) {
+            const int x = lg_randint(r, i * T, i * T + S), y = lg_randint(r, j * T, j * T + S);
+            if (!r.alive()) return false;
+            if (!lg_empty(L, x, y)) continue;
+            const int dx = x > ax0 ? x - ax0 : ax0 - x, dy = y > ay0 ? y - ay0 : ay0 - y;
+            if (dx + dy < 2) continue;
+            *ox = x; *oy = y;
+            return true;
+        }
+    };
+    for (int j = 1; j < rows; j++) { // remove_wall(1, j, 3)
+        if (S > 2) lg_rect(L, T + 1, j * T, T + S - 2, j * T, MGX_CODE_EMPTY);
+        mark(1, j, 3);
+    }
+    const int ridx = lg_randint(r, 0, rows);
+    const int door_color = lg_sorted_color(lg_randint(r, 0, 7)); // add_door(2, ridx, 2, locked=True)
+    int x, y;
+    door_xy(2, ridx, 2, &x, &y);
+    lg_set(L, x, y, MGX_K_DOOR_LOCKED | ((uint32_t)door_color << 4));
+    mark(2, ridx, 2);
+    fl[3 * ridx + 2] |= 16;
+    const int ball_color = lg_sorted_color(lg_randint(r, 0, 7)); // add_object(2, ridx, kind="ball")
+    if (!place(2, ridx, &x, &y)) return;
+    lg_set(L, x, y, MGX_K_BALL | ((uint32_t)ball_color << 4));
+    const int krow = lg_randint(r, 0, rows);                     // add_object(0, _rand_int(0, rows), 'key', door.color)
+    if (!place(0, krow, &x, &y)) return;
+    lg_set(L, x, y, MGX_K_KEY | ((uint32_t)door_color << 4));
+    const int aj = rows / 2;
+    for (;;) { // place_agent(1, rows // 2)
+        const int ax = lg_randint(r, T, T + S), ay = lg_randint(r, aj * T, aj * T + S);
+        if (!r.alive()) return;
+        if (!lg_empty(L, ax, ay)) continue;
+        const int d = lg_randint(r, 0, 4);
+        const uint32_t fc = lg_cell_code(L.cmds, L.ncmd, ax + (d == 0) - (d == 2), ay + (d == 1) - (d == 3));
+        L.ax = ax; L.ay = ay; L.adir = d;
+        if (fc == MGX_CODE_EMPTY || (fc & 15u) == MGX_K_WALL) break;
+    }
+    const int n_rooms = 3 * rows;
+    for (int it = 0; it <= 5000; it++) { // connect_all
+        uint32_t reach = 1u << (3 * aj + 1), frontier = reach; // rooms reachable from the agent's room
+        while (frontier) {
+            const int q = lg_ctz32(frontier);
+            frontier &= frontier - 1;
+            const int i = q % 3, j = q / 3;
+            for (int k = 0; k < 4; k++)
+                if (fl[q] & (1 << k)) {
+                    const int nq = 3 * (j + (k == 1) - (k == 3)) + i + (k == 0) - (k == 2);
+                    if (!(reach & (1u << nq))) { reach |= 1u << nq; frontier |= 1u << nq; }
+                }
+        }
+        if (reach == (1u << n_rooms) - 1u) break;
+        const int i = lg_randint(r, 0, 3), j = lg_randint(r, 0, rows), k = lg_randint(r, 0, 4);
+        if (!r.alive()) return;
+        const int ni = i + (k == 0) - (k == 2), nj = j + (k == 1) - (k == 3);
+        if (ni < 0 || ni > 2 || nj < 0 || nj >= rows) continue;    // not room.door_pos[k]
+        if (fl[3 * j + i] & (1 << k)) continue;                      // room.doors[k]
+        if ((fl[3 * j + i] | fl[3 * nj + ni]) & 16) continue;        // room.locked or room.neighbors[k].locked
+        const int color = lg_sorted_color(lg_randint(r, 0, 7));
+        door_xy(i, j, k, &x, &y);
+        lg_set(L, x, y, MGX_K_DOOR_CLOSED | ((uint32_t)color << 4));
+        mark(i, j, k);
+        if (L.too_big) return;
+    }
+    L.task = (uint32_t)MGX_K_BALL | ((uint32_t)ball_color << 4);
 }
 
 // GoToDoorEnv._gen_grid (envs/gotodoor.py:23-69, as modified by the fork): four locked doors on the four walls in four
@@ -655,6 +758,7 @@ LG_FN void lg_generate(const mgx_config &c, R &r, LgLevel &L)
     case MGX_LEVEL_REDBLUEDOORS: lg_gen_redbluedoors(c, r, L); break;
     case MGX_LEVEL_MEMORY: lg_gen_memory(c, r, L); break;
     case MGX_LEVEL_UNLOCK: lg_gen_unlock(c, r, L); break;
+    case MGX_LEVEL_KEYCORRIDOR: lg_gen_keycorridor(c, r, L); break;
     default: lg_gen_lavagap(c, r, L); break;
     }
 }

@@ -356,7 +356,7 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     CREATE_TRY(hipMalloc((void **)&h->ctr_d, sizeof(MgxCounters)));
     if (h->oh_nc >= 0 || h->flat) CREATE_TRY(hipMalloc((void **)&h->tri_d, (size_t)h->n * h->tri_bytes + 16));
     if (h->flat) { // the family's mission strings as character codes (wrappers.py:563-571)
-        const int rows = cfg->level_kind == MGX_LEVEL_FETCH ? 80 : (cfg->level_kind == MGX_LEVEL_GOTOOBJECT ? 24 : (cfg->level_kind == MGX_LEVEL_UNLOCK && cfg->level_arg0 ? 8 : 1));
+        const int rows = cfg->level_kind == MGX_LEVEL_FETCH ? 80 : (cfg->level_kind == MGX_LEVEL_GOTOOBJECT ? 24 : ((cfg->level_kind == MGX_LEVEL_UNLOCK && cfg->level_arg0) || cfg->level_kind == MGX_LEVEL_KEYCORRIDOR ? 8 : 1));
         std::vector<float> tab((size_t)rows * MGX_FLAT_MISSION, 0.f);
         for (int r = 0; r < rows; r++) {
             uint32_t task = 0;
@@ -364,9 +364,9 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
                 const int color = r & 7, ball = (r >> 3) & 1, tmpl = r >> 4;
                 if (color > 6) continue;
                 task = (uint32_t)(ball ? MGX_K_BALL : MGX_K_KEY) | ((uint32_t)color << 4) | ((uint32_t)tmpl << 8);
-            } else if (cfg->level_kind == MGX_LEVEL_UNLOCK && cfg->level_arg0) {
+            } else if ((cfg->level_kind == MGX_LEVEL_UNLOCK && cfg->level_arg0) || cfg->level_kind == MGX_LEVEL_KEYCORRIDOR) {
                 if (r > 6) continue;
-                task = (uint32_t)r; // colour of the box
+                task = (uint32_t)(cfg->level_kind == MGX_LEVEL_UNLOCK ? MGX_K_BOX : MGX_K_BALL) | ((uint32_t)r << 4); // the target's colour
             } else if (cfg->level_kind == MGX_LEVEL_GOTOOBJECT) {
                 const int color = r & 7, ty = r >> 3;
                 if (color > 6) continue;
@@ -667,7 +667,7 @@ static int run_step(mgx_handle h, bool do_step, const uint8_t *actions, uint8_t 
         HIP_TRY(mgx_launch_onehot(h->tri_d, (uint8_t *)o[0].dev, h->n * (h->tri_bytes / 3), h->oh_nc, h->oh_ns, h->stream));
     if (h->flat && o[0].dev)
         HIP_TRY(mgx_launch_flat(h->tri_d, h->agent_d, h->mission_d, (float *)o[0].dev, h->n, (int)h->tri_bytes,
-                                h->cfg.level_kind == MGX_LEVEL_FETCH ? 1 : (h->cfg.level_kind == MGX_LEVEL_GOTOOBJECT ? 2 : (h->cfg.level_kind == MGX_LEVEL_UNLOCK && h->cfg.level_arg0 ? 3 : 0)), h->stream));
+                                h->cfg.level_kind == MGX_LEVEL_FETCH ? 1 : (h->cfg.level_kind == MGX_LEVEL_GOTOOBJECT ? 2 : ((h->cfg.level_kind == MGX_LEVEL_UNLOCK && h->cfg.level_arg0) || h->cfg.level_kind == MGX_LEVEL_KEYCORRIDOR ? 3 : 0)), h->stream));
     if (do_step) {
         h->steps_total += h->n;
         if (h->profiling) h->prof_launches++;

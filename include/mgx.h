@@ -106,7 +106,9 @@ typedef enum {
     MGX_LEVEL_UNLOCK = 14,   /* Unlock / UnlockPickup / BlockedUnlockPickup (envs/unlock.py, unlockpickup.py, blockedunlockpickup.py:
                                 RoomGrid 1x2, room_size 6 -> 11x6): level_arg0 = 0 / 1 / 2; use with MGX_TASK_UNLOCK (0) or
                                 MGX_TASK_PICKUPBOX (1, 2) */
-    MGX_LEVEL_KIND_END = 15
+    MGX_LEVEL_KEYCORRIDOR = 15, /* KeyCorridor (envs/keycorridor.py) on RoomGrid 3 x R: level_arg0 = room_size (3..6), rows from the
+                                height; use with task_kind = MGX_TASK_PICKUPBOX */
+    MGX_LEVEL_KIND_END = 16
 } mgx_level_kind;
 
 /* task rules layered on MiniGridEnv.step by env subclasses (`step` overrides that only reshape reward/done) */
@@ -127,8 +129,10 @@ typedef enum {
                               cells | (success is the upper one) << 4. */
     MGX_TASK_UNLOCK = 7,   /* envs/unlock.py:33-41: `toggle` with the door open afterwards ends the episode with _reward().
                               Per-env task word = door y (the door is at x = 5). */
-    MGX_TASK_PICKUPBOX = 8, /* envs/unlockpickup.py:35-43, blockedunlockpickup.py:39-47: `pickup` while carrying the (only) box
-                              ends the episode with _reward().  Per-env task word = colour of the box (for the mission). */
+    MGX_TASK_PICKUPBOX = 8, /* envs/unlockpickup.py:35-43, blockedunlockpickup.py:39-47, keycorridor.py:51-59: `pickup` while
+                              carrying the target object (`self.carrying == self.obj`: the only box / ball of the level)
+                              ends the episode with _reward().  Per-env task word = the target's cell code
+                              (type | color << 4). */
     MGX_TASK_DYNOBS = 3,   /* envs/dynamicobstacles.py:60-89 (with level_kind = MGX_LEVEL_DYNOBS): actions >= 3 fold to 0;
                               before the base step every obstacle (blue ball) is re-placed in its 3x3 neighbourhood with
                               draws from the env's own RNG stream (place_obj, max_tries=100); moving forward while the

@@ -95,8 +95,8 @@ def task_word(env):
     """Fetch: target object as a cell code (type | color << 4).  GoToObject: tx | ty << 4 | (type - key) << 8 | color << 10."""
     if type(env).__name__ == "Unlock":
         return int(env.door.cur_pos[1])
-    if type(env).__name__ in ("UnlockPickup", "BlockedUnlockPickup"):
-        return M.COLOR_TO_IDX[env.obj.color]
+    if type(env).__name__ in ("UnlockPickup", "BlockedUnlockPickup") or type(env).__name__.startswith("KeyCorridor"):
+        return M.OBJECT_TO_IDX[env.obj.type] | (M.COLOR_TO_IDX[env.obj.color] << 4)
     if type(env).__name__.startswith("Memory"):
         return int(env.success_pos[0]) | (int(env.success_pos[1] < env.height // 2) << 4)
     if type(env).__name__.startswith("RedBlueDoor"):
@@ -305,7 +305,7 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
     meta = dict(env_id=name, W=W, H=H, max_steps=int(env0.max_steps), view=V,
                 see_through=bool(env0.see_through_walls), lava_v1=bool(v1), full_obs=bool(full_obs),
                 reseed=bool(reseed), extended=bool(n_actions > 7), alt_vis=not bool(env0.default_vis),
-                task=7 if type(env0).__name__ == "Unlock" else 8 if type(env0).__name__ in ("UnlockPickup", "BlockedUnlockPickup") else 6 if type(env0).__name__.startswith("Memory") else 5 if type(env0).__name__.startswith("RedBlueDoor") else 4 if type(env0).__name__.startswith(("GoToObject", "GotoEnv")) else (1 if hasattr(env0, "targetType") else (2 if hasattr(env0, "target_pos") else 0)),
+                task=7 if type(env0).__name__ == "Unlock" else 8 if type(env0).__name__ in ("UnlockPickup", "BlockedUnlockPickup") or type(env0).__name__.startswith("KeyCorridor") else 6 if type(env0).__name__.startswith("Memory") else 5 if type(env0).__name__.startswith("RedBlueDoor") else 4 if type(env0).__name__.startswith(("GoToObject", "GotoEnv")) else (1 if hasattr(env0, "targetType") else (2 if hasattr(env0, "target_pos") else 0)),
                 objstate=bool(objstate), dynobs=int(getattr(env0, "n_obstacles", 0)), gym_id=gym_id or "")
     z = dict(
         seed=np.zeros(K, np.int64), init_grid=np.zeros((K, W, H, 3), np.uint8),
@@ -514,6 +514,8 @@ def record_levels():
                           ("MiniGrid-GoToDoor-6x6-v0", range(64)), ("MiniGrid-GoToDoor-8x8-v0", range(128)),
                           ("MiniGrid-GoToObject-6x6-N2-v0", range(128)), ("MiniGrid-GoToObject-8x8-N2-v0", range(128)),
                           ("MiniGrid-RedBlueDoors-6x6-v0", range(128)), ("MiniGrid-RedBlueDoors-8x8-v0", range(128)),
+                          ("MiniGrid-KeyCorridorS3R1-v0", range(128)), ("MiniGrid-KeyCorridorS3R2-v0", range(128)), ("MiniGrid-KeyCorridorS3R3-v0", range(128)),
+                          ("MiniGrid-KeyCorridorS4R3-v0", range(128)), ("MiniGrid-KeyCorridorS5R3-v0", range(128)), ("MiniGrid-KeyCorridorS6R3-v0", range(128)),
                           ("MiniGrid-Unlock-v0", range(256)), ("MiniGrid-UnlockPickup-v0", range(256)), ("MiniGrid-BlockedUnlockPickup-v0", range(256)),
                           ("MiniGrid-MemoryS7-v0", range(64)), ("MiniGrid-MemoryS9-v0", range(64)), ("MiniGrid-MemoryS11-v0", range(64)),
                           ("MiniGrid-MemoryS13-v0", range(64)), ("MiniGrid-MemoryS13Random-v0", range(128)), ("MiniGrid-MemoryS17Random-v0", range(128)),
@@ -710,6 +712,50 @@ def main():
     record_case("Unlock", mk("MiniGrid-Unlock-v0"), list(range(8)), 400, scripts=[unlock_script(False)] * 3 + [None] * 5, reseed=False)
     record_case("UnlockPickup", mk("MiniGrid-UnlockPickup-v0"), list(range(8)), 400, scripts=[unlock_script(True)] * 3 + [None] * 5, reseed=False)
     record_case("BlockedUnlockPickup", mk("MiniGrid-BlockedUnlockPickup-v0"), list(range(8)), 500, scripts=[unlock_script(True)] * 4 + [None] * 4, reseed=False)
+
+    def keycorridor_script(env):
+        # fetch the key, open the locked door, drop the key, pick up the ball -- re-planning on the scratch env; doors on the
+        # way are opened as they come (plan_face treats closed doors as walls, so walk door by door)
+        acts = []
+
+        def do(seq):
+            for k in seq:
+                env.step(k)
+                acts.append(k)
+
+        def find(kind, pred=lambda o: True):
+            return [(x, y) for x in range(env.width) for y in range(env.height)
+                    if env.grid.get(x, y) is not None and env.grid.get(x, y).type == kind and pred(env.grid.get(x, y))]
+
+        def go(target, then):
+            for _ in range(12):
+                p = plan_face(env, target)
+                if p is not None:
+                    do(p + then)
+                    return True
+                opened = False
+                for d in find("door", lambda o: not o.is_open and not o.is_locked):
+                    q = plan_face(env, d)
+                    if q is not None:
+                        do(q + [5])
+                        opened = True
+                        break
+                if not opened:
+                    return False
+            return False
+        if not go(find("key")[0], [3]):
+            return acts
+        locked = find("door", lambda o: o.is_locked)
+        if not locked or not go(locked[0], [5]):
+            return acts
+        for _ in range(4):
+            if env.carrying is None:
+                break
+            do([0, 4])
+        go(find("ball")[0], [3])
+        return acts
+    for short, T in [("KeyCorridorS3R1", 200), ("KeyCorridorS3R3", 400), ("KeyCorridorS4R3", 500), ("KeyCorridorS6R3", 600)]:
+        record_case(short, mk("MiniGrid-%s-v0" % short), list(range(6)), T, scripts=[keycorridor_script] * 3 + [None] * 3, reseed=False)
 
     def memory_script(which):
         def f(env):

@@ -378,8 +378,8 @@ static void task_rule(const mgo_cfg *cf, const uint8_t *g, const uint8_t *aux, c
         }
     } else if (cf->task == 7) { /* Unlock.step envs/unlock.py:33-41; the door is at (5, task) */
         if (action == A_TOGGLE && door_open(cf, g, 5, (int)(task & 15u))) { *reward = 1 - 0.9 * ((double)steps / (double)cf->max_steps); *done = 1; }
-    } else if (cf->task == 8) { /* UnlockPickup.step envs/unlockpickup.py:35-43: carrying the (only) box of the level */
-        if (action == A_PICKUP && carry[0] == T_BOX) { *reward = 1 - 0.9 * ((double)steps / (double)cf->max_steps); *done = 1; }
+    } else if (cf->task == 8) { /* UnlockPickup.step envs/unlockpickup.py:35-43, KeyCorridor.step keycorridor.py:51-59: carrying the target */
+        if (action == A_PICKUP && carry[0] == (task & 15u) && carry[1] == ((task >> 4) & 7u)) { *reward = 1 - 0.9 * ((double)steps / (double)cf->max_steps); *done = 1; }
     } else if (cf->task == 6) { /* MemoryEnv.step envs/memory.py:92-99; task = x of the two end cells | (success is the upper one) << 4 */
         const int tx = (int)(task & 15u), up = (int)((task >> 4) & 1u);
         const int sy = up ? cf->H / 2 - 1 : cf->H / 2 + 1, fy = up ? cf->H / 2 + 1 : cf->H / 2 - 1;
