@@ -159,6 +159,9 @@ int check_levelgen_cfg(const mgx_config *cfg, const char *fn)
         if ((W - 3) / 2 > MGX_LG_MAX_RIVERS || (H - 3) / 2 > MGX_LG_MAX_RIVERS)
             return mgx_fail(MGX_ERR_UNSUPPORTED, "%s: crossing grid %dx%d has more than %d candidate rivers per axis", fn, W, H, MGX_LG_MAX_RIVERS);
         break;
+    case MGX_LEVEL_LOCKEDROOM:
+        if (W != 19 || H != 19) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: LockedRoom is 19x19", fn);
+        break;
     case MGX_LEVEL_KEYCORRIDOR: {
         const int S = cfg->level_arg0;
         if (S < 3 || S > 6 || W != 3 * (S - 1) + 1 || (H - 1) % (S - 1) != 0 || (H - 1) / (S - 1) < 1 || (H - 1) / (S - 1) > 3)
@@ -279,6 +282,8 @@ const std::vector<EnvId> &registry()
         {"MiniGrid-KeyCorridorS4R3-v0", mkt(10, 10, 480, 0, MGX_LEVEL_KEYCORRIDOR, 4, MGX_TASK_PICKUPBOX)},
         {"MiniGrid-KeyCorridorS5R3-v0", mkt(13, 13, 750, 0, MGX_LEVEL_KEYCORRIDOR, 5, MGX_TASK_PICKUPBOX)},
         {"MiniGrid-KeyCorridorS6R3-v0", mkt(16, 16, 1080, 0, MGX_LEVEL_KEYCORRIDOR, 6, MGX_TASK_PICKUPBOX)},
+        // LockedRoom: 19x19, max_steps = 10*size (envs/lockedroom.py:32-35)
+        {"MiniGrid-LockedRoom-v0", mkt(19, 19, 190, 0, MGX_LEVEL_LOCKEDROOM, 0, MGX_TASK_NOTE)},
         // FourRoomsEnv: 19x19, max_steps=500 (envs/fourrooms.py:14-17)
         {"MiniGrid-FourRooms-v0", mk(19, 19, 500, 0, 0, MGX_LEVEL_FOURROOMS, 0, 0)},
         // MultiRoomEnv: 25x25, max_steps = maxNumRooms*20 (envs/multiroom.py:36-39,223-246)
@@ -340,6 +345,13 @@ extern "C" int mgx_mission(const mgx_config *cfg, uint32_t task, char *out, int 
             m = buf;
         }
         break;
+    case MGX_LEVEL_LOCKEDROOM: {                                                                            // envs/lockedroom.py:108-112
+        const uint32_t lc = task & 7u, kc = (task >> 3) & 7u;
+        if (lc > 6 || kc > 6) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_mission: 0x%x is not a LockedRoom task word", task);
+        snprintf(buf, sizeof buf, "get the %s key from the %s room, unlock the %s door and go to the goal", colors[lc], colors[kc], colors[lc]);
+        m = buf;
+        break;
+    }
     case MGX_LEVEL_FOURROOMS: m = "Reach the goal"; break;                                                  // envs/fourrooms.py:69
     case MGX_LEVEL_GOTOOBJECT: {                                                                            // envs/gotoobject.py:63-64
         static const char *const types[3] = {"key", "ball", "box"};

@@ -645,6 +645,61 @@ LG_FN void lg_gen_keycorridor(const mgx_config &c, R &r, LgLevel &L)
     L.task = (uint32_t)MGX_K_BALL | ((uint32_t)ball_color << 4);
 }
 
+// LockedRoom._gen_grid (envs/lockedroom.py:37-113): a hallway between two columns of three rooms; one random room is
+// locked and holds the goal, the six doors get six distinct colours, the key of the locked door lies in another room.
+// task = colour of the locked room | colour of the key room << 3 (the mission names both).
+template <class R>
+LG_FN void lg_gen_lockedroom(const mgx_config &, R &r, LgLevel &L)
+{
+    const int W = L.W, H = L.H, lw = W / 2 - 2, rw = W / 2 + 2, h3 = H / 3;
+    L.ncmd = 0;
+    lg_rect(L, 0, 0, W - 1, 0, MGX_CODE_WALL_GREY);
+    lg_rect(L, 0, H - 1, W - 1, H - 1, MGX_CODE_WALL_GREY);
+    lg_rect(L, 0, 0, 0, H - 1, MGX_CODE_WALL_GREY);
+    lg_rect(L, W - 1, 0, W - 1, H - 1, MGX_CODE_WALL_GREY);
+    lg_rect(L, lw, 0, lw, H - 1, MGX_CODE_WALL_GREY);            // hallway walls
+    lg_rect(L, rw, 0, rw, H - 1, MGX_CODE_WALL_GREY);
+    for (int n = 1; n < 3; n++) {                                // room splitting walls (n = 0 is the outer wall)
+        lg_rect(L, 0, n * h3, lw - 1, n * h3, MGX_CODE_WALL_GREY);
+        lg_rect(L, rw, n * h3, W - 1, n * h3, MGX_CODE_WALL_GREY);
+    }
+    // rooms in the reference's list order: (left, right) for n = 0, 1, 2; top = (0 | rw, n*h3), size (lw+1, h3+1), door (lw | rw, n*h3 + 3)
+    const int locked = lg_randint(r, 0, 6);
+    auto rand_pos = [&](int room, int *x, int *y) { // Room.rand_pos: _rand_pos(topX+1, topX+sizeX-1, topY+1, topY+sizeY-1)
+        const int tx = (room & 1) ? rw : 0, ty = (room >> 1) * h3;
+        *x = lg_randint(r, tx + 1, tx + lw);
+        *y = lg_randint(r, ty + 1, ty + h3);
+    };
+    int x, y;
+    rand_pos(locked, &x, &y);
+    lg_set(L, x, y, MGX_CODE_GOAL_GREEN);
+    uint32_t left = 0x7Fu; // colours still unassigned, as a mask over the SORTED names (blue green grey purple red white yellow)
+    int color_of[6];
+    for (int room = 0; room < 6; room++) {
+        int n_left = 0;
+        for (int k = 0; k < 7; k++) n_left += (left >> k) & 1u;
+        int pick = lg_randint(r, 0, n_left), k = 0;
+        for (;; k++) if ((left >> k) & 1u) { if (pick == 0) break; pick--; }
+        left &= ~(1u << k);
+        color_of[room] = lg_sorted_color(k);
+        lg_set(L, (room & 1) ? rw : lw, (room >> 1) * h3 + 3, (room == locked ? MGX_K_DOOR_LOCKED : MGX_K_DOOR_CLOSED) | ((uint32_t)color_of[room] << 4));
+    }
+    int key_room;
+    do { key_room = lg_randint(r, 0, 6); } while (key_room == locked && r.alive());
+    rand_pos(key_room, &x, &y);
+    lg_set(L, x, y, MGX_K_KEY | ((uint32_t)color_of[locked] << 4));
+    L.ax = -1; L.ay = -1;
+    for (;;) { // place_agent(top=(lw, 0), size=(rw - lw, H))
+        const int ax = lg_randint(r, lw, rw), ay = lg_randint(r, 0, H);
+        if (!r.alive()) return;
+        if (!lg_empty(L, ax, ay)) continue;
+        L.ax = ax; L.ay = ay;
+        break;
+    }
+    L.adir = lg_randint(r, 0, 4);
+    L.task = (uint32_t)color_of[locked] | ((uint32_t)color_of[key_room] << 3);
+}
+
 // GoToDoorEnv._gen_grid (envs/gotodoor.py:23-69, as modified by the fork): four locked doors on the four walls in four
 // distinct colours, redrawn until one of them is red (the target); random agent.
 template <class R>
@@ -759,6 +814,7 @@ LG_FN void lg_generate(const mgx_config &c, R &r, LgLevel &L)
     case MGX_LEVEL_MEMORY: lg_gen_memory(c, r, L); break;
     case MGX_LEVEL_UNLOCK: lg_gen_unlock(c, r, L); break;
     case MGX_LEVEL_KEYCORRIDOR: lg_gen_keycorridor(c, r, L); break;
+    case MGX_LEVEL_LOCKEDROOM: lg_gen_lockedroom(c, r, L); break;
     default: lg_gen_lavagap(c, r, L); break;
     }
 }

@@ -108,7 +108,9 @@ typedef enum {
                                 MGX_TASK_PICKUPBOX (1, 2) */
     MGX_LEVEL_KEYCORRIDOR = 15, /* KeyCorridor (envs/keycorridor.py) on RoomGrid 3 x R: level_arg0 = room_size (3..6), rows from the
                                 height; use with task_kind = MGX_TASK_PICKUPBOX */
-    MGX_LEVEL_KIND_END = 16
+    MGX_LEVEL_LOCKEDROOM = 16, /* LockedRoom (envs/lockedroom.py), 19x19; use with task_kind = MGX_TASK_NOTE (the task word only
+                                names the mission: locked colour | key room colour << 3) */
+    MGX_LEVEL_KIND_END = 17
 } mgx_level_kind;
 
 /* task rules layered on MiniGridEnv.step by env subclasses (`step` overrides that only reshape reward/done) */
@@ -133,6 +135,7 @@ typedef enum {
                               carrying the target object (`self.carrying == self.obj`: the only box / ball of the level)
                               ends the episode with _reward().  Per-env task word = the target's cell code
                               (type | color << 4). */
+    MGX_TASK_NOTE = 9,     /* no rule on top of MiniGridEnv.step; the per-env task word only selects the mission string */
     MGX_TASK_DYNOBS = 3,   /* envs/dynamicobstacles.py:60-89 (with level_kind = MGX_LEVEL_DYNOBS): actions >= 3 fold to 0;
                               before the base step every obstacle (blue ball) is re-placed in its 3x3 neighbourhood with
                               draws from the env's own RNG stream (place_obj, max_tries=100); moving forward while the

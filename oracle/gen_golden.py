@@ -93,6 +93,11 @@ def contains_plane(env):
 
 def task_word(env):
     """Fetch: target object as a cell code (type | color << 4).  GoToObject: tx | ty << 4 | (type - key) << 8 | color << 10."""
+    if type(env).__name__ == "LockedRoom":
+        locked = [rm for rm in env.rooms if rm.locked][0]
+        key = [(x, y) for x in range(env.width) for y in range(env.height) if env.grid.get(x, y) is not None and env.grid.get(x, y).type == "key"][0]
+        kroom = [rm for rm in env.rooms if rm.top[0] < key[0] < rm.top[0] + rm.size[0] - 1 and rm.top[1] < key[1] < rm.top[1] + rm.size[1] - 1][0]
+        return M.COLOR_TO_IDX[locked.color] | (M.COLOR_TO_IDX[kroom.color] << 3)
     if type(env).__name__ == "Unlock":
         return int(env.door.cur_pos[1])
     if type(env).__name__ in ("UnlockPickup", "BlockedUnlockPickup") or type(env).__name__.startswith("KeyCorridor"):
@@ -305,7 +310,7 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
     meta = dict(env_id=name, W=W, H=H, max_steps=int(env0.max_steps), view=V,
                 see_through=bool(env0.see_through_walls), lava_v1=bool(v1), full_obs=bool(full_obs),
                 reseed=bool(reseed), extended=bool(n_actions > 7), alt_vis=not bool(env0.default_vis),
-                task=7 if type(env0).__name__ == "Unlock" else 8 if type(env0).__name__ in ("UnlockPickup", "BlockedUnlockPickup") or type(env0).__name__.startswith("KeyCorridor") else 6 if type(env0).__name__.startswith("Memory") else 5 if type(env0).__name__.startswith("RedBlueDoor") else 4 if type(env0).__name__.startswith(("GoToObject", "GotoEnv")) else (1 if hasattr(env0, "targetType") else (2 if hasattr(env0, "target_pos") else 0)),
+                task=9 if type(env0).__name__ == "LockedRoom" else 7 if type(env0).__name__ == "Unlock" else 8 if type(env0).__name__ in ("UnlockPickup", "BlockedUnlockPickup") or type(env0).__name__.startswith("KeyCorridor") else 6 if type(env0).__name__.startswith("Memory") else 5 if type(env0).__name__.startswith("RedBlueDoor") else 4 if type(env0).__name__.startswith(("GoToObject", "GotoEnv")) else (1 if hasattr(env0, "targetType") else (2 if hasattr(env0, "target_pos") else 0)),
                 objstate=bool(objstate), dynobs=int(getattr(env0, "n_obstacles", 0)), gym_id=gym_id or "")
     z = dict(
         seed=np.zeros(K, np.int64), init_grid=np.zeros((K, W, H, 3), np.uint8),
@@ -470,7 +475,8 @@ def record_flat():
     cases = [("MiniGrid-Empty-8x8-v0", [0], False), ("MiniGrid-DoorKey-5x5-v0", [1, 2], False),
              ("MiniGrid-Fetch-5x5-N2-v0", list(range(16)), False), ("MiniGrid-Fetch-8x8-N3-v0", list(range(8)), False),
              ("MiniGrid-GoToDoor-5x5-v0", [0, 1], False), ("MiniGrid-FourRooms-v0", [0], False),
-             ("MiniGrid-GoToObject-6x6-N2-v0", list(range(8)), False), ("MiniGrid-Dynamic-Obstacles-6x6-v0", [0, 1], False),
+             ("MiniGrid-GoToObject-6x6-N2-v0", list(range(8)), False), ("MiniGrid-LockedRoom-v0", list(range(6)), False),
+             ("MiniGrid-KeyCorridorS3R3-v0", [0, 1, 2], False), ("MiniGrid-UnlockPickup-v0", [0, 1, 2], False), ("MiniGrid-MemoryS9-v0", [0], False), ("MiniGrid-Dynamic-Obstacles-6x6-v0", [0, 1], False),
              ("MiniGrid-LavaCrossingS9N1-v0", [0], False), ("MiniGrid-SimpleCrossingS9N1-v0", [0], False),
              ("MiniGrid-MultiRoom-N2-S4-v0", [0], False), ("MiniGrid-Empty-5x5-v0", [0], True), ("MiniGrid-Fetch-5x5-N2-v0", [3, 4], True)]
     ids, seeds, fulls, acts, flats, missions = [], [], [], [], [], []
@@ -516,7 +522,7 @@ def record_levels():
                           ("MiniGrid-RedBlueDoors-6x6-v0", range(128)), ("MiniGrid-RedBlueDoors-8x8-v0", range(128)),
                           ("MiniGrid-KeyCorridorS3R1-v0", range(128)), ("MiniGrid-KeyCorridorS3R2-v0", range(128)), ("MiniGrid-KeyCorridorS3R3-v0", range(128)),
                           ("MiniGrid-KeyCorridorS4R3-v0", range(128)), ("MiniGrid-KeyCorridorS5R3-v0", range(128)), ("MiniGrid-KeyCorridorS6R3-v0", range(128)),
-                          ("MiniGrid-Unlock-v0", range(256)), ("MiniGrid-UnlockPickup-v0", range(256)), ("MiniGrid-BlockedUnlockPickup-v0", range(256)),
+                          ("MiniGrid-LockedRoom-v0", range(256)), ("MiniGrid-Unlock-v0", range(256)), ("MiniGrid-UnlockPickup-v0", range(256)), ("MiniGrid-BlockedUnlockPickup-v0", range(256)),
                           ("MiniGrid-MemoryS7-v0", range(64)), ("MiniGrid-MemoryS9-v0", range(64)), ("MiniGrid-MemoryS11-v0", range(64)),
                           ("MiniGrid-MemoryS13-v0", range(64)), ("MiniGrid-MemoryS13Random-v0", range(128)), ("MiniGrid-MemoryS17Random-v0", range(128)),
                           ("MiniGrid-MultiRoom-N4-S5-v0", range(128)), ("MiniGrid-MultiRoom-N6-v0", range(128)), ("MiniGrid-DistShift1-v0", range(2)),
@@ -756,6 +762,8 @@ def main():
         return acts
     for short, T in [("KeyCorridorS3R1", 200), ("KeyCorridorS3R3", 400), ("KeyCorridorS4R3", 500), ("KeyCorridorS6R3", 600)]:
         record_case(short, mk("MiniGrid-%s-v0" % short), list(range(6)), T, scripts=[keycorridor_script] * 3 + [None] * 3, reseed=False)
+
+    record_case("LockedRoom", mk("MiniGrid-LockedRoom-v0"), list(range(6)), 400, reseed=False)
 
     def memory_script(which):
         def f(env):
