@@ -162,6 +162,9 @@ int check_levelgen_cfg(const mgx_config *cfg, const char *fn)
     case MGX_LEVEL_LOCKEDROOM:
         if (W != 19 || H != 19) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: LockedRoom is 19x19", fn);
         break;
+    case MGX_LEVEL_PLAYGROUND:
+        if (W < 10 || H < 10 || W % 3 != 1 || H % 3 != 1) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: Playground grids are 3k+1 wide and high (19x19)", fn);
+        break;
     case MGX_LEVEL_KEYCORRIDOR: {
         const int S = cfg->level_arg0;
         if (S < 3 || S > 6 || W != 3 * (S - 1) + 1 || (H - 1) % (S - 1) != 0 || (H - 1) / (S - 1) < 1 || (H - 1) / (S - 1) > 3)
@@ -282,6 +285,8 @@ const std::vector<EnvId> &registry()
         {"MiniGrid-KeyCorridorS4R3-v0", mkt(10, 10, 480, 0, MGX_LEVEL_KEYCORRIDOR, 4, MGX_TASK_PICKUPBOX)},
         {"MiniGrid-KeyCorridorS5R3-v0", mkt(13, 13, 750, 0, MGX_LEVEL_KEYCORRIDOR, 5, MGX_TASK_PICKUPBOX)},
         {"MiniGrid-KeyCorridorS6R3-v0", mkt(16, 16, 1080, 0, MGX_LEVEL_KEYCORRIDOR, 6, MGX_TASK_PICKUPBOX)},
+        // PlaygroundV0: 19x19, max_steps = 100 (envs/playground_v0.py:10-11)
+        {"MiniGrid-Playground-v0", mk(19, 19, 100, 0, 0, MGX_LEVEL_PLAYGROUND, 0, 0)},
         // LockedRoom: 19x19, max_steps = 10*size (envs/lockedroom.py:32-35)
         {"MiniGrid-LockedRoom-v0", mkt(19, 19, 190, 0, MGX_LEVEL_LOCKEDROOM, 0, MGX_TASK_NOTE)},
         // FourRoomsEnv: 19x19, max_steps=500 (envs/fourrooms.py:14-17)

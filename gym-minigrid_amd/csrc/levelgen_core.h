@@ -700,6 +700,47 @@ LG_FN void lg_gen_lockedroom(const mgx_config &, R &r, LgLevel &L)
     L.task = (uint32_t)color_of[locked] | ((uint32_t)color_of[key_room] << 3);
 }
 
+// PlaygroundV0._gen_grid (envs/playground_v0.py:13-66): 3 x 3 rooms with one randomly placed, randomly coloured door in
+// every inner wall segment, random agent, 12 random objects.
+template <class R>
+LG_FN void lg_gen_playground(const mgx_config &, R &r, LgLevel &L)
+{
+    const int W = L.W, H = L.H, rw = W / 3, rh = H / 3;
+    L.ncmd = 0;
+    lg_rect(L, 0, 0, W - 1, 0, MGX_CODE_WALL_GREY);
+    lg_rect(L, 0, H - 1, W - 1, H - 1, MGX_CODE_WALL_GREY);
+    lg_rect(L, 0, 0, 0, H - 1, MGX_CODE_WALL_GREY);
+    lg_rect(L, W - 1, 0, W - 1, H - 1, MGX_CODE_WALL_GREY);
+    for (int j = 0; j < 3; j++)
+        for (int i = 0; i < 3; i++) {
+            const int xL = i * rw, yT = j * rh, xR = xL + rw, yB = yT + rh;
+            if (i + 1 < 3) {
+                lg_rect(L, xR, yT, xR, yT + rh - 1, MGX_CODE_WALL_GREY);       // vert_wall(xR, yT, roomH)
+                const int y = lg_randint(r, yT + 1, yB - 1);
+                const int color = lg_sorted_color(lg_randint(r, 0, 7));
+                lg_set(L, xR, y, MGX_K_DOOR_CLOSED | ((uint32_t)color << 4));
+            }
+            if (j + 1 < 3) {
+                lg_rect(L, xL, yB, xL + rw - 1, yB, MGX_CODE_WALL_GREY);       // horz_wall(xL, yB, roomW)
+                const int x = lg_randint(r, xL + 1, xR - 1);
+                const int color = lg_sorted_color(lg_randint(r, 0, 7));
+                lg_set(L, x, yB, MGX_K_DOOR_CLOSED | ((uint32_t)color << 4));
+            }
+            if (!r.alive() || L.too_big) return;
+        }
+    L.ax = -1; L.ay = -1;
+    lg_sample_free(r, L, W, H, false, &L.ax, &L.ay); // place_agent()
+    L.adir = lg_randint(r, 0, 4);
+    for (int k = 0; k < 12; k++) {
+        const int type = lg_randint(r, 0, 3);
+        const int color = lg_sorted_color(lg_randint(r, 0, 7));
+        int x, y;
+        lg_sample_free(r, L, W, H, true, &x, &y);    // place_obj(obj): not on the agent
+        if (!r.alive() || L.too_big) return;
+        lg_set(L, x, y, (uint32_t)(MGX_K_KEY + type) | ((uint32_t)color << 4));
+    }
+}
+
 // GoToDoorEnv._gen_grid (envs/gotodoor.py:23-69, as modified by the fork): four locked doors on the four walls in four
 // distinct colours, redrawn until one of them is red (the target); random agent.
 template <class R>
@@ -815,6 +856,7 @@ LG_FN void lg_generate(const mgx_config &c, R &r, LgLevel &L)
     case MGX_LEVEL_UNLOCK: lg_gen_unlock(c, r, L); break;
     case MGX_LEVEL_KEYCORRIDOR: lg_gen_keycorridor(c, r, L); break;
     case MGX_LEVEL_LOCKEDROOM: lg_gen_lockedroom(c, r, L); break;
+    case MGX_LEVEL_PLAYGROUND: lg_gen_playground(c, r, L); break;
     default: lg_gen_lavagap(c, r, L); break;
     }
 }

@@ -110,7 +110,8 @@ typedef enum {
                                 height; use with task_kind = MGX_TASK_PICKUPBOX */
     MGX_LEVEL_LOCKEDROOM = 16, /* LockedRoom (envs/lockedroom.py), 19x19; use with task_kind = MGX_TASK_NOTE (the task word only
                                 names the mission: locked colour | key room colour << 3) */
-    MGX_LEVEL_KIND_END = 17
+    MGX_LEVEL_PLAYGROUND = 17, /* PlaygroundV0 (envs/playground_v0.py), 19x19: nine rooms, random doors, 12 random objects, no mission */
+    MGX_LEVEL_KIND_END = 18
 } mgx_level_kind;
 
 /* task rules layered on MiniGridEnv.step by env subclasses (`step` overrides that only reshape reward/done) */

@@ -522,7 +522,7 @@ def record_levels():
                           ("MiniGrid-RedBlueDoors-6x6-v0", range(128)), ("MiniGrid-RedBlueDoors-8x8-v0", range(128)),
                           ("MiniGrid-KeyCorridorS3R1-v0", range(128)), ("MiniGrid-KeyCorridorS3R2-v0", range(128)), ("MiniGrid-KeyCorridorS3R3-v0", range(128)),
                           ("MiniGrid-KeyCorridorS4R3-v0", range(128)), ("MiniGrid-KeyCorridorS5R3-v0", range(128)), ("MiniGrid-KeyCorridorS6R3-v0", range(128)),
-                          ("MiniGrid-LockedRoom-v0", range(256)), ("MiniGrid-Unlock-v0", range(256)), ("MiniGrid-UnlockPickup-v0", range(256)), ("MiniGrid-BlockedUnlockPickup-v0", range(256)),
+                          ("MiniGrid-LockedRoom-v0", range(256)), ("MiniGrid-Playground-v0", range(256)), ("MiniGrid-Unlock-v0", range(256)), ("MiniGrid-UnlockPickup-v0", range(256)), ("MiniGrid-BlockedUnlockPickup-v0", range(256)),
                           ("MiniGrid-MemoryS7-v0", range(64)), ("MiniGrid-MemoryS9-v0", range(64)), ("MiniGrid-MemoryS11-v0", range(64)),
                           ("MiniGrid-MemoryS13-v0", range(64)), ("MiniGrid-MemoryS13Random-v0", range(128)), ("MiniGrid-MemoryS17Random-v0", range(128)),
                           ("MiniGrid-MultiRoom-N4-S5-v0", range(128)), ("MiniGrid-MultiRoom-N6-v0", range(128)), ("MiniGrid-DistShift1-v0", range(2)),
@@ -763,6 +763,7 @@ def main():
     for short, T in [("KeyCorridorS3R1", 200), ("KeyCorridorS3R3", 400), ("KeyCorridorS4R3", 500), ("KeyCorridorS6R3", 600)]:
         record_case(short, mk("MiniGrid-%s-v0" % short), list(range(6)), T, scripts=[keycorridor_script] * 3 + [None] * 3, reseed=False)
 
+    record_case("Playground", mk("MiniGrid-Playground-v0"), list(range(6)), 300, reseed=False)
     record_case("LockedRoom", mk("MiniGrid-LockedRoom-v0"), list(range(6)), 400, reseed=False)
 
     def memory_script(which):
