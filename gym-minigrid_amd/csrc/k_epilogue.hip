@@ -93,6 +93,7 @@ __device__ __forceinline__ int flat_row(const uint2 *rec, int64_t env, int fetch
     if (!fetch) return 0;
     const uint32_t task = rec[env].y >> 16;
     if (fetch == 2) return (int)(((task >> 8) & 3u) * 8u + ((task >> 10) & 7u)); // GoToObject: type, color
+    if (fetch == 5) return (int)((((task & 3u) * 8u + ((task >> 2) & 7u)) * 24u) + ((task >> 11) & 3u) * 8u + ((task >> 13) & 7u)); // PutNear
     if (fetch == 4) return (int)(task & 63u);                                    // LockedRoom: locked colour | key room colour << 3
     if (fetch == 3) return (int)((task >> 4) & 7u);                              // UnlockPickup / KeyCorridor: colour of the target
     return (int)((((task >> 8) & 7u) * 2u + ((task & 15u) == MGX_K_BALL ? 1u : 0u)) * 8u + ((task >> 4) & 7u));

@@ -35,7 +35,7 @@ namespace {
 // Task rules that env subclasses layer on MiniGridEnv.step (they run after the base step, time-out included).
 template <int CH, class CellAt>
 __device__ __forceinline__ void task_rule(const StepParams &p, const Lane &L, uint32_t act, float &reward, bool &done, CellAt cell_at,
-                                          int fidx = -1, uint32_t fc = 0)
+                                          int fidx = -1, uint32_t fc = 0, uint32_t carry0 = MGX_CODE_EMPTY)
 {
     if (p.task == MGX_TASK_FETCH) { // envs/fetch.py:74-86
         if (L.carry != MGX_CODE_EMPTY) {
@@ -63,6 +63,17 @@ __device__ __forceinline__ void task_rule(const StepParams &p, const Lane &L, ui
         const bool blue_before = ((bi == fidx ? fc : cell_at(bi)) & 15u) == MGX_K_DOOR_OPEN;
         if (blue_after) { reward = red_before ? (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps)) : 0.f; done = true; }
         else if (red_after && blue_before) { reward = 0.f; done = true; }
+    } else if (p.task == MGX_TASK_PUTNEAR) { // envs/putnear.py:91-110; carry0 = preCarrying
+        const uint32_t move = (uint32_t)(MGX_K_KEY + (L.task & 3u)) | (((L.task >> 2) & 7u) << 4);
+        if (act == 3 && L.carry != MGX_CODE_EMPTY && (L.carry & 0x7Fu) != move) done = true; // picked up (or holds) the wrong object
+        if (act == 4 && carry0 != MGX_CODE_EMPTY) {
+            if (L.carry == MGX_CODE_EMPTY) { // the drop happened: the object now lies in the front cell
+                const int ox = L.ax + (L.dir == 0) - (L.dir == 2), oy = L.ay + (L.dir == 1) - (L.dir == 3);
+                const int dx = ox - (int)((L.task >> 5) & 7u), dy = oy - (int)((L.task >> 8) & 7u);
+                if (dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1) reward = (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps));
+            }
+            done = true;
+        }
     } else if (p.task == MGX_TASK_UNLOCK) { // envs/unlock.py:33-41: the door is at (5, task)
         const int H = CH ? CH : p.H;
         if (act == 5 && (cell_at(5 * H + (int)(L.task & 15u)) & 15u) == MGX_K_DOOR_OPEN) { reward = (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps)); done = true; }
@@ -581,14 +592,14 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
     if (p.do_step) {
         const int fidx = transition_begin<CW, CH>(p, L, act, valid, bad_act, oob);
         if (fidx >= 0) {
-            const uint32_t fc = row[fidx];
+            const uint32_t fc = row[fidx], carry0 = L.carry;
             // hidden object state rides only on the run-time-size kernels (mgx_launch_step routes there): pruned from the sized ones
             const bool has_obj = CW == 0 && p.objaux != nullptr;
             const ObjRef obj = {has_obj ? p.objaux + env * S : nullptr, has_obj ? p.objcont + env * S : nullptr, has_obj ? p.objcarry + env : nullptr};
             const uint32_t nc = transition_apply<CH>(p, L, act, fc, reward, done, [&](int i) -> uint32_t { return row[i]; }, oob, fidx, obj);
             if constexpr (!GATHER) { if (nc != fc) g[fidx] = (uint8_t)nc; }
             if (valid && L.steps >= p.max_steps) done = true; // minigrid.py:1320-1321
-            if (p.task) task_rule<CH>(p, L, act, reward, done, [&](int i) -> uint32_t { return (GATHER && i == fidx) ? nc : (uint32_t)row[i]; }, fidx, fc);
+            if (p.task) task_rule<CH>(p, L, act, reward, done, [&](int i) -> uint32_t { return (GATHER && i == fidx) ? nc : (uint32_t)row[i]; }, fidx, fc, carry0);
             // the one cell a transition can change; skipped when the env is about to be restored anyway
             if (nc != fc && !(p.auto_reset && done)) { p.cells[env * S + fidx] = (uint8_t)nc; pidx = fidx; pcode = nc; }
         } else if (valid && L.steps >= p.max_steps) done = true;
@@ -681,14 +692,14 @@ __global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
         if (p.do_step) {
             const int fidx = transition_begin<CW, CH>(p, L, act, valid, bad_act, oob);
             if (fidx >= 0) {
-                const uint32_t fc = p.cells[env * S + fidx];
+                const uint32_t fc = p.cells[env * S + fidx], carry0 = L.carry;
                 // hidden object state rides only on the run-time-size kernels (mgx_launch_step routes there): pruned from the sized ones
             const bool has_obj = CW == 0 && p.objaux != nullptr;
             const ObjRef obj = {has_obj ? p.objaux + env * S : nullptr, has_obj ? p.objcont + env * S : nullptr, has_obj ? p.objcarry + env : nullptr};
                 const uint32_t nc = transition_apply<CH>(p, L, act, fc, reward, done,
                                                          [&](int i) -> uint32_t { return p.cells[env * S + i]; }, oob, fidx, obj);
                 if (valid && L.steps >= p.max_steps) done = true;
-                if (p.task) task_rule<CH>(p, L, act, reward, done, [&](int i) -> uint32_t { return (i == fidx) ? nc : (uint32_t)p.cells[env * S + i]; }, fidx, fc);
+                if (p.task) task_rule<CH>(p, L, act, reward, done, [&](int i) -> uint32_t { return (i == fidx) ? nc : (uint32_t)p.cells[env * S + i]; }, fidx, fc, carry0);
                 if (nc != fc && !(p.auto_reset && done)) {
                     p.cells[env * S + fidx] = (uint8_t)nc;
                     wr = (uint32_t)fidx | (nc << 16);

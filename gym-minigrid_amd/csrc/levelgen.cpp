@@ -162,6 +162,9 @@ int check_levelgen_cfg(const mgx_config *cfg, const char *fn)
     case MGX_LEVEL_LOCKEDROOM:
         if (W != 19 || H != 19) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: LockedRoom is 19x19", fn);
         break;
+    case MGX_LEVEL_PUTNEAR:
+        if (W > 8 || H > 8 || cfg->level_arg0 < 2 || cfg->level_arg0 > 4) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: PutNear needs W, H <= 8 and 2..4 objects", fn);
+        break;
     case MGX_LEVEL_PLAYGROUND:
         if (W < 10 || H < 10 || W % 3 != 1 || H % 3 != 1) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: Playground grids are 3k+1 wide and high (19x19)", fn);
         break;
@@ -285,6 +288,9 @@ const std::vector<EnvId> &registry()
         {"MiniGrid-KeyCorridorS4R3-v0", mkt(10, 10, 480, 0, MGX_LEVEL_KEYCORRIDOR, 4, MGX_TASK_PICKUPBOX)},
         {"MiniGrid-KeyCorridorS5R3-v0", mkt(13, 13, 750, 0, MGX_LEVEL_KEYCORRIDOR, 5, MGX_TASK_PICKUPBOX)},
         {"MiniGrid-KeyCorridorS6R3-v0", mkt(16, 16, 1080, 0, MGX_LEVEL_KEYCORRIDOR, 6, MGX_TASK_PICKUPBOX)},
+        // PutNearEnv: max_steps = 5*size, see_through_walls=True (envs/putnear.py:10-22,112-126)
+        {"MiniGrid-PutNear-6x6-N2-v0", mkt(6, 6, 30, 1, MGX_LEVEL_PUTNEAR, 2, MGX_TASK_PUTNEAR)},
+        {"MiniGrid-PutNear-8x8-N3-v0", mkt(8, 8, 40, 1, MGX_LEVEL_PUTNEAR, 3, MGX_TASK_PUTNEAR)},
         // PlaygroundV0: 19x19, max_steps = 100 (envs/playground_v0.py:10-11)
         {"MiniGrid-Playground-v0", mk(19, 19, 100, 0, 0, MGX_LEVEL_PLAYGROUND, 0, 0)},
         // LockedRoom: 19x19, max_steps = 10*size (envs/lockedroom.py:32-35)
@@ -354,6 +360,14 @@ extern "C" int mgx_mission(const mgx_config *cfg, uint32_t task, char *out, int 
         const uint32_t lc = task & 7u, kc = (task >> 3) & 7u;
         if (lc > 6 || kc > 6) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_mission: 0x%x is not a LockedRoom task word", task);
         snprintf(buf, sizeof buf, "get the %s key from the %s room, unlock the %s door and go to the goal", colors[lc], colors[kc], colors[lc]);
+        m = buf;
+        break;
+    }
+    case MGX_LEVEL_PUTNEAR: {                                                                               // envs/putnear.py:84-89
+        static const char *const types[3] = {"key", "ball", "box"};
+        const uint32_t mt = task & 3u, mc = (task >> 2) & 7u, tt = (task >> 11) & 3u, tc = (task >> 13) & 7u;
+        if (mt > 2 || tt > 2 || mc > 6 || tc > 6) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_mission: 0x%x is not a PutNear task word", task);
+        snprintf(buf, sizeof buf, "put the %s %s near the %s %s", colors[mc], types[mt], colors[tc], types[tt]);
         m = buf;
         break;
     }

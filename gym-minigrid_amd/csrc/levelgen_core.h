@@ -741,6 +741,54 @@ LG_FN void lg_gen_playground(const mgx_config &, R &r, LgLevel &L)
     }
 }
 
+// PutNearEnv._gen_grid (envs/putnear.py:24-89): like GoToObject, but no object may be placed within one cell of another
+// (reject_fn near_obj); a random object to move and a different random target.
+template <class R>
+LG_FN void lg_gen_putnear(const mgx_config &c, R &r, LgLevel &L)
+{
+    L.ncmd = 0;
+    lg_rect(L, 0, 0, L.W - 1, 0, MGX_CODE_WALL_GREY);
+    lg_rect(L, 0, L.H - 1, L.W - 1, L.H - 1, MGX_CODE_WALL_GREY);
+    lg_rect(L, 0, 0, 0, L.H - 1, MGX_CODE_WALL_GREY);
+    lg_rect(L, L.W - 1, 0, L.W - 1, L.H - 1, MGX_CODE_WALL_GREY);
+    const int first_obj = L.ncmd, n = c.level_arg0;
+    L.ax = -1; L.ay = -1;
+    int have = 0;
+    while (have < n) {
+        const int type = lg_randint(r, 0, 3);
+        const int color = lg_sorted_color(lg_randint(r, 0, 7));
+        if (!r.alive()) return;
+        const uint32_t code = (uint32_t)(MGX_K_KEY + type) | ((uint32_t)color << 4);
+        bool dup = false;
+        for (int k = 0; k < have; k++) dup = dup || L.cmds[first_obj + k].code == code;
+        if (dup) continue;
+        int x, y;
+        for (;;) { // place_obj(obj, reject_fn=near_obj)
+            x = lg_randint(r, 0, L.W); y = lg_randint(r, 0, L.H);
+            if (!r.alive()) return;
+            if (!lg_empty(L, x, y)) continue;
+            bool near = false;
+            for (int k = 0; k < have; k++) {
+                const int dx = x - (int)L.cmds[first_obj + k].x0, dy = y - (int)L.cmds[first_obj + k].y0;
+                near = near || (dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1);
+            }
+            if (!near) break;
+        }
+        if (L.too_big) return;
+        lg_set(L, x, y, code);
+        have++;
+    }
+    lg_sample_free(r, L, L.W, L.H, false, &L.ax, &L.ay);        // place_agent()
+    L.adir = lg_randint(r, 0, 4);
+    const int mi = lg_randint(r, 0, n);                         // the object to move
+    int ti;
+    do { ti = lg_randint(r, 0, n); } while (ti == mi && r.alive()); // the target
+    if (L.too_big || !r.alive()) return;
+    const LgCmd mc = L.cmds[first_obj + mi], tc = L.cmds[first_obj + ti];
+    L.task = (uint32_t)((mc.code & 15u) - MGX_K_KEY) | (((uint32_t)(mc.code >> 4) & 7u) << 2) | ((uint32_t)tc.x0 << 5) | ((uint32_t)tc.y0 << 8) |
+             ((uint32_t)((tc.code & 15u) - MGX_K_KEY) << 11) | (((uint32_t)(tc.code >> 4) & 7u) << 13);
+}
+
 // GoToDoorEnv._gen_grid (envs/gotodoor.py:23-69, as modified by the fork): four locked doors on the four walls in four
 // distinct colours, redrawn until one of them is red (the target); random agent.
 template <class R>
@@ -857,6 +905,7 @@ LG_FN void lg_generate(const mgx_config &c, R &r, LgLevel &L)
     case MGX_LEVEL_KEYCORRIDOR: lg_gen_keycorridor(c, r, L); break;
     case MGX_LEVEL_LOCKEDROOM: lg_gen_lockedroom(c, r, L); break;
     case MGX_LEVEL_PLAYGROUND: lg_gen_playground(c, r, L); break;
+    case MGX_LEVEL_PUTNEAR: lg_gen_putnear(c, r, L); break;
     default: lg_gen_lavagap(c, r, L); break;
     }
 }

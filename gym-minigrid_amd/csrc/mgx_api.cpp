@@ -240,7 +240,7 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     if (cfg->width < 3 || cfg->height < 3 || cfg->width > 255 || cfg->height > 255)
         return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: grid %dx%d outside 3..255 (Grid.__init__ asserts >= 3)", cfg->width, cfg->height);
     if (cfg->max_steps <= 0) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: max_steps must be positive");
-    if (cfg->task_kind < MGX_TASK_NONE || cfg->task_kind > MGX_TASK_NOTE)
+    if (cfg->task_kind < MGX_TASK_NONE || cfg->task_kind > MGX_TASK_PUTNEAR)
         return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: bad task_kind %d", cfg->task_kind);
     if ((cfg->task_kind == MGX_TASK_DYNOBS) != (cfg->level_kind == MGX_LEVEL_DYNOBS))
         return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: MGX_TASK_DYNOBS and MGX_LEVEL_DYNOBS go together (the obstacle walk continues the level's RNG stream)");
@@ -356,7 +356,7 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     CREATE_TRY(hipMalloc((void **)&h->ctr_d, sizeof(MgxCounters)));
     if (h->oh_nc >= 0 || h->flat) CREATE_TRY(hipMalloc((void **)&h->tri_d, (size_t)h->n * h->tri_bytes + 16));
     if (h->flat) { // the family's mission strings as character codes (wrappers.py:563-571)
-        const int rows = cfg->level_kind == MGX_LEVEL_FETCH ? 80 : (cfg->level_kind == MGX_LEVEL_GOTOOBJECT ? 24 : ((cfg->level_kind == MGX_LEVEL_UNLOCK && cfg->level_arg0) || cfg->level_kind == MGX_LEVEL_KEYCORRIDOR ? 8 : (cfg->level_kind == MGX_LEVEL_LOCKEDROOM ? 64 : 1)));
+        const int rows = cfg->level_kind == MGX_LEVEL_FETCH ? 80 : (cfg->level_kind == MGX_LEVEL_GOTOOBJECT ? 24 : ((cfg->level_kind == MGX_LEVEL_UNLOCK && cfg->level_arg0) || cfg->level_kind == MGX_LEVEL_KEYCORRIDOR ? 8 : (cfg->level_kind == MGX_LEVEL_LOCKEDROOM ? 64 : (cfg->level_kind == MGX_LEVEL_PUTNEAR ? 576 : 1))));
         std::vector<float> tab((size_t)rows * MGX_FLAT_MISSION, 0.f);
         for (int r = 0; r < rows; r++) {
             uint32_t task = 0;
@@ -367,6 +367,10 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
             } else if ((cfg->level_kind == MGX_LEVEL_UNLOCK && cfg->level_arg0) || cfg->level_kind == MGX_LEVEL_KEYCORRIDOR) {
                 if (r > 6) continue;
                 task = (uint32_t)(cfg->level_kind == MGX_LEVEL_UNLOCK ? MGX_K_BOX : MGX_K_BALL) | ((uint32_t)r << 4); // the target's colour
+            } else if (cfg->level_kind == MGX_LEVEL_PUTNEAR) {
+                const int a = r / 24, b = r % 24;
+                if ((a & 7) > 6 || (b & 7) > 6) continue;
+                task = (uint32_t)(a >> 3) | ((uint32_t)(a & 7) << 2) | ((uint32_t)(b >> 3) << 11) | ((uint32_t)(b & 7) << 13);
             } else if (cfg->level_kind == MGX_LEVEL_LOCKEDROOM) {
                 if ((r & 7) > 6 || (r >> 3) > 6) continue;
                 task = (uint32_t)r;
@@ -670,7 +674,7 @@ static int run_step(mgx_handle h, bool do_step, const uint8_t *actions, uint8_t 
         HIP_TRY(mgx_launch_onehot(h->tri_d, (uint8_t *)o[0].dev, h->n * (h->tri_bytes / 3), h->oh_nc, h->oh_ns, h->stream));
     if (h->flat && o[0].dev)
         HIP_TRY(mgx_launch_flat(h->tri_d, h->agent_d, h->mission_d, (float *)o[0].dev, h->n, (int)h->tri_bytes,
-                                h->cfg.level_kind == MGX_LEVEL_FETCH ? 1 : (h->cfg.level_kind == MGX_LEVEL_GOTOOBJECT ? 2 : ((h->cfg.level_kind == MGX_LEVEL_UNLOCK && h->cfg.level_arg0) || h->cfg.level_kind == MGX_LEVEL_KEYCORRIDOR ? 3 : (h->cfg.level_kind == MGX_LEVEL_LOCKEDROOM ? 4 : 0))), h->stream));
+                                h->cfg.level_kind == MGX_LEVEL_FETCH ? 1 : (h->cfg.level_kind == MGX_LEVEL_GOTOOBJECT ? 2 : ((h->cfg.level_kind == MGX_LEVEL_UNLOCK && h->cfg.level_arg0) || h->cfg.level_kind == MGX_LEVEL_KEYCORRIDOR ? 3 : (h->cfg.level_kind == MGX_LEVEL_LOCKEDROOM ? 4 : (h->cfg.level_kind == MGX_LEVEL_PUTNEAR ? 5 : 0)))), h->stream));
     if (do_step) {
         h->steps_total += h->n;
         if (h->profiling) h->prof_launches++;

@@ -96,7 +96,7 @@ class VecMiniGrid:
             self.observation_space = Box(0, 255, (1,) + self.obs_shape, "uint8")  # wrappers.py:543-548
         self.reward_range = (-1, 1) if cfg.task_kind == 3 else (0, 1)
         try:  # families whose mission names per-episode objects (Fetch, GoToObject, UnlockPickup, KeyCorridor, LockedRoom)
-            self.mission = self._mission_of(0) if cfg.task_kind not in (1, 4, 8, 9) else "per episode: see missions()"
+            self.mission = self._mission_of(0) if cfg.task_kind not in (1, 4, 8, 9, 10) else "per episode: see missions()"
         except _lib.MgxError:
             self.mission = "per episode: see missions()"
         self._h = ctypes.c_void_p()

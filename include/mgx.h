@@ -111,7 +111,8 @@ typedef enum {
     MGX_LEVEL_LOCKEDROOM = 16, /* LockedRoom (envs/lockedroom.py), 19x19; use with task_kind = MGX_TASK_NOTE (the task word only
                                 names the mission: locked colour | key room colour << 3) */
     MGX_LEVEL_PLAYGROUND = 17, /* PlaygroundV0 (envs/playground_v0.py), 19x19: nine rooms, random doors, 12 random objects, no mission */
-    MGX_LEVEL_KIND_END = 18
+    MGX_LEVEL_PUTNEAR = 18,  /* PutNearEnv (envs/putnear.py): level_arg0 = numObjs, grids up to 8x8; use with MGX_TASK_PUTNEAR */
+    MGX_LEVEL_KIND_END = 19
 } mgx_level_kind;
 
 /* task rules layered on MiniGridEnv.step by env subclasses (`step` overrides that only reshape reward/done) */
@@ -137,6 +138,10 @@ typedef enum {
                               ends the episode with _reward().  Per-env task word = the target's cell code
                               (type | color << 4). */
     MGX_TASK_NOTE = 9,     /* no rule on top of MiniGridEnv.step; the per-env task word only selects the mission string */
+    MGX_TASK_PUTNEAR = 10, /* envs/putnear.py:91-110: picking up anything but the object to move ends the episode; a `drop` while
+                              carrying ends it too, with _reward() when the object landed within one cell of the target's
+                              initial position.  Per-env task word = move type | move colour << 2 | tx << 5 | ty << 8 |
+                              target type << 11 | target colour << 13 (types: 0 key, 1 ball, 2 box). */
     MGX_TASK_DYNOBS = 3,   /* envs/dynamicobstacles.py:60-89 (with level_kind = MGX_LEVEL_DYNOBS): actions >= 3 fold to 0;
                               before the base step every obstacle (blue ball) is re-placed in its 3x3 neighbourhood with
                               draws from the env's own RNG stream (place_obj, max_tries=100); moving forward while the

@@ -93,6 +93,10 @@ def contains_plane(env):
 
 def task_word(env):
     """Fetch: target object as a cell code (type | color << 4).  GoToObject: tx | ty << 4 | (type - key) << 8 | color << 10."""
+    if type(env).__name__.startswith("PutNear"):
+        tx, ty = env.target_pos
+        return ((M.OBJECT_TO_IDX[env.move_type] - 5) | (M.COLOR_TO_IDX[env.moveColor] << 2) | (int(tx) << 5) | (int(ty) << 8) |
+                ((M.OBJECT_TO_IDX[env.target_type] - 5) << 11) | (M.COLOR_TO_IDX[env.target_color] << 13))
     if type(env).__name__ == "LockedRoom":
         locked = [rm for rm in env.rooms if rm.locked][0]
         key = [(x, y) for x in range(env.width) for y in range(env.height) if env.grid.get(x, y) is not None and env.grid.get(x, y).type == "key"][0]
@@ -310,7 +314,7 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
     meta = dict(env_id=name, W=W, H=H, max_steps=int(env0.max_steps), view=V,
                 see_through=bool(env0.see_through_walls), lava_v1=bool(v1), full_obs=bool(full_obs),
                 reseed=bool(reseed), extended=bool(n_actions > 7), alt_vis=not bool(env0.default_vis),
-                task=9 if type(env0).__name__ == "LockedRoom" else 7 if type(env0).__name__ == "Unlock" else 8 if type(env0).__name__ in ("UnlockPickup", "BlockedUnlockPickup") or type(env0).__name__.startswith("KeyCorridor") else 6 if type(env0).__name__.startswith("Memory") else 5 if type(env0).__name__.startswith("RedBlueDoor") else 4 if type(env0).__name__.startswith(("GoToObject", "GotoEnv")) else (1 if hasattr(env0, "targetType") else (2 if hasattr(env0, "target_pos") else 0)),
+                task=10 if type(env0).__name__.startswith("PutNear") else 9 if type(env0).__name__ == "LockedRoom" else 7 if type(env0).__name__ == "Unlock" else 8 if type(env0).__name__ in ("UnlockPickup", "BlockedUnlockPickup") or type(env0).__name__.startswith("KeyCorridor") else 6 if type(env0).__name__.startswith("Memory") else 5 if type(env0).__name__.startswith("RedBlueDoor") else 4 if type(env0).__name__.startswith(("GoToObject", "GotoEnv")) else (1 if hasattr(env0, "targetType") else (2 if hasattr(env0, "target_pos") else 0)),
                 objstate=bool(objstate), dynobs=int(getattr(env0, "n_obstacles", 0)), gym_id=gym_id or "")
     z = dict(
         seed=np.zeros(K, np.int64), init_grid=np.zeros((K, W, H, 3), np.uint8),
@@ -476,7 +480,7 @@ def record_flat():
              ("MiniGrid-Fetch-5x5-N2-v0", list(range(16)), False), ("MiniGrid-Fetch-8x8-N3-v0", list(range(8)), False),
              ("MiniGrid-GoToDoor-5x5-v0", [0, 1], False), ("MiniGrid-FourRooms-v0", [0], False),
              ("MiniGrid-GoToObject-6x6-N2-v0", list(range(8)), False), ("MiniGrid-LockedRoom-v0", list(range(6)), False),
-             ("MiniGrid-KeyCorridorS3R3-v0", [0, 1, 2], False), ("MiniGrid-UnlockPickup-v0", [0, 1, 2], False), ("MiniGrid-MemoryS9-v0", [0], False), ("MiniGrid-Dynamic-Obstacles-6x6-v0", [0, 1], False),
+             ("MiniGrid-KeyCorridorS3R3-v0", [0, 1, 2], False), ("MiniGrid-UnlockPickup-v0", [0, 1, 2], False), ("MiniGrid-MemoryS9-v0", [0], False), ("MiniGrid-PutNear-8x8-N3-v0", list(range(6)), False), ("MiniGrid-Dynamic-Obstacles-6x6-v0", [0, 1], False),
              ("MiniGrid-LavaCrossingS9N1-v0", [0], False), ("MiniGrid-SimpleCrossingS9N1-v0", [0], False),
              ("MiniGrid-MultiRoom-N2-S4-v0", [0], False), ("MiniGrid-Empty-5x5-v0", [0], True), ("MiniGrid-Fetch-5x5-N2-v0", [3, 4], True)]
     ids, seeds, fulls, acts, flats, missions = [], [], [], [], [], []
@@ -522,7 +526,7 @@ def record_levels():
                           ("MiniGrid-RedBlueDoors-6x6-v0", range(128)), ("MiniGrid-RedBlueDoors-8x8-v0", range(128)),
                           ("MiniGrid-KeyCorridorS3R1-v0", range(128)), ("MiniGrid-KeyCorridorS3R2-v0", range(128)), ("MiniGrid-KeyCorridorS3R3-v0", range(128)),
                           ("MiniGrid-KeyCorridorS4R3-v0", range(128)), ("MiniGrid-KeyCorridorS5R3-v0", range(128)), ("MiniGrid-KeyCorridorS6R3-v0", range(128)),
-                          ("MiniGrid-LockedRoom-v0", range(256)), ("MiniGrid-Playground-v0", range(256)), ("MiniGrid-Unlock-v0", range(256)), ("MiniGrid-UnlockPickup-v0", range(256)), ("MiniGrid-BlockedUnlockPickup-v0", range(256)),
+                          ("MiniGrid-PutNear-6x6-N2-v0", range(256)), ("MiniGrid-PutNear-8x8-N3-v0", range(256)), ("MiniGrid-LockedRoom-v0", range(256)), ("MiniGrid-Playground-v0", range(256)), ("MiniGrid-Unlock-v0", range(256)), ("MiniGrid-UnlockPickup-v0", range(256)), ("MiniGrid-BlockedUnlockPickup-v0", range(256)),
                           ("MiniGrid-MemoryS7-v0", range(64)), ("MiniGrid-MemoryS9-v0", range(64)), ("MiniGrid-MemoryS11-v0", range(64)),
                           ("MiniGrid-MemoryS13-v0", range(64)), ("MiniGrid-MemoryS13Random-v0", range(128)), ("MiniGrid-MemoryS17Random-v0", range(128)),
                           ("MiniGrid-MultiRoom-N4-S5-v0", range(128)), ("MiniGrid-MultiRoom-N6-v0", range(128)), ("MiniGrid-DistShift1-v0", range(2)),
@@ -763,6 +767,32 @@ def main():
     for short, T in [("KeyCorridorS3R1", 200), ("KeyCorridorS3R3", 400), ("KeyCorridorS4R3", 500), ("KeyCorridorS6R3", 600)]:
         record_case(short, mk("MiniGrid-%s-v0" % short), list(range(6)), T, scripts=[keycorridor_script] * 3 + [None] * 3, reseed=False)
 
+    def putnear_script(which):
+        def f(env):
+            # pick up the object to move (0) or another one (1); with 0 carry it next to the target and drop it
+            acts = []
+
+            def do(seq):
+                for k in seq:
+                    env.step(k)
+                    acts.append(k)
+            objs = [(x, y) for x in range(env.width) for y in range(env.height)
+                    if env.grid.get(x, y) is not None and env.grid.get(x, y).type in ("key", "ball", "box")]
+            mv = tuple(env.move_pos)
+            oth = [p for p in objs if p != mv]
+            do((plan_face(env, mv if which == 0 or not oth else oth[0]) or []) + [3])
+            if which == 0 and env.carrying is not None:
+                tx, ty = env.target_pos
+                for cand in [(tx + 1, ty), (tx - 1, ty), (tx, ty + 1), (tx, ty - 1), (tx + 1, ty + 1), (tx - 1, ty - 1)]:
+                    if 0 < cand[0] < env.width - 1 and 0 < cand[1] < env.height - 1 and env.grid.get(*cand) is None and tuple(env.agent_pos) != cand:
+                        p = plan_face(env, cand)
+                        if p is not None:
+                            do(p + [4])
+                            break
+            return acts
+        return f
+    record_case("PutNear-8x8-N3", mk("MiniGrid-PutNear-8x8-N3-v0"), list(range(10)), 300, scripts=[putnear_script(0), putnear_script(1)] * 3 + [None] * 4, reseed=False)
+    record_case("PutNear-6x6-N2", mk("MiniGrid-PutNear-6x6-N2-v0"), list(range(8)), 240, scripts=[putnear_script(1), putnear_script(0)] * 2 + [None] * 4, reseed=False)
     record_case("Playground", mk("MiniGrid-Playground-v0"), list(range(6)), 300, reseed=False)
     record_case("LockedRoom", mk("MiniGrid-LockedRoom-v0"), list(range(6)), 400, reseed=False)
 

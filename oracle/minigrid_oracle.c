@@ -376,6 +376,17 @@ static void task_rule(const mgo_cfg *cf, const uint8_t *g, const uint8_t *aux, c
                 if (c.c == 0) *reward = 1 - 0.9 * ((double)steps / (double)cf->max_steps); /* the target door is the red one */
             }
         }
+    } else if (cf->task == 10) { /* PutNearEnv.step envs/putnear.py:91-110; pre = something was carried before the step */
+        const uint32_t mt = T_KEY + (task & 3u), mc = (task >> 2) & 7u;
+        static const int DX[4] = {1, 0, -1, 0}, DY[4] = {0, 1, 0, -1};
+        if (action == A_PICKUP && carry[0] != T_EMPTY && (carry[0] != mt || carry[1] != mc)) *done = 1;
+        if (action == A_DROP && pre) {
+            if (carry[0] == T_EMPTY) { /* grid.get(ox, oy) is preCarrying: the drop happened */
+                int dx = agent[0] + DX[agent[2]] - (int)((task >> 5) & 7u), dy = agent[1] + DY[agent[2]] - (int)((task >> 8) & 7u);
+                if (dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1) *reward = 1 - 0.9 * ((double)steps / (double)cf->max_steps);
+            }
+            *done = 1;
+        }
     } else if (cf->task == 7) { /* Unlock.step envs/unlock.py:33-41; the door is at (5, task) */
         if (action == A_TOGGLE && door_open(cf, g, 5, (int)(task & 15u))) { *reward = 1 - 0.9 * ((double)steps / (double)cf->max_steps); *done = 1; }
     } else if (cf->task == 8) { /* UnlockPickup.step envs/unlockpickup.py:35-43, KeyCorridor.step keycorridor.py:51-59: carrying the target */
@@ -417,6 +428,7 @@ int mgo_step_batch(const mgo_cfg *cf, int64_t n, uint8_t *grid, uint8_t *aux, in
     for (int64_t e = 0; e < n; e++) {
         uint8_t *g = grid + e * cells * 3, *ax = aux + e * cells;
         int pre = 0;
+        if (cf->task == 10) pre = carry[e * 3] != T_EMPTY;
         if (cf->task == 5 && g_task)
             pre = door_open(cf, g, cf->H / 2, (int)(g_task[e] & 15u)) | (door_open(cf, g, cf->H / 2 + cf->H - 1, (int)((g_task[e] >> 4) & 15u)) << 1);
         const int act_e = (cf->task == 6 && actions[e] == A_PICKUP) ? A_TOGGLE : actions[e]; /* envs/memory.py:89-90 */
