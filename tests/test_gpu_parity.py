@@ -237,6 +237,44 @@ def test_seeded_reset_on_device(env_id):
     env.close()
 
 
+@pytest.mark.parametrize("env_id", ["MiniGrid-Fetch-8x8-N3-v0", "MiniGrid-GoToDoor-6x6-v0", "MiniGrid-GoToObject-8x8-N2-v0", "MiniGrid-PutNear-8x8-N3-v0",
+                                    "MiniGrid-RedBlueDoors-6x6-v0", "MiniGrid-MemoryS9-v0", "MiniGrid-MemoryS17Random-v0", "MiniGrid-Unlock-v0",
+                                    "MiniGrid-BlockedUnlockPickup-v0", "MiniGrid-KeyCorridorS3R2-v0", "MiniGrid-KeyCorridorS5R3-v0",
+                                    "MiniGrid-LockedRoom-v0", "MiniGrid-Playground-v0"])
+def test_task_families_on_device_vs_oracle(env_id):
+    """Every family with a task rule (or a per-episode mission): levels and task words generated on the GPU, then a
+    random walk with in-kernel auto-reset against the oracle running the same rule on the host-generated levels."""
+    N, T = 260, 80
+    seeds = np.arange(N, dtype=np.uint64) * 3 + 1
+    env = mg.VecMiniGrid(env_id, num_envs=N, seeds=seeds, auto_reset=True, backend="torch")
+    obs = to_np(env.reset())
+    grid, agent, task = mg.generate_levels(env_id, seeds, with_task=True)
+    cfg = mg.env_config(env_id)
+    orc = OracleEnvs(cfg.width, cfg.height, cfg.max_steps, cfg.see_through_walls, cfg.lava_v1, task=cfg.task_kind)
+    orc.set_state(grid, agent)
+    orc.task = task.copy()
+    assert np.array_equal(obs, orc.observe())
+    if cfg.task_kind:
+        assert np.array_equal(env.get_task(), task)
+    rs = np.random.RandomState(17)
+    dones = 0
+    for t in range(T):
+        a = rs.randint(0, 7, size=N).astype(np.uint8)
+        obs, rew, done, _ = env.step(a)
+        oo, orew, odone = orc.step(a)
+        orc.reset_where(odone)
+        want = np.where(odone.astype(bool)[:, None, None, None], orc.observe(), oo)
+        assert np.array_equal(to_np(done), odone), t
+        assert np.array_equal(to_np(rew), orew.astype(np.float32)), t
+        assert np.array_equal(to_np(obs), want), t
+        dones += int(odone.sum())
+    st = env.get_state()
+    assert np.array_equal(st["grid"], orc.grid) and np.array_equal(st["agent"], orc.agent) and np.array_equal(st["carry"], orc.carry)
+    assert env.stats()["episodes"] == dones
+    assert all(isinstance(m, str) for m in env.missions()[:3])
+    env.close()
+
+
 def test_faults_and_errors():
     N = 70
     grid, aux, agent, carry, steps = random_states(N, 8, 8, seed=3)
