@@ -435,6 +435,11 @@ extern "C" int mgx_generate_levels_ex(const mgx_config *cfg, int64_t n, const ui
 // (plain reference behaviour without ReseedWrapper, minigrid.py:836-839).  grid u8[K][W][H][3], agent i32[K][3].
 extern "C" int mgx_generate_level_stream(const mgx_config *cfg, uint64_t seed, int64_t K, uint8_t *grid, int32_t *agent)
 {
+    return mgx_generate_level_stream_ex(cfg, seed, K, grid, agent, nullptr);
+}
+
+extern "C" int mgx_generate_level_stream_ex(const mgx_config *cfg, uint64_t seed, int64_t K, uint8_t *grid, int32_t *agent, uint32_t *task)
+{
     if (!cfg || !grid || !agent || K < 0) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_generate_level_stream: null argument");
     int rc = check_levelgen_cfg(cfg, "mgx_generate_level_stream");
     if (rc) return rc;
@@ -452,6 +457,7 @@ extern "C" int mgx_generate_level_stream(const mgx_config *cfg, uint64_t seed, i
         for (auto &cd : codes) if (MGX_IS_OBSTACLE_MARK(cd)) cd = (uint8_t)MGX_CODE_BALL_BLUE; // DynObs order markers
         codes_to_triples(codes.data(), cells, grid + (size_t)k * cells * 3);
         agent[k * 3] = L.ax; agent[k * 3 + 1] = L.ay; agent[k * 3 + 2] = L.adir;
+        if (task) task[k] = L.task;
     }
     return MGX_OK;
 }

@@ -343,10 +343,11 @@ def generate_levels(env_id_or_cfg, seeds, with_task=False):
     return (grid, agent, task) if with_task else (grid, agent)
 
 
-def generate_level_stream(env_id_or_cfg, seed, K):
+def generate_level_stream(env_id_or_cfg, seed, K, with_task=False):
     """Host-side `env.seed(seed)` then K consecutive `env.reset()`s (the RNG stream continues across episodes)."""
     cfg = _lib.env_config(env_id_or_cfg) if isinstance(env_id_or_cfg, str) else env_id_or_cfg
     grid = np.empty((K, cfg.width, cfg.height, 3), np.uint8)
     agent = np.empty((K, 3), np.int32)
-    _lib.check(_lib.lib().mgx_generate_level_stream(ctypes.byref(cfg), ctypes.c_uint64(int(seed)), K, _ptr(grid), _ptr(agent)))
-    return grid, agent
+    task = np.zeros(K, np.uint32)
+    _lib.check(_lib.lib().mgx_generate_level_stream_ex(ctypes.byref(cfg), ctypes.c_uint64(int(seed)), K, _ptr(grid), _ptr(agent), _ptr(task)))
+    return (grid, agent, task) if with_task else (grid, agent)

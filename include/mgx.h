@@ -213,6 +213,8 @@ int mgx_generate_levels_ex(const mgx_config *cfg, int64_t n, const uint64_t *see
  * `env.reset()`s -- the env's RNG stream continues, every episode gets a new level (minigrid.py:836-839).
  * grid uint8 [K][W][H][3], agent int32 [K][3]. */
 int mgx_generate_level_stream(const mgx_config *cfg, uint64_t seed, int64_t K, uint8_t *grid, int32_t *agent);
+/* Same, also returning the per-level task words (uint32 [K], may be NULL). */
+int mgx_generate_level_stream_ex(const mgx_config *cfg, uint64_t seed, int64_t K, uint8_t *grid, int32_t *agent, uint32_t *task);
 
 /* env.seed(seeds[i]); env.reset() for every env with mask[i] != 0 (mask NULL = all).
  * For the families that draw random numbers the whole reset runs on the GPU (k_seed: SHA-512 key + MT19937

@@ -424,7 +424,12 @@ def record_level_streams():
                              ("MiniGrid-NormalGapS6-v0", [2], 300), ("MiniGrid-Empty-8x8-v0", [0], 5),
                              ("MiniGrid-MultiRoom-N2-S4-v0", [0], 300), ("MiniGrid-MultiRoom-N6-v0", [1, 4], 400),
                              ("MiniGrid-Fetch-8x8-N3-v0", [0, 2], 700), ("MiniGrid-GoToDoor-6x6-v0", [1], 700),
-                             ("MiniGrid-FourRooms-v0", [0, 3], 600)]:
+                             ("MiniGrid-FourRooms-v0", [0, 3], 600),
+                             ("MiniGrid-PutNear-6x6-N2-v0", [0], 400), ("MiniGrid-GoToObject-6x6-N2-v0", [1], 400),
+                             ("MiniGrid-KeyCorridorS3R3-v0", [0], 300), ("MiniGrid-KeyCorridorS6R3-v0", [2], 150),
+                             ("MiniGrid-Playground-v0", [0], 100), ("MiniGrid-LockedRoom-v0", [1], 150),
+                             ("MiniGrid-MemoryS13Random-v0", [0], 300), ("MiniGrid-BlockedUnlockPickup-v0", [0], 300),
+                             ("MiniGrid-RedBlueDoors-6x6-v0", [3], 300)]:
         env = gym.make(env_id)
         key = env_id.replace("MiniGrid-", "").replace("-v0", "")
         for s in seeds:

@@ -55,19 +55,27 @@ def test_reference_stream_traces(name):
 @pytest.mark.parametrize("env_id,N,T,L", [("MiniGrid-LavaCrossingS9N1-v0", 3000, 260, 100), ("MiniGrid-DoorKey-5x5-v0", 1500, 600, 8),
                                           ("MiniGrid-LavaGapS7-v1", 900, 450, 8), ("MiniGrid-Empty-Random-8x8-v0", 700, 600, 6),
                                           ("MiniGrid-SimpleCrossingS11N5-v0", 500, 1000, 6), ("MiniGrid-LavaCrossingS9N3-v0", 2000, 200, 100),
-                                          ("MiniGrid-MultiRoom-N4-S5-v0", 400, 330, 8), ("MiniGrid-MultiRoom-N2-S4-v0", 300, 170, 8)])
+                                          ("MiniGrid-MultiRoom-N4-S5-v0", 400, 330, 8), ("MiniGrid-MultiRoom-N2-S4-v0", 300, 170, 8),
+                                          ("MiniGrid-PutNear-6x6-N2-v0", 400, 200, 80), ("MiniGrid-GoToObject-6x6-N2-v0", 400, 150, 150),
+                                          ("MiniGrid-KeyCorridorS3R2-v0", 200, 600, 6), ("MiniGrid-Playground-v0", 150, 350, 8),
+                                          ("MiniGrid-LockedRoom-v0", 150, 420, 6), ("MiniGrid-MemoryS13Random-v0", 200, 300, 30),
+                                          ("MiniGrid-UnlockPickup-v0", 200, 620, 6), ("MiniGrid-RedBlueDoors-6x6-v0", 200, 300, 30)])
 def test_stream_vs_host_generator_and_oracle(env_id, N, T, L):
-    """Every env follows its own level stream: level k of env i == host generate_level_stream(seed_i)[k]."""
+    """Every env follows its own level stream: level k of env i == host generate_level_stream(seed_i)[k] (task word
+    included for the families that have one)."""
     seed = 77
     cfg = mg.env_config(env_id)
     env = mg.VecMiniGrid(env_id, num_envs=N, seeds=seed, auto_reset=True, new_level_each_episode=True, backend="torch")
     obs = to_np(env.reset())
-    levels = [mg.generate_level_stream(env_id, seed + i, L) for i in range(N)]
+    levels = [mg.generate_level_stream(env_id, seed + i, L, with_task=True) for i in range(N)]
     G = np.stack([lv[0] for lv in levels])      # (N, L, W, H, 3)
     A = np.stack([lv[1] for lv in levels])
+    K = np.stack([lv[2] for lv in levels])      # (N, L) task words
     ep = np.zeros(N, np.int64)
-    orc = make_oracle(cfg.width, cfg.height, cfg.max_steps, cfg.see_through_walls, cfg.lava_v1, G[:, 0],
-                      np.zeros(G[:, 0].shape[:3], np.uint8), A[:, 0])
+    from oracle.minigrid_oracle import OracleEnvs
+    orc = OracleEnvs(cfg.width, cfg.height, cfg.max_steps, cfg.see_through_walls, cfg.lava_v1, task=cfg.task_kind)
+    orc.set_state(G[:, 0], A[:, 0])
+    orc.task = K[:, 0].copy()
     assert np.array_equal(obs, orc.observe())
     acts = to_np(env.fill_actions(9, 0, T))
     for t in range(T):
@@ -77,6 +85,7 @@ def test_stream_vs_host_generator_and_oracle(env_id, N, T, L):
         ep[d] += 1
         assert ep.max() < L, "raise L"
         orc.grid0[d], orc.agent0[d] = G[d, ep[d]], A[d, ep[d]]
+        orc.task[d] = K[d, ep[d]]
         orc.reset_where(odone)
         want = np.where(d[:, None, None, None], orc.observe(), oo)
         assert np.array_equal(to_np(done), odone), t
