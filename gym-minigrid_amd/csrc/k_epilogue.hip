@@ -81,26 +81,19 @@ hipError_t mgx_launch_onehot(const uint8_t *tri, uint8_t *out, int64_t n_cells, 
 
 // FlatObsWrapper.observation (wrappers.py:556-577): out[env] = f32(image bytes) ++ one-hot of the mission string
 // (96 positions x 27 codes, 95 % of the row).  `pattern` holds that one-hot block as floats, one row of 2592 per
-// mission of the family (built by the host at create; Fetch: row = (template*2 + is_ball)*8 + color of the task word,
-// GoToObject: row = type*8 + color), so the kernel is a copy: a block owns a group of 4 envs (4*L floats is a whole number of
+// mission of the family (built by the host at create; mgx_mission_row in mgx_kernels.h maps the task word to the row), so the kernel is a copy: a block owns a group of 4 envs (4*L floats is a whole number of
 // 16-B quads, L itself is not), a lane one quad; inside the mission block a quad is one 4-byte-aligned dwordx4 read
 // of the L2-resident pattern and one non-temporal 16-B store.
 namespace {
 struct __attribute__((packed, aligned(4))) FlatQuad { uint32_t a, b, c, d; };
 
-__device__ __forceinline__ int flat_row(const uint2 *rec, int64_t env, int fetch)
+__device__ __forceinline__ int flat_row(const uint2 *rec, int64_t env, int family)
 {
-    if (!fetch) return 0;
-    const uint32_t task = rec[env].y >> 16;
-    if (fetch == 2) return (int)(((task >> 8) & 3u) * 8u + ((task >> 10) & 7u)); // GoToObject: type, color
-    if (fetch == 5) return (int)((((task & 3u) * 8u + ((task >> 2) & 7u)) * 24u) + ((task >> 11) & 3u) * 8u + ((task >> 13) & 7u)); // PutNear
-    if (fetch == 4) return (int)(task & 63u);                                    // LockedRoom: locked colour | key room colour << 3
-    if (fetch == 3) return (int)((task >> 4) & 7u);                              // UnlockPickup / KeyCorridor: colour of the target
-    return (int)((((task >> 8) & 7u) * 2u + ((task & 15u) == MGX_K_BALL ? 1u : 0u)) * 8u + ((task >> 4) & 7u));
+    return family == MGX_MF_CONST ? 0 : mgx_mission_row(family, rec[env].y >> 16);
 }
 
 __global__ __launch_bounds__(256) void k_flat(const uint8_t *__restrict__ tri, const uint2 *__restrict__ rec, const float *__restrict__ pattern,
-                                               float *__restrict__ out, int64_t n, int img, int fetch)
+                                               float *__restrict__ out, int64_t n, int img, int family)
 {
     const int L = img + MGX_FLAT_MISSION;
     const int64_t env_base = (int64_t)blockIdx.y * 4;
@@ -112,7 +105,7 @@ __global__ __launch_bounds__(256) void k_flat(const uint8_t *__restrict__ tri, c
     const int e = (g0 >= L) + (g0 >= 2 * L) + (g0 >= 3 * L);
     const int off = g0 - e * L;
     if (off >= img && off + 4 <= L) { // the whole quad lies in one env's mission block
-        const int row = flat_row(rec, env_base + e, fetch);
+        const int row = flat_row(rec, env_base + e, family);
         const FlatQuad v = *reinterpret_cast<const FlatQuad *>(pattern + (size_t)row * MGX_FLAT_MISSION + (off - img));
         nt_store16(reinterpret_cast<uint4 *>(dst), make_uint4(v.a, v.b, v.c, v.d));
         return;
@@ -125,7 +118,7 @@ __global__ __launch_bounds__(256) void k_flat(const uint8_t *__restrict__ tri, c
         float x = 0.f;
         if (g < n_here * L) {
             if (oj < img) x = (float)tri[(env_base + ej) * img + oj];
-            else x = pattern[(size_t)flat_row(rec, env_base + ej, fetch) * MGX_FLAT_MISSION + (oj - img)];
+            else x = pattern[(size_t)flat_row(rec, env_base + ej, family) * MGX_FLAT_MISSION + (oj - img)];
         }
         v[j] = x;
     }
@@ -135,7 +128,7 @@ __global__ __launch_bounds__(256) void k_flat(const uint8_t *__restrict__ tri, c
 }
 } // namespace
 
-hipError_t mgx_launch_flat(const uint8_t *tri, const uint2 *rec, const float *pattern, float *out, int64_t n, int img, int fetch, hipStream_t st)
+hipError_t mgx_launch_flat(const uint8_t *tri, const uint2 *rec, const float *pattern, float *out, int64_t n, int img, int family, hipStream_t st)
 {
     if (n == 0) return hipSuccess;
     const int quads = (4 * (img + MGX_FLAT_MISSION) + 3) / 4;
@@ -146,7 +139,7 @@ hipError_t mgx_launch_flat(const uint8_t *tri, const uint2 *rec, const float *pa
         const int64_t gy = groups - g0 < 65535 ? groups - g0 : 65535;
         const int64_t e0 = g0 * 4;
         hipLaunchKernelGGL(k_flat, dim3((unsigned)((quads + 255) / 256), (unsigned)gy), dim3(256), 0, st, tri + e0 * img, rec + e0, pattern,
-                           out + e0 * (img + MGX_FLAT_MISSION), n - e0 < gy * 4 ? n - e0 : gy * 4, img, fetch);
+                           out + e0 * (img + MGX_FLAT_MISSION), n - e0 < gy * 4 ? n - e0 : gy * 4, img, family);
     }
     return hipGetLastError();
 }

@@ -186,6 +186,20 @@ StepParams base_params(mgx_handle h)
     return p;
 }
 
+// which of the families of mgx_mission_row (mgx_kernels.h) the handle's missions belong to
+int mission_family(const mgx_config *cfg)
+{
+    switch (cfg->level_kind) {
+    case MGX_LEVEL_FETCH: return MGX_MF_FETCH;
+    case MGX_LEVEL_GOTOOBJECT: return MGX_MF_GOTOOBJECT;
+    case MGX_LEVEL_UNLOCK: return cfg->level_arg0 ? MGX_MF_PICKUP : MGX_MF_CONST;
+    case MGX_LEVEL_KEYCORRIDOR: return MGX_MF_PICKUP;
+    case MGX_LEVEL_LOCKEDROOM: return MGX_MF_LOCKEDROOM;
+    case MGX_LEVEL_PUTNEAR: return MGX_MF_PUTNEAR;
+    default: return MGX_MF_CONST;
+    }
+}
+
 LevelGenParams levelgen_params(mgx_handle h)
 {
     LevelGenParams g;
@@ -356,36 +370,24 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     CREATE_TRY(hipMalloc((void **)&h->ctr_d, sizeof(MgxCounters)));
     if (h->oh_nc >= 0 || h->flat) CREATE_TRY(hipMalloc((void **)&h->tri_d, (size_t)h->n * h->tri_bytes + 16));
     if (h->flat) { // the family's mission strings as character codes (wrappers.py:563-571)
-        const int rows = cfg->level_kind == MGX_LEVEL_FETCH ? 80 : (cfg->level_kind == MGX_LEVEL_GOTOOBJECT ? 24 : ((cfg->level_kind == MGX_LEVEL_UNLOCK && cfg->level_arg0) || cfg->level_kind == MGX_LEVEL_KEYCORRIDOR ? 8 : (cfg->level_kind == MGX_LEVEL_LOCKEDROOM ? 64 : (cfg->level_kind == MGX_LEVEL_PUTNEAR ? 576 : 1))));
+        const int family = mission_family(cfg), rows = mgx_mission_rows(family);
         std::vector<float> tab((size_t)rows * MGX_FLAT_MISSION, 0.f);
-        for (int r = 0; r < rows; r++) {
-            uint32_t task = 0;
-            if (cfg->level_kind == MGX_LEVEL_FETCH) {
-                const int color = r & 7, ball = (r >> 3) & 1, tmpl = r >> 4;
-                if (color > 6) continue;
-                task = (uint32_t)(ball ? MGX_K_BALL : MGX_K_KEY) | ((uint32_t)color << 4) | ((uint32_t)tmpl << 8);
-            } else if ((cfg->level_kind == MGX_LEVEL_UNLOCK && cfg->level_arg0) || cfg->level_kind == MGX_LEVEL_KEYCORRIDOR) {
-                if (r > 6) continue;
-                task = (uint32_t)(cfg->level_kind == MGX_LEVEL_UNLOCK ? MGX_K_BOX : MGX_K_BALL) | ((uint32_t)r << 4); // the target's colour
-            } else if (cfg->level_kind == MGX_LEVEL_PUTNEAR) {
-                const int a = r / 24, b = r % 24;
-                if ((a & 7) > 6 || (b & 7) > 6) continue;
-                task = (uint32_t)(a >> 3) | ((uint32_t)(a & 7) << 2) | ((uint32_t)(b >> 3) << 11) | ((uint32_t)(b & 7) << 13);
-            } else if (cfg->level_kind == MGX_LEVEL_LOCKEDROOM) {
-                if ((r & 7) > 6 || (r >> 3) > 6) continue;
-                task = (uint32_t)r;
-            } else if (cfg->level_kind == MGX_LEVEL_GOTOOBJECT) {
-                const int color = r & 7, ty = r >> 3;
-                if (color > 6) continue;
-                task = ((uint32_t)ty << 8) | ((uint32_t)color << 10);
-            }
+        std::vector<char> filled((size_t)rows, 0);
+        for (uint32_t task = 0; task < 65536u; task++) { // every task word that names a mission fills its row (once)
+            const int r = mgx_mission_row(family, task);
+            if (r < 0 || r >= rows || filled[(size_t)r]) continue;
+            if (family == MGX_MF_CONST && task) break;
+            // (the row of a pick-up target is its colour; its type is the family's: the box of UnlockPickup, the ball of KeyCorridor)
+            if (family == MGX_MF_PICKUP && (task & 15u) != (uint32_t)(cfg->level_kind == MGX_LEVEL_UNLOCK ? MGX_K_BOX : MGX_K_BALL)) continue;
             char m[128];
             const int len = mgx_mission(cfg, task, m, (int)sizeof m);
-            if (len < 0 || len > 96) { // assert len(mission) <= self.maxStrLen
-                int rc = len < 0 ? len : mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_create: mission string too long (%d chars)", len);
+            if (len < 0) continue; // not a task word of this family
+            if (len > 96) { // assert len(mission) <= self.maxStrLen
+                int rc = mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_create: mission string too long (%d chars)", len);
                 mgx_destroy(h);
                 return rc;
             }
+            filled[(size_t)r] = 1;
             int code = -1;
             for (int i = 0; i < len; i++) {
                 const char ch = (char)(m[i] >= 'A' && m[i] <= 'Z' ? m[i] - 'A' + 'a' : m[i]);
@@ -673,8 +675,7 @@ static int run_step(mgx_handle h, bool do_step, const uint8_t *actions, uint8_t 
     if (h->oh_nc >= 0 && o[0].dev)
         HIP_TRY(mgx_launch_onehot(h->tri_d, (uint8_t *)o[0].dev, h->n * (h->tri_bytes / 3), h->oh_nc, h->oh_ns, h->stream));
     if (h->flat && o[0].dev)
-        HIP_TRY(mgx_launch_flat(h->tri_d, h->agent_d, h->mission_d, (float *)o[0].dev, h->n, (int)h->tri_bytes,
-                                h->cfg.level_kind == MGX_LEVEL_FETCH ? 1 : (h->cfg.level_kind == MGX_LEVEL_GOTOOBJECT ? 2 : ((h->cfg.level_kind == MGX_LEVEL_UNLOCK && h->cfg.level_arg0) || h->cfg.level_kind == MGX_LEVEL_KEYCORRIDOR ? 3 : (h->cfg.level_kind == MGX_LEVEL_LOCKEDROOM ? 4 : (h->cfg.level_kind == MGX_LEVEL_PUTNEAR ? 5 : 0)))), h->stream));
+        HIP_TRY(mgx_launch_flat(h->tri_d, h->agent_d, h->mission_d, (float *)o[0].dev, h->n, (int)h->tri_bytes, mission_family(&h->cfg), h->stream));
     if (do_step) {
         h->steps_total += h->n;
         if (h->profiling) h->prof_launches++;

@@ -105,7 +105,26 @@ hipError_t mgx_launch_consume(const ConsumeParams &p, hipStream_t st);
 hipError_t mgx_launch_step(const StepParams &p, int mode, int waves_per_block, hipStream_t st);
 hipError_t mgx_raise_lds_limit(int W, int H, int mode, int bytes, int view, int alt_vis, int object_state);
 #define MGX_FLAT_MISSION (96 * 27) /* FlatObsWrapper: maxStrLen x numCharCodes (wrappers.py:534-537) */
-hipError_t mgx_launch_flat(const uint8_t *tri, const uint2 *rec, const float *pattern, float *out, int64_t n, int img, int fetch, hipStream_t st);
+// How the per-env task word selects the mission (a row of k_flat's pattern table), per family.  One definition for the
+// host (which fills the rows from mgx_mission) and the kernel.
+enum { MGX_MF_CONST = 0, MGX_MF_FETCH, MGX_MF_GOTOOBJECT, MGX_MF_PICKUP, MGX_MF_LOCKEDROOM, MGX_MF_PUTNEAR };
+__host__ __device__ inline int mgx_mission_rows(int family)
+{
+    return family == MGX_MF_FETCH ? 80 : family == MGX_MF_GOTOOBJECT ? 24 : family == MGX_MF_PICKUP ? 8 : family == MGX_MF_LOCKEDROOM ? 64 :
+           family == MGX_MF_PUTNEAR ? 576 : 1;
+}
+__host__ __device__ inline int mgx_mission_row(int family, uint32_t task)
+{
+    switch (family) {
+    case MGX_MF_FETCH: return (int)((((task >> 8) & 7u) * 2u + ((task & 15u) == 6u /* ball */ ? 1u : 0u)) * 8u + ((task >> 4) & 7u)); // template, type, colour
+    case MGX_MF_GOTOOBJECT: return (int)(((task >> 8) & 3u) * 8u + ((task >> 10) & 7u));                                                // type, colour
+    case MGX_MF_PICKUP: return (int)((task >> 4) & 7u);                                                                                  // colour of the target
+    case MGX_MF_LOCKEDROOM: return (int)(task & 63u);                                                                                    // locked colour | key room colour << 3
+    case MGX_MF_PUTNEAR: return (int)((((task & 3u) * 8u + ((task >> 2) & 7u)) * 24u) + ((task >> 11) & 3u) * 8u + ((task >> 13) & 7u));
+    default: return 0;
+    }
+}
+hipError_t mgx_launch_flat(const uint8_t *tri, const uint2 *rec, const float *pattern, float *out, int64_t n, int img, int family, hipStream_t st);
 hipError_t mgx_launch_onehot(const uint8_t *tri, uint8_t *out, int64_t n_cells, int nc, int ns, hipStream_t st);
 struct ObjStateParams {
     const uint8_t *contains_in, *carry_aux_in, *carry_contains_in;
