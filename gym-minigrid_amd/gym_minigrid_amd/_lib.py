@@ -11,6 +11,10 @@ MGX_OK = 0
 ERR_NAMES = {-1: "INVALID_ARG", -2: "INVALID_STATE", -3: "INVALID_ACTION", -4: "OUT_OF_BOUNDS",
              -5: "UNSUPPORTED", -6: "HIP", -7: "NO_LEVELGEN"}
 OBS_PARTIAL, OBS_FULL, OBS_PARTIAL_ONEHOT, OBS_FULL_ONEHOT, OBS_FULL_ONEHOT_NOCOLOR, OBS_PARTIAL_FLAT, OBS_FULL_FLAT = 0, 1, 2, 3, 4, 5, 6
+# mgx_task_kind (include/mgx.h)
+(TASK_NONE, TASK_FETCH, TASK_GOTODOOR, TASK_DYNOBS, TASK_GOTOOBJECT, TASK_REDBLUEDOORS, TASK_MEMORY, TASK_UNLOCK, TASK_PICKUPBOX, TASK_NOTE,
+ TASK_PUTNEAR) = range(11)
+TASKS_WITH_EPISODE_MISSION = (TASK_FETCH, TASK_GOTOOBJECT, TASK_PICKUPBOX, TASK_NOTE, TASK_PUTNEAR)  # the mission names per-episode objects
 
 
 class MgxError(RuntimeError):

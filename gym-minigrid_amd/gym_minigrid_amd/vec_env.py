@@ -88,15 +88,15 @@ class VecMiniGrid:
             self.obs_dtype = "float32"
         self.n_actions = 9 if extended_actions else 7
         self.action_space = Discrete(self.n_actions)  # minigrid.py:788-792
-        if cfg.task_kind == 3:  # Dynamic-Obstacles: Discrete(3), larger actions fold to 0 (envs/dynamicobstacles.py:32-33,61-63)
+        if cfg.task_kind == _lib.TASK_DYNOBS:  # Dynamic-Obstacles: Discrete(3), larger actions fold to 0 (envs/dynamicobstacles.py:32-33,61-63)
             self.action_space = Discrete(3)
             self.n_actions = 256
         self.observation_space = Dict({"image": Box(0, 255, self.obs_shape, "uint8")})
         if self.obs_dtype == "float32":
             self.observation_space = Box(0, 255, (1,) + self.obs_shape, "uint8")  # wrappers.py:543-548
-        self.reward_range = (-1, 1) if cfg.task_kind == 3 else (0, 1)
+        self.reward_range = (-1, 1) if cfg.task_kind == _lib.TASK_DYNOBS else (0, 1)
         try:  # families whose mission names per-episode objects (Fetch, GoToObject, UnlockPickup, KeyCorridor, LockedRoom)
-            self.mission = self._mission_of(0) if cfg.task_kind not in (1, 4, 8, 9, 10) else "per episode: see missions()"
+            self.mission = self._mission_of(0) if cfg.task_kind not in _lib.TASKS_WITH_EPISODE_MISSION else "per episode: see missions()"
         except _lib.MgxError:
             self.mission = "per episode: see missions()"
         self._h = ctypes.c_void_p()
@@ -278,7 +278,7 @@ class VecMiniGrid:
 
     def missions(self):
         """obs['mission'] of every env (minigrid.py:1373-1379); only Fetch missions differ between envs."""
-        if self.cfg.task_kind == 0:
+        if self.cfg.task_kind == _lib.TASK_NONE:
             return [self.mission] * self.num_envs
         cache = {}
         return [cache.setdefault(int(t), self._mission_of(int(t))) for t in self.get_task()]

@@ -122,6 +122,11 @@ typedef enum {
                               the target object.  Per-env task word = target cell code | mission template << 8. */
     MGX_TASK_GOTODOOR = 2, /* envs/gotodoor.py:71-93: the `done` action next to any door ends the episode, next to the
                               target (red) door it also pays _reward(). */
+    MGX_TASK_DYNOBS = 3,   /* envs/dynamicobstacles.py:60-89 (with level_kind = MGX_LEVEL_DYNOBS): actions >= 3 fold to 0;
+                              before the base step every obstacle (blue ball) is re-placed in its 3x3 neighbourhood with
+                              draws from the env's own RNG stream (place_obj, max_tries=100); moving forward while the
+                              front cell was occupied by anything but the goal gives reward -1 and done.  State enters
+                              through mgx_reset only (the RNG stream is part of it): mgx_set_state is refused. */
     MGX_TASK_GOTOOBJECT = 4, /* envs/gotoobject.py:68-84: `toggle` ends the episode; `done` ends it and pays _reward() when the agent
                               is within one cell (Chebyshev) of the target's INITIAL position.  Per-env task word =
                               tx | ty << 4 | (type - key) << 8 | color << 10. */
@@ -142,11 +147,6 @@ typedef enum {
                               carrying ends it too, with _reward() when the object landed within one cell of the target's
                               initial position.  Per-env task word = move type | move colour << 2 | tx << 5 | ty << 8 |
                               target type << 11 | target colour << 13 (types: 0 key, 1 ball, 2 box). */
-    MGX_TASK_DYNOBS = 3,   /* envs/dynamicobstacles.py:60-89 (with level_kind = MGX_LEVEL_DYNOBS): actions >= 3 fold to 0;
-                              before the base step every obstacle (blue ball) is re-placed in its 3x3 neighbourhood with
-                              draws from the env's own RNG stream (place_obj, max_tries=100); moving forward while the
-                              front cell was occupied by anything but the goal gives reward -1 and done.  State enters
-                              through mgx_reset only (the RNG stream is part of it): mgx_set_state is refused. */
 } mgx_task_kind;
 
 typedef struct {
