@@ -91,14 +91,14 @@ typedef enum {
                                + 16 * (0 both river directions, 1 horizontal only (ori=0), 2 vertical only (ori=1)) */
     MGX_LEVEL_LAVAGAP = 4,  /* LavaGapEnv:  level_arg0 = const gap column (0/1), level_arg1 = obstacle type */
     MGX_LEVEL_DISTSHIFT = 5, /* DistShiftEnv (envs/distshift.py): level_arg0 = strip2_row; no randomness */
+    MGX_LEVEL_MULTIROOM = 6, /* MultiRoomEnv (envs/multiroom.py): level_arg0 = minNumRooms | maxNumRooms << 8 (<= 8),
+                                level_arg1 = maxRoomSize */
     MGX_LEVEL_FETCH = 7,     /* FetchEnv (envs/fetch.py): level_arg0 = numObjs; use with task_kind = MGX_TASK_FETCH */
     MGX_LEVEL_GOTODOOR = 8,  /* GoToDoorEnv (envs/gotodoor.py); use with task_kind = MGX_TASK_GOTODOOR */
     MGX_LEVEL_FOURROOMS = 9, /* FourRoomsEnv (envs/fourrooms.py:8-70), random agent and goal */
     MGX_LEVEL_DYNOBS = 10,   /* DynamicObstaclesEnv (envs/dynamicobstacles.py): level_arg0 = n_obstacles after the
                                 constructor's clamp (<= 8), level_arg1 = 1 for a random agent start; use with
                                 task_kind = MGX_TASK_DYNOBS */
-    MGX_LEVEL_MULTIROOM = 6, /* MultiRoomEnv (envs/multiroom.py): level_arg0 = minNumRooms | maxNumRooms << 8 (<= 8),
-                                level_arg1 = maxRoomSize */
     MGX_LEVEL_GOTOOBJECT = 11, /* GoToObjectEnv (envs/gotoobject.py): level_arg0 = numObjs; use with task_kind = MGX_TASK_GOTOOBJECT */
     MGX_LEVEL_REDBLUEDOORS = 12, /* RedBlueDoorEnv (envs/redbluedoors.py): width = 2*height; use with task_kind = MGX_TASK_REDBLUEDOORS */
     MGX_LEVEL_MEMORY = 13,   /* MemoryEnv (envs/memory.py): odd square grids 7..17, level_arg0 = random_length; use with
