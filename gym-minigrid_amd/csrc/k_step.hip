@@ -834,6 +834,14 @@ hipError_t raise_lds_limit(int mode, int bytes)
 #define MGX_SIZED(X) X(5, 5) X(6, 6) X(7, 7) X(8, 8) X(9, 9) X(11, 11) X(16, 16)
 #define MGX_VIEWS(X) X(3) X(5) X(9) X(11)  /* agent_view_size other than 7: run-time grid size only */
 
+// The step kernels are their own code object; HIP loads it on first use (18 ms measured).  mgx_create asks for it up
+// front so that the first mgx_step is not the one that pays.
+hipError_t mgx_preload_step_kernels()
+{
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k_step<0, 0, 0, 7>));
+}
+
 hipError_t mgx_launch_step(const StepParams &p, int mode, int waves_per_block, hipStream_t st)
 {
     const dim3 block(64 * waves_per_block);

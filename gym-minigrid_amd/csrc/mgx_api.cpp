@@ -443,6 +443,7 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
         CREATE_TRY(hipMemsetAsync(h->mt0_d, 0, (size_t)h->n_pad * 624 * sizeof(uint32_t), h->stream));
         CREATE_TRY(hipMemsetAsync(h->pos0_d, 0, (size_t)h->n_pad * sizeof(uint32_t), h->stream));
     }
+    CREATE_TRY(mgx_preload_step_kernels());
     CREATE_TRY(hipEventCreate(&h->ev0));
     CREATE_TRY(hipEventCreate(&h->ev1));
     CREATE_TRY(hipStreamSynchronize(h->stream));

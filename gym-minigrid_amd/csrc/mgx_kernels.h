@@ -103,6 +103,7 @@ hipError_t mgx_launch_seed(const uint64_t *seeds, const uint8_t *mask, const uin
                            uint8_t *regen, uint64_t *seed0, uint8_t *has_seed, uint8_t *reseeded, int skip_same, int64_t n, hipStream_t st);
 hipError_t mgx_launch_consume(const ConsumeParams &p, hipStream_t st);
 hipError_t mgx_launch_step(const StepParams &p, int mode, int waves_per_block, hipStream_t st);
+hipError_t mgx_preload_step_kernels();
 hipError_t mgx_raise_lds_limit(int W, int H, int mode, int bytes, int view, int alt_vis, int object_state);
 #define MGX_FLAT_MISSION (96 * 27) /* FlatObsWrapper: maxStrLen x numCharCodes (wrappers.py:534-537) */
 // How the per-env task word selects the mission (a row of k_flat's pattern table), per family.  One definition for the
