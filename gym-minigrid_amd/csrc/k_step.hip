@@ -623,8 +623,45 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
         if (valid) p.agent[env] = pack_rec(L, p.task);
     }
     if (p.obs) {
-        if constexpr (GATHER) emit_partial_obs<CW, CH, V, ALT, true>(p, L, lds, row, env0, lane, pidx, pcode);
-        else if (MODE == 0) emit_partial_obs<CW, CH, V, ALT>(p, L, lds, g, env0, lane);
+        if constexpr (GATHER) {
+            if (p.H >= 8) {
+                // The VxV view always lies inside a world-aligned VxV window whose columns (fixed world x) are V contiguous
+                // bytes: V unaligned 8-byte loads per lane instead of V*V byte loads.  The window goes to this lane's
+                // LDS slot as a tiny 7x8 "grid" (cells outside the real grid = grey wall, which is what Grid.slice pads
+                // with) and the ordinary closed-form gather runs on it.
+                static_assert(V == 7, "the gather form is instantiated for the default view only");
+                const int H = p.H, W = p.W;
+                const int x0 = L.dir == 0 ? L.ax : (L.dir == 2 ? L.ax - 6 : L.ax - 3);
+                const int y0 = L.dir == 1 ? L.ay : (L.dir == 3 ? L.ay - 6 : L.ay - 3);
+                const int yc = y0 < 0 ? 0 : (y0 > H - 8 ? H - 8 : y0), sh = y0 - yc; // loaded bytes start at yc
+                const u64 wall = 0x0101010101010101ull * MGX_CODE_WALL_GREY;
+                const u64 keep = sh >= 0 ? (sh == 0 ? ~0ull : ((1ull << (8 * (8 - sh))) - 1ull)) : ~((1ull << (8 * -sh)) - 1ull);
+                struct __attribute__((packed)) U8 { uint32_t a, b; };
+                u64 w[7];
+#pragma unroll
+                for (int k = 0; k < 7; k++) {
+                    const int x = x0 + k;
+                    w[k] = wall;
+                    if (x >= 0 && x < W) {
+                        const U8 v = *reinterpret_cast<const U8 *>(row + x * H + yc);
+                        const u64 v64 = (u64)v.a | ((u64)v.b << 32);
+                        const u64 sv = sh >= 0 ? v64 >> (8 * sh) : v64 << (8 * -sh);
+                        w[k] = (sv & keep) | (wall & ~keep);
+                    }
+                }
+                uint32_t *win32 = reinterpret_cast<uint32_t *>(lds) + lane * 15; // 60 B per lane: odd dword stride
+#pragma unroll
+                for (int k = 0; k < 7; k++) { win32[2 * k] = (uint32_t)w[k]; win32[2 * k + 1] = (uint32_t)(w[k] >> 32); }
+                uint8_t *win = reinterpret_cast<uint8_t *>(win32);
+                if (pidx >= 0) { // the front cell this step changed (the agent did not move then)
+                    const int px = L.ax + (L.dir == 0) - (L.dir == 2) - x0, py = L.ay + (L.dir == 1) - (L.dir == 3) - y0;
+                    win[px * 8 + py] = (uint8_t)pcode;
+                }
+                Lane Lw = L;
+                Lw.ax = L.ax - x0; Lw.ay = L.ay - y0;
+                emit_partial_obs<7, 8, V, ALT, false>(p, Lw, lds, win, env0, lane);
+            } else emit_partial_obs<CW, CH, V, ALT, true>(p, L, lds, row, env0, lane, pidx, pcode);
+        } else if (MODE == 0) emit_partial_obs<CW, CH, V, ALT>(p, L, lds, g, env0, lane);
         else emit_full_obs<CW, CH>(p, L, valid, lds, g, LS, env0, lane);
     }
 }
