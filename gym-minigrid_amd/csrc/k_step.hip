@@ -868,7 +868,7 @@ hipError_t raise_lds_limit(int mode, int bytes)
 
 } // namespace
 
-#define MGX_SIZED(X) X(5, 5) X(6, 6) X(7, 7) X(8, 8) X(9, 9) X(11, 11) X(16, 16)
+#define MGX_SIZED(X) X(5, 5) X(6, 6) X(7, 7) X(8, 8) X(9, 9) X(11, 11) X(16, 16) X(10, 10) X(13, 13) X(16, 8) X(12, 6) X(11, 6)
 #define MGX_VIEWS(X) X(3) X(5) X(9) X(11)  /* agent_view_size other than 7: run-time grid size only */
 
 // The step kernels are their own code object; HIP loads it on first use (18 ms measured).  mgx_create asks for it up

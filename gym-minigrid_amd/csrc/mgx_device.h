@@ -79,7 +79,7 @@ __device__ __forceinline__ void stage_tile(const uint8_t *__restrict__ cells, in
     if constexpr (CS != 0 && ((CS >> 2) & 1)) {
         // S/4 already odd (5x5, 6x6, 7x7, 9x9, 11x11): the LDS image has the layout of the HBM run, a straight 16-B copy
         uint4 *l128 = reinterpret_cast<uint4 *>(lds);
-#pragma unroll
+#pragma unroll 4
         for (int c = lane; c < n_chunks; c += 64) l128[c] = src[c];
         return;
     }
