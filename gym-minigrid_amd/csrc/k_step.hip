@@ -607,12 +607,19 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
         if (p.reward && valid) __builtin_nontemporal_store(reward, &p.reward[env]);
         if (p.done && valid) __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), &p.done[env]);
         wave_stats(p, valid, done, reward, bad_act, oob, lane, tile);
+        if constexpr (GATHER) {
+            // restore global -> global, by the whole wave one finished env at a time: these rows are long (> 256 B), a lane
+            // copying its own row touches 64 different lines per instruction (MultiRoom's synchronised time-outs: +15 us
+            // per step on average); the observation below reads the snapshot itself
+            for (u64 m = __ballot(p.auto_reset && valid && done); m; m &= m - 1) {
+                const int64_t e = env0 + __builtin_ctzll(m);
+                const uint32_t *s = reinterpret_cast<const uint32_t *>(p.cells0 + e * S);
+                uint32_t *d = reinterpret_cast<uint32_t *>(p.cells + e * S);
+                for (int i = lane; i < (S >> 2); i += 64) d[i] = s[i];
+            }
+        }
         if (p.auto_reset && valid && done) {
-            if constexpr (GATHER) { // global -> global; the observation below reads the snapshot itself
-                const uint32_t *s = reinterpret_cast<const uint32_t *>(p.cells0 + env * S);
-                uint32_t *d = reinterpret_cast<uint32_t *>(p.cells + env * S);
-#pragma unroll 8
-                for (int i = 0; i < (S >> 2); i++) d[i] = s[i];
+            if constexpr (GATHER) {
                 row = p.cells0 + env * S;
                 pidx = -1;
             } else restore_own<CS>(p, env, g);
