@@ -30,6 +30,7 @@ def init_process_group(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs between processes on this pool
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
