@@ -133,6 +133,7 @@ def main():
                          "path on a one-GPU box; the numbers it prints are meaningless")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL between the ranks (before HIP starts)
     import torch
     import gym_minigrid_amd as mg
     from gym_minigrid_amd import dist as mdist
