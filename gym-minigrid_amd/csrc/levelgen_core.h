@@ -554,6 +554,7 @@ template <class R>
 LG_FN void lg_gen_keycorridor(const mgx_config &c, R &r, LgLevel &L)
 {
     const int S = c.level_arg0, T = S - 1, rows = (L.H - 1) / T, W = L.W, H = L.H;
+    if (6 * L.max_rivers < 27) { L.too_big = true; return; } // needs 27 words of workspace
     int16_t *dr = L.ws, *dd = L.ws + 9, *fl = L.ws + 18;
     L.ncmd = 0;
     for (int k = 0; k <= 3; k++) lg_rect(L, k * T, 0, k * T, H - 1, MGX_CODE_WALL_GREY);
