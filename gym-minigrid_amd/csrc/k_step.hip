@@ -34,8 +34,8 @@ namespace {
 
 // Task rules that env subclasses layer on MiniGridEnv.step (they run after the base step, time-out included).
 template <int CH, class CellAt>
-__device__ __forceinline__ void task_rule(const StepParams &p, const Lane &L, uint32_t act, float &reward, bool &done, CellAt cell_at,
-                                          int fidx = -1, uint32_t fc = 0, uint32_t carry0 = MGX_CODE_EMPTY)
+__device__ __forceinline__ void task_rule(const StepParams &p, Lane &L, uint32_t act, float &reward, bool &done, CellAt cell_at,
+                                          int fidx, uint32_t fc, uint32_t carry0, bool &fault)
 {
     if (p.task == MGX_TASK_FETCH) { // envs/fetch.py:74-86
         if (L.carry != MGX_CODE_EMPTY) {
@@ -63,6 +63,21 @@ __device__ __forceinline__ void task_rule(const StepParams &p, const Lane &L, ui
         const bool blue_before = ((bi == fidx ? fc : cell_at(bi)) & 15u) == MGX_K_DOOR_OPEN;
         if (blue_after) { reward = red_before ? (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps)) : 0.f; done = true; }
         else if (red_after && blue_before) { reward = 0.f; done = true; }
+    } else if (p.task == MGX_TASK_TWOGOALS) { // envs/twogoals.py:118-146 on top of the base transition; L.task = goal_count, fc = the
+                                              // front cell BEFORE the step (a toggled goal is gone afterwards)
+        if (act == 5) {
+            if (fc == MGX_CODE_EMPTY) fault = true; // `fwd_cell.type` on None: AttributeError
+            else if ((fc & 15u) == MGX_K_GOAL) {
+                const uint32_t color = (fc >> 4) & 7u;
+                reward = color == 1u ? 0.25f : (color == 4u ? 0.5f : 0.f);
+                L.task += 1u;
+            }
+        }
+        if (act == 6) done = true;
+        if (L.task >= 2u) { // reward += 1. - 0.9 * self.step_count/self.max_steps   (NOT _reward(): the product comes first)
+            reward = (float)((double)reward + (1.0 - (0.9 * (double)L.steps) / (double)p.max_steps));
+            done = true;
+        }
     } else if (p.task == MGX_TASK_PUTNEAR) { // envs/putnear.py:91-110; carry0 = preCarrying
         const uint32_t move = (uint32_t)(MGX_K_KEY + (L.task & 3u)) | (((L.task >> 2) & 7u) << 4);
         if (act == 3 && L.carry != MGX_CODE_EMPTY && (L.carry & 0x7Fu) != move) done = true; // picked up (or holds) the wrong object
@@ -111,7 +126,7 @@ __device__ __forceinline__ int transition_begin(const StepParams &p, Lane &L, ui
                          ((uint32_t)(L.ay >= 1) << 3);
     const uint32_t need = 0xFu & ~(1u << ((dir + 2) & 3));
     oob = valid && ((okm & need) != need);
-    bad_act = valid && act >= (p.extended ? 9u : MGX_NUM_ACTIONS_K);
+    bad_act = valid && (act >= (p.extended ? 9u : MGX_NUM_ACTIONS_K) || (p.task == MGX_TASK_TWOGOALS && (act == 3u || act == 4u)));
     if (!valid || oob || bad_act) return -1;
     return (L.ax + dx) * H + (L.ay + dy);
 }
@@ -599,7 +614,7 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
             const uint32_t nc = transition_apply<CH>(p, L, act, fc, reward, done, [&](int i) -> uint32_t { return row[i]; }, oob, fidx, obj);
             if constexpr (!GATHER) { if (nc != fc) g[fidx] = (uint8_t)nc; }
             if (valid && L.steps >= p.max_steps) done = true; // minigrid.py:1320-1321
-            if (p.task) task_rule<CH>(p, L, act, reward, done, [&](int i) -> uint32_t { return (GATHER && i == fidx) ? nc : (uint32_t)row[i]; }, fidx, fc, carry0);
+            if (p.task) task_rule<CH>(p, L, act, reward, done, [&](int i) -> uint32_t { return (GATHER && i == fidx) ? nc : (uint32_t)row[i]; }, fidx, fc, carry0, oob);
             // the one cell a transition can change; skipped when the env is about to be restored anyway
             if (nc != fc && !(p.auto_reset && done)) { p.cells[env * S + fidx] = (uint8_t)nc; pidx = fidx; pcode = nc; }
         } else if (valid && L.steps >= p.max_steps) done = true;
@@ -743,7 +758,7 @@ __global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
                 const uint32_t nc = transition_apply<CH>(p, L, act, fc, reward, done,
                                                          [&](int i) -> uint32_t { return p.cells[env * S + i]; }, oob, fidx, obj);
                 if (valid && L.steps >= p.max_steps) done = true;
-                if (p.task) task_rule<CH>(p, L, act, reward, done, [&](int i) -> uint32_t { return (i == fidx) ? nc : (uint32_t)p.cells[env * S + i]; }, fidx, fc, carry0);
+                if (p.task) task_rule<CH>(p, L, act, reward, done, [&](int i) -> uint32_t { return (i == fidx) ? nc : (uint32_t)p.cells[env * S + i]; }, fidx, fc, carry0, oob);
                 if (nc != fc && !(p.auto_reset && done)) {
                     p.cells[env * S + fidx] = (uint8_t)nc;
                     wr = (uint32_t)fidx | (nc << 16);

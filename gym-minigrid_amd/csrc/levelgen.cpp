@@ -162,6 +162,9 @@ int check_levelgen_cfg(const mgx_config *cfg, const char *fn)
     case MGX_LEVEL_LOCKEDROOM:
         if (W != 19 || H != 19) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: LockedRoom is 19x19", fn);
         break;
+    case MGX_LEVEL_TWOGOALS:
+        if (W < 4 || H < 4) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: TwoGoals needs at least 4x4", fn);
+        break;
     case MGX_LEVEL_PUTNEAR:
         if (W > 8 || H > 8 || cfg->level_arg0 < 2 || cfg->level_arg0 > 4) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: PutNear needs W, H <= 8 and 2..4 objects", fn);
         break;
@@ -288,6 +291,15 @@ const std::vector<EnvId> &registry()
         {"MiniGrid-KeyCorridorS4R3-v0", mkt(10, 10, 480, 0, MGX_LEVEL_KEYCORRIDOR, 4, MGX_TASK_PICKUPBOX)},
         {"MiniGrid-KeyCorridorS5R3-v0", mkt(13, 13, 750, 0, MGX_LEVEL_KEYCORRIDOR, 5, MGX_TASK_PICKUPBOX)},
         {"MiniGrid-KeyCorridorS6R3-v0", mkt(16, 16, 1080, 0, MGX_LEVEL_KEYCORRIDOR, 6, MGX_TASK_PICKUPBOX)},
+        // TwoGoalsEnv: max_steps = size^2, see_through_walls=True (envs/twogoals.py:9-29,148-222; '-9x9-v0' names a missing class)
+        {"MiniGrid-TwoGoals-5x5-v0", mkt(5, 5, 25, 1, MGX_LEVEL_TWOGOALS, 0, MGX_TASK_TWOGOALS)},
+        {"MiniGrid-TwoGoals-Random-5x5-v0", mkt(5, 5, 25, 1, MGX_LEVEL_TWOGOALS, 1, MGX_TASK_TWOGOALS)},
+        {"MiniGrid-TwoGoals-6x6-v0", mkt(6, 6, 36, 1, MGX_LEVEL_TWOGOALS, 0, MGX_TASK_TWOGOALS)},
+        {"MiniGrid-TwoGoals-Random-6x6-v0", mkt(6, 6, 36, 1, MGX_LEVEL_TWOGOALS, 1, MGX_TASK_TWOGOALS)},
+        {"MiniGrid-TwoGoals-8x8-v0", mkt(8, 8, 64, 1, MGX_LEVEL_TWOGOALS, 0, MGX_TASK_TWOGOALS)},
+        {"MiniGrid-TwoGoals-Random-9x9-v0", mkt(9, 9, 81, 1, MGX_LEVEL_TWOGOALS, 1, MGX_TASK_TWOGOALS)},
+        {"MiniGrid-TwoGoals-16x16-v0", mkt(16, 16, 256, 1, MGX_LEVEL_TWOGOALS, 0, MGX_TASK_TWOGOALS)},
+        {"MiniGrid-TwoGoals-Random-16x16-v0", mkt(16, 16, 256, 1, MGX_LEVEL_TWOGOALS, 1, MGX_TASK_TWOGOALS)},
         // PutNearEnv: max_steps = 5*size, see_through_walls=True (envs/putnear.py:10-22,112-126)
         {"MiniGrid-PutNear-6x6-N2-v0", mkt(6, 6, 30, 1, MGX_LEVEL_PUTNEAR, 2, MGX_TASK_PUTNEAR)},
         {"MiniGrid-PutNear-8x8-N3-v0", mkt(8, 8, 40, 1, MGX_LEVEL_PUTNEAR, 3, MGX_TASK_PUTNEAR)},
@@ -371,6 +383,7 @@ extern "C" int mgx_mission(const mgx_config *cfg, uint32_t task, char *out, int 
         m = buf;
         break;
     }
+    case MGX_LEVEL_TWOGOALS: m = "get to the green or red goal square"; break;                              // envs/twogoals.py:50
     case MGX_LEVEL_FOURROOMS: m = "Reach the goal"; break;                                                  // envs/fourrooms.py:69
     case MGX_LEVEL_GOTOOBJECT: {                                                                            // envs/gotoobject.py:63-64
         static const char *const types[3] = {"key", "ball", "box"};

@@ -790,6 +790,26 @@ LG_FN void lg_gen_putnear(const mgx_config &c, R &r, LgLevel &L)
              ((uint32_t)((tc.code & 15u) - MGX_K_KEY) << 11) | (((uint32_t)(tc.code >> 4) & 7u) << 13);
 }
 
+// TwoGoalsEnv._gen_grid (envs/twogoals.py:31-50): a yellow goal bottom-right, a green one bottom-left, fixed or random agent.
+template <class R>
+LG_FN void lg_gen_twogoals(const mgx_config &c, R &r, LgLevel &L)
+{
+    L.ncmd = 0;
+    lg_rect(L, 0, 0, L.W - 1, 0, MGX_CODE_WALL_GREY);
+    lg_rect(L, 0, L.H - 1, L.W - 1, L.H - 1, MGX_CODE_WALL_GREY);
+    lg_rect(L, 0, 0, 0, L.H - 1, MGX_CODE_WALL_GREY);
+    lg_rect(L, L.W - 1, 0, L.W - 1, L.H - 1, MGX_CODE_WALL_GREY);
+    lg_set(L, L.W - 2, L.H - 2, MGX_K_GOAL | (4u << 4)); // Goal(color1 = 'yellow')
+    lg_set(L, 1, L.H - 2, MGX_K_GOAL | (1u << 4));       // Goal(color2 = 'green')
+    if (c.level_arg0 == 0) { L.ax = 1; L.ay = 1; L.adir = 0; }
+    else {
+        L.ax = -1; L.ay = -1;
+        lg_sample_free(r, L, L.W, L.H, false, &L.ax, &L.ay);
+        L.adir = lg_randint(r, 0, 4);
+    }
+    L.task = 0; // goal_count
+}
+
 // GoToDoorEnv._gen_grid (envs/gotodoor.py:23-69, as modified by the fork): four locked doors on the four walls in four
 // distinct colours, redrawn until one of them is red (the target); random agent.
 template <class R>
@@ -884,7 +904,10 @@ LG_FN void lg_gen_dynobs(const mgx_config &c, R &r, LgLevel &L)
 }
 
 // true if the family draws random numbers (Empty with a fixed start does not)
-LG_FN bool lg_uses_rng(const mgx_config &c) { return !(c.level_kind == MGX_LEVEL_EMPTY && c.level_arg0 == 0) && c.level_kind != MGX_LEVEL_DISTSHIFT; }
+LG_FN bool lg_uses_rng(const mgx_config &c)
+{
+    return !((c.level_kind == MGX_LEVEL_EMPTY || c.level_kind == MGX_LEVEL_TWOGOALS) && c.level_arg0 == 0) && c.level_kind != MGX_LEVEL_DISTSHIFT;
+}
 
 template <class R>
 LG_FN void lg_generate(const mgx_config &c, R &r, LgLevel &L)
@@ -907,6 +930,7 @@ LG_FN void lg_generate(const mgx_config &c, R &r, LgLevel &L)
     case MGX_LEVEL_LOCKEDROOM: lg_gen_lockedroom(c, r, L); break;
     case MGX_LEVEL_PLAYGROUND: lg_gen_playground(c, r, L); break;
     case MGX_LEVEL_PUTNEAR: lg_gen_putnear(c, r, L); break;
+    case MGX_LEVEL_TWOGOALS: lg_gen_twogoals(c, r, L); break;
     default: lg_gen_lavagap(c, r, L); break;
     }
 }

@@ -254,7 +254,7 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     if (cfg->width < 3 || cfg->height < 3 || cfg->width > 255 || cfg->height > 255)
         return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: grid %dx%d outside 3..255 (Grid.__init__ asserts >= 3)", cfg->width, cfg->height);
     if (cfg->max_steps <= 0) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: max_steps must be positive");
-    if (cfg->task_kind < MGX_TASK_NONE || cfg->task_kind > MGX_TASK_PUTNEAR)
+    if (cfg->task_kind < MGX_TASK_NONE || cfg->task_kind > MGX_TASK_TWOGOALS)
         return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: bad task_kind %d", cfg->task_kind);
     if ((cfg->task_kind == MGX_TASK_DYNOBS) != (cfg->level_kind == MGX_LEVEL_DYNOBS))
         return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: MGX_TASK_DYNOBS and MGX_LEVEL_DYNOBS go together (the obstacle walk continues the level's RNG stream)");
@@ -312,7 +312,7 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     h->wave_lds = (need + 15) & ~15;
     // a family that draws no random numbers (Empty with a fixed start) has only one level: nothing to generate
     const bool uses_rng = cfg->level_kind != MGX_LEVEL_NONE && cfg->level_kind != MGX_LEVEL_DISTSHIFT &&
-                          !(cfg->level_kind == MGX_LEVEL_EMPTY && cfg->level_arg0 == 0);
+                          !((cfg->level_kind == MGX_LEVEL_EMPTY || cfg->level_kind == MGX_LEVEL_TWOGOALS) && cfg->level_arg0 == 0);
     h->device_levels = uses_rng && h->cells <= 4096;
     h->stream_mode = cfg->new_level_each_episode && uses_rng;
     h->tri_bytes = h->partial ? view * view * 3 : (int64_t)h->cells * 3;

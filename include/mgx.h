@@ -112,7 +112,8 @@ typedef enum {
                                 names the mission: locked colour | key room colour << 3) */
     MGX_LEVEL_PLAYGROUND = 17, /* PlaygroundV0 (envs/playground_v0.py), 19x19: nine rooms, random doors, 12 random objects, no mission */
     MGX_LEVEL_PUTNEAR = 18,  /* PutNearEnv (envs/putnear.py): level_arg0 = numObjs, grids up to 8x8; use with MGX_TASK_PUTNEAR */
-    MGX_LEVEL_KIND_END = 19
+    MGX_LEVEL_TWOGOALS = 19, /* TwoGoalsEnv (envs/twogoals.py): level_arg0 = 1 for a random agent start; use with MGX_TASK_TWOGOALS */
+    MGX_LEVEL_KIND_END = 20
 } mgx_level_kind;
 
 /* task rules layered on MiniGridEnv.step by env subclasses (`step` overrides that only reshape reward/done) */
@@ -147,6 +148,11 @@ typedef enum {
                               carrying ends it too, with _reward() when the object landed within one cell of the target's
                               initial position.  Per-env task word = move type | move colour << 2 | tx << 5 | ty << 8 |
                               target type << 11 | target colour << 13 (types: 0 key, 1 ball, 2 box). */
+    MGX_TASK_TWOGOALS = 11 /* envs/twogoals.py:82-146, the fork's own step: `toggle` on a goal removes it and pays 0.25 (green) /
+                              0.5 (yellow); after the second one the episode ends with + 1 - 0.9*steps/max_steps; `done` ends
+                              it; `pickup` / `drop` hit the reference's `assert False` (counted as invalid actions) and
+                              `toggle` on an empty cell its AttributeError (counted with the out-of-bounds faults).  The
+                              per-env task word is the running goal count. */
 } mgx_task_kind;
 
 typedef struct {

@@ -314,7 +314,7 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
     meta = dict(env_id=name, W=W, H=H, max_steps=int(env0.max_steps), view=V,
                 see_through=bool(env0.see_through_walls), lava_v1=bool(v1), full_obs=bool(full_obs),
                 reseed=bool(reseed), extended=bool(n_actions > 7), alt_vis=not bool(env0.default_vis),
-                task=10 if type(env0).__name__.startswith("PutNear") else 9 if type(env0).__name__ == "LockedRoom" else 7 if type(env0).__name__ == "Unlock" else 8 if type(env0).__name__ in ("UnlockPickup", "BlockedUnlockPickup") or type(env0).__name__.startswith("KeyCorridor") else 6 if type(env0).__name__.startswith("Memory") else 5 if type(env0).__name__.startswith("RedBlueDoor") else 4 if type(env0).__name__.startswith(("GoToObject", "GotoEnv")) else (1 if hasattr(env0, "targetType") else (2 if hasattr(env0, "target_pos") else 0)),
+                task=11 if type(env0).__name__.startswith("TwoGoals") else 10 if type(env0).__name__.startswith("PutNear") else 9 if type(env0).__name__ == "LockedRoom" else 7 if type(env0).__name__ == "Unlock" else 8 if type(env0).__name__ in ("UnlockPickup", "BlockedUnlockPickup") or type(env0).__name__.startswith("KeyCorridor") else 6 if type(env0).__name__.startswith("Memory") else 5 if type(env0).__name__.startswith("RedBlueDoor") else 4 if type(env0).__name__.startswith(("GoToObject", "GotoEnv")) else (1 if hasattr(env0, "targetType") else (2 if hasattr(env0, "target_pos") else 0)),
                 objstate=bool(objstate), dynobs=int(getattr(env0, "n_obstacles", 0)), gym_id=gym_id or "")
     z = dict(
         seed=np.zeros(K, np.int64), init_grid=np.zeros((K, W, H, 3), np.uint8),
@@ -363,6 +363,9 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
                 lc = env.grid.get(*env.left_pos)
                 if rc is not None and rc.type == "goal" and not (lc is not None and lc.type == "goal"):
                     a = 6
+            if type(env).__name__.startswith("TwoGoals"):   # its own step() raises on pickup / drop and on toggling an empty cell
+                if a in (3, 4) or (a == 5 and env.grid.get(*env.front_pos) is None):
+                    a = 1
             o, r, d, info = env.step(int(a))
             assert info == {}
             z["actions"][k, t] = a
@@ -531,6 +534,8 @@ def record_levels():
                           ("MiniGrid-RedBlueDoors-6x6-v0", range(128)), ("MiniGrid-RedBlueDoors-8x8-v0", range(128)),
                           ("MiniGrid-KeyCorridorS3R1-v0", range(128)), ("MiniGrid-KeyCorridorS3R2-v0", range(128)), ("MiniGrid-KeyCorridorS3R3-v0", range(128)),
                           ("MiniGrid-KeyCorridorS4R3-v0", range(128)), ("MiniGrid-KeyCorridorS5R3-v0", range(128)), ("MiniGrid-KeyCorridorS6R3-v0", range(128)),
+                          ("MiniGrid-TwoGoals-8x8-v0", range(4)), ("MiniGrid-TwoGoals-Random-5x5-v0", range(64)), ("MiniGrid-TwoGoals-Random-6x6-v0", range(64)),
+                          ("MiniGrid-TwoGoals-Random-9x9-v0", range(64)), ("MiniGrid-TwoGoals-Random-16x16-v0", range(64)),
                           ("MiniGrid-PutNear-6x6-N2-v0", range(256)), ("MiniGrid-PutNear-8x8-N3-v0", range(256)), ("MiniGrid-LockedRoom-v0", range(256)), ("MiniGrid-Playground-v0", range(256)), ("MiniGrid-Unlock-v0", range(256)), ("MiniGrid-UnlockPickup-v0", range(256)), ("MiniGrid-BlockedUnlockPickup-v0", range(256)),
                           ("MiniGrid-MemoryS7-v0", range(64)), ("MiniGrid-MemoryS9-v0", range(64)), ("MiniGrid-MemoryS11-v0", range(64)),
                           ("MiniGrid-MemoryS13-v0", range(64)), ("MiniGrid-MemoryS13Random-v0", range(128)), ("MiniGrid-MemoryS17Random-v0", range(128)),
@@ -798,6 +803,21 @@ def main():
         return f
     record_case("PutNear-8x8-N3", mk("MiniGrid-PutNear-8x8-N3-v0"), list(range(10)), 300, scripts=[putnear_script(0), putnear_script(1)] * 3 + [None] * 4, reseed=False)
     record_case("PutNear-6x6-N2", mk("MiniGrid-PutNear-6x6-N2-v0"), list(range(8)), 240, scripts=[putnear_script(1), putnear_script(0)] * 2 + [None] * 4, reseed=False)
+    def twogoals_script(env):
+        acts = []
+        for color in ("green", "yellow"):
+            pos = [(x, y) for x in range(env.width) for y in range(env.height) if env.grid.get(x, y) is not None and env.grid.get(x, y).type == "goal" and env.grid.get(x, y).color == color]
+            a = (plan_face(env, pos[0], passable_extra=()) or []) + [5]
+            for k in a:
+                env.step(k)
+            acts += a
+        return acts
+    import io, contextlib                                 # TwoGoalsEnv.step prints its goal count every step
+    for short, gid, seeds in [("TwoGoals-8x8", "MiniGrid-TwoGoals-8x8-v0", range(6)), ("TwoGoals-Random-6x6", "MiniGrid-TwoGoals-Random-6x6-v0", range(8)),
+                              ("TwoGoals-Random-16x16", "MiniGrid-TwoGoals-Random-16x16-v0", range(4))]:
+        with contextlib.redirect_stdout(io.StringIO()) as buf:
+            record_case(short, mk(gid), list(seeds), 300, scripts=[twogoals_script] * 2 + [None] * (len(seeds) - 2), reseed=False)
+        print(buf.getvalue().strip().splitlines()[-1])
     record_case("Playground", mk("MiniGrid-Playground-v0"), list(range(6)), 300, reseed=False)
     record_case("LockedRoom", mk("MiniGrid-LockedRoom-v0"), list(range(6)), 400, reseed=False)
 

@@ -241,7 +241,8 @@ static int step_state(const mgo_cfg *cf, uint8_t *g, uint8_t *aux, int32_t *agen
         if (*steps >= cf->max_steps) *done = 1;
         return MGO_ERR_OOB;
     }
-    if (action < 0 || action > (cf->extended ? A_STRAFE_RIGHT : A_DONE)) {
+    if (action < 0 || action > (cf->extended ? A_STRAFE_RIGHT : A_DONE) ||
+        (cf->task == 11 && (action == A_PICKUP || action == A_DROP))) { /* TwoGoalsEnv.step has no such branches */
         /* the reference asserts here */
         if (*steps >= cf->max_steps) *done = 1;
         return MGO_ERR_ACTION;
@@ -416,8 +417,9 @@ static void task_rule(const mgo_cfg *cf, const uint8_t *g, const uint8_t *aux, c
 /* One reference `env.step(a)` per env, in place.  obs may be NULL.  full may be NULL.
  * Returns 0, or the first per-env error code (processing continues for the rest);
  * err (optional, i32[n]) receives the per-env code. */
-static const uint32_t *g_task = 0; /* per-env task words for the next mgo_step_batch / mgo_rollout call (test harness state) */
-void mgo_set_task(const uint32_t *task) { g_task = task; }
+static uint32_t *g_task = 0; /* per-env task words for the next mgo_step_batch / mgo_rollout call (test harness state;
+                               TwoGoals keeps its running goal count there) */
+void mgo_set_task(uint32_t *task) { g_task = task; }
 
 int mgo_step_batch(const mgo_cfg *cf, int64_t n, uint8_t *grid, uint8_t *aux, int32_t *agent,
                    uint8_t *carry, uint8_t *carry_aux, int32_t *steps, const uint8_t *actions,
@@ -429,13 +431,25 @@ int mgo_step_batch(const mgo_cfg *cf, int64_t n, uint8_t *grid, uint8_t *aux, in
         uint8_t *g = grid + e * cells * 3, *ax = aux + e * cells;
         int pre = 0;
         if (cf->task == 10) pre = carry[e * 3] != T_EMPTY;
+        if (cf->task == 11) { /* TwoGoals: the front cell before the step, type | color << 4 (0 = outside the grid) */
+            const int32_t *ag = agent + e * 3;
+            const int fx = ag[0] + DIR_TO_VEC[ag[2]][0], fy = ag[1] + DIR_TO_VEC[ag[2]][1];
+            if (fx >= 0 && fx < cf->W && fy >= 0 && fy < cf->H) { const cell_t c = grid_get(cf, g, ax, fx, fy); pre = c.t | (c.c << 4); }
+        }
         if (cf->task == 5 && g_task)
             pre = door_open(cf, g, cf->H / 2, (int)(g_task[e] & 15u)) | (door_open(cf, g, cf->H / 2 + cf->H - 1, (int)((g_task[e] >> 4) & 15u)) << 1);
         const int act_e = (cf->task == 6 && actions[e] == A_PICKUP) ? A_TOGGLE : actions[e]; /* envs/memory.py:89-90 */
         int rc = step_state(cf, g, ax, agent + e * 3, carry + e * 3, carry_aux + e, steps + e,
                             act_e, reward + e, done + e,
                             g_contains ? g_contains + e * cells * 3 : 0, g_carry_contains ? g_carry_contains + e * 3 : 0);
-        if (cf->task && rc == MGO_OK)
+        if (cf->task == 11 && rc == MGO_OK && g_task) { /* TwoGoalsEnv.step envs/twogoals.py:118-146 on top of the base transition */
+            if (act_e == A_TOGGLE) {
+                if ((pre & 15) == T_EMPTY) rc = MGO_ERR_REFBUG; /* fwd_cell.type on None: AttributeError */
+                else if ((pre & 15) == T_GOAL) { reward[e] = (pre >> 4) == 1 ? 0.25 : ((pre >> 4) == 4 ? 0.5 : 0.0); g_task[e] += 1; }
+            }
+            if (act_e == A_DONE) done[e] = 1;
+            if (g_task[e] >= 2) { reward[e] += 1. - 0.9 * steps[e] / cf->max_steps; done[e] = 1; }
+        } else if (cf->task && rc == MGO_OK)
             task_rule(cf, g, ax, agent + e * 3, carry + e * 3, steps[e], g_task ? g_task[e] : 0u, act_e, reward + e, done + e, pre);
         if (err) err[e] = rc;
         if (rc && !first) first = rc;

@@ -97,12 +97,14 @@ class OracleEnvs:
         err = np.zeros(self.n, np.int32)
         lib().mgo_set_contains(_p(self.contains), _p(self.carry_contains))
         if self.cfg.task:
-            self._task = np.ascontiguousarray(self.task if self.task is not None else np.zeros(self.n), np.uint32)
+            self._task = np.ascontiguousarray(self.task if self.task is not None else np.zeros(self.n), np.uint32).copy()
             lib().mgo_set_task(_p(self._task))
         lib().mgo_step_batch(ctypes.byref(self.cfg), ctypes.c_int64(self.n), _p(self.grid), _p(self.aux),
                              _p(self.agent), _p(self.carry), _p(self.carry_aux), _p(self.steps), _p(a),
                              _p(obs), _p(fo), _p(reward), _p(done), _p(err))
         self.err = err
+        if self.cfg.task == 11:      # TwoGoals: the task word is the running goal count, updated by the step
+            self.task = self._task
         if full:
             return obs, fo, reward, done
         return obs, reward, done
@@ -116,6 +118,8 @@ class OracleEnvs:
         self.carry[m] = (1, 0, 0)
         self.carry_aux[m] = 0
         self.steps[m] = 0
+        if self.cfg.task == 11 and self.task is not None:
+            self.task[m] = 0
         if self.contains is not None:
             self.contains[m] = self.contains0[m]
             self.carry_contains[m] = (1, 0, 0)

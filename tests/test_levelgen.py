@@ -13,7 +13,8 @@ IDS = ["Empty-8x8", "Empty-16x16", "Empty-5x5", "Empty-6x6", "DoorKey-5x5", "Doo
        "MultiRoom-N2-S4", "MultiRoom-N4-S5", "MultiRoom-N6", "Fetch-5x5-N2", "Fetch-6x6-N2", "Fetch-8x8-N3",
        "GoToDoor-5x5", "GoToDoor-6x6", "GoToDoor-8x8", "FourRooms", "GoToObject-6x6-N2", "GoToObject-8x8-N2", "RedBlueDoors-6x6", "RedBlueDoors-8x8", "MemoryS7", "MemoryS9", "MemoryS11", "MemoryS13",
        "MemoryS13Random", "MemoryS17Random", "Unlock", "UnlockPickup", "BlockedUnlockPickup",
-       "KeyCorridorS3R1", "KeyCorridorS3R2", "KeyCorridorS3R3", "KeyCorridorS4R3", "KeyCorridorS5R3", "KeyCorridorS6R3", "LockedRoom", "Playground", "PutNear-6x6-N2", "PutNear-8x8-N3"]
+       "KeyCorridorS3R1", "KeyCorridorS3R2", "KeyCorridorS3R3", "KeyCorridorS4R3", "KeyCorridorS5R3", "KeyCorridorS6R3", "LockedRoom", "Playground", "PutNear-6x6-N2", "PutNear-8x8-N3", "TwoGoals-8x8", "TwoGoals-Random-5x5",
+       "TwoGoals-Random-6x6", "TwoGoals-Random-9x9", "TwoGoals-Random-16x16"]
 
 
 @pytest.mark.parametrize("key", IDS)
@@ -23,7 +24,7 @@ def test_levels_match_reference(levels, key):
     grid, agent, task = mg.generate_levels(env_id, seeds, with_task=True)
     assert np.array_equal(grid, levels[key + ":grid"])
     assert np.array_equal(agent, levels[key + ":agent"])
-    if key.startswith(("GoToObject", "RedBlueDoors", "Memory", "Unlock", "BlockedUnlock", "KeyCorridor", "LockedRoom", "PutNear")):
+    if key.startswith(("GoToObject", "RedBlueDoors", "Memory", "Unlock", "BlockedUnlock", "KeyCorridor", "LockedRoom", "PutNear", "TwoGoals")):
         assert np.array_equal(task, levels[key + ":task"])      # target position, type and colour / door rows
     else:
         assert np.array_equal(task & 0xFF, levels[key + ":task"])   # Fetch target (the high byte is the mission template)

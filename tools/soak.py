@@ -21,7 +21,7 @@ FAMILIES = ["MiniGrid-Empty-8x8-v0", "MiniGrid-DoorKey-8x8-v0", "MiniGrid-LavaCr
             "MiniGrid-LavaGapS7-v1", "MiniGrid-MultiRoom-N4-S5-v0", "MiniGrid-FourRooms-v0", "MiniGrid-Fetch-8x8-N3-v0",
             "MiniGrid-GoToDoor-8x8-v0", "MiniGrid-GoToObject-8x8-N2-v0", "MiniGrid-PutNear-8x8-N3-v0", "MiniGrid-RedBlueDoors-8x8-v0",
             "MiniGrid-MemoryS13Random-v0", "MiniGrid-UnlockPickup-v0", "MiniGrid-BlockedUnlockPickup-v0", "MiniGrid-KeyCorridorS4R3-v0",
-            "MiniGrid-LockedRoom-v0", "MiniGrid-Playground-v0"]
+            "MiniGrid-LockedRoom-v0", "MiniGrid-Playground-v0", "MiniGrid-TwoGoals-8x8-v0", "MiniGrid-TwoGoals-Random-16x16-v0"]
 
 
 def main():
