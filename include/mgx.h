@@ -15,9 +15,20 @@
  *   mgx_observe                gen_obs()                          minigrid.py:1359-1381
  *   mgx_step                   step(action)                       minigrid.py:1227-1325
  *                              (+ FullyObsWrapper.observation     wrappers.py:326-338 when obs_mode = MGX_OBS_FULL)
+ *   mgx_rollout                the caller's `for t: env.step(a[t])` loop as one hipGraph launch     run_tests.py:41-68
  *   mgx_generate_levels        _gen_grid of the built-in families envs/empty.py:30-57, envs/doorkey.py:15-44,
- *                                                                 envs/crossing.py:24-92, envs/lavagap.py:21-59,
- *                                                                 envs/distshift.py:30-52, envs/multiroom.py:40-219
+ *     (_ex, _level_stream(_ex))                                   envs/crossing.py:24-92, envs/lavagap.py:21-59,
+ *                                                                 envs/distshift.py:30-52, envs/multiroom.py:40-219,
+ *                                                                 envs/fourrooms.py, fetch.py, gotodoor.py, gotoobject.py,
+ *                                                                 putnear.py, redbluedoors.py, memory.py, unlock*.py,
+ *                                                                 keycorridor.py (+ roomgrid.py), lockedroom.py,
+ *                                                                 playground_v0.py, dynamicobstacles.py, twogoals.py
+ *   mgx_set/get_task           per-episode attributes of the task envs (targetType, target_pos, ...) as one word
+ *   mgx_set/get_object_state   Goal/Box.toggletimes, triage_color, Box.contains              minigrid.py:156-181,332-364
+ *   mgx_get_direction          obs['direction']                   minigrid.py:1375-1379
+ *   mgx_mission                obs['mission'] / env.mission       minigrid.py:1373-1379, the envs' `self.mission = ...`
+ *   obs_mode one-hot / flat    OneHotPartialObsWrapper, FullyObsOneHotWrapper, FlatObsWrapper   wrappers.py:203-243,340-415,528-577
+ *   task_kind                  the `step` overrides of the task envs (mgx_task_kind below cites each)
  *
  * Conventions
  *   - every function returns 0 (MGX_OK) or a negative mgx_status; mgx_last_error()
