@@ -281,6 +281,30 @@ def test_task_families_on_device_vs_oracle(env_id):
     env.close()
 
 
+@pytest.mark.parametrize("env_id", ["MiniGrid-PutNear-8x8-N3-v0", "MiniGrid-RedBlueDoors-6x6-v0", "MiniGrid-TwoGoals-Random-6x6-v0", "MiniGrid-MemoryS9-v0",
+                                    "MiniGrid-KeyCorridorS5R3-v0", "MiniGrid-GoToObject-6x6-N2-v0", "MiniGrid-Dynamic-Obstacles-6x6-v0"])
+def test_task_families_fully_observable(env_id):
+    """The task rules also run inside the FullyObs kernels (direct, ragged direct and LDS form, by grid size)."""
+    N, T = 200, 60
+    seeds = np.arange(N, dtype=np.uint64) + 50
+    full = mg.VecMiniGrid(env_id, num_envs=N, seeds=seeds, auto_reset=True, backend="torch", obs_mode="full")
+    part = mg.VecMiniGrid(env_id, num_envs=N, seeds=seeds, auto_reset=True, backend="torch")
+    full.reset(); part.reset()
+    rs = np.random.RandomState(4)
+    import torch
+    for t in range(T):
+        a = torch.from_numpy(rs.randint(0, 7, size=N).astype(np.uint8)).cuda()
+        fo, fr, fd, _ = full.step(a)
+        po, pr, pd, _ = part.step(a)
+        assert torch.equal(fr, pr) and torch.equal(fd, pd), (env_id, t)
+        st = part.get_state()                                  # FullyObsWrapper.observation of the same state
+        want = st["grid"].copy()
+        want[np.arange(N), st["agent"][:, 0], st["agent"][:, 1]] = np.stack([np.full(N, 10), np.zeros(N, int), st["agent"][:, 2]], 1)
+        assert np.array_equal(fo.cpu().numpy(), want), (env_id, t)
+    assert full.stats() == part.stats()
+    full.close(); part.close()
+
+
 def test_faults_and_errors():
     N = 70
     grid, aux, agent, carry, steps = random_states(N, 8, 8, seed=3)
