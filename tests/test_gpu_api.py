@@ -186,3 +186,37 @@ def test_reset_restores_default_object_state():
     assert np.array_equal(st["grid"], grid) and (st["aux"] == 0).all()
     assert (os_["contains"] == np.array([1, 0, 0], np.uint8)).all() and (os_["carry_aux"] == 0).all()
     env.close()
+
+
+@pytest.mark.parametrize("case,mission", [("DoorKey-8x8", "use the key to open the door and then get to the goal"),
+                                          ("Empty-5x5", "get to the green goal square"),
+                                          ("LavaCrossingS9N3", "avoid the lava and get to the green goal square"), ("MultiRoom-N2-S4", None)])
+def test_single_env_adapter_replays_reference_loop(case, mission):
+    """gym_minigrid_amd.make(id): the reference's own caller loop (seed, reset, step, `if done: seed; reset`) against a
+    recorded trace -- obs dict, float reward, bool done, the attributes callers read."""
+    from conftest import load_case
+    meta, z = load_case(case)
+    assert meta["reseed"]
+    env = mg.make("MiniGrid-%s-v0" % case)
+    assert env.actions.forward == 2 and env.action_space.n == 7
+    for k in range(2):
+        seed = int(z["seed"][k])
+        env.seed(seed)
+        obs = env.reset()
+        assert set(obs) == {"image", "direction", "mission"}
+        assert np.array_equal(obs["image"], z["init_obs"][k])
+        if mission is not None:
+            assert obs["mission"] == mission == env.mission
+        assert np.array_equal(env.encode_grid(), z["init_grid"][k]) and env.step_count == 0 and env.carrying is None
+        for t in range(min(z["actions"].shape[1], 300)):
+            obs, reward, done, info = env.step(int(z["actions"][k, t]))
+            assert isinstance(reward, float) and isinstance(done, bool) and info == {}
+            assert np.array_equal(obs["image"], z["obs"][k, t]), (case, k, t)
+            assert obs["direction"] == z["direction"][k, t] == env.agent_dir
+            assert reward == float(np.float32(z["reward"][k, t])) and done == bool(z["done"][k, t])
+            assert env.agent_pos == tuple(z["agent"][k, t, :2]) and env.step_count == z["steps"][k, t]
+            if done:
+                env.seed(seed)
+                obs = env.reset()
+                assert np.array_equal(obs["image"], z["init_obs"][k])
+    env.close()
