@@ -2,7 +2,7 @@
 """Long parity soak on the GPU box (not part of the test suite): every family, N envs x T steps with in-kernel auto-reset,
 every observation / reward / done byte against the CPU oracle running the same rule on host-generated levels.
 
-    python tools/soak.py [N] [T]
+    python tools/soak.py [N] [T] [partial|full]
 """
 import os
 import sys
@@ -27,27 +27,29 @@ FAMILIES = ["MiniGrid-Empty-8x8-v0", "MiniGrid-DoorKey-8x8-v0", "MiniGrid-LavaCr
 def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
     T = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+    full = len(sys.argv) > 3 and sys.argv[3] == "full"  # FullyObsWrapper kernels (direct / ragged / LDS form by grid size)
     total = 0
     for env_id in FAMILIES:
         t0 = time.perf_counter()
         seeds = np.arange(N, dtype=np.uint64) * 11 + 3
-        env = mg.VecMiniGrid(env_id, num_envs=N, seeds=seeds, auto_reset=True, backend="torch")
+        env = mg.VecMiniGrid(env_id, num_envs=N, seeds=seeds, auto_reset=True, backend="torch", obs_mode="full" if full else "partial")
         obs = env.reset().cpu().numpy()
         grid, agent, task = mg.generate_levels(env_id, seeds, with_task=True)
         cfg = mg.env_config(env_id)
         orc = OracleEnvs(cfg.width, cfg.height, cfg.max_steps, cfg.see_through_walls, cfg.lava_v1, task=cfg.task_kind)
         orc.set_state(grid, agent)
         orc.task = task.copy()
-        assert np.array_equal(obs, orc.observe()), env_id
+        assert np.array_equal(obs, orc.observe(True)[int(full)]), env_id
         rs = np.random.RandomState(5)
         episodes = 0
         for t in range(T):
             a = rs.randint(0, 7, size=N).astype(np.uint8)
             obs, rew, done, _ = env.step(torch.from_numpy(a).cuda())
-            oo, orew, odone = orc.step(a)
+            oo, of, orew, odone = orc.step(a, True)
+            oo = of if full else oo
             orc.reset_where(odone)
             if odone.any():
-                oo[odone.astype(bool)] = orc.observe()[odone.astype(bool)]
+                oo[odone.astype(bool)] = orc.observe(True)[int(full)][odone.astype(bool)]
             assert np.array_equal(done.cpu().numpy(), odone), (env_id, t)
             assert np.array_equal(rew.cpu().numpy(), orew.astype(np.float32)), (env_id, t)
             assert np.array_equal(obs.cpu().numpy(), oo), (env_id, t)
@@ -58,7 +60,7 @@ def main():
         env.close()
         total += N * T
         print("%-40s %d envs x %d steps, %8d episodes: every byte equal  (%.1f s)" % (env_id, N, T, episodes, time.perf_counter() - t0), flush=True)
-    print("soak ok: %d env-steps compared" % total, flush=True)
+    print("soak ok (%s obs): %d env-steps compared" % ("full" if full else "partial", total), flush=True)
 
 
 if __name__ == "__main__":
