@@ -132,6 +132,14 @@ __global__ __launch_bounds__(256) void k_direction(const uint2 *__restrict__ rec
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (uint8_t)((rec[i].x >> 16) & 3u);
 }
+__global__ __launch_bounds__(256) void k_pose(const uint2 *__restrict__ rec, int32_t *__restrict__ out, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const uint32_t r = rec[i].x;
+        out[3 * i] = (int32_t)(r & 255u); out[3 * i + 1] = (int32_t)((r >> 8) & 255u); out[3 * i + 2] = (int32_t)((r >> 16) & 3u);
+    }
+}
 } // namespace
 
 namespace {
@@ -208,6 +216,12 @@ hipError_t mgx_launch_task(uint2 *rec, uint2 *rec0, const uint32_t *set, uint32_
 hipError_t mgx_launch_direction(const uint2 *rec, uint8_t *out, int64_t n, hipStream_t st)
 {
     hipLaunchKernelGGL(k_direction, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rec, out, n);
+    return hipGetLastError();
+}
+
+hipError_t mgx_launch_pose(const uint2 *rec, int32_t *out, int64_t n, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_pose, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rec, out, n);
     return hipGetLastError();
 }
 

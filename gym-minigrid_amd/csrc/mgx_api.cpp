@@ -827,6 +827,17 @@ extern "C" int mgx_get_direction(mgx_handle h, uint8_t *direction)
     return finish_out(h, &o, 1);
 }
 
+extern "C" int mgx_get_pose(mgx_handle h, int32_t *pose)
+{
+    int rc = check_handle(h, "mgx_get_pose");
+    if (rc) return rc;
+    if (!pose) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_get_pose: null argument");
+    OutArg o;
+    if ((rc = dev_out(h, 3, pose, (size_t)h->n * 3 * sizeof(int32_t), &o, 4))) return rc;
+    HIP_TRY(mgx_launch_pose(h->agent_d, (int32_t *)o.dev, h->n, h->stream));
+    return finish_out(h, &o, 1);
+}
+
 extern "C" int mgx_reset(mgx_handle h, const uint64_t *seeds, const uint8_t *mask, uint8_t *obs)
 {
     int rc = check_handle(h, "mgx_reset");

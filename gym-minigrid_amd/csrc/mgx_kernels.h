@@ -139,6 +139,7 @@ struct ObjStateParams {
 hipError_t mgx_launch_objstate(const ObjStateParams &p, hipStream_t st);
 hipError_t mgx_launch_task(uint2 *rec, uint2 *rec0, const uint32_t *set, uint32_t *get, int64_t n, hipStream_t st);
 hipError_t mgx_launch_direction(const uint2 *rec, uint8_t *out, int64_t n, hipStream_t st);
+hipError_t mgx_launch_pose(const uint2 *rec, int32_t *out, int64_t n, hipStream_t st);
 hipError_t mgx_launch_pack(const PackParams &p, hipStream_t st);
 hipError_t mgx_launch_unpack(const PackParams &p, hipStream_t st);
 hipError_t mgx_launch_fill_actions(uint8_t *out, uint64_t seed, int64_t env0, int64_t t0, int64_t n, int64_t T, hipStream_t st);

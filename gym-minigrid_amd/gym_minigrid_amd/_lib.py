@@ -73,6 +73,7 @@ SIGNATURES = {
     "mgx_get_object_state": (_int, [_vp, _vp, _vp, _vp]),
     "mgx_observe": (_int, [_vp, _vp]),
     "mgx_get_direction": (_int, [_vp, _vp]),
+    "mgx_get_pose": (_int, [_vp, _vp]),
     "mgx_step": (_int, [_vp, _vp, _vp, _vp, _vp]),
     "mgx_get_stats": (_int, [_vp, ctypes.POINTER(Stats)]),
     "mgx_read_stats_async": (_int, [_vp, _vp]),

@@ -61,11 +61,11 @@ class SingleEnv:
 
     @property
     def agent_pos(self):
-        return tuple(int(v) for v in self._state()["agent"][0, :2])
+        return tuple(int(v) for v in self._vec.pose()[0, :2])
 
     @property
     def agent_dir(self):
-        return int(self._state()["agent"][0, 2])
+        return int(self._vec.pose()[0, 2])
 
     @property
     def step_count(self):

@@ -230,6 +230,16 @@ class VecMiniGrid:
         _lib.check(_lib.lib().mgx_get_direction(self._h, _ptr(self._dir)))
         return self._dir
 
+    def pose(self):
+        """env.agent_pos / agent_dir per env, int32 (N, 3) = (x, y, dir): the 'pos' and 'dir' AgentExtraInfoWrapper adds to the
+        observation (wrappers.py:169-187).  No device sync with the torch backend."""
+        if getattr(self, "_pose", None) is None:
+            self._pose = self._new((self.num_envs, 3), "int32")
+        if self._torch is not None:
+            self._bind_stream()
+        _lib.check(_lib.lib().mgx_get_pose(self._h, _ptr(self._pose)))
+        return self._pose
+
     # ------------------------------------------------------------------ state injection / inspection
     def set_state(self, grid, agent, aux=None, carry=None, steps=None):
         """Reference-encoded state (host numpy arrays): grid (N,W,H,3) u8, agent (N,3) i32, aux (N,W,H) u8,

@@ -26,6 +26,7 @@
  *   mgx_set/get_task           per-episode attributes of the task envs (targetType, target_pos, ...) as one word
  *   mgx_set/get_object_state   Goal/Box.toggletimes, triage_color, Box.contains              minigrid.py:156-181,332-364
  *   mgx_get_direction          obs['direction']                   minigrid.py:1375-1379
+ *   mgx_get_pose               env.agent_pos, env.agent_dir ('pos', 'dir' of AgentExtraInfoWrapper)   minigrid.py:816-818, wrappers.py:169-187
  *   mgx_mission                obs['mission'] / env.mission       minigrid.py:1373-1379, the envs' `self.mission = ...`
  *   obs_mode one-hot / flat    OneHotPartialObsWrapper, FullyObsOneHotWrapper, FlatObsWrapper   wrappers.py:203-243,340-415,528-577
  *   task_kind                  the `step` overrides of the task envs (mgx_task_kind below cites each)
@@ -271,6 +272,11 @@ int mgx_rollout(mgx_handle h, int64_t T, const uint8_t *actions, uint8_t *obs, f
 
 /* obs['direction'] (minigrid.py:1375-1379): agent_dir of every env, uint8 [N]. */
 int mgx_get_direction(mgx_handle h, uint8_t *direction);
+
+/* env.agent_pos and env.agent_dir of every env (minigrid.py:816-818; the 'pos' and 'dir' entries AgentExtraInfoWrapper
+ * adds to the observation, wrappers.py:169-187): int32 [N][3] = (x, y, dir).  Asynchronous for a device buffer (unlike
+ * mgx_get_state, which synchronises): meant to be read next to the observations of every step. */
+int mgx_get_pose(mgx_handle h, int32_t *pose);
 
 /* One lockstep env.step(actions[i]) for all N envs.  reward / done may be NULL. */
 int mgx_step(mgx_handle h, const uint8_t *actions, uint8_t *obs, float *reward, uint8_t *done);

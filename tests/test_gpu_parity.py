@@ -63,6 +63,7 @@ def test_golden_trace_no_autoreset(name, backend):
         assert np.array_equal(done, z["done"][sel, t]), (name, t)
         if t % every == 0 or done.any():
             assert np.array_equal(to_np(env.direction()), z["direction"][sel, t]), (name, t)
+            assert np.array_equal(to_np(env.pose()), z["agent"][sel, t]), (name, t)
             check_state(env, z["grid"][sel, t], z["agent"][sel, t], z["carry"][sel, t], z["steps"][sel, t],
                         aux=z["aux"][sel, t] if objstate else None, where=(name, t))
             if objstate:
