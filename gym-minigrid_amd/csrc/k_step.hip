@@ -645,13 +645,15 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
         if (valid) p.agent[env] = pack_rec(L, p.task);
     }
     if (p.obs) {
-        if constexpr (GATHER) {
+        if constexpr (GATHER && V != 7) {
+            // other view sizes reach this form only when the tile image cannot fit the LDS (grids past ~50x50): V*V byte loads
+            emit_partial_obs<CW, CH, V, ALT, true>(p, L, lds, row, env0, lane, pidx, pcode);
+        } else if constexpr (GATHER) {
             if (p.H >= 8) {
                 // The VxV view always lies inside a world-aligned VxV window whose columns (fixed world x) are V contiguous
                 // bytes: V unaligned 8-byte loads per lane instead of V*V byte loads.  The window goes to this lane's
                 // LDS slot as a tiny 7x8 "grid" (cells outside the real grid = grey wall, which is what Grid.slice pads
                 // with) and the ordinary closed-form gather runs on it.
-                static_assert(V == 7, "the gather form is instantiated for the default view only");
                 const int H = p.H, W = p.W;
                 const int x0 = L.dir == 0 ? L.ax : (L.dir == 2 ? L.ax - 6 : L.ax - 3);
                 const int y0 = L.dir == 1 ? L.ay : (L.dir == 3 ? L.ay - 6 : L.ay - 3);
@@ -906,9 +908,12 @@ hipError_t mgx_launch_step(const StepParams &p, int mode, int waves_per_block, h
     const dim3 block(64 * waves_per_block);
     const dim3 grid((p.n_tiles + waves_per_block - 1) / waves_per_block);
     const size_t shmem = (size_t)waves_per_block * p.wave_lds;
-    if (mode == 3) { // large grids, default view and visibility: gather form
-        hipLaunchKernelGGL((k_step<0, 0, 3, 7>), grid, block, shmem, st, p);
-        return hipGetLastError();
+    if (mode == 3) { // large grids: gather form (the default view and visibility by the size rule, anything else when the tile image cannot fit the LDS)
+#define VCASE(v) if (p.view == v) { if (p.alt_vis) hipLaunchKernelGGL((k_step<0, 0, 3, v, true>), grid, block, shmem, st, p); \
+                                    else hipLaunchKernelGGL((k_step<0, 0, 3, v>), grid, block, shmem, st, p); return hipGetLastError(); }
+        MGX_VIEWS(VCASE) VCASE(7)
+#undef VCASE
+        return hipErrorInvalidValue;
     }
     if (mode == 0 && p.alt_vis) { // default_vis=False: run-time grid size only
 #define VCASE(v) if (p.view == v) { hipLaunchKernelGGL((k_step<0, 0, 0, v, true>), grid, block, shmem, st, p); return hipGetLastError(); }

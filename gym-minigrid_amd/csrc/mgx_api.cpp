@@ -314,6 +314,8 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     const char *force = getenv("MGX_PARTIAL_KERNEL"); // "staged" / "gather": override the size rule (tests, tuning)
     const bool gather_ok = h->partial && view == 7 && !cfg->alt_visibility && !cfg->object_state;
     if (gather_ok && (force ? !strcmp(force, "gather") : h->S > 256)) { h->kernel_mode = 3; need = obs_img; }
+    // any other partial view whose tile image cannot fit the LDS (past ~50x50) takes the gather form too, with byte loads
+    if (h->partial && h->kernel_mode == 0 && need > 160 * 1024) { h->kernel_mode = 3; need = obs_img; }
     h->wave_lds = (need + 15) & ~15;
     // a family that draws no random numbers (Empty with a fixed start) has only one level: nothing to generate
     const bool uses_rng = cfg->level_kind != MGX_LEVEL_NONE && cfg->level_kind != MGX_LEVEL_DISTSHIFT &&

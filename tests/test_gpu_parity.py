@@ -456,9 +456,9 @@ def test_ragged_batch_sizes(N):
 
 def test_largest_grids():
     """Beyond 16x16 the default partial view is gathered straight from HBM (no LDS tile image), so the grid size is
-    bounded by the 255 of the record's coordinate bytes only.  The staged forms (other view sizes, default_vis=False)
-    still need the 64-env tile in one wave's 160 KiB of LDS and are refused loudly past ~50x50; FullyObs keeps no LDS
-    image when W*H % 4 == 0."""
+    bounded by the 255 of the record's coordinate bytes only (other view sizes / default_vis=False / object_state take
+    the same form once the 64-env tile no longer fits one wave's 160 KiB of LDS, past ~50x50: test_large_grid_other_views);
+    FullyObs keeps no LDS image beyond 128 cells."""
     W = H = 50
     N = 70
     grid, aux, agent, carry, steps = random_states(N, W, H, seed=5, density=0.2)
@@ -474,8 +474,6 @@ def test_largest_grids():
         want = np.where(odone.astype(bool)[:, None, None, None], orc.observe(), oo)
         assert np.array_equal(to_np(obs), want)
     env.close()
-    with pytest.raises(mg.MgxError):
-        mg.VecMiniGrid(config=cfg_from(60, 60, 9, False), num_envs=4, backend="numpy", agent_view_size=5)
     for (W, H) in [(60, 60), (200, 150)]:
         N = 67
         grid, aux, agent, carry, steps = random_states(N, W, H, seed=6, density=0.3)
@@ -538,3 +536,59 @@ def test_object_state_random_batch_vs_oracle(W, H, extended, mode):
             orc.reset_where(d)
             env.set_state(orc.grid, orc.agent, aux=orc.aux, carry=orc.carry, steps=orc.steps)
             env.set_object_state(contains=orc.contains, carry_aux=orc.carry_aux, carry_contains=orc.carry_contains)
+
+
+def test_configuration_fuzz():
+    """tools/fuzz.py, 120 seeded draws: grid size x view size x visibility rule x action set x obs mode x hidden object
+    state x batch size x kernel form, each against the oracle on random rooms (6,300 draws were run once: profiles/r01_fuzz.log)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("mgx_fuzz", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    rs = np.random.RandomState(77)
+    saved = {k: os.environ.get(k) for k in ("MGX_PARTIAL_KERNEL", "MGX_FULL_KERNEL")}
+    try:
+        for trial in range(120):
+            fuzz.one(rs, 7700000 + trial)
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("view,alt,objstate", [(5, True, False), (11, False, False), (9, False, True)])
+def test_large_grid_other_views(view, alt, objstate):
+    """Past ~50x50 the tile image of 64 envs cannot fit the LDS: every view size / visibility rule / hidden object state
+    runs on the gather form there (byte loads for view != 7)."""
+    W, H, N, T = 70, 61, 130, 30
+    grid, aux, agent, carry, steps = random_states(N, W, H, seed=view)
+    contains = None
+    if objstate:
+        aux, contains = random_object_state(grid, seed=3)
+        carry = steps = None
+    orc = OracleEnvs(W, H, 19, False, False, view=view, alt_vis=alt)
+    orc.set_state(grid, agent, aux=aux, carry=carry, steps=steps)
+    env = mg.VecMiniGrid(config=cfg_from(W, H, 19, False), num_envs=N, auto_reset=not objstate, backend="torch", agent_view_size=view,
+                         default_vis=not alt, object_state=objstate)
+    env.set_state(grid, agent, aux=aux, carry=carry, steps=steps)
+    if objstate:
+        orc.set_contains(contains)
+        env.set_object_state(contains=contains)
+    assert np.array_equal(to_np(env.observe()), orc.observe())
+    rs = np.random.RandomState(1)
+    for t in range(T):
+        a = rs.randint(0, 7, size=N).astype(np.uint8)
+        obs, rew, done, _ = env.step(a)
+        oo, orew, odone = orc.step(a)
+        d = odone.astype(bool)
+        if not objstate:
+            orc.reset_where(odone)
+            oo = oo.copy()
+            oo[d] = orc.observe()[d]
+        elif d.any():
+            break
+        assert np.array_equal(to_np(obs), oo) and np.array_equal(to_np(done), odone) and np.array_equal(to_np(rew), orew.astype(np.float32)), t
+    check_state(env, orc.grid, orc.agent, orc.carry, orc.steps, aux=orc.aux)
+    env.close()
