@@ -143,11 +143,11 @@ __global__ __launch_bounds__(256) void k_pose(const uint2 *__restrict__ rec, int
 } // namespace
 
 namespace {
-__global__ __launch_bounds__(256) void k_task(uint2 *rec, uint2 *rec0, const uint32_t *set, uint32_t *get, int64_t n)
+__global__ __launch_bounds__(256) void k_task(uint2 *rec, uint2 *rec0, const uint32_t *set, uint32_t *get, const uint8_t *mask, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (set) {
+    if (set && (!mask || mask[i])) {
         rec[i].y = (rec[i].y & 0xFFFFu) | (set[i] << 16);
         rec0[i].y = (rec0[i].y & 0xFFFFu) | (set[i] << 16);
     }
@@ -207,9 +207,9 @@ hipError_t mgx_launch_objstate(const ObjStateParams &p, hipStream_t st)
     return hipGetLastError();
 }
 
-hipError_t mgx_launch_task(uint2 *rec, uint2 *rec0, const uint32_t *set, uint32_t *get, int64_t n, hipStream_t st)
+hipError_t mgx_launch_task(uint2 *rec, uint2 *rec0, const uint32_t *set, uint32_t *get, const uint8_t *mask, int64_t n, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_task, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rec, rec0, set, get, n);
+    hipLaunchKernelGGL(k_task, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rec, rec0, set, get, mask, n);
     return hipGetLastError();
 }
 

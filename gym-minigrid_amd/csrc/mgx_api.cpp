@@ -793,15 +793,24 @@ extern "C" int mgx_get_object_state(mgx_handle h, uint8_t *contains, uint8_t *ca
     return objstate_io(h, "mgx_get_object_state", nullptr, nullptr, nullptr, contains, carry_aux, carry_contains);
 }
 
+// (mask: only those envs -- the word of TwoGoals is a running count that an unmasked env must keep)
+static int set_task_impl(mgx_handle h, const uint32_t *task, const uint8_t *mask)
+{
+    int rc;
+    const void *d, *dm;
+    if ((rc = dev_in(h, 4, task, (size_t)h->n * sizeof(uint32_t), &d, 4))) return rc;
+    if ((rc = dev_in(h, 5, mask, (size_t)h->n, &dm))) return rc;
+    HIP_TRY(mgx_launch_task(h->agent_d, h->agent0_d, (const uint32_t *)d, nullptr, (const uint8_t *)dm, h->n, h->stream));
+    return MGX_OK;
+}
+
 extern "C" int mgx_set_task(mgx_handle h, const uint32_t *task)
 {
     int rc = check_handle(h, "mgx_set_task");
     if (rc) return rc;
     if (!task) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_set_task: null argument");
     if (h->cfg.task_kind == MGX_TASK_NONE) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_set_task: this handle has no task rule");
-    const void *d;
-    if ((rc = dev_in(h, 4, task, (size_t)h->n * sizeof(uint32_t), &d, 4))) return rc;
-    HIP_TRY(mgx_launch_task(h->agent_d, h->agent0_d, (const uint32_t *)d, nullptr, h->n, h->stream));
+    if ((rc = set_task_impl(h, task, nullptr))) return rc;
     if (h->has_seed_d) HIP_TRY(hipMemsetAsync(h->has_seed_d, 0, (size_t)h->n_pad, h->stream)); // the snapshot's task word changed
     return MGX_OK;
 }
@@ -814,7 +823,7 @@ extern "C" int mgx_get_task(mgx_handle h, uint32_t *task)
     if (h->cfg.task_kind == MGX_TASK_NONE) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_get_task: this handle has no task rule");
     OutArg o;
     if ((rc = dev_out(h, 3, task, (size_t)h->n * sizeof(uint32_t), &o, 4))) return rc;
-    HIP_TRY(mgx_launch_task(h->agent_d, h->agent0_d, nullptr, (uint32_t *)o.dev, h->n, h->stream));
+    HIP_TRY(mgx_launch_task(h->agent_d, h->agent0_d, nullptr, (uint32_t *)o.dev, nullptr, h->n, h->stream));
     return finish_out(h, &o, 1);
 }
 
@@ -887,7 +896,7 @@ extern "C" int mgx_reset(mgx_handle h, const uint64_t *seeds, const uint8_t *mas
     if (rc) return rc;
     rc = set_state_impl(h, grid.data(), nullptr, agent.data(), nullptr, nullptr, mask);
     if (rc) return rc;
-    if (!task.empty() && (rc = mgx_set_task(h, task.data()))) return rc; // (unmasked envs get their old word back: regenerated identically)
+    if (!task.empty() && (rc = set_task_impl(h, task.data(), mask))) return rc; // (masked: TwoGoals' word is a running count an unmasked env must keep)
     HIP_TRY(hipStreamSynchronize(h->stream)); // the host vectors above are about to go away
     if (obs) return run_step(h, false, nullptr, obs, nullptr, nullptr);
     return MGX_OK;

@@ -137,7 +137,7 @@ struct ObjStateParams {
     int W, H, S;
 };
 hipError_t mgx_launch_objstate(const ObjStateParams &p, hipStream_t st);
-hipError_t mgx_launch_task(uint2 *rec, uint2 *rec0, const uint32_t *set, uint32_t *get, int64_t n, hipStream_t st);
+hipError_t mgx_launch_task(uint2 *rec, uint2 *rec0, const uint32_t *set, uint32_t *get, const uint8_t *mask, int64_t n, hipStream_t st);
 hipError_t mgx_launch_direction(const uint2 *rec, uint8_t *out, int64_t n, hipStream_t st);
 hipError_t mgx_launch_pose(const uint2 *rec, int32_t *out, int64_t n, hipStream_t st);
 hipError_t mgx_launch_pack(const PackParams &p, hipStream_t st);

@@ -220,3 +220,53 @@ def test_single_env_adapter_replays_reference_loop(case, mission):
                 obs = env.reset()
                 assert np.array_equal(obs["image"], z["init_obs"][k])
     env.close()
+
+
+def _load_tool(name):
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("mgx_tool_" + name, os.path.join(os.path.dirname(__file__), "..", "tools", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_masked_reset_keeps_running_task_word_of_other_envs():
+    """TwoGoals' task word is the running goal count: a caller-side reset(mask) of the finished envs must not touch the
+    count of the envs still in their episode (fixed-layout ids take mgx_reset's host path: found by tools/fuzz_ids.py)."""
+    from oracle.minigrid_oracle import OracleEnvs
+    env_id, N = "MiniGrid-TwoGoals-6x6-v0", 700
+    cfg = mg.env_config(env_id)
+    seeds = np.arange(N, dtype=np.uint64)
+    env = mg.VecMiniGrid(env_id, num_envs=N, seeds=seeds, auto_reset=False, backend="torch")
+    env.reset()
+    grid, agent, task = mg.generate_levels(env_id, seeds, with_task=True)
+    orc = OracleEnvs(cfg.width, cfg.height, cfg.max_steps, cfg.see_through_walls, cfg.lava_v1, task=cfg.task_kind)
+    orc.set_state(grid, agent)
+    orc.task = task.copy()
+    rs = np.random.RandomState(3)
+    resets = 0
+    for t in range(150):
+        a = rs.choice([0, 1, 2, 2, 2, 5, 6], size=N).astype(np.uint8)
+        obs, rew, done, _ = env.step(torch.from_numpy(a).cuda())
+        oo, orew, odone = orc.step(a)
+        assert np.array_equal(to_np(done), odone), t
+        assert np.array_equal(to_np(rew), orew.astype(np.float32)), t
+        assert np.array_equal(to_np(obs), oo), t
+        if odone.any():
+            env.reset(mask=done)
+            orc.reset_where(odone)
+            resets += int(odone.sum())
+        assert np.array_equal(env.get_task(), orc.task), t
+    assert resets > 50
+    env.close()
+
+
+def test_every_env_id_fuzz_round():
+    """tools/fuzz_ids.py, one seeded round: all built-in ids, random 64-bit seeds / batch size / obs mode, in-kernel
+    auto-reset or the caller's reset(mask=done) loop, against the oracle on host-generated levels (25 more rounds were
+    run once: profiles/r01_fuzz.log)."""
+    fz = _load_tool("fuzz_ids")
+    rs = np.random.RandomState(2024)
+    for env_id in mg.env_ids():
+        fz.one(env_id, rs)
