@@ -270,3 +270,4 @@ def test_every_env_id_fuzz_round():
     rs = np.random.RandomState(2024)
     for env_id in mg.env_ids():
         fz.one(env_id, rs)
+        fz.one_stream(env_id, rs)   # new_level_each_episode against generate_level_stream

@@ -93,6 +93,49 @@ def one(env_id, rs):
     return N * T, dict(N=N, full=full, caller_reset=caller_reset, small_seeds=bool(small))
 
 
+def one_stream(env_id, rs):
+    """new_level_each_episode: every env follows its own level stream; level k of env i == host generate_level_stream(seed_i)[k]."""
+    cfg = mg.env_config(env_id)
+    N = int(rs.choice([1, 63, 65, 200]))
+    T, L = 100, 60
+    full = bool(rs.randint(2))
+    seeds = rs.randint(0, 2 ** 63, size=N, dtype=np.int64).astype(np.uint64) if rs.uniform() < 0.5 else rs.randint(0, 30, size=N).astype(np.uint64)
+    try:
+        env = mg.VecMiniGrid(env_id, num_envs=N, seeds=seeds, auto_reset=True, new_level_each_episode=True, backend="torch", obs_mode="full" if full else "partial")
+    except mg.MgxError:
+        return 0, None          # Dynamic-Obstacles: the flag is refused (the obstacle walk shares the stream)
+    obs = np_(env.reset())
+    levels = [mg.generate_level_stream(env_id, int(sd), L, with_task=True) for sd in seeds]
+    G, A, K = (np.stack([lv[j] for lv in levels]) for j in range(3))
+    orc = OracleEnvs(cfg.width, cfg.height, cfg.max_steps, cfg.see_through_walls, cfg.lava_v1, task=cfg.task_kind)
+    orc.set_state(G[:, 0], A[:, 0])
+    orc.task = K[:, 0].copy()
+    observe = lambda: orc.observe(True)[int(full)]  # noqa: E731
+    assert np.array_equal(obs, observe()), (env_id, "stream reset")
+    ep = np.zeros(N, np.int64)
+    for t in range(T):
+        a = rs.choice([0, 1, 2, 2, 2, 3, 4, 5, 6], size=N).astype(np.uint8)
+        obs, rew, done, _ = env.step(torch.from_numpy(a).cuda())
+        o1, o2, orew, odone = orc.step(a, True)
+        oo = (o2 if full else o1).copy()
+        d = odone.astype(bool)
+        ep[d] += 1
+        if ep.max() >= L:
+            break
+        orc.grid0[d], orc.agent0[d] = G[d, ep[d]], A[d, ep[d]]
+        orc.reset_where(odone)
+        orc.task[d] = K[d, ep[d]]
+        oo[d] = observe()[d]
+        assert np.array_equal(np_(done), odone), (env_id, t)
+        assert np.array_equal(np_(rew), orew.astype(np.float32)), (env_id, t)
+        assert np.array_equal(np_(obs), oo), (env_id, t, "stream")
+        if t % 25 == 24:
+            assert not cfg.task_kind or np.array_equal(env.get_task(), orc.task), (env_id, t, "task words")
+    env.clear_faults()
+    env.close()
+    return N * T, dict(N=N, full=full, stream=True)
+
+
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -104,6 +147,10 @@ def main():
             n, desc = one(env_id, rs)
             total += n
             print("round %d %-46s ok  %s  (%.0f s)" % (r, env_id, desc, time.perf_counter() - t0), flush=True)
+            n, desc = one_stream(env_id, rs)
+            total += n
+            if desc:
+                print("round %d %-46s ok  %s  (%.0f s)" % (r, env_id, desc, time.perf_counter() - t0), flush=True)
     print("fuzz_ids ok: %d ids x %d rounds, %d env-steps, every byte equal" % (len(ids), rounds, total), flush=True)
 
 
