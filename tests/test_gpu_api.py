@@ -271,3 +271,4 @@ def test_every_env_id_fuzz_round():
     for env_id in mg.env_ids():
         fz.one(env_id, rs)
         fz.one_stream(env_id, rs)   # new_level_each_episode against generate_level_stream
+        fz.one_epilogue(env_id, rs)  # one-hot / flat modes against the wrappers' formulas on a twin env

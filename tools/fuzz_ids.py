@@ -136,6 +136,48 @@ def one_stream(env_id, rs):
     return N * T, dict(N=N, full=full, stream=True)
 
 
+def one_epilogue(env_id, rs):
+    """The one-hot / flat observation modes against the wrappers' formulas applied to a twin env's (type, color, state)
+    images (same seeds, same actions), with in-kernel auto-reset or the caller's reset(mask=done)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import onehot
+    from oracle.minigrid_oracle import flat_obs
+    mode = str(rs.choice(["partial_onehot", "full_onehot", "full_onehot_nocolor", "flat", "full_flat"]))
+    base = "partial" if mode in ("partial_onehot", "flat") else "full"
+    N = int(rs.choice([1, 63, 65, 200]))
+    caller_reset = bool(rs.randint(2))
+    seeds = rs.randint(0, 40, size=N).astype(np.uint64)
+    a_env = mg.VecMiniGrid(env_id, num_envs=N, seeds=seeds, auto_reset=not caller_reset, backend="torch", obs_mode=base)
+    b_env = mg.VecMiniGrid(env_id, num_envs=N, seeds=seeds, auto_reset=not caller_reset, backend="torch", obs_mode=mode)
+
+    def expand(img):
+        if mode == "partial_onehot":
+            return onehot(img, 7, 3)
+        if mode == "full_onehot":
+            return onehot(img, 7, 4)
+        if mode == "full_onehot_nocolor":
+            return onehot(img, 0, 4)
+        ms = a_env.missions()
+        return np.stack([flat_obs(img[i], ms[i]) for i in range(N)])
+
+    oa, ob = np_(a_env.reset()), np_(b_env.reset())
+    assert np.array_equal(expand(oa), ob), (env_id, mode, "reset")
+    dyn = mg.env_config(env_id).task_kind == _lib.TASK_DYNOBS
+    for t in range(40):
+        a = torch.from_numpy(rs.choice([0, 1, 2, 2, 2, 5, 6] if not dyn else [0, 1, 2, 2], size=N).astype(np.uint8)).cuda()
+        oa, ra, da, _ = a_env.step(a)
+        ob, rb, db, _ = b_env.step(a)
+        assert np.array_equal(np_(da), np_(db)) and np.array_equal(np_(ra), np_(rb)), (env_id, mode, t)
+        assert np.array_equal(expand(np_(oa)), np_(ob)), (env_id, mode, t)
+        if caller_reset and np_(da).any():
+            oa, ob = a_env.reset(mask=da), b_env.reset(mask=db)
+            assert np.array_equal(expand(np_(oa)), np_(ob)), (env_id, mode, t, "masked reset")
+    for e in (a_env, b_env):
+        e.clear_faults()
+        e.close()
+    return N * 40, dict(N=N, mode=mode, caller_reset=caller_reset)
+
+
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -151,6 +193,9 @@ def main():
             total += n
             if desc:
                 print("round %d %-46s ok  %s  (%.0f s)" % (r, env_id, desc, time.perf_counter() - t0), flush=True)
+            n, desc = one_epilogue(env_id, rs)
+            total += n
+            print("round %d %-46s ok  %s  (%.0f s)" % (r, env_id, desc, time.perf_counter() - t0), flush=True)
     print("fuzz_ids ok: %d ids x %d rounds, %d env-steps, every byte equal" % (len(ids), rounds, total), flush=True)
 
 
