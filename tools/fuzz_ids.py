@@ -178,6 +178,37 @@ def one_epilogue(env_id, rs):
     return N * 40, dict(N=N, mode=mode, caller_reset=caller_reset)
 
 
+def one_rollout(env_id, rs):
+    """rollout(T) (one hipGraph launch, captured once and replayed) against the same steps taken one mgx_step at a time on a twin env."""
+    N = int(rs.choice([64, 192, 1024]))
+    T = int(rs.choice([1, 7, 32]))
+    mode = str(rs.choice(["partial", "full", "partial_onehot", "flat"]))
+    stream = bool(rs.randint(2))
+    seeds = rs.randint(0, 1000, size=N).astype(np.uint64)
+    kw = dict(num_envs=N, seeds=seeds, auto_reset=True, backend="torch", obs_mode=mode)
+    try:
+        a_env = mg.VecMiniGrid(env_id, new_level_each_episode=stream, **kw)
+    except mg.MgxError:
+        stream = False
+        a_env = mg.VecMiniGrid(env_id, **kw)
+    b_env = mg.VecMiniGrid(env_id, new_level_each_episode=stream, **kw)
+    assert torch.equal(a_env.reset(), b_env.reset())
+    dyn = mg.env_config(env_id).task_kind == _lib.TASK_DYNOBS
+    acts = torch.empty((T, N), dtype=torch.uint8, device="cuda")
+    for rep in range(3):          # capture, then two replays
+        acts.copy_(torch.from_numpy(rs.choice([0, 1, 2, 2, 2, 5, 6] if not dyn else [0, 1, 2, 2], size=(T, N)).astype(np.uint8)))
+        obs, rew, done = a_env.rollout(acts)
+        for t in range(T):
+            o, r, d, _ = b_env.step(acts[t])
+            assert torch.equal(obs[t], o) and torch.equal(rew[t], r) and torch.equal(done[t], d), (env_id, mode, stream, rep, t)
+    sa, sb = a_env.stats(), b_env.stats()
+    assert sa == sb, (env_id, sa, sb)
+    for e in (a_env, b_env):
+        e.clear_faults()
+        e.close()
+    return N * T * 3, dict(N=N, T=T, mode=mode, stream=stream, rollout=True)
+
+
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -194,6 +225,9 @@ def main():
             if desc:
                 print("round %d %-46s ok  %s  (%.0f s)" % (r, env_id, desc, time.perf_counter() - t0), flush=True)
             n, desc = one_epilogue(env_id, rs)
+            total += n
+            print("round %d %-46s ok  %s  (%.0f s)" % (r, env_id, desc, time.perf_counter() - t0), flush=True)
+            n, desc = one_rollout(env_id, rs)
             total += n
             print("round %d %-46s ok  %s  (%.0f s)" % (r, env_id, desc, time.perf_counter() - t0), flush=True)
     print("fuzz_ids ok: %d ids x %d rounds, %d env-steps, every byte equal" % (len(ids), rounds, total), flush=True)
