@@ -140,3 +140,26 @@ def test_set_state_is_refused():
     with pytest.raises(mg.MgxError):
         mg.VecMiniGrid("MiniGrid-Dynamic-Obstacles-5x5-v0", num_envs=3, backend="numpy", new_level_each_episode=True)
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_id,size,n_obst,view", [("MiniGrid-Dynamic-Obstacles-6x6-v0", 6, 3, 3), ("MiniGrid-Dynamic-Obstacles-8x8-v0", 8, 4, 5),
+                                                      ("MiniGrid-Dynamic-Obstacles-16x16-v0", 16, 8, 9), ("MiniGrid-Dynamic-Obstacles-Random-6x6-v0", 6, 3, 11)])
+def test_gpu_other_view_sizes(env_id, size, n_obst, view):
+    """ViewSizeWrapper over a Dynamic-Obstacles env: the obstacle walk is the same, the view kernels are the run-time-size ones."""
+    N, T = 64 * 2 + 5, 50
+    seeds = np.arange(N, dtype=np.uint64) * 31 + 2
+    orc = DynObsOracle(size, n_obst, "Random" in env_id, seeds, view=view)
+    env = mg.VecMiniGrid(env_id, num_envs=N, seeds=seeds, auto_reset=True, backend="torch", agent_view_size=view)
+    assert np.array_equal(env.reset().cpu().numpy(), orc.observe())
+    rs = np.random.RandomState(4)
+    for t in range(T):
+        a = rs.choice([0, 1, 2, 2, 7], size=N).astype(np.uint8)
+        obs, rew, done, _ = env.step(a)
+        oo, orew, odone = orc.step(a)
+        orc.reset_where(odone)
+        oo = np.where(odone.astype(bool)[:, None, None, None], orc.observe(), oo)
+        assert np.array_equal(done.cpu().numpy(), odone), t
+        assert np.array_equal(rew.cpu().numpy(), orew.astype(np.float32)), t
+        assert np.array_equal(obs.cpu().numpy(), oo), t
+    env.close()
