@@ -273,3 +273,4 @@ def test_every_env_id_fuzz_round():
         fz.one_stream(env_id, rs)   # new_level_each_episode against generate_level_stream
         fz.one_epilogue(env_id, rs)  # one-hot / flat modes against the wrappers' formulas on a twin env
         fz.one_rollout(env_id, rs)   # hipGraph rollout (capture + replays) against single steps on a twin env
+        fz.one_options(env_id, rs)   # view size / extended actions / default_vis=False / object_state on the built-in ids

@@ -178,6 +178,51 @@ def one_epilogue(env_id, rs):
     return N * 40, dict(N=N, mode=mode, caller_reset=caller_reset)
 
 
+def one_options(env_id, rs):
+    """ViewSizeWrapper / extended_actions / default_vis=False / object_state on the built-in ids: the task rules under
+    the run-time-size kernels."""
+    cfg = mg.env_config(env_id)
+    if cfg.task_kind == _lib.TASK_DYNOBS:
+        return 0, None
+    view = int(rs.choice([3, 5, 7, 9, 11]))
+    ext, alt = bool(rs.randint(2)), bool(rs.randint(2))
+    objstate = rs.uniform() < 0.25
+    full = rs.uniform() < 0.3
+    N = int(rs.choice([1, 65, 400]))
+    seeds = rs.randint(0, 2 ** 40, size=N).astype(np.uint64)
+    env = mg.VecMiniGrid(env_id, num_envs=N, seeds=seeds, auto_reset=True, backend="torch", obs_mode="full" if full else "partial",
+                         agent_view_size=view, extended_actions=ext, default_vis=not alt, object_state=objstate)
+    obs = np_(env.reset())
+    grid, agent, task = mg.generate_levels(env_id, seeds, with_task=True)
+    orc = OracleEnvs(cfg.width, cfg.height, cfg.max_steps, cfg.see_through_walls, cfg.lava_v1, view=view, extended=ext, alt_vis=alt, task=cfg.task_kind)
+    orc.set_state(grid, agent)
+    orc.task = task.copy()
+    if objstate:
+        empty = np.zeros((N, cfg.width, cfg.height, 3), np.uint8)
+        empty[..., 0] = 1
+        orc.set_contains(empty)
+    observe = lambda: orc.observe(True)[int(full)]  # noqa: E731
+    assert np.array_equal(obs, observe()), (env_id, "options reset")
+    nact = 9 if ext else 7
+    for t in range(80):
+        a = rs.randint(0, nact, size=N).astype(np.uint8)
+        a[rs.uniform(size=N) < 0.3] = 2
+        obs, rew, done, _ = env.step(torch.from_numpy(a).cuda())
+        o1, o2, orew, odone = orc.step(a, True)
+        oo = (o2 if full else o1).copy()
+        d = odone.astype(bool)
+        orc.reset_where(odone)
+        oo[d] = observe()[d]
+        assert np.array_equal(np_(done), odone), (env_id, t, view, ext, alt, objstate)
+        assert np.array_equal(np_(rew), orew.astype(np.float32)), (env_id, t, view, ext, alt, objstate)
+        assert np.array_equal(np_(obs), oo), (env_id, t, view, ext, alt, objstate)
+    st = env.get_state()
+    assert np.array_equal(st["grid"], orc.grid) and np.array_equal(st["agent"], orc.agent) and np.array_equal(st["aux"], orc.aux), env_id
+    env.clear_faults()
+    env.close()
+    return N * 80, dict(N=N, view=view, ext=ext, alt=alt, objstate=bool(objstate), full=bool(full))
+
+
 def one_rollout(env_id, rs):
     """rollout(T) (one hipGraph launch, captured once and replayed) against the same steps taken one mgx_step at a time on a twin env."""
     N = int(rs.choice([64, 192, 1024]))
@@ -230,6 +275,10 @@ def main():
             n, desc = one_rollout(env_id, rs)
             total += n
             print("round %d %-46s ok  %s  (%.0f s)" % (r, env_id, desc, time.perf_counter() - t0), flush=True)
+            n, desc = one_options(env_id, rs)
+            total += n
+            if desc:
+                print("round %d %-46s ok  %s  (%.0f s)" % (r, env_id, desc, time.perf_counter() - t0), flush=True)
     print("fuzz_ids ok: %d ids x %d rounds, %d env-steps, every byte equal" % (len(ids), rounds, total), flush=True)
 
 
