@@ -103,7 +103,7 @@ int ensure(Staging &s, size_t bytes)
 // Is `p` device memory we can hand to a kernel directly?  Asked on every call (hipPointerGetAttributes, ~0.15 us per
 // pointer: 7.3 -> 7.8 us per mgx_step call from Python): remembering the answer would be wrong the day an address is
 // freed as device memory and comes back as host memory, and a kernel reading a host pointer faults the GPU.
-// 0: host memory, 1: memory of the current device (check_handle made it the handle's), 2: memory of another GPU
+// 0: host memory, 1: memory of the current device (DeviceGuard made it the handle's), 2: memory of another GPU
 int ptr_kind(const void *p)
 {
     hipPointerAttribute_t a;
@@ -233,13 +233,27 @@ int launch_levelgen(mgx_handle h)
     return MGX_OK;
 }
 
-int check_handle(mgx_handle h, const char *fn)
-{
-    if (!h) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: null handle", fn);
-    hipError_t e = hipSetDevice(h->device);
-    if (e != hipSuccess) return mgx_fail(MGX_ERR_HIP, "%s: hipSetDevice(%d): %s", fn, h->device, hipGetErrorString(e));
-    return MGX_OK;
-}
+// Every entry point runs with the handle's device current and puts the caller's device back on the way out (a process
+// that drives several GPUs -- or torch with another current device -- must not find it changed behind its back).
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    int enter_device(int device, const char *fn)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+        if (prev == device) return MGX_OK;
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) return mgx_fail(MGX_ERR_HIP, "%s: hipSetDevice(%d): %s", fn, device, hipGetErrorString(e));
+        changed = prev >= 0;
+        return MGX_OK;
+    }
+    int enter(mgx_handle h, const char *fn)
+    {
+        if (!h) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: null handle", fn);
+        return enter_device(h->device, fn);
+    }
+    ~DeviceGuard() { if (changed) (void)hipSetDevice(prev); }
+};
 
 int read_counters(mgx_handle h, MgxCounters *c)
 {
@@ -281,7 +295,8 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     if (e != hipSuccess || ndev == 0)
         return mgx_fail(MGX_ERR_HIP, "mgx_create: no HIP device (%s); libmgx has no CPU fallback", e == hipSuccess ? "count=0" : hipGetErrorString(e));
     if (device < 0 || device >= ndev) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: device %d of %d", device, ndev);
-    HIP_TRY(hipSetDevice(device));
+    DeviceGuard dev_guard;
+    { int rc_ = dev_guard.enter_device(device, "mgx_create"); if (rc_) return rc_; }
 
     mgx_env_s *h = new (std::nothrow) mgx_env_s();
     if (!h) return mgx_fail(MGX_ERR_HIP, "mgx_create: out of host memory");
@@ -462,7 +477,8 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
 extern "C" int mgx_destroy(mgx_handle h)
 {
     if (!h) return MGX_OK;
-    (void)hipSetDevice(h->device);
+    DeviceGuard dev_guard;
+    (void)dev_guard.enter_device(h->device, "mgx_destroy");
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->cells_d); (void)hipFree(h->cells0_d); (void)hipFree(h->agent_d); (void)hipFree(h->agent0_d);
     (void)hipFree(h->ctr_d); (void)hipFree(h->tri_d); (void)hipFree(h->mission_d);
@@ -483,7 +499,8 @@ extern "C" int mgx_destroy(mgx_handle h)
 
 extern "C" int mgx_set_stream(mgx_handle h, void *hip_stream)
 {
-    int rc = check_handle(h, "mgx_set_stream");
+    DeviceGuard dev_guard;
+    int rc = dev_guard.enter(h, "mgx_set_stream");
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream)); // hand-over point: everything enqueued so far is complete
     h->stream = (hipStream_t)hip_stream; // NULL is a real stream: the device's default (null) stream
@@ -492,7 +509,8 @@ extern "C" int mgx_set_stream(mgx_handle h, void *hip_stream)
 
 extern "C" int mgx_use_own_stream(mgx_handle h)
 {
-    int rc = check_handle(h, "mgx_use_own_stream");
+    DeviceGuard dev_guard;
+    int rc = dev_guard.enter(h, "mgx_use_own_stream");
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->stream = h->own_stream;
@@ -508,7 +526,8 @@ extern "C" int mgx_obs_bytes(mgx_handle h, int64_t *per_env)
 
 extern "C" int mgx_sync(mgx_handle h)
 {
-    int rc = check_handle(h, "mgx_sync");
+    DeviceGuard dev_guard;
+    int rc = dev_guard.enter(h, "mgx_sync");
     if (rc) return rc;
     MgxCounters c;
     rc = read_counters(h, &c);
@@ -525,7 +544,8 @@ extern "C" int mgx_sync(mgx_handle h)
 
 extern "C" int mgx_clear_faults(mgx_handle h)
 {
-    int rc = check_handle(h, "mgx_clear_faults");
+    DeviceGuard dev_guard;
+    int rc = dev_guard.enter(h, "mgx_clear_faults");
     if (rc) return rc;
     MgxCounters c;
     rc = read_counters(h, &c);
@@ -537,7 +557,8 @@ extern "C" int mgx_clear_faults(mgx_handle h)
 
 extern "C" int mgx_get_stats(mgx_handle h, mgx_stats *out)
 {
-    int rc = check_handle(h, "mgx_get_stats");
+    DeviceGuard dev_guard;
+    int rc = dev_guard.enter(h, "mgx_get_stats");
     if (rc) return rc;
     if (!out) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_get_stats: null argument");
     MgxCounters c;
@@ -558,7 +579,8 @@ extern "C" int mgx_get_stats(mgx_handle h, mgx_stats *out)
 // tensor that is then all-reduced over RCCL for logging: out[0] = episodes finished, out[1] = reward sum.
 extern "C" int mgx_read_stats_async(mgx_handle h, double *out2_dev)
 {
-    int rc = check_handle(h, "mgx_read_stats_async");
+    DeviceGuard dev_guard;
+    int rc = dev_guard.enter(h, "mgx_read_stats_async");
     if (rc) return rc;
     if (!out2_dev || !is_device_ptr(out2_dev) || ((uintptr_t)out2_dev & 7))
         return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_read_stats_async: need an 8-byte aligned device pointer");
@@ -611,7 +633,8 @@ static int set_state_impl(mgx_handle h, const uint8_t *grid, const uint8_t *aux,
 extern "C" int mgx_set_state(mgx_handle h, const uint8_t *grid, const uint8_t *aux, const int32_t *agent,
                              const uint8_t *carry, const int32_t *steps)
 {
-    int rc = check_handle(h, "mgx_set_state");
+    DeviceGuard dev_guard;
+    int rc = dev_guard.enter(h, "mgx_set_state");
     if (rc) return rc;
     if (h->dynobs)
         return mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_set_state: a Dynamic-Obstacles state includes the env's RNG stream and the obstacle order; use mgx_reset(seeds, mask)");
@@ -620,7 +643,8 @@ extern "C" int mgx_set_state(mgx_handle h, const uint8_t *grid, const uint8_t *a
 
 extern "C" int mgx_get_state(mgx_handle h, uint8_t *grid, uint8_t *aux, int32_t *agent, uint8_t *carry, int32_t *steps)
 {
-    int rc = check_handle(h, "mgx_get_state");
+    DeviceGuard dev_guard;
+    int rc = dev_guard.enter(h, "mgx_get_state");
     if (rc) return rc;
     const size_t n = (size_t)h->n, cells = (size_t)h->cells;
     // get_state is a debugging / checkpoint path: stage everything through fresh device buffers
@@ -694,14 +718,16 @@ static int run_step(mgx_handle h, bool do_step, const uint8_t *actions, uint8_t 
 
 extern "C" int mgx_step(mgx_handle h, const uint8_t *actions, uint8_t *obs, float *reward, uint8_t *done)
 {
-    int rc = check_handle(h, "mgx_step");
+    DeviceGuard dev_guard;
+    int rc = dev_guard.enter(h, "mgx_step");
     if (rc) return rc;
     return run_step(h, true, actions, obs, reward, done);
 }
 
 extern "C" int mgx_observe(mgx_handle h, uint8_t *obs)
 {
-    int rc = check_handle(h, "mgx_observe");
+    DeviceGuard dev_guard;
+    int rc = dev_guard.enter(h, "mgx_observe");
     if (rc) return rc;
     if (!obs) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_observe: obs is required");
     return run_step(h, false, nullptr, obs, nullptr, nullptr);
@@ -712,7 +738,8 @@ extern "C" int mgx_observe(mgx_handle h, uint8_t *obs)
 // afterwards (same T and buffers), so small batches are not bound by one host launch per kernel.
 extern "C" int mgx_rollout(mgx_handle h, int64_t T, const uint8_t *actions, uint8_t *obs, float *reward, uint8_t *done)
 {
-    int rc = check_handle(h, "mgx_rollout");
+    DeviceGuard dev_guard;
+    int rc = dev_guard.enter(h, "mgx_rollout");
     if (rc) return rc;
     if (T <= 0 || !actions) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_rollout: T > 0 and actions are required");
     const void *args[4] = {actions, obs, reward, done};
@@ -754,7 +781,8 @@ extern "C" int mgx_rollout(mgx_handle h, int64_t T, const uint8_t *actions, uint
 
 static int objstate_io(mgx_handle h, const char *fn, const uint8_t *ci, const uint8_t *ai, const uint8_t *cci, uint8_t *co, uint8_t *ao, uint8_t *cco)
 {
-    int rc = check_handle(h, fn);
+    DeviceGuard dev_guard;
+    int rc = dev_guard.enter(h, fn);
     if (rc) return rc;
     if (!h->objaux_d) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: the handle was not created with object_state = 1", fn);
     const size_t n = (size_t)h->n, cells = (size_t)h->cells;
@@ -806,7 +834,8 @@ static int set_task_impl(mgx_handle h, const uint32_t *task, const uint8_t *mask
 
 extern "C" int mgx_set_task(mgx_handle h, const uint32_t *task)
 {
-    int rc = check_handle(h, "mgx_set_task");
+    DeviceGuard dev_guard;
+    int rc = dev_guard.enter(h, "mgx_set_task");
     if (rc) return rc;
     if (!task) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_set_task: null argument");
     if (h->cfg.task_kind == MGX_TASK_NONE) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_set_task: this handle has no task rule");
@@ -817,7 +846,8 @@ extern "C" int mgx_set_task(mgx_handle h, const uint32_t *task)
 
 extern "C" int mgx_get_task(mgx_handle h, uint32_t *task)
 {
-    int rc = check_handle(h, "mgx_get_task");
+    DeviceGuard dev_guard;
+    int rc = dev_guard.enter(h, "mgx_get_task");
     if (rc) return rc;
     if (!task) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_get_task: null argument");
     if (h->cfg.task_kind == MGX_TASK_NONE) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_get_task: this handle has no task rule");
@@ -829,7 +859,8 @@ extern "C" int mgx_get_task(mgx_handle h, uint32_t *task)
 
 extern "C" int mgx_get_direction(mgx_handle h, uint8_t *direction)
 {
-    int rc = check_handle(h, "mgx_get_direction");
+    DeviceGuard dev_guard;
+    int rc = dev_guard.enter(h, "mgx_get_direction");
     if (rc) return rc;
     if (!direction) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_get_direction: null argument");
     OutArg o;
@@ -840,7 +871,8 @@ extern "C" int mgx_get_direction(mgx_handle h, uint8_t *direction)
 
 extern "C" int mgx_get_pose(mgx_handle h, int32_t *pose)
 {
-    int rc = check_handle(h, "mgx_get_pose");
+    DeviceGuard dev_guard;
+    int rc = dev_guard.enter(h, "mgx_get_pose");
     if (rc) return rc;
     if (!pose) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_get_pose: null argument");
     OutArg o;
@@ -851,7 +883,8 @@ extern "C" int mgx_get_pose(mgx_handle h, int32_t *pose)
 
 extern "C" int mgx_reset(mgx_handle h, const uint64_t *seeds, const uint8_t *mask, uint8_t *obs)
 {
-    int rc = check_handle(h, "mgx_reset");
+    DeviceGuard dev_guard;
+    int rc = dev_guard.enter(h, "mgx_reset");
     if (rc) return rc;
     if (h->cfg.level_kind == MGX_LEVEL_NONE)
         return mgx_fail(MGX_ERR_NO_LEVELGEN, "mgx_reset: this handle has no built-in level generator; use mgx_set_state");
@@ -905,7 +938,8 @@ extern "C" int mgx_reset(mgx_handle h, const uint64_t *seeds, const uint8_t *mas
 // ------------------------------------------------------------------------------------------------ bench helpers
 extern "C" int mgx_fill_actions(mgx_handle h, uint64_t seed, int64_t env0, int64_t t0, int64_t T, uint8_t *actions)
 {
-    int rc = check_handle(h, "mgx_fill_actions");
+    DeviceGuard dev_guard;
+    int rc = dev_guard.enter(h, "mgx_fill_actions");
     if (rc) return rc;
     if (!actions || T < 0) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_fill_actions: bad argument");
     if (is_device_ptr(actions)) {
@@ -922,7 +956,8 @@ extern "C" uint32_t mgx_action_at(uint64_t seed, int64_t env, int64_t t) { retur
 
 extern "C" int mgx_profile_begin(mgx_handle h)
 {
-    int rc = check_handle(h, "mgx_profile_begin");
+    DeviceGuard dev_guard;
+    int rc = dev_guard.enter(h, "mgx_profile_begin");
     if (rc) return rc;
     h->profiling = true;
     h->prof_launches = 0;
@@ -932,7 +967,8 @@ extern "C" int mgx_profile_begin(mgx_handle h)
 
 extern "C" int mgx_profile_end(mgx_handle h, int64_t *launches, double *total_ms)
 {
-    int rc = check_handle(h, "mgx_profile_end");
+    DeviceGuard dev_guard;
+    int rc = dev_guard.enter(h, "mgx_profile_end");
     if (rc) return rc;
     if (!h->profiling) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_profile_end without mgx_profile_begin");
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
