@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void k_pack_state(const PackParams p)
         if (!p.mask || p.mask[e]) {
             uint32_t code = 0;
             if (c < cells) {
-                const uint8_t *tr = p.grid + (e * cells + c) * 3;
+                const uint8_t *tr = p.grid + ((p.bcast ? 0 : e) * cells + c) * 3;
                 const uint32_t ty = tr[0], co = tr[1], st = tr[2];
                 const uint32_t ax = p.aux ? p.aux[e * cells + c] : 0u;
                 uint32_t k = ty;
@@ -44,7 +44,8 @@ __global__ __launch_bounds__(256) void k_pack_state(const PackParams p)
         }
     }
     if (t < p.n && (!p.mask || p.mask[t])) {
-        const int32_t x = p.agent[t * 3], y = p.agent[t * 3 + 1], d = p.agent[t * 3 + 2];
+        const int64_t ts = p.bcast ? 0 : t;
+        const int32_t x = p.agent[ts * 3], y = p.agent[ts * 3 + 1], d = p.agent[ts * 3 + 2];
         if (x < 0 || x >= p.W || y < 0 || y >= p.H || d < 0 || d > 3) bad = true;
         uint32_t cc = MGX_CODE_EMPTY;
         if (p.carry) {

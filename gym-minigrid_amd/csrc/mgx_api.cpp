@@ -64,6 +64,8 @@ struct mgx_env_s {
     // new level each episode: per-env MT19937 block + read index, regeneration flags
     bool stream_mode = false; // new level each episode
     bool device_levels = false; // the family draws random numbers: mgx_reset seeds and generates on the GPU
+    bool one_level = false;          // the family draws none (Empty with a fixed start, DistShift, fixed TwoGoals): its level does not depend on the seed
+    bool snapshot_is_level = false;  // ... and every env's episode-start snapshot holds it: mgx_reset is a restore (k_consume)
     uint32_t *mt_d = nullptr, *mt_idx_d = nullptr, *mt_init_d = nullptr;
     uint8_t *regen_d = nullptr;
     uint64_t *seed0_d = nullptr;                  // seed of the level the episode-start snapshot holds ...
@@ -336,6 +338,7 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     const bool uses_rng = cfg->level_kind != MGX_LEVEL_NONE && cfg->level_kind != MGX_LEVEL_DISTSHIFT &&
                           !((cfg->level_kind == MGX_LEVEL_EMPTY || cfg->level_kind == MGX_LEVEL_TWOGOALS) && cfg->level_arg0 == 0);
     h->device_levels = uses_rng && h->cells <= 4096;
+    h->one_level = cfg->level_kind != MGX_LEVEL_NONE && !uses_rng;
     h->stream_mode = cfg->new_level_each_episode && uses_rng;
     h->tri_bytes = h->partial ? view * view * 3 : (int64_t)h->cells * 3;
     h->obs_bytes = h->oh_nc < 0 ? h->tri_bytes : h->tri_bytes / 3 * (11 + h->oh_nc + h->oh_ns);
@@ -590,19 +593,21 @@ extern "C" int mgx_read_stats_async(mgx_handle h, double *out2_dev)
 
 // ------------------------------------------------------------------------------------------------ state I/O
 static int set_state_impl(mgx_handle h, const uint8_t *grid, const uint8_t *aux, const int32_t *agent,
-                          const uint8_t *carry, const int32_t *steps, const uint8_t *mask_host)
+                          const uint8_t *carry, const int32_t *steps, const uint8_t *mask_host, bool bcast = false)
 {
     if (!grid || !agent) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_set_state: grid and agent are required");
-    const size_t n = (size_t)h->n, cells = (size_t)h->cells;
+    const size_t n = (size_t)h->n, cells = (size_t)h->cells, n_src = bcast ? 1 : n; // bcast: grid / agent hold one env for all
     PackParams p;
     memset(&p, 0, sizeof p);
     const void *d;
     int rc;
-    if ((rc = dev_in(h, 0, grid, n * cells * 3, &d))) return rc;
+    h->snapshot_is_level = false;
+    p.bcast = bcast ? 1 : 0;
+    if ((rc = dev_in(h, 0, grid, n_src * cells * 3, &d))) return rc;
     p.grid = (const uint8_t *)d;
     if ((rc = dev_in(h, 1, aux, n * cells, &d))) return rc;
     p.aux = (const uint8_t *)d;
-    if ((rc = dev_in(h, 2, agent, n * 3 * sizeof(int32_t), &d, 4))) return rc;
+    if ((rc = dev_in(h, 2, agent, n_src * 3 * sizeof(int32_t), &d, 4))) return rc;
     p.agent = (const int32_t *)d;
     if ((rc = dev_in(h, 3, carry, n * 3, &d))) return rc;
     p.carry = (const uint8_t *)d;
@@ -840,6 +845,7 @@ extern "C" int mgx_set_task(mgx_handle h, const uint32_t *task)
     if (!task) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_set_task: null argument");
     if (h->cfg.task_kind == MGX_TASK_NONE) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_set_task: this handle has no task rule");
     if ((rc = set_task_impl(h, task, nullptr))) return rc;
+    h->snapshot_is_level = false; // the snapshot's task word changed
     if (h->has_seed_d) HIP_TRY(hipMemsetAsync(h->has_seed_d, 0, (size_t)h->n_pad, h->stream)); // the snapshot's task word changed
     return MGX_OK;
 }
@@ -920,6 +926,46 @@ extern "C" int mgx_reset(mgx_handle h, const uint64_t *seeds, const uint8_t *mas
         // (with a mask only the 64-env tiles that hold a reset env are re-observed; the rest of `obs` is left as it is)
         if (obs) return run_step(h, false, nullptr, obs, nullptr, nullptr, is_device_ptr(obs) ? (const uint8_t *)dm : nullptr);
         return MGX_OK;
+    }
+    if (h->one_level && (h->snapshot_is_level || !mask)) {
+        // One level for every seed.  The first full reset generates it once on the host and k_pack_state hands it to
+        // every env (the first version generated and uploaded N copies: 300 ms per reset at 1 Mi envs, during which
+        // the GPU went idle); from then on a reset -- full or masked -- is a restore of the snapshot on the device.
+        const void *dm = nullptr;
+        if (!h->snapshot_is_level) {
+            std::vector<uint8_t> g1(cells * 3);
+            int32_t a1[3];
+            uint32_t t1 = 0;
+            const uint64_t s0 = 0;
+            if ((rc = mgx_generate_levels_ex(&h->cfg, 1, &s0, g1.data(), a1, h->cfg.task_kind != MGX_TASK_NONE ? &t1 : nullptr))) return rc;
+            if ((rc = set_state_impl(h, g1.data(), nullptr, a1, nullptr, nullptr, nullptr, true))) return rc;
+            if (h->cfg.task_kind != MGX_TASK_NONE) {
+                std::vector<uint32_t> tw(n, t1);
+                if ((rc = set_task_impl(h, tw.data(), nullptr))) return rc;
+                HIP_TRY(hipStreamSynchronize(h->stream)); // `tw` is about to go away
+            }
+            HIP_TRY(hipStreamSynchronize(h->stream)); // so are `g1` / `a1`
+            h->snapshot_is_level = true;
+        } else {
+            if ((rc = dev_in(h, 5, mask, n, &dm))) return rc;
+            ConsumeParams c;
+            memset(&c, 0, sizeof c);
+            c.mask = (const uint8_t *)dm;
+            c.cells = h->cells_d; c.cells0 = h->cells0_d; c.agent = h->agent_d; c.agent0 = h->agent0_d; c.regen = nullptr;
+            c.objaux = h->objaux_d; c.objaux0 = h->objaux0_d; c.objcont = h->objcont_d; c.objcont0 = h->objcont0_d; c.objcarry = h->objcarry_d;
+            c.n = h->n; c.S = h->S; c.flag_regen = 0;
+            HIP_TRY(mgx_launch_consume(c, h->stream));
+        }
+        if (obs) return run_step(h, false, nullptr, obs, nullptr, nullptr, (dm && is_device_ptr(obs)) ? (const uint8_t *)dm : nullptr);
+        return MGX_OK;
+    }
+    // per-seed levels generated on the host (grids beyond 64x64, or the first reset of a one-level family under a mask)
+    std::vector<uint64_t> seeds_host;
+    if (is_device_ptr(seeds)) { // the host generators read them
+        seeds_host.resize(n);
+        HIP_TRY(hipMemcpyAsync(seeds_host.data(), seeds, n * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        seeds = seeds_host.data();
     }
     std::vector<uint8_t> grid(n * cells * 3);
     std::vector<int32_t> agent(n * 3);

@@ -70,6 +70,7 @@ struct PackParams {
     MgxCounters *ctr;
     int64_t n;
     int W, H, S, has_task;
+    int bcast; // grid / agent hold ONE env that every (masked) env receives
 };
 
 struct ConsumeParams {

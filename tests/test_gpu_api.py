@@ -274,3 +274,41 @@ def test_every_env_id_fuzz_round():
         fz.one_epilogue(env_id, rs)  # one-hot / flat modes against the wrappers' formulas on a twin env
         fz.one_rollout(env_id, rs)   # hipGraph rollout (capture + replays) against single steps on a twin env
         fz.one_options(env_id, rs)   # view size / extended actions / default_vis=False / object_state on the built-in ids
+
+
+@pytest.mark.parametrize("env_id", ["MiniGrid-Empty-8x8-v0", "MiniGrid-DistShift2-v0", "MiniGrid-TwoGoals-8x8-v0"])
+def test_one_level_families_reset_on_the_device(env_id):
+    """Families whose level does not depend on the seed: the first full reset hands one host-generated level to every env,
+    later resets (full or masked) restore the snapshot on the device; a state injection in between takes the masked reset
+    back to the per-env host path (the unmasked envs must keep what was injected)."""
+    N = 300
+    cfg = mg.env_config(env_id)
+    grid, agent = mg.generate_levels(env_id, np.zeros(N, np.uint64))
+    env = mg.VecMiniGrid(env_id, num_envs=N, seeds=np.arange(N, dtype=np.uint64) * 977, auto_reset=False, backend="torch")
+    env.reset()
+    st = env.get_state()
+    assert np.array_equal(st["grid"], grid) and np.array_equal(st["agent"], agent)
+    rs = np.random.RandomState(0)
+    for _ in range(12):
+        env.step(rs.randint(0, 3, size=N).astype(np.uint8))
+    moved = env.get_state()
+    mask = (np.arange(N) % 3 == 0).astype(np.uint8)
+    env.reset(mask=mask)                                     # device restore of the masked envs only
+    st = env.get_state()
+    m = mask.astype(bool)
+    assert np.array_equal(st["agent"][m], agent[m]) and (st["steps"][m] == 0).all() and np.array_equal(st["grid"][m], grid[m])
+    assert np.array_equal(st["agent"][~m], moved["agent"][~m]) and np.array_equal(st["steps"][~m], moved["steps"][~m])
+    # inject a state, then a masked reset: masked envs get the level, the others keep the injected one
+    g2 = grid.copy()
+    g2[:, 1, 2] = (6, 2, 0) if tuple(agent[0, :2]) != (1, 2) else (1, 0, 0)
+    a2 = agent.copy()
+    env.set_state(g2, a2)
+    env.reset(mask=torch.from_numpy(mask).cuda())
+    st = env.get_state()
+    assert np.array_equal(st["grid"][m], grid[m]) and np.array_equal(st["grid"][~m], g2[~m])
+    env.reset()                                              # full reset: everyone back on the level
+    st = env.get_state()
+    assert np.array_equal(st["grid"], grid) and np.array_equal(st["agent"], agent) and (st["steps"] == 0).all()
+    if cfg.task_kind:
+        assert (env.get_task() == 0).all()
+    env.close()

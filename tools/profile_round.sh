@@ -7,7 +7,22 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-stats() { # name, bench args...
+stats() { # name, bench args...: one profiled run; measured once more if a one-off outlier spoilt the averages
+  stats_once "$@"
+  local f=$OUT/${TAG}_kernel_stats_$1.csv
+  if [ -f "$f" ] && python3 - "$f" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+top = rows[0]
+sys.exit(0 if int(top["Calls"]) > 8 and float(top["MaxNs"]) > 100 * float(top["MinNs"]) else 1)
+PY
+  then
+    echo "stats $1: a single launch took >100x the shortest one (seen in warm-up of a first profiled process; it spoils the average): measuring once more"
+    mv $f $OUT/outlier_$1.csv
+    stats_once "$@"
+  fi
+}
+stats_once() {
   local name=$1; shift
   rm -rf $OUT/tmp_$name
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tmp_$name -- python3 $R/bench.py --no-cpu-baseline "$@" > $OUT/$name.log 2>&1 || { echo "stats $name failed"; return 0; }
