@@ -286,3 +286,9 @@ hipError_t mgx_launch_dynobs(const DynObsParams &p, hipStream_t st)
     hipLaunchKernelGGL((k_dynobs<0, 0>), grid, block, shmem, st, p);
     return hipGetLastError();
 }
+
+hipError_t mgx_preload_dynobs_kernels()
+{
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k_dynobs_init));
+}

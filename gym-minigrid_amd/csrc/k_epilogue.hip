@@ -143,3 +143,9 @@ hipError_t mgx_launch_flat(const uint8_t *tri, const uint2 *rec, const float *pa
     }
     return hipGetLastError();
 }
+
+hipError_t mgx_preload_epilogue_kernels()
+{
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k_flat));
+}

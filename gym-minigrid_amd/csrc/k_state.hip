@@ -256,3 +256,9 @@ hipError_t mgx_launch_read_stats(const MgxCounters *ctr, double *out2, hipStream
 
 uint32_t mgx_action_of(uint64_t seed, uint64_t env, uint64_t t) { return action_of(seed, env, t); }
 
+
+hipError_t mgx_preload_state_kernels()
+{
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k_pack_state));
+}

@@ -469,6 +469,10 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
         CREATE_TRY(hipMemsetAsync(h->pos0_d, 0, (size_t)h->n_pad * sizeof(uint32_t), h->stream));
     }
     CREATE_TRY(mgx_preload_step_kernels());
+    CREATE_TRY(mgx_preload_state_kernels());
+    if (h->device_levels || h->one_level) CREATE_TRY(mgx_preload_levelgen_kernels());
+    if (h->oh_nc >= 0 || h->flat) CREATE_TRY(mgx_preload_epilogue_kernels());
+    if (h->dynobs) CREATE_TRY(mgx_preload_dynobs_kernels());
     CREATE_TRY(hipEventCreate(&h->ev0));
     CREATE_TRY(hipEventCreate(&h->ev1));
     CREATE_TRY(hipStreamSynchronize(h->stream));

@@ -105,6 +105,11 @@ hipError_t mgx_launch_seed(const uint64_t *seeds, const uint8_t *mask, const uin
 hipError_t mgx_launch_consume(const ConsumeParams &p, hipStream_t st);
 hipError_t mgx_launch_step(const StepParams &p, int mode, int waves_per_block, hipStream_t st);
 hipError_t mgx_preload_step_kernels();
+// (every .hip file is a code object of its own; one lookup each loads it at mgx_create instead of inside the first reset / step)
+hipError_t mgx_preload_levelgen_kernels();
+hipError_t mgx_preload_state_kernels();
+hipError_t mgx_preload_epilogue_kernels();
+hipError_t mgx_preload_dynobs_kernels();
 hipError_t mgx_raise_lds_limit(int W, int H, int mode, int bytes, int view, int alt_vis, int object_state);
 #define MGX_FLAT_MISSION (96 * 27) /* FlatObsWrapper: maxStrLen x numCharCodes (wrappers.py:534-537) */
 // How the per-env task word selects the mission (a row of k_flat's pattern table), per family.  One definition for the
