@@ -238,6 +238,9 @@ int mgx_generate_level_stream_ex(const mgx_config *cfg, uint64_t seed, int64_t K
  * For the families that draw random numbers the whole reset runs on the GPU (k_seed: SHA-512 key + MT19937
  * init_by_array per env, then k_levelgen); an env whose seed is the one it already has is restored from its
  * episode-start snapshot instead (same result: the level and the RNG state are functions of the seed).
+ * Families whose level does not depend on the seed (Empty with a fixed start, DistShift, fixed TwoGoals) generate it
+ * once on the host at the first full reset; every later reset is a restore on the device.  Grids beyond 64x64 cells
+ * with a random family are generated per env on the host (seeds may still be a device pointer).
  * obs (optional) receives the current observation of all envs; with a mask and a DEVICE obs buffer only the 64-env
  * tiles that contain a reset env are rewritten (pass the buffer the last mgx_step wrote, as the reference's
  * `if done: obs = env.reset()` loop does, and the other entries are already right). */
