@@ -312,3 +312,28 @@ def test_one_level_families_reset_on_the_device(env_id):
     if cfg.task_kind:
         assert (env.get_task() == 0).all()
     env.close()
+
+
+def test_reset_of_a_random_family_beyond_64x64_runs_on_the_host_generator():
+    """W*H > 4096 with a family that draws random numbers: per-env host generation inside mgx_reset, with the seeds and
+    the mask handed over as device tensors."""
+    cfg = mg.env_config("MiniGrid-Empty-Random-6x6-v0")
+    cfg.width, cfg.height, cfg.max_steps = 70, 66, 50
+    N = 130
+    seeds = np.arange(N, dtype=np.uint64) * 104729 + 11
+    env = mg.VecMiniGrid(config=cfg, num_envs=N, seeds=seeds, auto_reset=False, backend="torch")
+    obs = env.reset()
+    grid, agent = mg.generate_levels(cfg, seeds)
+    st = env.get_state()
+    assert np.array_equal(st["grid"], grid) and np.array_equal(st["agent"], agent)
+    assert len({tuple(a) for a in agent}) > 20               # the starts really are random
+    orc = make_oracle(70, 66, 50, cfg.see_through_walls, cfg.lava_v1, grid, np.zeros((N, 70, 66), np.uint8), agent)
+    assert np.array_equal(to_np(obs), orc.observe())
+    for _ in range(5):
+        env.step(np.full(N, 2, np.uint8))
+    mask = torch.from_numpy((np.arange(N) % 2).astype(np.uint8)).cuda()
+    env.reset(mask=mask)
+    st2 = env.get_state()
+    m = (np.arange(N) % 2).astype(bool)
+    assert np.array_equal(st2["agent"][m], agent[m]) and (st2["steps"][m] == 0).all() and (st2["steps"][~m] == 5).all()
+    env.close()
