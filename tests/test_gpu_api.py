@@ -126,11 +126,11 @@ def test_rollout_graph_equals_stepping(env_id, N, T):
     a_env.close(); b_env.close()
 
 
+@pytest.mark.parametrize("N", [300, 1500])                 # (one partial 512-env span / whole spans + a partial one)
 @pytest.mark.parametrize("env_id", ["MiniGrid-DoorKey-8x8-v0", "MiniGrid-LavaCrossingS9N1-v0", "MiniGrid-Fetch-8x8-N3-v0"])
-def test_masked_reset_same_and_changed_seeds(env_id):
+def test_masked_reset_same_and_changed_seeds(env_id, N):
     """reset(mask): an env that keeps its seed is restored from the episode-start snapshot (no re-seeding), one whose
     seed changed is re-seeded and regenerated; either way the state equals `seed(s); reset()` of the reference."""
-    N = 300
     seeds = np.arange(N, dtype=np.uint64) + 7
     env = mg.VecMiniGrid(env_id, num_envs=N, seeds=seeds, auto_reset=False, backend="numpy")
     env.reset()
