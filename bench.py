@@ -1,30 +1,49 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/sec of the batched MiniGrid hot path on N MI355X GPUs of one node.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config empty8|doorkey8|lava4m|empty16full]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one lockstep `env.step(actions)` (transition + gen_obs + encode, with in-kernel auto-reset) over
-every env of the rank: by default BASELINE.json configs[1], MiniGrid-Empty-8x8-v0 with 1,048,576 envs PER GPU
-(weak scaling: per-GPU work is fixed as N grows; envs shard by global index, no data-path collective).
-Inputs (synthetic counter-based actions for all K+W steps, env state) are resident in HBM before the timed
-region.  The timed region is bracketed by barrier + torch.cuda.synchronize() on both sides; the reported time
-is the MAX over ranks; rank 0 prints ONE JSON line.
+Started plainly with --gpus N > 1 (WORLD_SIZE unset) this process is only a LAUNCHER: it makes no torch / HIP call,
+starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child (one rank per GPU over RCCL),
+relays rank 0's single JSON line and exits with the child's code.  Nothing that has touched the GPU is ever re-exec'ed.
+
+A "step" is one lockstep `env.step(actions)` (transition + gen_obs + encode, with in-kernel auto-reset) over every env
+of the rank.  Workloads are BASELINE.json's configs:
+  empty8       configs[1]  MiniGrid-Empty-8x8-v0, 1,048,576 envs per GPU, uint8 (N,7,7,3)       (default, the bench line)
+  doorkey8     configs[2]  MiniGrid-DoorKey-8x8-v0, 1,048,576 envs per GPU
+  lava4m       configs[3]  MiniGrid-LavaCrossingS9N1-v0, 524,288 envs per GPU (4,194,304 over 8 GPUs), RCCL gather of
+                           the per-env done/reward vectors every --log-every steps on a side stream
+  empty16full  configs[4]  MiniGrid-Empty-16x16-v0 + FullyObsWrapper encode, 262,144 envs per GPU
+Weak scaling: per-GPU work is fixed as N grows; envs shard by global index (seeds and synthetic actions are keyed by the
+GLOBAL env index), no data-path collective.  For N > 1 the logging exchange (north_star: "RCCL ... to gather the
+done/reward scalars") runs every --log-every steps: an all-gather of done u8 + reward f32 of every rank, issued on a
+side stream behind a snapshot of the step's outputs, so the step stream never waits for it.
+Inputs (synthetic counter-based actions for all K+W steps, env state) are resident in HBM before the timed region.
+The timed region is bracketed by barrier + torch.cuda.synchronize() on both sides; the reported time is the MAX over
+ranks; rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline     dominant kernel (k_step) against the HBM roof: algorithmic bytes per launch / the kernel's average
-               duration measured with HIP events on the launch stream over the timed region.  The bytes are
-               those of THIS layout (233 B/env-step for 8x8 + 7x7 view) -- smaller than
-               SURVEY.md section 8d's 372 B, which assumed 3-byte cells; the survey-basis rate is given beside it
-               (it exceeds the HBM peak precisely because the layout moves fewer bytes).  `traffic` = HBM bytes per
-               launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE, KiB).
+  roofline     the step kernel (k_step / k_step_fulldirect) against the HBM roof: algorithmic bytes per launch / the
+               kernel's average duration, measured with HIP event pairs around every 8th launch of THAT kernel on the
+               launch stream inside the timed region (mgx_profile_kernel; `span_us_per_step` beside it is the whole
+               stream span / steps, which also holds k_dynobs / epilogues / k_levelgen where a workload has them).
+               The bytes are those of THIS layout (233 B/env-step for 8x8 + 7x7 view) -- smaller
+               than SURVEY.md section 8d's 372 B, which assumed 3-byte cells; the survey-basis rate is given beside it.
+               `traffic` = HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2
+               + WRITE_SIZE, KiB), keyed by workload in profiles/traffic.json.  `per_rank` lists every rank's figure;
+               the top-level achieved/frac is the SLOWEST rank's.
   cpu_baseline the CPU oracle (C restatement of the reference, oracle/minigrid_oracle.c; kind "port") timed on
-               one host core of this box on a bounded sample of the same workload.
+               one host core of this box on a bounded sample of the same workload (rank 0, N = 1 only).
+  episodes_in_timed_region   episodes that ended (and were auto-reset) inside the K timed steps, over all ranks: a short
+               window on a time-out-only workload (Empty-8x8: every 256 steps) honestly shows 0 here.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,6 +54,12 @@ for p in (ROOT, os.path.join(ROOT, "gym-minigrid_amd")):
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s is the measured streaming ceiling
 
+CONFIGS = {
+    "empty8": dict(env="MiniGrid-Empty-8x8-v0", envs_per_gpu=1048576, obs_mode="partial", baseline="configs[1]"),
+    "doorkey8": dict(env="MiniGrid-DoorKey-8x8-v0", envs_per_gpu=1048576, obs_mode="partial", baseline="configs[2]"),
+    "lava4m": dict(env="MiniGrid-LavaCrossingS9N1-v0", envs_per_gpu=524288, obs_mode="partial", baseline="configs[3]"),
+    "empty16full": dict(env="MiniGrid-Empty-16x16-v0", envs_per_gpu=262144, obs_mode="full", baseline="configs[4]"),
+}
 
 OBS_CHANNELS = {"partial": 3, "full": 3, "partial_onehot": 21, "full_onehot": 22, "full_onehot_nocolor": 15, "flat": 3, "full_flat": 3}
 FLAT_MISSION = 27 * 96  # FlatObsWrapper: float32 image ++ one-hot mission string
@@ -66,6 +91,12 @@ def layout_bytes_per_step(W, H, obs_mode, view=7):
     if obs_mode.endswith("flat"):
         obs = (obs + FLAT_MISSION) * 4 + 2 * 3 * n
     return cells + 8 + 8 + 1 + obs + 4 + 1
+
+
+def step_kernel_bytes_per_step(W, H, obs_mode, view=7):
+    """What the STEP KERNEL alone streams (the one-hot / flat epilogues are kernels of their own): its output is the triples."""
+    cells = (W * H + 3) // 4 * 4
+    return cells + 8 + 8 + 1 + obs_cells(W, H, obs_mode, view) * 3 + 4 + 1
 
 
 def cpu_baseline(env_id, obs_mode, target_seconds=10.0):
@@ -114,16 +145,20 @@ def cpu_baseline(env_id, obs_mode, target_seconds=10.0):
     return out
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1024)
     ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--env", default="MiniGrid-Empty-8x8-v0")
-    ap.add_argument("--envs-per-gpu", type=int, default=1048576)
-    ap.add_argument("--obs-mode", default="partial", choices=sorted(OBS_CHANNELS))
+    ap.add_argument("--config", default="empty8", choices=sorted(CONFIGS), help="a BASELINE.json workload (see the module docstring)")
+    ap.add_argument("--env", default=None, help="override the config's env id")
+    ap.add_argument("--envs-per-gpu", type=int, default=None, help="override the config's batch per GPU")
+    ap.add_argument("--obs-mode", default=None, choices=sorted(OBS_CHANNELS))
     ap.add_argument("--view", type=int, default=7, help="agent_view_size (ViewSizeWrapper)")
-    ap.add_argument("--log-every", type=int, default=256, help="all-reduce (episodes, reward_sum) every L steps")
+    ap.add_argument("--log", default="gather", choices=("gather", "allreduce", "none"),
+                    help="N > 1 logging exchange every --log-every steps: all-gather of per-env done/reward on a side stream "
+                         "(default), all-reduce of (episodes, reward_sum), or none")
+    ap.add_argument("--log-every", type=int, default=256)
     ap.add_argument("--new-level-each-episode", action="store_true",
                     help="plain reference episode boundary: every reset draws a new level on the GPU (k_levelgen)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -131,7 +166,95 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="REHEARSAL ONLY: every rank uses cuda:0 (with --backend gloo) to exercise the multi-rank code "
                          "path on a one-GPU box; the numbers it prints are meaningless")
-    args = ap.parse_args()
+    ap.add_argument("--dry-run-ranks", action="store_true",
+                    help="PLUMBING TEST ONLY (no GPU, gloo): launcher -> ranks -> rendezvous -> sharding -> logging gather -> "
+                         "one JSON line, with a stand-in for the env that derives done/reward from the action stream; "
+                         "the numbers it prints are meaningless")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="launcher: give up on the rank processes after this many seconds")
+    args = ap.parse_args(argv)
+    c = CONFIGS[args.config]
+    args.env = args.env or c["env"]
+    args.envs_per_gpu = args.envs_per_gpu or c["envs_per_gpu"]
+    args.obs_mode = args.obs_mode or c["obs_mode"]
+    return args
+
+
+# ---------------------------------------------------------------------------------------------- launcher (no GPU call)
+def launch_ranks(args, argv):
+    """python bench.py --gpus N with WORLD_SIZE unset: start the N rank processes, relay rank 0's JSON line."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC between the ranks (RCCL), before any rank starts HIP
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, start_new_session=True, text=True)
+    try:
+        out, _ = proc.communicate(timeout=args.launch_timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, 15)  # the process group this launcher created (start_new_session), nothing else
+            time.sleep(5)
+            os.killpg(proc.pid, 9)
+        except ProcessLookupError:
+            pass
+        proc.wait()
+        sys.stderr.write("bench.py launcher: the rank processes did not finish within %.0f s\n" % args.launch_timeout)
+        return 124
+    line = None
+    for ln in out.splitlines():
+        if ln.startswith('{"metric"'):
+            line = ln
+        elif ln.strip():
+            sys.stderr.write(ln + "\n")      # anything else the ranks printed is not the result line
+    if proc.returncode != 0:
+        sys.stderr.write("bench.py launcher: torch.distributed.run exited with %d\n" % proc.returncode)
+        return proc.returncode
+    if line is None:
+        sys.stderr.write("bench.py launcher: rank 0 printed no result line\n")
+        return 1
+    print(line, flush=True)
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------- dry-run stand-in
+class _DryEnv:
+    """--dry-run-ranks: no simulator, no GPU.  done/reward are pure functions of the synthetic action stream and the
+    GLOBAL env index, so the gathered vectors can be checked against a formula on every rank."""
+
+    def __init__(self, n_local, offset):
+        import torch
+        self.n, self.offset, self.torch = n_local, offset, torch
+        self.done = torch.zeros(n_local, dtype=torch.uint8)
+        self.reward = torch.zeros(n_local, dtype=torch.float32)
+        self.episodes = 0.0
+        self.reward_sum = 0.0
+
+    @staticmethod
+    def outputs(a):
+        return (a == 6).astype("uint8"), (a.astype("float32") * 0.125)
+
+    def actions(self, offset, n, t):
+        import numpy as np
+        import gym_minigrid_amd as mg
+        return mg.action_stream(0, np.arange(offset, offset + n), t)
+
+    def step(self, t):
+        d, r = self.outputs(self.actions(self.offset, self.n, t))
+        self.done.copy_(self.torch.from_numpy(d))
+        self.reward.copy_(self.torch.from_numpy(r))
+        self.episodes += float(d.sum())
+        self.reward_sum += float(r.sum())
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL between the ranks (before HIP starts)
     import torch
@@ -139,62 +262,122 @@ def main():
     from gym_minigrid_amd import dist as mdist
     import torch.distributed as dist
 
-    rank, local_rank, world = mdist.init_process_group(args.backend)
+    dry = args.dry_run_ranks
+    rank, local_rank, world = mdist.init_process_group("gloo" if dry else args.backend)
     if args.rehearse_on_one_gpu:
         local_rank = 0
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
-    if not torch.cuda.is_available():
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not dry and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if dry:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
 
     n_local = args.envs_per_gpu
     n_total = n_local * world
     offset = rank * n_local
     K, Wm = args.steps, args.warmup
-    env = mg.VecMiniGrid(args.env, num_envs=n_local, device=local_rank, seeds=0, obs_mode=args.obs_mode,
-                         auto_reset=True, backend="torch", env_offset=offset,
-                         new_level_each_episode=args.new_level_each_episode, agent_view_size=args.view)
-    env.reset()
-    # synthetic inputs for every step, resident in HBM before timing starts
-    acts = env.fill_actions(0, 0, K + Wm)
     stats2 = torch.zeros(2, dtype=torch.float64, device=dev)
+    stats0 = torch.zeros(2, dtype=torch.float64, device=dev)
+
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
 
     def barrier():
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
+
+    logger = mdist.GatherLogger(n_local, dev, world) if (world > 1 and args.log == "gather") else None
+    if dry:
+        env = _DryEnv(n_local, offset)
+        step = lambda t: env.step(t)
+        outputs = lambda: (env.done, env.reward)
+        read_stats = lambda out: out.copy_(torch.tensor([env.episodes, env.reward_sum], dtype=torch.float64))
+    else:
+        env = mg.VecMiniGrid(args.env, num_envs=n_local, device=local_rank, seeds=0, obs_mode=args.obs_mode,
+                             auto_reset=True, backend="torch", env_offset=offset,
+                             new_level_each_episode=args.new_level_each_episode, agent_view_size=args.view)
+        env.reset()
+        # synthetic inputs for every step, resident in HBM before timing starts
+        acts = env.fill_actions(0, 0, K + Wm)
+        step = lambda t: env.step(acts[t])
+        outputs = lambda: (env._done, env._reward)
+        read_stats = env.read_stats_async
 
     for t in range(Wm):
-        env.step(acts[t])
+        step(t)
+    read_stats(stats0)
     barrier()
-    env.profile_begin()
+    if not dry:
+        env.profile_begin(stride=8)
     t0 = time.perf_counter()
     for t in range(Wm, Wm + K):
-        env.step(acts[t])
+        step(t)
         if world > 1 and args.log_every > 0 and (t - Wm + 1) % args.log_every == 0:
-            env.read_stats_async(stats2)
-            mdist.allreduce_log(stats2)      # RCCL over xGMI, 16 bytes, logging only
-    launches, kernel_ms = env.profile_end()  # HIP events on the launch stream
+            if logger is not None:
+                logger.submit(*outputs())        # RCCL all-gather of done/reward over xGMI, on the side stream
+            elif args.log == "allreduce":
+                read_stats(stats2)
+                mdist.allreduce_log(stats2)      # 16 bytes
+    launches, span_ms = (K, 0.0) if dry else env.profile_end()  # HIP events on the launch stream
+    if logger is not None:
+        logger.wait()
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    env.read_stats_async(stats2)
+
+    # ---- after the timed region: totals, per-rank kernel times, a check of the gathered vectors
+    read_stats(stats2)
+    local_totals = (stats2 - stats0).clone()
     mdist.allreduce_log(stats2)
-    env.sync()
+    mdist.allreduce_log(stats0)
+    sync()
     episodes, reward_sum = [float(x) for x in stats2.tolist()]
+    ep0 = float(stats0.tolist()[0])
+    gather_checked = None
+    if logger is not None:
+        if logger.submitted == 0:            # a short run: exercise the exchange once, outside the timed region
+            logger.submit(*outputs())
+        gd, gr = logger.wait()
+        sync()
+        # the gathered vectors hold every rank's shard in global env order: own shard in place, totals equal the sum of the shards'
+        own = slice(rank * n_local, (rank + 1) * n_local)
+        ok = bool(torch.equal(gd[own], logger.done)) and bool(torch.equal(gr[own], logger.reward))
+        sums = torch.tensor([float(logger.done.sum()), float(logger.reward.double().sum())], dtype=torch.float64, device=dev)
+        mdist.allreduce_log(sums)
+        ok = ok and float(gd.sum()) == float(sums[0]) and abs(float(gr.double().sum()) - float(sums[1])) <= 1e-6 * max(1.0, abs(float(sums[1])))
+        if dry:                                # the stand-in's outputs are a formula of the global index: check every element
+            d_all, r_all = env.outputs(env.actions(0, n_total, Wm + (K // args.log_every) * args.log_every - 1 if K >= args.log_every else Wm + K - 1))
+            ok = ok and bool((gd.numpy() == d_all).all()) and bool((gr.numpy() == r_all).all())
+        flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        gather_checked = bool(flag.item() == 1.0)
+        if not gather_checked:
+            raise SystemExit("bench.py: the gathered done/reward vectors do not match the shards")
+    k_n, k_ms = (0, 0.0) if dry else env.profile_kernel()
+    avg_kernel_s = (k_ms * 1e-3 / k_n) if k_n else (span_ms * 1e-3 / max(launches, 1))
+    mine = torch.tensor([avg_kernel_s, span_ms * 1e-3 / max(launches, 1), float(local_totals[0])], dtype=torch.float64, device=dev)
+    per = [torch.zeros_like(mine) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(per, mine)
+    else:
+        per = [mine]
+    sync()
 
     if rank == 0:
         cfg = mg.env_config(args.env)
-        bps = layout_bytes_per_step(cfg.width, cfg.height, args.obs_mode, args.view)
+        bps = step_kernel_bytes_per_step(cfg.width, cfg.height, args.obs_mode, args.view)
+        lbps = layout_bytes_per_step(cfg.width, cfg.height, args.obs_mode, args.view)
         sbps = survey_bytes_per_step(cfg.width, cfg.height, args.obs_mode, args.view)
-        avg_kernel_s = kernel_ms * 1e-3 / max(launches, 1)
-        achieved = bps * n_local / avg_kernel_s / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
@@ -204,28 +387,50 @@ def main():
                 traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        per_rank = []
+        for r, v in enumerate(per):
+            ks, ss, ep = [float(x) for x in v.tolist()]
+            ach = bps * n_local / ks / 1e9 if ks > 0 else 0.0
+            per_rank.append({"rank": r, "avg_kernel_us": ks * 1e6, "span_us_per_step": ss * 1e6, "achieved": ach,
+                             "frac": ach / HBM_PEAK_GBS, "episodes": ep})
+        slow = min(per_rank, key=lambda x: x["achieved"])
+        obs_desc = ("float32 (N,%d) FlatObs" % (obs_cells(cfg.width, cfg.height, args.obs_mode, args.view) * 3 + FLAT_MISSION) if args.obs_mode.endswith("flat")
+                    else "uint8 (N,%d,%d,%d)" % (args.view, args.view, OBS_CHANNELS[args.obs_mode]) if args.obs_mode.startswith("partial")
+                    else "uint8 (N,W,H,%d) FullyObs" % OBS_CHANNELS[args.obs_mode])
+        exchange = "none" if world == 1 else ("RCCL all-gather of done u8 + reward f32 (%d B per rank) every %d steps on a side stream" % (5 * n_local, args.log_every)
+                                              if logger is not None else ("all-reduce of (episodes, reward_sum) every %d steps" % args.log_every if args.log == "allreduce" else "none"))
         out = {
             "metric": "env-steps/sec", "value": n_total * K / dt, "unit": "env-steps/s", "n_gpus": world,
             "steps": K, "warmup": Wm, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s, %d batched envs per GPU (%d total), obs %s, uniform random actions 0..6 "
-                                   "(counter-based), auto-reset on done" % (args.env, n_local, n_total,
-                                                                            "float32 (N,%d) FlatObs" % (obs_cells(cfg.width, cfg.height, args.obs_mode, args.view) * 3 + FLAT_MISSION) if args.obs_mode.endswith("flat")
-                                                                            else "uint8 (N,%d,%d,%d)" % (args.view, args.view, OBS_CHANNELS[args.obs_mode]) if args.obs_mode.startswith("partial")
-                                                                            else "uint8 (N,W,H,%d) FullyObs" % OBS_CHANNELS[args.obs_mode]),
+                                   "(counter-based), auto-reset on done" % (args.env, n_local, n_total, obs_desc),
+                       "name": args.config, "baseline_config": CONFIGS[args.config]["baseline"] if (args.env == CONFIGS[args.config]["env"] and n_local == CONFIGS[args.config]["envs_per_gpu"] and args.obs_mode == CONFIGS[args.config]["obs_mode"]) else None,
                        "env_id": args.env, "envs_per_gpu": n_local, "obs_mode": args.obs_mode, "parallelism": "env-shard x%d" % world,
+                       "logging_exchange": exchange,
                        "new_level_each_episode": bool(args.new_level_each_episode)},
-            "episodes": episodes, "reward_sum": reward_sum,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_step" + ("+k_onehot" if "onehot" in args.obs_mode else "") + ("+k_flat" if args.obs_mode.endswith("flat") else "") + ("+k_levelgen" if args.new_level_each_episode else ""), "avg_kernel_us": avg_kernel_s * 1e6, "launches": launches,
-                         "algorithmic_bytes_per_env_step": bps, "measured_streaming_ceiling": 6290.0,
-                         "survey_bytes_per_env_step": sbps, "achieved_on_survey_bytes": sbps * n_local / avg_kernel_s / 1e9},
+            "episodes": episodes, "reward_sum": reward_sum, "episodes_in_timed_region": episodes - ep0,
+            "roofline": {"bound": "hbm", "achieved": slow["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": slow["frac"], "traffic": traffic,
+                         "kernel": "k_step_fulldirect" if (args.obs_mode.startswith("full") and (cfg.width * cfg.height) % 4 == 0) else "k_step",
+                         "avg_kernel_us": slow["avg_kernel_us"], "kernel_samples": k_n, "launches": launches,
+                         "span_us_per_step": slow["span_us_per_step"],
+                         "algorithmic_bytes_per_env_step": bps, "layout_bytes_per_env_step_all_kernels": lbps,
+                         "measured_streaming_ceiling": 6290.0,
+                         "survey_bytes_per_env_step": sbps, "achieved_on_survey_bytes": sbps * n_local / (slow["avg_kernel_us"] * 1e-6) / 1e9 if slow["avg_kernel_us"] > 0 else 0.0,
+                         "per_rank": per_rank},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if gather_checked is not None:
+            out["gather_checked"] = gather_checked
+        if dry:
+            out["dry_run"] = True
+        if args.rehearse_on_one_gpu:
+            out["rehearsal_on_one_gpu"] = True
+        if world == 1 and not args.no_cpu_baseline and not dry:
             out["cpu_baseline"] = cpu_baseline(args.env, args.obs_mode)
         print(json.dumps(out), flush=True)
-    env.close()
+    if not dry:
+        env.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -18,7 +18,7 @@
 #include "mgx.h"
 #include "mgx_internal.h"
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__) /* hipcc: the generators also compile for the gfx950 device (k_levelgen, k_dynobs) */
 #define LG_FN __host__ __device__ inline
 #else
 #define LG_FN inline

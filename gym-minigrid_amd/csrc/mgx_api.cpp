@@ -16,6 +16,8 @@
 #include "mgx_internal.h"
 #include "mgx_kernels.h"
 
+#define MGX_PROF_MAX_SAMPLES 256
+
 // ------------------------------------------------------------------------------------------------ errors
 static thread_local char g_err[512] = "";
 
@@ -87,6 +89,11 @@ struct mgx_env_s {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool profiling = false;
     int64_t prof_launches = 0, steps_total = 0;
+    // per-launch samples of the step kernel alone (mgx_profile_begin_sampled): event pairs around every stride-th launch
+    std::vector<hipEvent_t> prof_ev;   // 2 per sample, created on first use
+    int prof_stride = 8, prof_samples = 0;
+    double prof_kernel_ms = 0.0;
+    int64_t prof_kernel_n = 0;
     unsigned long long base_bad_act = 0, base_oob = 0;
 };
 
@@ -499,6 +506,7 @@ extern "C" int mgx_destroy(mgx_handle h)
     for (auto &s : h->st_out) if (s.dev) (void)hipFree(s.dev);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    for (hipEvent_t ev : h->prof_ev) (void)hipEventDestroy(ev);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return MGX_OK;
@@ -712,7 +720,22 @@ static int run_step(mgx_handle h, bool do_step, const uint8_t *actions, uint8_t 
     if ((rc = dev_out(h, 2, done, (size_t)h->n, &o[2]))) return rc;
     p.obs = (uint8_t *)o[0].dev; p.reward = (float *)o[1].dev; p.done = (uint8_t *)o[2].dev;
     if ((h->oh_nc >= 0 || h->flat) && p.obs) p.obs = h->tri_d; // the simulator writes triples; the epilogue below expands them
+    // profiling: this launch alone between its own two events (not while a graph is being captured)
+    const bool sample = do_step && h->profiling && !h->assume_device && h->prof_samples < MGX_PROF_MAX_SAMPLES &&
+                        (h->prof_launches % h->prof_stride) == 0;
+    if (sample) {
+        while ((int)h->prof_ev.size() < 2 * (h->prof_samples + 1)) {
+            hipEvent_t ev = nullptr;
+            HIP_TRY(hipEventCreate(&ev));
+            h->prof_ev.push_back(ev);
+        }
+        HIP_TRY(hipEventRecord(h->prof_ev[2 * h->prof_samples], h->stream));
+    }
     HIP_TRY(mgx_launch_step(p, h->kernel_mode, h->wpb, h->stream));
+    if (sample) {
+        HIP_TRY(hipEventRecord(h->prof_ev[2 * h->prof_samples + 1], h->stream));
+        h->prof_samples++;
+    }
     if (h->oh_nc >= 0 && o[0].dev)
         HIP_TRY(mgx_launch_onehot(h->tri_d, (uint8_t *)o[0].dev, h->n * (h->tri_bytes / 3), h->oh_nc, h->oh_ns, h->stream));
     if (h->flat && o[0].dev)
@@ -1004,18 +1027,25 @@ extern "C" int mgx_fill_actions(mgx_handle h, uint64_t seed, int64_t env0, int64
 
 extern "C" uint32_t mgx_action_at(uint64_t seed, int64_t env, int64_t t) { return mgx_action_of(seed, (uint64_t)env, (uint64_t)t); }
 
-extern "C" int mgx_profile_begin(mgx_handle h)
+extern "C" int mgx_profile_begin_sampled(mgx_handle h, int stride)
 {
     DeviceGuard dev_guard;
     int rc = dev_guard.enter(h, "mgx_profile_begin");
     if (rc) return rc;
+    if (stride < 1) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_profile_begin_sampled: stride must be >= 1");
     h->profiling = true;
     h->prof_launches = 0;
+    h->prof_stride = stride;
+    h->prof_samples = 0;
+    h->prof_kernel_ms = 0.0;
+    h->prof_kernel_n = 0;
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     return MGX_OK;
 }
 
-extern "C" int mgx_profile_end(mgx_handle h, int64_t *launches, double *total_ms)
+extern "C" int mgx_profile_begin(mgx_handle h) { return mgx_profile_begin_sampled(h, 8); }
+
+extern "C" int mgx_profile_end(mgx_handle h, int64_t *launches, double *span_ms)
 {
     DeviceGuard dev_guard;
     int rc = dev_guard.enter(h, "mgx_profile_end");
@@ -1026,7 +1056,23 @@ extern "C" int mgx_profile_end(mgx_handle h, int64_t *launches, double *total_ms
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->profiling = false;
+    for (int i = 0; i < h->prof_samples; i++) {
+        float k = 0.f;
+        HIP_TRY(hipEventElapsedTime(&k, h->prof_ev[2 * i], h->prof_ev[2 * i + 1]));
+        h->prof_kernel_ms += (double)k;
+    }
+    h->prof_kernel_n = h->prof_samples;
+    h->prof_samples = 0;
     if (launches) *launches = h->prof_launches;
-    if (total_ms) *total_ms = (double)ms;
+    if (span_ms) *span_ms = (double)ms;
+    return MGX_OK;
+}
+
+extern "C" int mgx_profile_kernel(mgx_handle h, int64_t *samples, double *sum_ms)
+{
+    if (!h) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_profile_kernel: null handle");
+    if (h->profiling) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_profile_kernel: call mgx_profile_end first");
+    if (samples) *samples = h->prof_kernel_n;
+    if (sum_ms) *sum_ms = h->prof_kernel_ms;
     return MGX_OK;
 }

@@ -332,12 +332,20 @@ class VecMiniGrid:
         _lib.check(_lib.lib().mgx_fill_actions(self._h, ctypes.c_uint64(seed), self.env_offset, int(t0), int(T), _ptr(out)))
         return out
 
-    def profile_begin(self):
-        _lib.check(_lib.lib().mgx_profile_begin(self._h))
+    def profile_begin(self, stride=8):
+        """Start timing (include/mgx.h): the stream span + every `stride`-th step-kernel launch on its own."""
+        _lib.check(_lib.lib().mgx_profile_begin_sampled(self._h, int(stride)))
 
     def profile_end(self):
+        """-> (step-kernel launches in the span, span ms).  profile_kernel() then gives the per-launch samples."""
         n, ms = ctypes.c_int64(), ctypes.c_double()
         _lib.check(_lib.lib().mgx_profile_end(self._h, ctypes.byref(n), ctypes.byref(ms)))
+        return n.value, ms.value
+
+    def profile_kernel(self):
+        """-> (sampled launches, summed duration ms) of the step kernel alone over the last profiled span."""
+        n, ms = ctypes.c_int64(), ctypes.c_double()
+        _lib.check(_lib.lib().mgx_profile_kernel(self._h, ctypes.byref(n), ctypes.byref(ms)))
         return n.value, ms.value
 
 

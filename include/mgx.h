@@ -304,11 +304,19 @@ int mgx_fill_actions(mgx_handle h, uint64_t seed, int64_t env0, int64_t t0, int6
 /* The same stream as a plain function (no handle, no GPU): action of global env `env` at step `t`. */
 uint32_t mgx_action_at(uint64_t seed, int64_t env, int64_t t);
 
-/* Timing of the step kernel alone, measured with HIP events on the handle's stream:
- * mgx_profile_begin() starts bracketing every subsequent step kernel launch;
- * mgx_profile_end() synchronises and returns launches and their summed duration. */
+/* Timing with HIP events on the handle's stream, two measurements at once:
+ *  - the SPAN: one event at mgx_profile_begin(), one at mgx_profile_end(); `span_ms` covers everything the handle
+ *    enqueued in between (k_dynobs, the step kernel, one-hot / flat epilogues, k_levelgen, launch gaps) and `launches` is
+ *    the number of step-kernel launches inside it;
+ *  - the STEP KERNEL ALONE: every `stride`-th launch of the step kernel (k_step / k_step_fulldirect, nothing else) is
+ *    bracketed by its own event pair, up to 256 pairs per span (later launches are not sampled).  mgx_profile_kernel()
+ *    returns how many were sampled and the sum of their durations; valid after mgx_profile_end().  Launches recorded
+ *    into mgx_rollout's graph are counted in `launches` but not sampled.
+ * mgx_profile_begin(h) == mgx_profile_begin_sampled(h, 8). */
 int mgx_profile_begin(mgx_handle h);
-int mgx_profile_end(mgx_handle h, int64_t *launches, double *total_ms);
+int mgx_profile_begin_sampled(mgx_handle h, int stride);
+int mgx_profile_end(mgx_handle h, int64_t *launches, double *span_ms);
+int mgx_profile_kernel(mgx_handle h, int64_t *samples, double *sum_ms);
 
 #ifdef __cplusplus
 }

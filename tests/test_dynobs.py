@@ -163,3 +163,44 @@ def test_gpu_other_view_sizes(env_id, size, n_obst, view):
         assert np.array_equal(rew.cpu().numpy(), orew.astype(np.float32)), t
         assert np.array_equal(obs.cpu().numpy(), oo), t
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("new_seeds", [False, True])
+def test_masked_reset_keeps_pending_auto_reset_of_other_envs(new_seeds):
+    """auto_reset=1 AND caller-side reset(mask) on one handle: an env that finished on the previous step is restored
+    lazily (k_step raises its flag, the next k_dynobs restores obstacle order + RNG position).  A masked reset of OTHER
+    envs between the two must not lose that flag (k_seed_masked used to clear the flags of the whole 512-env span)."""
+    env_id, size, n_obst, N, T = "MiniGrid-Dynamic-Obstacles-8x8-v0", 8, 4, 64 * 9 + 5, 80
+    seeds = (np.arange(N, dtype=np.uint64) * 104729 + 11) % 1000003
+    orc = DynObsOracle(size, n_obst, False, seeds)
+    env = mg.VecMiniGrid(env_id, num_envs=N, seeds=seeds, auto_reset=True, backend="torch")
+    assert np.array_equal(env.reset().cpu().numpy(), orc.observe())
+    rs = np.random.RandomState(12)
+    saw_both = 0
+    for t in range(T):
+        a = rs.choice([0, 1, 2, 2, 2, 5], size=N).astype(np.uint8)
+        obs, rew, done, _ = env.step(a)
+        oo, orew, odone = orc.step(a)
+        orc.reset_where(odone)
+        oo = np.where(odone.astype(bool)[:, None, None, None], orc.observe(), oo)
+        assert np.array_equal(done.cpu().numpy(), odone), t
+        assert np.array_equal(rew.cpu().numpy(), orew.astype(np.float32)), t
+        assert np.array_equal(obs.cpu().numpy(), oo), t
+        if t % 3 == 1:
+            # reset a few envs that did NOT just finish (neighbours of finished ones included: same 512-env span)
+            m = (rs.uniform(size=N) < 0.08) & ~odone.astype(bool)
+            near = np.roll(odone.astype(bool), 1) & ~odone.astype(bool)
+            m |= near
+            if new_seeds:
+                seeds = seeds.copy()
+                seeds[m] = (seeds[m] * 31 + t + 1) % 1000003
+                env.seed(seeds)
+                orc.seeds = [int(s) for s in seeds]
+            saw_both += int(odone.any() and m.any())
+            robs = env.reset(mask=m.astype(np.uint8))
+            orc.reset_where(m)
+            assert np.array_equal(robs.cpu().numpy()[m], orc.observe()[m]), t
+        assert np.array_equal(env.get_state()["grid"], orc.base.grid), t
+    assert saw_both > 10
+    env.close()

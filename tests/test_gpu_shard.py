@@ -1,0 +1,79 @@
+"""Sharding on the HIP path (BASELINE config 4: LavaCrossingS9N1 sharded over GPUs by global env index).
+One GPU, three handles: A = envs [0, N/2) (env_offset 0), B = envs [N/2, N) (env_offset N/2), C = all N envs.
+Integer seeds (env i gets seed + GLOBAL index), the synthetic action stream keyed by the GLOBAL index (k_fill_actions),
+in-kernel auto-reset: every observation, reward, done flag, the final state and the counters of A || B must equal C's,
+byte for byte -- "results do not depend on the number of GPUs" pinned on k_seed / k_levelgen / k_fill_actions / k_step
+themselves, not on the CPU oracle standing in for them (tests/test_dist_gloo.py).  The concatenation A || B is also
+exactly what dist.gather_done_reward / GatherLogger deliver (rank-major = global env order)."""
+import numpy as np
+import pytest
+import torch
+
+import gym_minigrid_amd as mg
+from gym_minigrid_amd import dist as mdist
+from helpers import make_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("env_id,mode,stream,n_a,n_b,T", [
+    ("MiniGrid-LavaCrossingS9N1-v0", "partial", False, 3000, 3000, 400),   # config 4's family, shards not tile-aligned
+    ("MiniGrid-LavaCrossingS9N1-v0", "partial", True, 1500, 1501, 400),    # a new level per episode: per-env RNG streams
+    ("MiniGrid-DoorKey-8x8-v0", "full", False, 1000, 1090, 300),
+    ("MiniGrid-Dynamic-Obstacles-8x8-v0", "partial", False, 700, 640, 120),  # RNG inside step()
+])
+def test_two_shards_equal_one_handle(env_id, mode, stream, n_a, n_b, T):
+    seed, aseed = 7, 3
+    N = n_a + n_b
+    kw = dict(seeds=seed, obs_mode=mode, auto_reset=True, backend="torch", new_level_each_episode=stream)
+    A = mg.VecMiniGrid(env_id, num_envs=n_a, env_offset=0, **kw)
+    B = mg.VecMiniGrid(env_id, num_envs=n_b, env_offset=n_a, **kw)
+    C = mg.VecMiniGrid(env_id, num_envs=N, env_offset=0, **kw)
+    oa, ob, oc = A.reset(), B.reset(), C.reset()
+    assert torch.equal(torch.cat([oa, ob]), oc)
+    aa, ab, ac = A.fill_actions(aseed, 0, T), B.fill_actions(aseed, 0, T), C.fill_actions(aseed, 0, T)
+    assert torch.equal(torch.cat([aa, ab], dim=1), ac)
+    assert np.array_equal(ac[:, n_a - 2:n_a + 2].cpu().numpy(),
+                          mg.action_stream(aseed, np.arange(n_a - 2, n_a + 2)[None, :], np.arange(T)[:, None]))
+    episodes = 0
+    for t in range(T):
+        oa, ra, da, _ = A.step(aa[t])
+        ob, rb, db, _ = B.step(ab[t])
+        oc, rc, dc, _ = C.step(ac[t])
+        assert torch.equal(torch.cat([oa, ob]), oc), t
+        assert torch.equal(torch.cat([ra, rb]), rc) and torch.equal(torch.cat([da, db]), dc), t
+        episodes += int(dc.sum())
+    assert episodes > N // 4          # the comparison crossed many in-kernel resets
+    if "Dynamic" not in env_id:
+        sa, sb, sc = A.get_state(), B.get_state(), C.get_state()
+        for k in sc:
+            assert np.array_equal(np.concatenate([sa[k], sb[k]]), sc[k]), k
+    ta, tb, tc = A.stats(), B.stats(), C.stats()
+    assert ta["episodes"] + tb["episodes"] == tc["episodes"] == episodes
+    assert abs(ta["reward_sum"] + tb["reward_sum"] - tc["reward_sum"]) < 1e-9
+    for e in (A, B, C):
+        e.sync()
+        e.close()
+
+
+def test_shard_b_matches_the_oracle_directly():
+    """A handle with env_offset != 0 against the CPU oracle fed the same global seeds / actions (no handle C involved)."""
+    env_id, off, n, T, seed = "MiniGrid-LavaCrossingS9N1-v0", 524288 * 3 + 17, 2000, 200, 5
+    cfg = mg.env_config(env_id)
+    B = mg.VecMiniGrid(env_id, num_envs=n, env_offset=off, seeds=seed, auto_reset=True, backend="torch")
+    obs = B.reset()
+    gidx = np.arange(off, off + n)
+    grid, agent = mg.generate_levels(env_id, (seed + gidx).astype(np.uint64))
+    orc = make_oracle(cfg.width, cfg.height, cfg.max_steps, cfg.see_through_walls, cfg.lava_v1, grid, np.zeros(grid.shape[:3], np.uint8), agent)
+    assert np.array_equal(obs.cpu().numpy(), orc.observe())
+    acts = B.fill_actions(9, 0, T)
+    for t in range(T):
+        obs, rew, done, _ = B.step(acts[t])
+        a = mg.action_stream(9, gidx, t)
+        assert np.array_equal(acts[t].cpu().numpy(), a)
+        o_obs, o_rew, o_done = orc.step(a)
+        orc.reset_where(o_done)
+        want = np.where(o_done.astype(bool)[:, None, None, None], orc.observe(), o_obs)
+        assert np.array_equal(obs.cpu().numpy(), want), t
+        assert np.array_equal(done.cpu().numpy(), o_done) and np.array_equal(rew.cpu().numpy(), o_rew.astype(np.float32))
+    B.close()
