@@ -602,8 +602,8 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
     const uint8_t *row = GATHER ? p.cells + env * S : g; // where cells are read from
     float reward = 0.f;
     bool done = false, bad_act = false, oob = false;
-    int pidx = -1;
-    uint32_t pcode = 0;
+    int pidx = -1, undo_idx = -1;
+    uint32_t pcode = 0, undo_code = 0;
     if (p.do_step) {
         const int fidx = transition_begin<CW, CH>(p, L, act, valid, bad_act, oob);
         if (fidx >= 0) {
@@ -612,21 +612,24 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
             const bool has_obj = CW == 0 && p.objaux != nullptr;
             const ObjRef obj = {has_obj ? p.objaux + env * S : nullptr, has_obj ? p.objcont + env * S : nullptr, has_obj ? p.objcarry + env : nullptr};
             const uint32_t nc = transition_apply<CH>(p, L, act, fc, reward, done, [&](int i) -> uint32_t { return row[i]; }, oob, fidx, obj);
-            if constexpr (!GATHER) { if (nc != fc) g[fidx] = (uint8_t)nc; }
+            if constexpr (!GATHER) { if (nc != fc) { g[fidx] = (uint8_t)nc; undo_idx = fidx; undo_code = fc; } }
             if (valid && L.steps >= p.max_steps) done = true; // minigrid.py:1320-1321
             if (p.task) task_rule<CH>(p, L, act, reward, done, [&](int i) -> uint32_t { return (GATHER && i == fidx) ? nc : (uint32_t)row[i]; }, fidx, fc, carry0, oob);
             // the one cell a transition can change; skipped when the env is about to be restored anyway
-            if (nc != fc && !(p.auto_reset && done)) { p.cells[env * S + fidx] = (uint8_t)nc; pidx = fidx; pcode = nc; }
+            if (nc != fc && !(p.auto_reset && done)) { p.cells[env * S + fidx] = (uint8_t)nc; pidx = fidx; pcode = nc; L.dirty = MGX_REC_DIRTY; }
         } else if (valid && L.steps >= p.max_steps) done = true;
         if (crash) { reward = -1.f; done = true; } // envs/dynamicobstacles.py:83-86
         if (p.reward && valid) __builtin_nontemporal_store(reward, &p.reward[env]);
         if (p.done && valid) __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), &p.done[env]);
         wave_stats(p, valid, done, reward, bad_act, oob, lane, tile);
+        // the snapshot differs from the current cells only if a step changed one (dirty), if it holds the NEXT level (stream
+        // mode) or if k_dynobs moved obstacles (both: p.regen)
+        const bool needs_copy = L.dirty != 0u || p.regen != nullptr;
         if constexpr (GATHER) {
             // restore global -> global, by the whole wave one finished env at a time: these rows are long (> 256 B), a lane
             // copying its own row touches 64 different lines per instruction (MultiRoom's synchronised time-outs: +15 us
             // per step on average); the observation below reads the snapshot itself
-            for (u64 m = __ballot(p.auto_reset && valid && done); m; m &= m - 1) {
+            for (u64 m = __ballot(p.auto_reset && valid && done && needs_copy); m; m &= m - 1) {
                 const int64_t e = env0 + __builtin_ctzll(m);
                 const uint32_t *s = reinterpret_cast<const uint32_t *>(p.cells0 + e * S);
                 uint32_t *d = reinterpret_cast<uint32_t *>(p.cells + e * S);
@@ -637,7 +640,8 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
             if constexpr (GATHER) {
                 row = p.cells0 + env * S;
                 pidx = -1;
-            } else restore_own<CS>(p, env, g);
+            } else if (needs_copy) restore_own<CS>(p, env, g);
+            else if (undo_idx >= 0) g[undo_idx] = (uint8_t)undo_code; // a terminal step that changed a cell (Fetch's pickup): only the LDS image saw it
             if (CW == 0) restore_objstate(p, env);
             L = unpack_rec(p.agent0[env], p.task);
             if (p.regen) p.regen[env] = 1; // the next-level buffer was consumed: k_levelgen refills it after this launch
@@ -765,6 +769,7 @@ __global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
                     p.cells[env * S + fidx] = (uint8_t)nc;
                     wr = (uint32_t)fidx | (nc << 16);
                     changed = 1;
+                    L.dirty = MGX_REC_DIRTY;
                 }
             } else if (valid && L.steps >= p.max_steps) done = true;
             if (crash) { reward = -1.f; done = true; }
@@ -772,9 +777,9 @@ __global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
             if (p.done && valid) __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), &p.done[env]);
             wave_stats(p, valid, done, reward, bad_act, oob, lane, tile);
             if (p.auto_reset && valid && done) {
+                reset = L.dirty != 0u || p.regen != nullptr; // else the cells already equal the snapshot: nothing to copy back
                 L = unpack_rec(p.agent0[env], p.task);
                 if (CW == 0) restore_objstate(p, env);
-                reset = true;
                 if (p.regen) p.regen[env] = 1;
             }
             if (valid) p.agent[env] = pack_rec(L, p.task);

@@ -81,6 +81,8 @@ struct mgx_env_s {
     // Dynamic-Obstacles: obstacle order (+ episode-start copy), RNG block snapshot, folded actions
     bool dynobs = false;
     uint8_t *obst_d = nullptr, *obst0_d = nullptr, *act_d = nullptr;
+    uint8_t *restart_d = nullptr; // u8[n_pad]: the in-kernel auto-reset restarted this env's episode; the next k_dynobs restores obstacle
+                                  // order + RNG position first (NOT regen_d: those flags mean "k_levelgen, make this env a new level")
     uint32_t *mt0_d = nullptr, *pos0_d = nullptr;
     // object_state: hidden Goal/Box planes (+ episode-start snapshots) and the carried object's pair
     uint8_t *objaux_d = nullptr, *objaux0_d = nullptr, *objcont_d = nullptr, *objcont0_d = nullptr;
@@ -195,7 +197,7 @@ StepParams base_params(mgx_handle h)
     p.extended = h->cfg.extended_actions ? 1 : 0;
     p.alt_vis = h->cfg.alt_visibility ? 1 : 0;
     p.task = h->cfg.task_kind;
-    p.regen = (h->stream_mode || h->dynobs) ? h->regen_d : nullptr;
+    p.regen = h->dynobs ? h->restart_d : (h->stream_mode ? h->regen_d : nullptr);
     p.objaux = h->objaux_d; p.objcont = h->objcont_d; p.objaux0 = h->objaux0_d; p.objcont0 = h->objcont0_d; p.objcarry = h->objcarry_d;
     return p;
 }
@@ -229,7 +231,7 @@ DynObsParams dynobs_params(mgx_handle h)
 {
     DynObsParams d;
     memset(&d, 0, sizeof d);
-    d.cells = h->cells_d; d.cells0 = h->cells0_d; d.agent = h->agent_d; d.act_out = h->act_d; d.regen = h->regen_d;
+    d.cells = h->cells_d; d.cells0 = h->cells0_d; d.agent = h->agent_d; d.act_out = h->act_d; d.regen = h->restart_d;
     d.obst = h->obst_d; d.obst0 = h->obst0_d; d.mt = h->mt_d; d.mt0 = h->mt0_d; d.pos = h->mt_idx_d; d.pos0 = h->pos0_d;
     d.n = h->n; d.W = h->W; d.H = h->H; d.S = h->S; d.n_obst = h->cfg.level_arg0;
     d.n_tiles = (int)(h->n_pad / 64); d.LS = h->LS; d.wave_lds = mgx_dynobs_wave_lds(h->LS);
@@ -358,6 +360,8 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     }
     h->wpb = LDS_DEFAULT / h->wave_lds;
     if (h->wpb > 4) h->wpb = 4;
+    if (const char *dbg = getenv("MGX_DEBUG_WAVE_LDS")) h->wave_lds = atoi(dbg); // TIMING EXPERIMENTS ONLY: wrong results
+    if (const char *dbg = getenv("MGX_DEBUG_WPB")) h->wpb = atoi(dbg);
     if (h->wpb < 1) {
         h->wpb = 1;
         hipError_t e2 = mgx_raise_lds_limit(h->W, h->H, h->kernel_mode == 0 ? 0 : 1, h->wave_lds, h->view, h->cfg.alt_visibility ? 1 : 0, h->cfg.object_state ? 1 : 0);
@@ -468,6 +472,8 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
         CREATE_TRY(hipMalloc((void **)&h->obst_d, (size_t)h->n_pad * 8));
         CREATE_TRY(hipMalloc((void **)&h->obst0_d, (size_t)h->n_pad * 8));
         CREATE_TRY(hipMalloc((void **)&h->act_d, (size_t)h->n_pad));
+        CREATE_TRY(hipMalloc((void **)&h->restart_d, (size_t)h->n_pad));
+        CREATE_TRY(hipMemsetAsync(h->restart_d, 0, (size_t)h->n_pad, h->stream));
         CREATE_TRY(hipMalloc((void **)&h->mt0_d, (size_t)h->n_pad * 624 * sizeof(uint32_t)));
         CREATE_TRY(hipMalloc((void **)&h->pos0_d, (size_t)h->n_pad * sizeof(uint32_t)));
         CREATE_TRY(hipMemsetAsync(h->obst_d, 0, (size_t)h->n_pad * 8, h->stream));
@@ -501,7 +507,7 @@ extern "C" int mgx_destroy(mgx_handle h)
     (void)hipFree(h->seed0_d); (void)hipFree(h->has_seed_d); (void)hipFree(h->reseeded_d);
     if (h->roll_exec) (void)hipGraphExecDestroy(h->roll_exec);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
-    (void)hipFree(h->obst_d); (void)hipFree(h->obst0_d); (void)hipFree(h->act_d); (void)hipFree(h->mt0_d); (void)hipFree(h->pos0_d);
+    (void)hipFree(h->obst_d); (void)hipFree(h->obst0_d); (void)hipFree(h->act_d); (void)hipFree(h->restart_d); (void)hipFree(h->mt0_d); (void)hipFree(h->pos0_d);
     for (auto &s : h->st_in) if (s.dev) (void)hipFree(s.dev);
     for (auto &s : h->st_out) if (s.dev) (void)hipFree(s.dev);
     if (h->ev0) (void)hipEventDestroy(h->ev0);

@@ -104,20 +104,25 @@ struct Lane {
     uint32_t carry; // cell code, MGX_CODE_EMPTY = nothing
     int steps;
     uint32_t task;  // per-env task word (16 bits), only with a task rule
+    uint32_t dirty; // bit 23 of record word 0: a step has changed a cell since the episode started (cells != cells0).  An
+                    // in-kernel auto-reset copies the snapshot back only then: in Empty / Crossing / LavaGap / FourRooms
+                    // nothing ever changes, so their resets (40 % of LavaCrossing's waves see one per step) move no cells.
 };
+#define MGX_REC_DIRTY (1u << 23)
 
 // record word 1 = step_count, or step_count | task << 16 for handles with a task rule (max_steps <= 65535 there)
 __device__ __forceinline__ Lane unpack_rec(uint2 r, int has_task = 0)
 {
     Lane L;
     L.ax = r.x & 255u; L.ay = (r.x >> 8) & 255u; L.dir = (r.x >> 16) & 3u; L.carry = r.x >> 24;
+    L.dirty = r.x & MGX_REC_DIRTY;
     L.steps = has_task ? (int)(r.y & 0xFFFFu) : (int)r.y;
     L.task = has_task ? r.y >> 16 : 0u;
     return L;
 }
 __device__ __forceinline__ uint2 pack_rec(const Lane &L, int has_task = 0)
 {
-    return make_uint2((uint32_t)L.ax | ((uint32_t)L.ay << 8) | ((uint32_t)L.dir << 16) | (L.carry << 24),
+    return make_uint2((uint32_t)L.ax | ((uint32_t)L.ay << 8) | ((uint32_t)L.dir << 16) | L.dirty | (L.carry << 24),
                       has_task ? ((uint32_t)L.steps & 0xFFFFu) | (L.task << 16) : (uint32_t)L.steps);
 }
 

@@ -50,7 +50,8 @@ struct StepParams {
     uint8_t *objaux, *objcont;
     const uint8_t *objaux0, *objcont0;
     uint16_t *objcarry;
-    uint8_t *regen;        // stream mode: set to 1 for every env that consumed its next-level buffer (else null)
+    uint8_t *regen;        // stream mode: set to 1 for every env that consumed its next-level buffer; Dynamic-Obstacles: the
+                           // handle's own `restart` flags for k_dynobs (else null)
     const uint8_t *obs_mask; // observe after a masked reset: 64-env tiles without a masked env are skipped (else null)
     int64_t n;
     int n_tiles;
@@ -88,7 +89,7 @@ struct DynObsParams {
     uint8_t *act_out;       // ... folded to 0..2, bit 7 = "moved forward while the front cell was not clear"
     const uint8_t *mask;    // k_dynobs_init: envs that were re-seeded and get a new snapshot (null = all)
     const uint8_t *mask_reset; // k_dynobs_init: envs being reset (null = all); those not re-seeded only raise regen
-    uint8_t *regen;         // set by the step kernels' in-kernel reset: restore obstacle order + RNG position first
+    uint8_t *regen;         // the handle's `restart` flags, set by the step kernels' in-kernel reset: restore obstacle order + RNG position first
     uint8_t *obst, *obst0;  // u8[n_pad][8] position x << 4 | y of obstacle i (placement order), and at episode start
     uint32_t *mt, *mt0;     // u32[n_pad][624] MT19937 words (lazily regenerated in place past the first block) + snapshot
     uint32_t *pos, *pos0;   // u32[n_pad] words drawn since the block in `mt0` was generated (= mt_idx right after reset)
