@@ -602,17 +602,19 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
     const uint8_t *row = GATHER ? p.cells + env * S : g; // where cells are read from
     float reward = 0.f;
     bool done = false, bad_act = false, oob = false;
-    int pidx = -1, undo_idx = -1;
-    uint32_t pcode = 0, undo_code = 0;
+    int pidx = -1;
+    uint32_t pcode = 0;
     if (p.do_step) {
         const int fidx = transition_begin<CW, CH>(p, L, act, valid, bad_act, oob);
+        uint32_t fc = 0, nc = 0; // forward cell before / after the transition
         if (fidx >= 0) {
-            const uint32_t fc = row[fidx], carry0 = L.carry;
+            const uint32_t carry0 = L.carry;
+            fc = row[fidx];
             // hidden object state rides only on the run-time-size kernels (mgx_launch_step routes there): pruned from the sized ones
             const bool has_obj = CW == 0 && p.objaux != nullptr;
             const ObjRef obj = {has_obj ? p.objaux + env * S : nullptr, has_obj ? p.objcont + env * S : nullptr, has_obj ? p.objcarry + env : nullptr};
-            const uint32_t nc = transition_apply<CH>(p, L, act, fc, reward, done, [&](int i) -> uint32_t { return row[i]; }, oob, fidx, obj);
-            if constexpr (!GATHER) { if (nc != fc) { g[fidx] = (uint8_t)nc; undo_idx = fidx; undo_code = fc; } }
+            nc = transition_apply<CH>(p, L, act, fc, reward, done, [&](int i) -> uint32_t { return row[i]; }, oob, fidx, obj);
+            if constexpr (!GATHER) { if (nc != fc) g[fidx] = (uint8_t)nc; }
             if (valid && L.steps >= p.max_steps) done = true; // minigrid.py:1320-1321
             if (p.task) task_rule<CH>(p, L, act, reward, done, [&](int i) -> uint32_t { return (GATHER && i == fidx) ? nc : (uint32_t)row[i]; }, fidx, fc, carry0, oob);
             // the one cell a transition can change; skipped when the env is about to be restored anyway
@@ -641,7 +643,7 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
                 row = p.cells0 + env * S;
                 pidx = -1;
             } else if (needs_copy) restore_own<CS>(p, env, g);
-            else if (undo_idx >= 0) g[undo_idx] = (uint8_t)undo_code; // a terminal step that changed a cell (Fetch's pickup): only the LDS image saw it
+            else if (nc != fc) g[fidx] = (uint8_t)fc; // a terminal step that changed a cell (Fetch's pickup): only the LDS image saw it
             if (CW == 0) restore_objstate(p, env);
             L = unpack_rec(p.agent0[env], p.task);
             if (p.regen) p.regen[env] = 1; // the next-level buffer was consumed: k_levelgen refills it after this launch

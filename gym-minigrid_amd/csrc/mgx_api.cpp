@@ -360,8 +360,6 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     }
     h->wpb = LDS_DEFAULT / h->wave_lds;
     if (h->wpb > 4) h->wpb = 4;
-    if (const char *dbg = getenv("MGX_DEBUG_WAVE_LDS")) h->wave_lds = atoi(dbg); // TIMING EXPERIMENTS ONLY: wrong results
-    if (const char *dbg = getenv("MGX_DEBUG_WPB")) h->wpb = atoi(dbg);
     if (h->wpb < 1) {
         h->wpb = 1;
         hipError_t e2 = mgx_raise_lds_limit(h->W, h->H, h->kernel_mode == 0 ? 0 : 1, h->wave_lds, h->view, h->cfg.alt_visibility ? 1 : 0, h->cfg.object_state ? 1 : 0);
