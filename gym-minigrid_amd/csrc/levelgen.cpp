@@ -180,6 +180,13 @@ int check_levelgen_cfg(const mgx_config *cfg, const char *fn)
     case MGX_LEVEL_UNLOCK:
         if (W != 11 || H != 6 || cfg->level_arg0 < 0 || cfg->level_arg0 > 2) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: the Unlock family is 11x6 with variant 0..2", fn);
         break;
+    case MGX_LEVEL_OBSTRUCTEDMAZE: {
+        const int nq = cfg->level_arg1 & 7;
+        const bool ok1d = cfg->level_arg1 == 0 && W == 11 && H == 6, ok2d = (nq == 1 || nq == 2 || nq == 4) && (cfg->level_arg1 & ~15) == 0 && W == 16 && H == 16;
+        if ((!ok1d && !ok2d) || cfg->level_arg0 < 0 || cfg->level_arg0 > 3)
+            return mgx_fail(MGX_ERR_INVALID_ARG, "%s: ObstructedMaze is 11x6 (level_arg1 = 0) or 16x16 (level_arg1 = num_quarters 1/2/4 [| 8]), level_arg0 = 0..3", fn);
+        break;
+    }
     case MGX_LEVEL_MEMORY:
         if (W != H || !(H & 1) || H < 7 || H > 17) return mgx_fail(MGX_ERR_INVALID_ARG, "%s: Memory grids are odd squares of 7..17", fn);
         break;
@@ -215,6 +222,15 @@ mgx_config mkt(int w, int h, int max_steps, int see, int kind, int a0, int task)
 {
     mgx_config c = mk(w, h, max_steps, see, 0, kind, a0, 0);
     c.task_kind = task;
+    return c;
+}
+
+// ObstructedMaze: max_steps = 4 * num_rooms_visited * room_size^2 (envs/obstructedmaze.py:17-18); boxes need the contains plane
+mgx_config mko(int w, int h, int rooms_visited, int flags, int layout)
+{
+    mgx_config c = mk(w, h, 4 * rooms_visited * 36, 0, 0, MGX_LEVEL_OBSTRUCTEDMAZE, flags, layout);
+    c.task_kind = MGX_TASK_PICKUPBOX;
+    c.object_state = flags & 1;
     return c;
 }
 
@@ -300,6 +316,16 @@ const std::vector<EnvId> &registry()
         {"MiniGrid-TwoGoals-Random-9x9-v0", mkt(9, 9, 81, 1, MGX_LEVEL_TWOGOALS, 1, MGX_TASK_TWOGOALS)},
         {"MiniGrid-TwoGoals-16x16-v0", mkt(16, 16, 256, 1, MGX_LEVEL_TWOGOALS, 0, MGX_TASK_TWOGOALS)},
         {"MiniGrid-TwoGoals-Random-16x16-v0", mkt(16, 16, 256, 1, MGX_LEVEL_TWOGOALS, 1, MGX_TASK_TWOGOALS)},
+        // ObstructedMaze (envs/obstructedmaze.py:76-223): flags bit 0 = key in box, bit 1 = door blocked; layout = quarters [| 8: agent in room (2, 1)]
+        {"MiniGrid-ObstructedMaze-1Dl-v0", mko(11, 6, 2, 0, 0)},
+        {"MiniGrid-ObstructedMaze-1Dlh-v0", mko(11, 6, 2, 1, 0)},
+        {"MiniGrid-ObstructedMaze-1Dlhb-v0", mko(11, 6, 2, 3, 0)},
+        {"MiniGrid-ObstructedMaze-2Dl-v0", mko(16, 16, 4, 0, 1 | 8)},
+        {"MiniGrid-ObstructedMaze-2Dlh-v0", mko(16, 16, 4, 1, 1 | 8)},
+        {"MiniGrid-ObstructedMaze-2Dlhb-v0", mko(16, 16, 4, 3, 1 | 8)},
+        {"MiniGrid-ObstructedMaze-1Q-v0", mko(16, 16, 5, 3, 1)},
+        {"MiniGrid-ObstructedMaze-2Q-v0", mko(16, 16, 11, 3, 2)},
+        {"MiniGrid-ObstructedMaze-Full-v0", mko(16, 16, 25, 3, 4)},
         // PutNearEnv: max_steps = 5*size, see_through_walls=True (envs/putnear.py:10-22,112-126)
         {"MiniGrid-PutNear-6x6-N2-v0", mkt(6, 6, 30, 1, MGX_LEVEL_PUTNEAR, 2, MGX_TASK_PUTNEAR)},
         {"MiniGrid-PutNear-8x8-N3-v0", mkt(8, 8, 40, 1, MGX_LEVEL_PUTNEAR, 3, MGX_TASK_PUTNEAR)},
@@ -383,6 +409,7 @@ extern "C" int mgx_mission(const mgx_config *cfg, uint32_t task, char *out, int 
         m = buf;
         break;
     }
+    case MGX_LEVEL_OBSTRUCTEDMAZE: m = "pick up the blue ball"; break;                                      // envs/obstructedmaze.py:40 (COLOR_NAMES[0])
     case MGX_LEVEL_TWOGOALS: m = "get to the green or red goal square"; break;                              // envs/twogoals.py:50
     case MGX_LEVEL_FOURROOMS: m = "Reach the goal"; break;                                                  // envs/fourrooms.py:69
     case MGX_LEVEL_GOTOOBJECT: {                                                                            // envs/gotoobject.py:63-64
@@ -422,6 +449,12 @@ extern "C" int mgx_generate_levels(const mgx_config *cfg, int64_t n, const uint6
 
 extern "C" int mgx_generate_levels_ex(const mgx_config *cfg, int64_t n, const uint64_t *seeds, uint8_t *grid, int32_t *agent, uint32_t *task)
 {
+    return mgx_generate_levels_full(cfg, n, seeds, grid, agent, task, nullptr);
+}
+
+extern "C" int mgx_generate_levels_full(const mgx_config *cfg, int64_t n, const uint64_t *seeds, uint8_t *grid, int32_t *agent, uint32_t *task,
+                                        uint8_t *contains)
+{
     if (!cfg || !seeds || !grid || !agent || n < 0) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_generate_levels: null argument");
     int rc = check_levelgen_cfg(cfg, "mgx_generate_levels");
     if (rc) return rc;
@@ -438,6 +471,10 @@ extern "C" int mgx_generate_levels_ex(const mgx_config *cfg, int64_t n, const ui
         lg_paint(L, codes.data());
         for (auto &cd : codes) if (MGX_IS_OBSTACLE_MARK(cd)) cd = (uint8_t)MGX_CODE_BALL_BLUE; // DynObs order markers
         codes_to_triples(codes.data(), cells, grid + (size_t)e * cells * 3);
+        if (contains) {
+            lg_paint_contains(L, codes.data());
+            codes_to_triples(codes.data(), cells, contains + (size_t)e * cells * 3);
+        }
         agent[e * 3] = L.ax; agent[e * 3 + 1] = L.ay; agent[e * 3 + 2] = L.adir;
         if (task) task[e] = L.task;
     }
@@ -452,6 +489,12 @@ extern "C" int mgx_generate_level_stream(const mgx_config *cfg, uint64_t seed, i
 }
 
 extern "C" int mgx_generate_level_stream_ex(const mgx_config *cfg, uint64_t seed, int64_t K, uint8_t *grid, int32_t *agent, uint32_t *task)
+{
+    return mgx_generate_level_stream_full(cfg, seed, K, grid, agent, task, nullptr);
+}
+
+extern "C" int mgx_generate_level_stream_full(const mgx_config *cfg, uint64_t seed, int64_t K, uint8_t *grid, int32_t *agent, uint32_t *task,
+                                              uint8_t *contains)
 {
     if (!cfg || !grid || !agent || K < 0) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_generate_level_stream: null argument");
     int rc = check_levelgen_cfg(cfg, "mgx_generate_level_stream");
@@ -469,6 +512,10 @@ extern "C" int mgx_generate_level_stream_ex(const mgx_config *cfg, uint64_t seed
         lg_paint(L, codes.data());
         for (auto &cd : codes) if (MGX_IS_OBSTACLE_MARK(cd)) cd = (uint8_t)MGX_CODE_BALL_BLUE; // DynObs order markers
         codes_to_triples(codes.data(), cells, grid + (size_t)k * cells * 3);
+        if (contains) {
+            lg_paint_contains(L, codes.data());
+            codes_to_triples(codes.data(), cells, contains + (size_t)k * cells * 3);
+        }
         agent[k * 3] = L.ax; agent[k * 3 + 1] = L.ay; agent[k * 3 + 2] = L.adir;
         if (task) task[k] = L.task;
     }

@@ -28,6 +28,7 @@
 #define MGX_CODE_LAVA (MGX_K_LAVA)                         /* Lava(): red = 0          */
 #define MGX_CODE_DOOR_YELLOW_LOCKED (MGX_K_DOOR_LOCKED | (4 << 4))
 #define MGX_CODE_KEY_YELLOW (MGX_K_KEY | (4 << 4))
+#define MGX_CODE_BALL_BLUE (MGX_K_BALL | (2u << 4))
 #define MGX_LG_MAX_RIVERS 32
 
 #define MGX_LG_WS_WORDS (6 * MGX_LG_MAX_RIVERS)
@@ -37,7 +38,8 @@
 // instead of being drawn cell by cell: the sequential part of a generator -- the random decisions -- then touches a
 // few bytes only, queries like "is this cell free?" scan the list, and the grid itself is painted afterwards, on the
 // GPU by all 64 lanes in parallel (k_levelgen spent most of its time drawing walls with one lane before this).
-struct alignas(4) LgCmd { uint8_t x0, y0, x1, y1, code, pad[3]; }; // two dwords (never 8-byte accesses: GPU slices are 4-byte aligned)
+struct alignas(4) LgCmd { uint8_t x0, y0, x1, y1, code, cont, pad[2]; }; // two dwords (never 8-byte accesses: GPU slices are 4-byte aligned)
+// (cont: cell code of Box.contains for a one-cell command that paints a box, 0 = nothing inside)
 
 struct LgLevel {
     LgCmd *cmds; // max_cmds entries (MGX_LG_MAX_CMDS always suffices)
@@ -57,10 +59,16 @@ LG_FN void lg_rect(LgLevel &L, int x0, int y0, int x1, int y1, uint32_t code)
     if (L.ncmd >= L.max_cmds) { L.too_big = true; return; }
     LgCmd c;
     c.x0 = (uint8_t)x0; c.y0 = (uint8_t)y0; c.x1 = (uint8_t)x1; c.y1 = (uint8_t)y1; c.code = (uint8_t)code;
-    c.pad[0] = c.pad[1] = c.pad[2] = 0;
+    c.cont = 0; c.pad[0] = c.pad[1] = 0;
     L.cmds[L.ncmd++] = c;
 }
 LG_FN void lg_set(LgLevel &L, int x, int y, uint32_t code) { lg_rect(L, x, y, x, y, code); }
+// a Box with something inside (Box.contains, minigrid.py:332-364): handles created with object_state keep it in a plane of its own
+LG_FN void lg_set_box(LgLevel &L, int x, int y, uint32_t code, uint32_t contains)
+{
+    lg_rect(L, x, y, x, y, code);
+    if (!L.too_big) L.cmds[L.ncmd - 1].cont = (uint8_t)contains;
+}
 
 // code of cell (x, y) under the first n commands (an unpainted cell is empty)
 LG_FN uint32_t lg_cell_code(const LgCmd *cmds, int n, int x, int y)
@@ -73,12 +81,27 @@ LG_FN uint32_t lg_cell_code(const LgCmd *cmds, int n, int x, int y)
     return code;
 }
 LG_FN bool lg_empty(const LgLevel &L, int x, int y) { return lg_cell_code(L.cmds, L.ncmd, x, y) == MGX_CODE_EMPTY; }
+// code of what the box in cell (x, y) contains (MGX_CODE_EMPTY: nothing, or no box there)
+LG_FN uint32_t lg_cell_cont(const LgCmd *cmds, int n, int x, int y)
+{
+    uint32_t cont = 0;
+    for (int i = 0; i < n; i++) {
+        const LgCmd c = cmds[i];
+        if (x >= c.x0 && x <= c.x1 && y >= c.y0 && y <= c.y1) cont = c.cont;
+    }
+    return cont ? cont : (uint32_t)MGX_CODE_EMPTY;
+}
 
 // serial paint (host): g[x*H + y]
 LG_FN void lg_paint(const LgLevel &L, uint8_t *g)
 {
     for (int x = 0; x < L.W; x++)
         for (int y = 0; y < L.H; y++) g[x * L.H + y] = (uint8_t)lg_cell_code(L.cmds, L.ncmd, x, y);
+}
+LG_FN void lg_paint_contains(const LgLevel &L, uint8_t *g)
+{
+    for (int x = 0; x < L.W; x++)
+        for (int y = 0; y < L.H; y++) g[x * L.H + y] = (uint8_t)lg_cell_cont(L.cmds, L.ncmd, x, y);
 }
 
 LG_FN int lg_ctz32(uint32_t x) { int n = 0; while (!(x & 1u)) { x >>= 1; n++; } return n; } // (x != 0)
@@ -646,6 +669,101 @@ LG_FN void lg_gen_keycorridor(const mgx_config &c, R &r, LgLevel &L)
     L.task = (uint32_t)MGX_K_BALL | ((uint32_t)ball_color << 4);
 }
 
+// ObstructedMaze (envs/obstructedmaze.py) on RoomGrid(room_size=6) (roomgrid.py:118-166): 1 x 2 rooms (1Dl / 1Dlh / 1Dlhb:
+// level_arg1 = 0) or 3 x 3 (2Dl / 2Dlh / 2Dlhb / 1Q / 2Q / Full: level_arg1 = num_quarters | 8 if the agent starts in room
+// (2, 1) instead of (1, 1)).  level_arg0: bit 0 = keys hidden in boxes, bit 1 = doors blocked by a ball.  A blue ball is
+// the target (task word = its cell code, MGX_TASK_PICKUPBOX); blocking balls are green, boxes grey (COLOR_NAMES[0..2]).
+// Draw order: door positions room by room, door_colors = _rand_subset(COLOR_NAMES, 7), then per locked door the place of
+// its key / box (place_in_room: reject_next_to the parked agent), the target's room and place, the agent.
+// L.ws: [q] y of the right door, [9+q] x of the down door of room q = cols*j + i.
+template <class R>
+LG_FN void lg_gen_obstructedmaze(const mgx_config &c, R &r, LgLevel &L)
+{
+    const int S = 6, T = 5, W = L.W, H = L.H, cols = (W - 1) / T, rows = (H - 1) / T;
+    if (6 * L.max_rivers < 18) { L.too_big = true; return; }
+    const bool in_box = (c.level_arg0 & 1) != 0, blocked = (c.level_arg0 & 2) != 0;
+    int16_t *dr = L.ws, *dd = L.ws + 9;
+    L.ncmd = 0;
+    for (int k = 0; k <= cols; k++) lg_rect(L, k * T, 0, k * T, H - 1, MGX_CODE_WALL_GREY);
+    for (int k = 0; k <= rows; k++) lg_rect(L, 0, k * T, W - 1, k * T, MGX_CODE_WALL_GREY);
+    for (int j = 0; j < rows; j++)
+        for (int i = 0; i < cols; i++) {
+            const int q = cols * j + i;
+            dr[q] = 0; dd[q] = 0;
+            if (i < cols - 1) dr[q] = (int16_t)lg_randint(r, j * T + 1, j * T + S - 1);
+            if (j < rows - 1) dd[q] = (int16_t)lg_randint(r, i * T + 1, i * T + S - 1);
+        }
+    int colors[7], pool[7]; // door_colors: _rand_elem + remove, seven times (the last one draws nothing)
+    for (int k = 0; k < 7; k++) pool[k] = k;
+    for (int n = 7; n > 0; n--) {
+        const int idx = lg_randint(r, 0, n);
+        colors[7 - n] = lg_sorted_color(pool[idx]);
+        for (int k = idx; k + 1 < n; k++) pool[k] = pool[k + 1];
+    }
+    if (!r.alive()) return;
+    const int ax0 = (cols / 2) * T + S / 2, ay0 = (rows / 2) * T + S / 2; // RoomGrid parks the agent here while objects are placed
+    auto door_xy = [&](int i, int j, int k, int *x, int *y) { // room.door_pos[k]
+        if (k == 0) { *x = i * T + S - 1; *y = dr[cols * j + i]; }
+        else if (k == 1) { *x = dd[cols * j + i]; *y = j * T + S - 1; }
+        else if (k == 2) { *x = i * T; *y = dr[cols * j + i - 1]; }
+        else { *x = dd[cols * (j - 1) + i]; *y = j * T; }
+    };
+    auto place = [&](int i, int j, int *ox, int *oy) -> bool { // place_in_room: place_obj(room.top, room.size, reject_next_to)
+        for (;;) {
+            const int x = lg_randint(r, i * T, i * T + S < W ? i * T + S : W), y = lg_randint(r, j * T, j * T + S < H ? j * T + S : H);
+            if (!r.alive()) return false;
+            if (!lg_empty(L, x, y)) continue;
+            const int dx = x > ax0 ? x - ax0 : ax0 - x, dy = y > ay0 ? y - ay0 : ay0 - y;
+            if (dx + dy < 2) continue;
+            *ox = x; *oy = y;
+            return true;
+        }
+    };
+    auto add_door = [&](int i, int j, int k, int color, bool locked, bool hide, bool block) -> bool { // envs/obstructedmaze.py:52-74
+        int x, y;
+        door_xy(i, j, k, &x, &y);
+        lg_set(L, x, y, (uint32_t)(locked ? MGX_K_DOOR_LOCKED : MGX_K_DOOR_CLOSED) | ((uint32_t)color << 4));
+        if (block) lg_set(L, x - ((k == 0) - (k == 2)), y - ((k == 1) - (k == 3)), MGX_K_BALL | (1u << 4)); // grid.set: whatever lay there is gone
+        if (locked) {
+            int kx, ky;
+            if (!place(i, j, &kx, &ky)) return false;
+            const uint32_t key = MGX_K_KEY | ((uint32_t)color << 4);
+            if (hide) lg_set_box(L, kx, ky, MGX_K_BOX | (5u << 4), key);
+            else lg_set(L, kx, ky, key);
+        }
+        return true;
+    };
+    int ai, aj, bi, bj;
+    if (c.level_arg1 == 0) { // ObstructedMaze_1Dlhb._gen_grid
+        if (!add_door(0, 0, 0, colors[0], true, in_box, blocked)) return;
+        bi = 1; bj = 0; ai = 0; aj = 0;
+    } else {                 // ObstructedMaze_Full._gen_grid
+        const int nq = c.level_arg1 & 7;
+        const int side_i[4] = {2, 1, 0, 1}, side_j[4] = {1, 2, 1, 0}, corner_i[4] = {2, 2, 0, 0}, corner_j[4] = {0, 2, 2, 0};
+        for (int q = 0; q < nq; q++) {
+            if (!add_door(1, 1, q, colors[q], false, false, false)) return;
+            for (int kk = -1; kk <= 1; kk += 2)
+                if (!add_door(side_i[q], side_j[q], (q + kk + 4) & 3, colors[(q + kk + 7) % 7], true, in_box, blocked)) return;
+        }
+        const int br = lg_randint(r, 0, nq); // _rand_elem(corners)
+        bi = corner_i[br]; bj = corner_j[br];
+        ai = (c.level_arg1 & 8) ? 2 : 1; aj = 1;
+    }
+    int x, y;
+    if (!place(bi, bj, &x, &y)) return; // add_object(ball_room, "ball", blue)
+    lg_set(L, x, y, MGX_CODE_BALL_BLUE);
+    for (;;) { // RoomGrid.place_agent(i, j): a free cell of the room whose front cell is empty or a wall
+        const int ax = lg_randint(r, ai * T, ai * T + S < W ? ai * T + S : W), ay = lg_randint(r, aj * T, aj * T + S < H ? aj * T + S : H);
+        if (!r.alive()) return;
+        if (!lg_empty(L, ax, ay)) continue;
+        const int d = lg_randint(r, 0, 4);
+        const uint32_t fc = lg_cell_code(L.cmds, L.ncmd, ax + (d == 0) - (d == 2), ay + (d == 1) - (d == 3));
+        L.ax = ax; L.ay = ay; L.adir = d;
+        if (fc == MGX_CODE_EMPTY || (fc & 15u) == MGX_K_WALL) break;
+    }
+    L.task = MGX_CODE_BALL_BLUE;
+}
+
 // LockedRoom._gen_grid (envs/lockedroom.py:37-113): a hallway between two columns of three rooms; one random room is
 // locked and holds the goal, the six doors get six distinct colours, the key of the locked door lies in another room.
 // task = colour of the locked room | colour of the key room << 3 (the mission names both).
@@ -882,7 +1000,6 @@ LG_FN void lg_gen_fourrooms(const mgx_config &, R &r, LgLevel &L)
 // room that is a < 1e-12 event and is not restated).  Obstacle i is painted with a marker code (bit 7 | i << 4 | ball)
 // so that the reset path can recover the ORDER of the obstacles, which step() walks (k_dynobs_init turns the markers
 // into plain blue balls; the host generators do the same after painting).
-#define MGX_CODE_BALL_BLUE (MGX_K_BALL | (2u << 4))
 #define MGX_CODE_OBSTACLE(i) (0x80u | ((uint32_t)(i) << 4) | MGX_K_BALL)
 #define MGX_IS_OBSTACLE_MARK(code) (((code) & 0x8Fu) == (0x80u | MGX_K_BALL))
 template <class R>
@@ -931,6 +1048,7 @@ LG_FN void lg_generate(const mgx_config &c, R &r, LgLevel &L)
     case MGX_LEVEL_PLAYGROUND: lg_gen_playground(c, r, L); break;
     case MGX_LEVEL_PUTNEAR: lg_gen_putnear(c, r, L); break;
     case MGX_LEVEL_TWOGOALS: lg_gen_twogoals(c, r, L); break;
+    case MGX_LEVEL_OBSTRUCTEDMAZE: lg_gen_obstructedmaze(c, r, L); break;
     default: lg_gen_lavagap(c, r, L); break;
     }
 }

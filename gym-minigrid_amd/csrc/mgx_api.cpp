@@ -222,6 +222,7 @@ LevelGenParams levelgen_params(mgx_handle h)
     memset(&g, 0, sizeof g);
     g.cfg = h->cfg;
     g.mt = h->mt_d; g.mt_idx = h->mt_idx_d; g.regen = h->regen_d; g.cells0 = h->cells0_d; g.agent0 = h->agent0_d;
+    g.objaux0 = h->objaux0_d; g.objcont0 = h->objcont0_d;
     g.ctr = h->ctr_d;
     g.n = h->n; g.n_tiles = (int)(h->n_pad / 64); g.S = h->S;
     return g;
@@ -284,6 +285,8 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     if (cfg->width < 3 || cfg->height < 3 || cfg->width > 255 || cfg->height > 255)
         return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: grid %dx%d outside 3..255 (Grid.__init__ asserts >= 3)", cfg->width, cfg->height);
     if (cfg->max_steps <= 0) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: max_steps must be positive");
+    if (cfg->level_kind == MGX_LEVEL_OBSTRUCTEDMAZE && (cfg->level_arg0 & 1) && !cfg->object_state)
+        return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: ObstructedMaze levels with keys hidden in boxes need object_state = 1 (Box.contains)");
     if (cfg->task_kind < MGX_TASK_NONE || cfg->task_kind > MGX_TASK_TWOGOALS)
         return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_create: bad task_kind %d", cfg->task_kind);
     if ((cfg->task_kind == MGX_TASK_DYNOBS) != (cfg->level_kind == MGX_LEVEL_DYNOBS))
@@ -378,11 +381,6 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
             return rc_;                                                                      \
         }                                                                                    \
     } while (0)
-    if (cfg->object_state && cfg->new_level_each_episode) {
-        int rc = mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_create: object_state cannot be combined with new_level_each_episode (generated levels hold default objects only)");
-        delete h;
-        return rc;
-    }
     if (cfg->new_level_each_episode) {
         const char *why = nullptr;
         if (!cfg->auto_reset) why = "needs auto_reset = 1";
@@ -849,7 +847,14 @@ static int objstate_io(mgx_handle h, const char *fn, const uint8_t *ci, const ui
 
 extern "C" int mgx_set_object_state(mgx_handle h, const uint8_t *contains, const uint8_t *carry_aux, const uint8_t *carry_contains)
 {
-    return objstate_io(h, "mgx_set_object_state", contains, carry_aux, carry_contains, nullptr, nullptr, nullptr);
+    int rc = objstate_io(h, "mgx_set_object_state", contains, carry_aux, carry_contains, nullptr, nullptr, nullptr);
+    if (rc || !contains) return rc;
+    // the snapshot's contains plane is no longer the generated level's: the next mgx_reset regenerates instead of restoring
+    DeviceGuard dev_guard;
+    if ((rc = dev_guard.enter(h, "mgx_set_object_state"))) return rc;
+    h->snapshot_is_level = false;
+    if (h->has_seed_d) HIP_TRY(hipMemsetAsync(h->has_seed_d, 0, (size_t)h->n_pad, h->stream));
+    return MGX_OK;
 }
 
 extern "C" int mgx_get_object_state(mgx_handle h, uint8_t *contains, uint8_t *carry_aux, uint8_t *carry_contains)

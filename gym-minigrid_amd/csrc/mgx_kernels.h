@@ -32,6 +32,8 @@ struct LevelGenParams {
     uint8_t *regen;    // u8[n_pad]        work flags, cleared here
     uint8_t *cells0;   // next-level buffer (codes) and its agent record
     uint2 *agent0;
+    uint8_t *objaux0, *objcont0; // object_state handles (else null): the next level's hidden-state planes -- aux all zero,
+                                 // contains = what the generator put into boxes (ObstructedMaze's keys)
     MgxCounters *ctr;
     int64_t n;
     int n_tiles, S;
@@ -77,7 +79,8 @@ struct PackParams {
 struct ConsumeParams {
     const uint8_t *mask; // u8[n] or null
     uint8_t *cells; const uint8_t *cells0; uint2 *agent; const uint2 *agent0; uint8_t *regen;
-    uint8_t *objaux, *objaux0, *objcont, *objcont0; uint16_t *objcarry; // object_state handles (else null): back to defaults
+    uint8_t *objaux, *objaux0, *objcont, *objcont0; uint16_t *objcarry; // object_state handles (else null): aux planes to 0,
+                                                                        // contains <- the generated level's (objcont0), nothing carried
     int64_t n;
     int S, flag_regen;
 };

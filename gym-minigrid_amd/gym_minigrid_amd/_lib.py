@@ -62,6 +62,8 @@ SIGNATURES = {
     "mgx_generate_levels": (_int, [ctypes.POINTER(Config), _i64, _vp, _vp, _vp]),
     "mgx_generate_level_stream_ex": (_int, [ctypes.POINTER(Config), ctypes.c_uint64, _i64, _vp, _vp, _vp]),
     "mgx_generate_levels_ex": (_int, [ctypes.POINTER(Config), _i64, _vp, _vp, _vp, _vp]),
+    "mgx_generate_levels_full": (_int, [ctypes.POINTER(Config), _i64, _vp, _vp, _vp, _vp, _vp]),
+    "mgx_generate_level_stream_full": (_int, [ctypes.POINTER(Config), ctypes.c_uint64, _i64, _vp, _vp, _vp, _vp]),
     "mgx_rollout": (_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "mgx_set_task": (_int, [_vp, _vp]),
     "mgx_get_task": (_int, [_vp, _vp]),

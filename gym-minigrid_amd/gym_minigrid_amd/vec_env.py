@@ -44,7 +44,8 @@ class VecMiniGrid:
                      episode draws a NEW level from the env's own RNG stream (generated on the GPU); False: every
                      episode replays the level of reset() (ReseedWrapper(seeds=[s_i])).
     object_state=True: keep the hidden Goal/Box state (toggletimes, triage_color, Box.contains; minigrid.py:156-181,332-364)
-                     per cell; injected with set_state(aux=...) + set_object_state(...).
+                     per cell; injected with set_state(aux=...) + set_object_state(...).  Default: what the env id needs
+                     (on for the ObstructedMaze levels that hide keys in boxes, off elsewhere).
     default_vis=False: the fork's alternative occlusion model (minigrid.py:649-709).
     extended_actions: ExtendedActions (minigrid.py:747-764): actions 7 / 8 strafe left / right.
     agent_view_size: ViewSizeWrapper (wrappers.py:579-608): 3, 5, 7 (default), 9 or 11.
@@ -53,7 +54,7 @@ class VecMiniGrid:
 
     def __init__(self, env_id=None, num_envs=1, device=0, seeds=0, obs_mode="partial", auto_reset=True,
                  config=None, backend="torch", env_offset=0, check_actions=False, new_level_each_episode=False,
-                 agent_view_size=7, extended_actions=False, default_vis=True, object_state=False):
+                 agent_view_size=7, extended_actions=False, default_vis=True, object_state=None):
         L = _lib.lib()
         if config is None:
             if env_id is None:
@@ -70,7 +71,8 @@ class VecMiniGrid:
         cfg.agent_view_size = int(agent_view_size)
         cfg.extended_actions = int(bool(extended_actions))
         cfg.alt_visibility = int(not default_vis)
-        cfg.object_state = int(bool(object_state))
+        if object_state is not None:  # None: the id's own need (ObstructedMaze's boxed keys switch it on)
+            cfg.object_state = int(bool(object_state))
         self.cfg = cfg
         self.num_envs = int(num_envs)
         self.device = int(device)
@@ -349,23 +351,27 @@ class VecMiniGrid:
         return n.value, ms.value
 
 
-def generate_levels(env_id_or_cfg, seeds, with_task=False):
-    """Host-side `env.seed(s); env.reset()` of a built-in family -> (grid (n,W,H,3) u8, agent (n,3) i32[, task (n,) u32])."""
+def generate_levels(env_id_or_cfg, seeds, with_task=False, with_contains=False):
+    """Host-side `env.seed(s); env.reset()` of a built-in family -> (grid (n,W,H,3) u8, agent (n,3) i32[, task (n,) u32]
+    [, contains (n,W,H,3) u8: Box.contains of every cell, (1,0,0) = nothing])."""
     cfg = _lib.env_config(env_id_or_cfg) if isinstance(env_id_or_cfg, str) else env_id_or_cfg
     s = np.ascontiguousarray(seeds, dtype=np.uint64)
     n = s.shape[0]
     grid = np.empty((n, cfg.width, cfg.height, 3), np.uint8)
     agent = np.empty((n, 3), np.int32)
     task = np.zeros(n, np.uint32)
-    _lib.check(_lib.lib().mgx_generate_levels_ex(ctypes.byref(cfg), n, _ptr(s), _ptr(grid), _ptr(agent), _ptr(task)))
-    return (grid, agent, task) if with_task else (grid, agent)
+    contains = np.empty((n, cfg.width, cfg.height, 3), np.uint8) if with_contains else None
+    _lib.check(_lib.lib().mgx_generate_levels_full(ctypes.byref(cfg), n, _ptr(s), _ptr(grid), _ptr(agent), _ptr(task), _ptr(contains)))
+    out = (grid, agent) + ((task,) if with_task else ()) + ((contains,) if with_contains else ())
+    return out
 
 
-def generate_level_stream(env_id_or_cfg, seed, K, with_task=False):
+def generate_level_stream(env_id_or_cfg, seed, K, with_task=False, with_contains=False):
     """Host-side `env.seed(seed)` then K consecutive `env.reset()`s (the RNG stream continues across episodes)."""
     cfg = _lib.env_config(env_id_or_cfg) if isinstance(env_id_or_cfg, str) else env_id_or_cfg
     grid = np.empty((K, cfg.width, cfg.height, 3), np.uint8)
     agent = np.empty((K, 3), np.int32)
     task = np.zeros(K, np.uint32)
-    _lib.check(_lib.lib().mgx_generate_level_stream_ex(ctypes.byref(cfg), ctypes.c_uint64(int(seed)), K, _ptr(grid), _ptr(agent), _ptr(task)))
-    return (grid, agent, task) if with_task else (grid, agent)
+    contains = np.empty((K, cfg.width, cfg.height, 3), np.uint8) if with_contains else None
+    _lib.check(_lib.lib().mgx_generate_level_stream_full(ctypes.byref(cfg), ctypes.c_uint64(int(seed)), K, _ptr(grid), _ptr(agent), _ptr(task), _ptr(contains)))
+    return (grid, agent) + ((task,) if with_task else ()) + ((contains,) if with_contains else ())

@@ -22,7 +22,8 @@
  *                                                                 envs/fourrooms.py, fetch.py, gotodoor.py, gotoobject.py,
  *                                                                 putnear.py, redbluedoors.py, memory.py, unlock*.py,
  *                                                                 keycorridor.py (+ roomgrid.py), lockedroom.py,
- *                                                                 playground_v0.py, dynamicobstacles.py, twogoals.py
+ *                                                                 playground_v0.py, dynamicobstacles.py, twogoals.py,
+ *                                                                 obstructedmaze.py
  *   mgx_set/get_task           per-episode attributes of the task envs (targetType, target_pos, ...) as one word
  *   mgx_set/get_object_state   Goal/Box.toggletimes, triage_color, Box.contains              minigrid.py:156-181,332-364
  *   mgx_get_direction          obs['direction']                   minigrid.py:1375-1379
@@ -125,7 +126,12 @@ typedef enum {
     MGX_LEVEL_PLAYGROUND = 17, /* PlaygroundV0 (envs/playground_v0.py), 19x19: nine rooms, random doors, 12 random objects, no mission */
     MGX_LEVEL_PUTNEAR = 18,  /* PutNearEnv (envs/putnear.py): level_arg0 = numObjs, grids up to 8x8; use with MGX_TASK_PUTNEAR */
     MGX_LEVEL_TWOGOALS = 19, /* TwoGoalsEnv (envs/twogoals.py): level_arg0 = 1 for a random agent start; use with MGX_TASK_TWOGOALS */
-    MGX_LEVEL_KIND_END = 20
+    MGX_LEVEL_OBSTRUCTEDMAZE = 20, /* ObstructedMaze (envs/obstructedmaze.py) on RoomGrid(room_size 6): level_arg0 bit 0 = keys hidden
+                                in boxes (Box.contains: needs object_state = 1), bit 1 = doors blocked by a ball; level_arg1 = 0
+                                for the 1 x 2 mazes (11x6: 1Dl / 1Dlh / 1Dlhb), else num_quarters (1, 2, 4) | 8 if the agent starts
+                                in room (2, 1) (16x16: 2Dl / 2Dlh / 2Dlhb; 1Q / 2Q / Full start in (1, 1)); use with
+                                task_kind = MGX_TASK_PICKUPBOX (target: the blue ball) */
+    MGX_LEVEL_KIND_END = 21
 } mgx_level_kind;
 
 /* task rules layered on MiniGridEnv.step by env subclasses (`step` overrides that only reshape reward/done) */
@@ -151,7 +157,7 @@ typedef enum {
                               cells | (success is the upper one) << 4. */
     MGX_TASK_UNLOCK = 7,   /* envs/unlock.py:33-41: `toggle` with the door open afterwards ends the episode with _reward().
                               Per-env task word = door y (the door is at x = 5). */
-    MGX_TASK_PICKUPBOX = 8, /* envs/unlockpickup.py:35-43, blockedunlockpickup.py:39-47, keycorridor.py:51-59: `pickup` while
+    MGX_TASK_PICKUPBOX = 8, /* envs/unlockpickup.py:35-43, blockedunlockpickup.py:39-47, keycorridor.py:51-59, obstructedmaze.py:42-50: `pickup` while
                               carrying the target object (`self.carrying == self.obj`: the only box / ball of the level)
                               ends the episode with _reward().  Per-env task word = the target's cell code
                               (type | color << 4). */
@@ -226,6 +232,10 @@ int mgx_generate_levels(const mgx_config *cfg, int64_t n, const uint64_t *seeds,
 
 /* Same, also returning the per-env task word (uint32 [n], may be NULL) of the families that have one (Fetch). */
 int mgx_generate_levels_ex(const mgx_config *cfg, int64_t n, const uint64_t *seeds, uint8_t *grid, int32_t *agent, uint32_t *task);
+/* Same, also returning Box.contains of every cell (uint8 [n][W][H][3], encode() of the contents, (1,0,0) = nothing; may be
+ * NULL): the keys ObstructedMaze hides in boxes.  The format of mgx_set_object_state's `contains`. */
+int mgx_generate_levels_full(const mgx_config *cfg, int64_t n, const uint64_t *seeds, uint8_t *grid, int32_t *agent, uint32_t *task,
+                             uint8_t *contains);
 
 /* Plain reference behaviour without ReseedWrapper (pure CPU): `env.seed(seed)` once, then K consecutive
  * `env.reset()`s -- the env's RNG stream continues, every episode gets a new level (minigrid.py:836-839).
@@ -233,6 +243,9 @@ int mgx_generate_levels_ex(const mgx_config *cfg, int64_t n, const uint64_t *see
 int mgx_generate_level_stream(const mgx_config *cfg, uint64_t seed, int64_t K, uint8_t *grid, int32_t *agent);
 /* Same, also returning the per-level task words (uint32 [K], may be NULL). */
 int mgx_generate_level_stream_ex(const mgx_config *cfg, uint64_t seed, int64_t K, uint8_t *grid, int32_t *agent, uint32_t *task);
+/* Same, also returning Box.contains of every cell of every level (uint8 [K][W][H][3], may be NULL). */
+int mgx_generate_level_stream_full(const mgx_config *cfg, uint64_t seed, int64_t K, uint8_t *grid, int32_t *agent, uint32_t *task,
+                                   uint8_t *contains);
 
 /* env.seed(seeds[i]); env.reset() for every env with mask[i] != 0 (mask NULL = all).
  * For the families that draw random numbers the whole reset runs on the GPU (k_seed: SHA-512 key + MT19937

@@ -32,7 +32,8 @@ File format (one .npz per case), all arrays stacked over traces (leading dim K):
   re-seeding with the SAME seed = ReseedWrapper(seeds=[s]), wrappers.py:24-28; meta.reseed=False: plain
   `reset()`, the env's RNG stream continues and every episode gets a new level):
   reset_k (R,) trace index, reset_t (R,) step index after which reset happened,
-  reset_grid (R,W,H,3), reset_aux (R,W,H), reset_agent (R,3), reset_obs (R,7,7,3)
+  reset_grid (R,W,H,3), reset_aux (R,W,H), reset_agent (R,3), reset_obs (R,7,7,3), reset_task (R,),
+  reset_contains (R,W,H,3) (objstate), reset_full (R,W,H,3) (full_obs)
 """
 import json
 import os
@@ -104,7 +105,7 @@ def task_word(env):
         return M.COLOR_TO_IDX[locked.color] | (M.COLOR_TO_IDX[kroom.color] << 3)
     if type(env).__name__ == "Unlock":
         return int(env.door.cur_pos[1])
-    if type(env).__name__ in ("UnlockPickup", "BlockedUnlockPickup") or type(env).__name__.startswith("KeyCorridor"):
+    if type(env).__name__ in ("UnlockPickup", "BlockedUnlockPickup") or type(env).__name__.startswith(("KeyCorridor", "ObstructedMaze")):
         return M.OBJECT_TO_IDX[env.obj.type] | (M.COLOR_TO_IDX[env.obj.color] << 4)
     if type(env).__name__.startswith("Memory"):
         return int(env.success_pos[0]) | (int(env.success_pos[1] < env.height // 2) << 4)
@@ -314,7 +315,7 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
     meta = dict(env_id=name, W=W, H=H, max_steps=int(env0.max_steps), view=V,
                 see_through=bool(env0.see_through_walls), lava_v1=bool(v1), full_obs=bool(full_obs),
                 reseed=bool(reseed), extended=bool(n_actions > 7), alt_vis=not bool(env0.default_vis),
-                task=11 if type(env0).__name__.startswith("TwoGoals") else 10 if type(env0).__name__.startswith("PutNear") else 9 if type(env0).__name__ == "LockedRoom" else 7 if type(env0).__name__ == "Unlock" else 8 if type(env0).__name__ in ("UnlockPickup", "BlockedUnlockPickup") or type(env0).__name__.startswith("KeyCorridor") else 6 if type(env0).__name__.startswith("Memory") else 5 if type(env0).__name__.startswith("RedBlueDoor") else 4 if type(env0).__name__.startswith(("GoToObject", "GotoEnv")) else (1 if hasattr(env0, "targetType") else (2 if hasattr(env0, "target_pos") else 0)),
+                task=11 if type(env0).__name__.startswith("TwoGoals") else 10 if type(env0).__name__.startswith("PutNear") else 9 if type(env0).__name__ == "LockedRoom" else 7 if type(env0).__name__ == "Unlock" else 8 if type(env0).__name__ in ("UnlockPickup", "BlockedUnlockPickup") or type(env0).__name__.startswith(("KeyCorridor", "ObstructedMaze")) else 6 if type(env0).__name__.startswith("Memory") else 5 if type(env0).__name__.startswith("RedBlueDoor") else 4 if type(env0).__name__.startswith(("GoToObject", "GotoEnv")) else (1 if hasattr(env0, "targetType") else (2 if hasattr(env0, "target_pos") else 0)),
                 objstate=bool(objstate), dynobs=int(getattr(env0, "n_obstacles", 0)), gym_id=gym_id or "")
     z = dict(
         seed=np.zeros(K, np.int64), init_grid=np.zeros((K, W, H, 3), np.uint8),
@@ -333,7 +334,7 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
         z["contains"] = np.zeros((K, T, W, H, 3), np.uint8)
         z["carry_aux"] = np.zeros((K, T), np.uint8)
         z["carry_contains"] = np.zeros((K, T, 3), np.uint8)
-    rk, rt, rg, ra, rag, ro, rtask, rcont = [], [], [], [], [], [], [], []
+    rk, rt, rg, ra, rag, ro, rtask, rcont, rfull = [], [], [], [], [], [], [], [], []
     for k, s in enumerate(seeds):
         env = make_env()
         env.seed(int(s))
@@ -396,6 +397,8 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
                 ro.append(o2["image"])
                 rtask.append(task_word(env))
                 rcont.append(contains_plane(env))
+                if full_obs:
+                    rfull.append(full_image(env))
     R = len(rk)
     z["reset_k"] = np.asarray(rk, np.int32)
     z["reset_t"] = np.asarray(rt, np.int32)
@@ -406,6 +409,8 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
     z["reset_task"] = np.asarray(rtask, np.uint32)
     if objstate:
         z["reset_contains"] = np.asarray(rcont, np.uint8).reshape(R, W, H, 3)
+    if full_obs:
+        z["reset_full"] = np.asarray(rfull, np.uint8).reshape(R, W, H, 3)   # FullyObsWrapper image returned by reset()
     z["meta"] = np.frombuffer(json.dumps(meta).encode(), np.uint8)
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **z)
@@ -518,6 +523,126 @@ def record_flat():
     print("flat.npz %6.1f KB  %d episodes" % (os.path.getsize(path) / 1024, len(ids)))
 
 
+OBSTRUCTED = ["1Dl", "1Dlh", "1Dlhb", "2Dl", "2Dlh", "2Dlhb", "1Q", "2Q", "Full"]
+
+
+def record_levels_obstructed():
+    """ObstructedMaze (envs/obstructedmaze.py): seed -> initial grid / agent / target / Box.contains plane (keys hidden in boxes),
+    and no-reseed level streams for three of the ids.  A file of its own: levels.npz is not re-recorded for it."""
+    out = {}
+    big = [1337, 2 ** 32 - 1, 2 ** 32, 2 ** 40 + 12345, 2 ** 64 - 1]
+    for short in OBSTRUCTED:
+        env = gym.make("MiniGrid-ObstructedMaze-%s-v0" % short)
+        ss = list(range(128 if short.startswith("1D") else 64)) + big
+        grids, agents, tasks, conts = [], [], [], []
+        for sd in ss:
+            env.seed(int(sd))
+            env.reset()
+            grids.append(env.grid.encode())
+            agents.append((env.agent_pos[0], env.agent_pos[1], env.agent_dir))
+            tasks.append(task_word(env))
+            conts.append(contains_plane(env))
+            assert env.mission == "pick up the blue ball"
+        key = "ObstructedMaze-" + short
+        out[key + ":seeds"] = np.asarray(ss, np.uint64)
+        out[key + ":grid"] = np.asarray(grids, np.uint8)
+        out[key + ":agent"] = np.asarray(agents, np.int32)
+        out[key + ":task"] = np.asarray(tasks, np.uint32)
+        out[key + ":contains"] = np.asarray(conts, np.uint8)
+        out[key + ":max_steps"] = np.asarray([env.max_steps, int(env.see_through_walls)], np.int32)
+    for short, sd, K in [("1Dlhb", 3, 400), ("2Dlh", 1, 150), ("Full", 2, 100)]:
+        env = gym.make("MiniGrid-ObstructedMaze-%s-v0" % short)
+        env.seed(sd)
+        grids, agents, conts = [], [], []
+        for _ in range(K):
+            env.reset()
+            grids.append(env.grid.encode())
+            agents.append((env.agent_pos[0], env.agent_pos[1], env.agent_dir))
+            conts.append(contains_plane(env))
+        key = "stream:ObstructedMaze-%s:%d" % (short, sd)
+        out[key + ":grid"] = np.asarray(grids, np.uint8)
+        out[key + ":agent"] = np.asarray(agents, np.int32)
+        out[key + ":contains"] = np.asarray(conts, np.uint8)
+    path = os.path.join(OUT, "levels_obstructed.npz")
+    np.savez_compressed(path, **out)
+    print("levels_obstructed.npz %6.1f KB" % (os.path.getsize(path) / 1024))
+
+
+def obstructed_script(env):
+    """Open boxes, pick up keys, move blocking balls aside, unlock doors, then pick up the blue ball -- re-planning on the
+    scratch env after every sub-goal.  Not every level gets solved within the cap; whatever prefix results is recorded."""
+    acts = []
+
+    def do(seq):
+        for k in seq:
+            if len(acts) < 330:
+                env.step(k)
+                acts.append(k)
+
+    def find(kind, pred=lambda o: True):
+        return [(x, y) for x in range(env.width) for y in range(env.height)
+                if env.grid.get(x, y) is not None and env.grid.get(x, y).type == kind and pred(env.grid.get(x, y))]
+
+    def reach(cands):
+        best = None
+        for c in cands:
+            p = plan_face(env, c)
+            if p is not None and (best is None or len(p) < len(best)):
+                best = p
+        return best
+
+    def drop():
+        for _ in range(4):
+            if env.carrying is None:
+                return
+            do([0, 4])
+
+    blocked_door, useless = None, set()
+    for _ in range(90):
+        if env.step_count >= env.max_steps - 2 or len(acts) >= 320:
+            break
+        blue = reach(find("ball", lambda o: o.color == "blue"))
+        if blue is not None:
+            if env.carrying is not None:
+                drop()
+                continue
+            do(blue + [3])
+            break
+        c = env.carrying
+        if c is not None and c.type == "key":
+            doors = find("door", lambda o: o.is_locked and o.color == c.color)
+            p = reach(doors)
+            if p is not None:
+                do(p + [5])
+                continue
+            drop()               # its door cannot be faced: a ball stands in front of it, or it is in another room
+            blocked_door = doors[0] if doors else None
+            if blocked_door is None:
+                useless.add(c.color)
+            continue
+        if c is not None:
+            drop()               # a blocking ball: put it down anywhere
+            continue
+        if blocked_door is not None:
+            bx, by = blocked_door
+            color = env.grid.get(bx, by).color
+            p = reach([q for q in find("ball", lambda o: o.color == "green") if abs(q[0] - bx) + abs(q[1] - by) == 1])
+            blocked_door = None
+            if p is not None:
+                do(p + [3])
+                continue
+            useless.add(color)
+        for kind, then, pred in (("key", [3], lambda o: o.color not in useless), ("box", [5], lambda o: True),
+                                 ("door", [5], lambda o: not o.is_open and not o.is_locked)):
+            p = reach(find(kind, pred))
+            if p is not None:
+                do(p + then)
+                break
+        else:
+            break
+    return acts
+
+
 def record_levels():
     """Seeded level generation known answers: seed -> initial grid/agent."""
     out = {}
@@ -575,7 +700,8 @@ def main():
     only = sys.argv[2:] if len(sys.argv) > 2 and sys.argv[1] == "--only" else None
     if only and not any(w.startswith("case:") for w in only):   # e.g. --only flat onehot: re-record just those fixture files
         for what in only:
-            {"flat": record_flat, "onehot": record_onehot, "levels": record_levels, "level_streams": record_level_streams}[what]()
+            {"flat": record_flat, "onehot": record_onehot, "levels": record_levels, "level_streams": record_level_streams,
+             "levels_obstructed": record_levels_obstructed}[what]()
         return
     if only:                                                     # e.g. --only case:DynObs  (prefix of the case names)
         global record_case
@@ -817,7 +943,7 @@ def main():
                               ("TwoGoals-Random-16x16", "MiniGrid-TwoGoals-Random-16x16-v0", range(4))]:
         with contextlib.redirect_stdout(io.StringIO()) as buf:
             record_case(short, mk(gid), list(seeds), 300, scripts=[twogoals_script] * 2 + [None] * (len(seeds) - 2), reseed=False)
-        print(buf.getvalue().strip().splitlines()[-1])
+        print((buf.getvalue().strip().splitlines() or [""])[-1])
     record_case("Playground", mk("MiniGrid-Playground-v0"), list(range(6)), 300, reseed=False)
     record_case("LockedRoom", mk("MiniGrid-LockedRoom-v0"), list(range(6)), 400, reseed=False)
 
@@ -833,6 +959,27 @@ def main():
     record_case("MemoryS17Random", mk("MiniGrid-MemoryS17Random-v0"), list(range(4)), 400, scripts=[memory_script(1), memory_script(0), None, None], reseed=False)
     record_case("GoToObject-8x8-N2", mk("MiniGrid-GoToObject-8x8-N2-v0"), list(range(8)), 400, scripts=[gotoobject_script(0), gotoobject_script(1)] * 2 + [None] * 4, reseed=False)
     record_case("GoToObject-6x6-N2", mk("MiniGrid-GoToObject-6x6-N2-v0"), list(range(6)), 300, scripts=[gotoobject_script(1), gotoobject_script(0)] + [None] * 4, reseed=False)
+    # ObstructedMaze (envs/obstructedmaze.py): RoomGrid mazes, keys hidden in boxes (Box.contains), doors blocked by balls
+    for short, T, K in [("1Dl", 400, 6), ("1Dlh", 400, 6), ("1Dlhb", 500, 8), ("2Dlhb", 450, 6), ("1Q", 450, 4), ("Full", 400, 4)]:
+        box = short not in ("1Dl", "2Dl")
+        record_case("ObstructedMaze-" + short, mk("MiniGrid-ObstructedMaze-%s-v0" % short), list(range(K)), T,
+                    scripts=[obstructed_script] * (K - 2) + [None] * 2, reseed=False, objstate=box, gym_id="MiniGrid-ObstructedMaze-%s-v0" % short)
+    # the same task families with ReseedWrapper semantics at the episode boundary (seed(s); reset() -> the same level again):
+    # what the in-kernel auto-reset reproduces; pins its reset observations and task words to the reference
+    record_case("ObstructedMaze-1Dlhb-reseed", mk("MiniGrid-ObstructedMaze-1Dlhb-v0"), list(range(6)), 700, scripts=[obstructed_script] * 4 + [None] * 2, objstate=True, gym_id="MiniGrid-ObstructedMaze-1Dlhb-v0")
+    record_case("Fetch-8x8-N3-reseed", mk("MiniGrid-Fetch-8x8-N3-v0"), list(range(6)), 700, scripts=[fetch_script(0), fetch_script(1)] * 2 + [None] * 2)
+    record_case("GoToDoor-5x5-reseed", mk("MiniGrid-GoToDoor-5x5-v0"), list(range(4)), 300, scripts=[gotodoor_script(1), gotodoor_script(0), None, None])
+    record_case("GoToObject-6x6-N2-reseed", mk("MiniGrid-GoToObject-6x6-N2-v0"), list(range(4)), 400, scripts=[gotoobject_script(1), gotoobject_script(0), None, None])
+    record_case("RedBlueDoors-6x6-reseed", mk("MiniGrid-RedBlueDoors-6x6-v0"), list(range(4)), 400, scripts=[redblue_script("br"), redblue_script("rb"), None, None])
+    record_case("UnlockPickup-reseed", mk("MiniGrid-UnlockPickup-v0"), list(range(4)), 650, scripts=[unlock_script(True)] * 2 + [None] * 2)
+    record_case("Unlock-reseed", mk("MiniGrid-Unlock-v0"), list(range(4)), 650, scripts=[unlock_script(False)] * 2 + [None] * 2)
+    record_case("KeyCorridorS3R3-reseed", mk("MiniGrid-KeyCorridorS3R3-v0"), list(range(4)), 600, scripts=[keycorridor_script] * 2 + [None] * 2)
+    record_case("PutNear-6x6-N2-reseed", mk("MiniGrid-PutNear-6x6-N2-v0"), list(range(6)), 200, scripts=[putnear_script(1), putnear_script(0)] * 2 + [None] * 2)
+    record_case("MemoryS7-reseed", mk("MiniGrid-MemoryS7-v0"), list(range(4)), 450, scripts=[memory_script(0), memory_script(1), None, None])
+    record_case("LockedRoom-reseed", mk("MiniGrid-LockedRoom-v0"), list(range(3)), 420)
+    with contextlib.redirect_stdout(io.StringIO()) as buf:
+        record_case("TwoGoals-8x8-reseed", mk("MiniGrid-TwoGoals-8x8-v0"), list(range(4)), 300, scripts=[twogoals_script] * 2 + [None] * 2)
+    print((buf.getvalue().strip().splitlines() or [""])[-1])
     # plain reference semantics at the episode boundary: reset() WITHOUT re-seeding (a new level every episode)
     record_case("LavaCrossingS9N1-stream", mk("MiniGrid-LavaCrossingS9N1-v0"), list(range(6)), 500, reseed=False)
     record_case("DoorKey-5x5-stream", mk("MiniGrid-DoorKey-5x5-v0"), [0, 1, 2], 800, reseed=False)

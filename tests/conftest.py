@@ -20,7 +20,7 @@ def pytest_configure(config):
 def golden_cases():
     """Trace cases whose state can be injected with set_state (DynObs-* carry an RNG stream: tests/test_dynobs.py)."""
     return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and not f.startswith("DynObs-")
-                  and f not in ("levels.npz", "level_streams.npz", "onehot.npz", "flat.npz"))
+                  and f not in ("levels.npz", "level_streams.npz", "onehot.npz", "flat.npz", "levels_obstructed.npz"))
 
 
 def load_case(name):

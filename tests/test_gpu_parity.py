@@ -102,27 +102,31 @@ def test_golden_trace_autoreset(name):
     """auto_reset=True: terminal reward/done are reported, obs is the first observation of the next episode
     (the reference's recorded `reset()` observation), state is the episode start."""
     meta, z = load_case(name)
-    if meta["full_obs"]:
-        pytest.skip("reset observations are recorded for the partial view")
     if not meta.get("reseed", True):
-        pytest.skip("stream-mode episode boundaries are covered by test_stream_mode")
-    if meta.get("task", 0):
-        pytest.skip("task envs are recorded without re-seeding")
+        pytest.skip("recorded without re-seeding (a new level per episode): the in-kernel reset of those is test_stream_mode's")
     K, T = z["actions"].shape
     N = 64 + K
     sel = np.arange(N) % K
-    env = mg.VecMiniGrid(config=cfg_from(meta["W"], meta["H"], meta["max_steps"], meta["see_through"], meta["lava_v1"]),
-                         num_envs=N, auto_reset=True, backend="numpy", agent_view_size=meta.get("view", 7), extended_actions=meta.get("extended", False), default_vis=not meta.get("alt_vis", False),
-                         object_state=meta.get("objstate", False))
+    full, task, objstate = meta["full_obs"], meta.get("task", 0), meta.get("objstate", False)
+    env = mg.VecMiniGrid(config=cfg_from(meta["W"], meta["H"], meta["max_steps"], meta["see_through"], meta["lava_v1"], task),
+                         num_envs=N, obs_mode="full" if full else "partial", auto_reset=True, backend="numpy", agent_view_size=meta.get("view", 7),
+                         extended_actions=meta.get("extended", False), default_vis=not meta.get("alt_vis", False), object_state=objstate)
     env.set_state(z["init_grid"][sel], z["init_agent"][sel], aux=z["init_aux"][sel])
-    if meta.get("objstate", False):
+    if objstate:
         env.set_object_state(contains=z["init_contains"][sel])
+    if task:
+        env.set_task(z["init_task"][sel])
+    # what the reference's `env.seed(s); env.reset()` returned after each done: recorded per reset (== the episode start)
+    want_obs, init_obs = (z["full"], z["init_full"]) if full else (z["obs"], z["init_obs"])
+    reset_obs = {(int(k), int(t)): r for r, (k, t) in enumerate(zip(z["reset_k"], z["reset_t"]))}
+    rkey = "reset_full" if full else "reset_obs"
     dones = 0
     for t in range(T):
         obs, rew, done, _ = env.step(z["actions"][sel, t])
-        want = z["obs"][sel, t].copy()
+        want = want_obs[sel, t].copy()
         d = z["done"][sel, t].astype(bool)
-        want[d] = z["init_obs"][sel][d]
+        for i in np.flatnonzero(d):
+            want[i] = z[rkey][reset_obs[(int(sel[i]), t)]]
         assert np.array_equal(obs, want), (name, t)
         assert np.array_equal(rew, z["reward"][sel, t].astype(np.float32))
         assert np.array_equal(done, z["done"][sel, t])
@@ -132,6 +136,12 @@ def test_golden_trace_autoreset(name):
             assert np.array_equal(st["grid"][d], z["init_grid"][sel][d])
             assert np.array_equal(st["agent"][d], z["init_agent"][sel][d])
             assert (st["steps"][d] == 0).all() and (st["carry"][d] == (1, 0, 0)).all()
+            if task and task != 11:        # (TwoGoals' word is a running count: back to 0)
+                assert np.array_equal(env.get_task()[d], z["init_task"][sel][d])
+            if objstate:
+                os_ = env.get_object_state()
+                assert np.array_equal(os_["contains"][d], z["init_contains"][sel][d])
+                assert (os_["carry_contains"][d] == (1, 0, 0)).all()
     s = env.stats()
     assert s["episodes"] == dones and s["steps"] == N * T
     assert abs(s["reward_sum"] - float(z["reward"][sel].astype(np.float32).astype(np.float64).sum())) < 1e-9

@@ -58,6 +58,11 @@ def test_oracle_replays_reference_trace(name):
                 assert np.array_equal(z["reset_aux"][r], z["init_aux"][k])
                 assert np.array_equal(z["reset_agent"][r], z["init_agent"][k])
                 assert np.array_equal(z["reset_obs"][r], z["init_obs"][k])
+                assert z["reset_task"][r] == z["init_task"][k]
+                if full:
+                    assert np.array_equal(z["reset_full"][r], z["init_full"][k])
+                if objstate:
+                    assert np.array_equal(z["reset_contains"][r], z["init_contains"][k])
             else:                         # the RNG stream continued: a new level, injected from the recording
                 env.grid0[k], env.aux0[k], env.agent0[k] = z["reset_grid"][r], z["reset_aux"][r], z["reset_agent"][r]
                 if meta.get("task", 0):
@@ -66,6 +71,8 @@ def test_oracle_replays_reference_trace(name):
                     env.contains0[k] = z["reset_contains"][r]
         env.reset_where(done)
         if done.any():
-            o = env.observe()
+            o = env.observe(full=True) if full else env.observe()
             for k, r in resets.get(t, []):
-                assert np.array_equal(o[k], z["reset_obs"][r])
+                assert np.array_equal((o[0] if full else o)[k], z["reset_obs"][r])
+                if full:
+                    assert np.array_equal(o[1][k], z["reset_full"][r])   # FullyObsWrapper image returned by the reference's reset()

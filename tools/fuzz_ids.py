@@ -44,10 +44,12 @@ def one(env_id, rs):
         orc = DynObsOracle(cfg.width, cfg.level_arg0, "Random" in env_id, seeds)
         observe = lambda: orc.base.observe(True)[int(full)]  # noqa: E731
     else:
-        grid, agent, task = mg.generate_levels(env_id, seeds, with_task=True)
+        grid, agent, task, contains = mg.generate_levels(env_id, seeds, with_task=True, with_contains=True)
         orc = OracleEnvs(cfg.width, cfg.height, cfg.max_steps, cfg.see_through_walls, cfg.lava_v1, task=cfg.task_kind)
         orc.set_state(grid, agent)
         orc.task = task.copy()
+        if cfg.object_state:           # ObstructedMaze: keys hidden in boxes
+            orc.set_contains(contains)
         observe = lambda: orc.observe(True)[int(full)]  # noqa: E731
     assert np.array_equal(obs, observe()), (env_id, "reset")
     nact = 3 if dyn else 7
@@ -105,11 +107,13 @@ def one_stream(env_id, rs):
     except mg.MgxError:
         return 0, None          # Dynamic-Obstacles: the flag is refused (the obstacle walk shares the stream)
     obs = np_(env.reset())
-    levels = [mg.generate_level_stream(env_id, int(sd), L, with_task=True) for sd in seeds]
-    G, A, K = (np.stack([lv[j] for lv in levels]) for j in range(3))
+    levels = [mg.generate_level_stream(env_id, int(sd), L, with_task=True, with_contains=True) for sd in seeds]
+    G, A, K, C = (np.stack([lv[j] for lv in levels]) for j in range(4))
     orc = OracleEnvs(cfg.width, cfg.height, cfg.max_steps, cfg.see_through_walls, cfg.lava_v1, task=cfg.task_kind)
     orc.set_state(G[:, 0], A[:, 0])
     orc.task = K[:, 0].copy()
+    if cfg.object_state:
+        orc.set_contains(C[:, 0])
     observe = lambda: orc.observe(True)[int(full)]  # noqa: E731
     assert np.array_equal(obs, observe()), (env_id, "stream reset")
     ep = np.zeros(N, np.int64)
@@ -123,6 +127,8 @@ def one_stream(env_id, rs):
         if ep.max() >= L:
             break
         orc.grid0[d], orc.agent0[d] = G[d, ep[d]], A[d, ep[d]]
+        if cfg.object_state:
+            orc.contains0[d] = C[d, ep[d]]
         orc.reset_where(odone)
         orc.task[d] = K[d, ep[d]]
         oo[d] = observe()[d]
@@ -186,21 +192,19 @@ def one_options(env_id, rs):
         return 0, None
     view = int(rs.choice([3, 5, 7, 9, 11]))
     ext, alt = bool(rs.randint(2)), bool(rs.randint(2))
-    objstate = rs.uniform() < 0.25
+    objstate = bool(cfg.object_state) or rs.uniform() < 0.25   # (ObstructedMaze's boxed keys need the plane)
     full = rs.uniform() < 0.3
     N = int(rs.choice([1, 65, 400]))
     seeds = rs.randint(0, 2 ** 40, size=N).astype(np.uint64)
     env = mg.VecMiniGrid(env_id, num_envs=N, seeds=seeds, auto_reset=True, backend="torch", obs_mode="full" if full else "partial",
                          agent_view_size=view, extended_actions=ext, default_vis=not alt, object_state=objstate)
     obs = np_(env.reset())
-    grid, agent, task = mg.generate_levels(env_id, seeds, with_task=True)
+    grid, agent, task, contains = mg.generate_levels(env_id, seeds, with_task=True, with_contains=True)
     orc = OracleEnvs(cfg.width, cfg.height, cfg.max_steps, cfg.see_through_walls, cfg.lava_v1, view=view, extended=ext, alt_vis=alt, task=cfg.task_kind)
     orc.set_state(grid, agent)
     orc.task = task.copy()
     if objstate:
-        empty = np.zeros((N, cfg.width, cfg.height, 3), np.uint8)
-        empty[..., 0] = 1
-        orc.set_contains(empty)
+        orc.set_contains(contains)    # empty everywhere but in ObstructedMaze's boxes
     observe = lambda: orc.observe(True)[int(full)]  # noqa: E731
     assert np.array_equal(obs, observe()), (env_id, "options reset")
     nact = 9 if ext else 7
