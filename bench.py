@@ -26,9 +26,11 @@ ranks; rank 0 prints ONE JSON line.
 
 Extra objects on the line:
   roofline     the step kernel (k_step / k_step_fulldirect) against the HBM roof: algorithmic bytes per launch / the
-               kernel's average duration, measured with HIP event pairs around every 8th launch of THAT kernel on the
-               launch stream inside the timed region (mgx_profile_kernel; `span_us_per_step` beside it is the whole
-               stream span / steps, which also holds k_dynobs / epilogues / k_levelgen where a workload has them).
+               kernel's average duration, measured with HIP events on the launch stream inside the timed region two ways:
+               `event_pair_us` = event pairs around every 8th launch of THAT kernel (mgx_profile_kernel; includes the ~2 us
+               the two markers take), `span_us_per_step` = the whole stream span / steps (includes launch gaps and, where a
+               workload has them, k_dynobs / epilogues / k_levelgen).  Both bound the kernel from above; `avg_kernel_us` is
+               the smaller one, rocprofv3's per-dispatch average under profiles/ reads just below it.
                The bytes are those of THIS layout (233 B/env-step for 8x8 + 7x7 view) -- smaller
                than SURVEY.md section 8d's 372 B, which assumed 3-byte cells; the survey-basis rate is given beside it.
                `traffic` = HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2
@@ -364,8 +366,14 @@ def main():
         if not gather_checked:
             raise SystemExit("bench.py: the gathered done/reward vectors do not match the shards")
     k_n, k_ms = (0, 0.0) if dry else env.profile_kernel()
-    avg_kernel_s = (k_ms * 1e-3 / k_n) if k_n else (span_ms * 1e-3 / max(launches, 1))
-    mine = torch.tensor([avg_kernel_s, span_ms * 1e-3 / max(launches, 1), float(local_totals[0])], dtype=torch.float64, device=dev)
+    span_s = span_ms * 1e-3 / max(launches, 1)
+    sampled_s = (k_ms * 1e-3 / k_n) if k_n else span_s
+    # Two upper bounds of the step kernel's mean duration: the per-launch event pairs (kernel + the ~2 us the two event
+    # markers themselves take in the queue) and the stream span / launches (kernel + inter-kernel gap + whatever else the
+    # workload enqueues per step).  The smaller of the two is still an upper bound, so the rate derived from it is a lower
+    # bound; rocprofv3's per-dispatch duration (profiles/) is the tie-breaker and reads slightly below both.
+    avg_kernel_s = min(sampled_s, span_s)
+    mine = torch.tensor([avg_kernel_s, span_s, float(local_totals[0]), sampled_s], dtype=torch.float64, device=dev)
     per = [torch.zeros_like(mine) for _ in range(world)]
     if world > 1:
         dist.all_gather(per, mine)
@@ -389,9 +397,9 @@ def main():
                 traffic = None
         per_rank = []
         for r, v in enumerate(per):
-            ks, ss, ep = [float(x) for x in v.tolist()]
+            ks, ss, ep, es = [float(x) for x in v.tolist()]
             ach = bps * n_local / ks / 1e9 if ks > 0 else 0.0
-            per_rank.append({"rank": r, "avg_kernel_us": ks * 1e6, "span_us_per_step": ss * 1e6, "achieved": ach,
+            per_rank.append({"rank": r, "avg_kernel_us": ks * 1e6, "span_us_per_step": ss * 1e6, "event_pair_us": es * 1e6, "achieved": ach,
                              "frac": ach / HBM_PEAK_GBS, "episodes": ep})
         slow = min(per_rank, key=lambda x: x["achieved"])
         obs_desc = ("float32 (N,%d) FlatObs" % (obs_cells(cfg.width, cfg.height, args.obs_mode, args.view) * 3 + FLAT_MISSION) if args.obs_mode.endswith("flat")
@@ -414,7 +422,7 @@ def main():
                          "frac": slow["frac"], "traffic": traffic,
                          "kernel": "k_step_fulldirect" if (args.obs_mode.startswith("full") and (cfg.width * cfg.height) % 4 == 0) else "k_step",
                          "avg_kernel_us": slow["avg_kernel_us"], "kernel_samples": k_n, "launches": launches,
-                         "span_us_per_step": slow["span_us_per_step"],
+                         "span_us_per_step": slow["span_us_per_step"], "event_pair_us": slow["event_pair_us"],
                          "algorithmic_bytes_per_env_step": bps, "layout_bytes_per_env_step_all_kernels": lbps,
                          "measured_streaming_ceiling": 6290.0,
                          "survey_bytes_per_env_step": sbps, "achieved_on_survey_bytes": sbps * n_local / (slow["avg_kernel_us"] * 1e-6) / 1e9 if slow["avg_kernel_us"] > 0 else 0.0,

@@ -741,6 +741,28 @@ __global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
         const int u = tid + 256 * k;
         pf[k] = cells32[u < n_units ? u : 0];
     }
+    // RAGGED with a compile-time size (19x19 FourRooms / LockedRoom / Playground, 25x25 MultiRoom): the units of the tile's flat
+    // cell sequence are known per thread, so ALL of a thread's unaligned dword loads go out here, before phase A -- the
+    // run-time-size form below issues one load per loop trip and waits for it (23 dependent round trips per thread at 19x19:
+    // FourRooms FullyObs ran at 2.7 TB/s), and divides by a run-time cell count per unit.
+    constexpr int RCELLS = CW * CH;                                       // (0 for the run-time-size instance)
+    constexpr int KPR = (RAGGED && RCELLS) ? (64 * RCELLS / 4 + 255) / 256 : 0; // units per thread of a full tile
+    uint32_t pr[KPR ? KPR : 1], pr2[KPR ? KPR : 1];
+    struct __attribute__((packed)) PU4 { uint32_t v; };
+    if constexpr (KPR != 0) {
+        const int n_flat_pf = (nv >= 64 ? 64 : (int)nv) * RCELLS;
+#pragma unroll
+        for (int k = 0; k < KPR; k++) {
+            const int f0 = 4 * (tid + 256 * k);
+            const int e = f0 / RCELLS, c = f0 - e * RCELLS;              // compile-time divisor
+            const bool in = f0 < n_flat_pf;
+            const uint8_t *rowp = p.cells + (env0 + (in ? e : 0)) * S;
+            pr[k] = reinterpret_cast<const PU4 *>(rowp + (in ? c : 0))->v; // c + 3 <= S - 1: inside the padded row
+            // a unit that straddles two envs takes its upper bytes from the next env's first cells
+            const bool straddle = in && c + 3 >= RCELLS && f0 + (RCELLS - c) < n_flat_pf;
+            pr2[k] = straddle ? *reinterpret_cast<const uint32_t *>(rowp + S) : 0u;
+        }
+    }
     s_lut[tid] = decode_triple_full(tid);
 
     if (tid < 64) { // phase A: wave 0
@@ -805,6 +827,51 @@ __global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
         uint8_t *out = p.obs + env0 * (int64_t)cells * 3;
         const int n_flat = nenv * cells, n_u = (n_flat + 3) >> 2;
         struct __attribute__((packed)) U4 { uint32_t v; };
+        if constexpr (KPR != 0) {
+#pragma unroll
+            for (int k = 0; k < KPR; k++) {
+                const int u = tid + 256 * k;
+                const int f0 = 4 * u;
+                if (f0 >= n_flat) break;
+                const int e = f0 / RCELLS, c = f0 - e * RCELLS;
+                const int n_lo = RCELLS - c < 4 ? RCELLS - c : 4;        // cells of this unit that belong to env e (1..4)
+                uint32_t w = pr[k];
+                {
+                    const uint32_t info = s_info[e];
+                    if ((info >> 18) & 1u) w = reinterpret_cast<const U4 *>(p.cells0 + (env0 + e) * S + c)->v; // env e was reset: its snapshot (rare)
+                    if ((info >> 19) & 1u) {
+                        const uint32_t x = s_wr[e], d = (x & 0xFFFFu) - (uint32_t)c;
+                        if (d < 4u) w = (w & ~(0xFFu << (8u * d))) | ((x >> 16) << (8u * d));
+                    }
+                    const uint32_t d = (info & 0xFFFFu) - (uint32_t)c, code = MGX_K_AGENT | (((info >> 16) & 3u) << 4);
+                    if (d < 4u) w = (w & ~(0xFFu << (8u * d))) | (code << (8u * d));
+                }
+                if (n_lo < 4) { // the rest of the unit: the first 4 - n_lo cells of env e + 1 (or nothing past the tile's last cell)
+                    uint32_t w2 = pr2[k];
+                    if (f0 + n_lo < n_flat) {
+                        const uint32_t info = s_info[e + 1];
+                        if ((info >> 18) & 1u) w2 = *reinterpret_cast<const uint32_t *>(p.cells0 + (env0 + e + 1) * S);
+                        if ((info >> 19) & 1u) {
+                            const uint32_t x = s_wr[e + 1], d = x & 0xFFFFu;
+                            if (d < 4u) w2 = (w2 & ~(0xFFu << (8u * d))) | ((x >> 16) << (8u * d));
+                        }
+                        const uint32_t d = info & 0xFFFFu, code = MGX_K_AGENT | (((info >> 16) & 3u) << 4);
+                        if (d < 4u) w2 = (w2 & ~(0xFFu << (8u * d))) | (code << (8u * d));
+                    } else w2 = 0x01010101u * MGX_CODE_EMPTY;
+                    const uint32_t keep = (1u << (8 * n_lo)) - 1u;        // n_lo in 1..3
+                    w = (w & keep) | (w2 << (8 * n_lo));
+                }
+                const uint32_t t0 = s_lut[w & 255u], t1 = s_lut[(w >> 8) & 255u], t2 = s_lut[(w >> 16) & 255u], t3 = s_lut[w >> 24];
+                const uint32_t a = __builtin_amdgcn_perm(t1, t0, 0x04020100u), b = __builtin_amdgcn_perm(t2, t1, 0x05040201u),
+                               cc = __builtin_amdgcn_perm(t3, t2, 0x06050402u);
+                if (f0 + 4 <= n_flat) nt_store12(reinterpret_cast<uint32_t *>(out + 12 * (int64_t)u), a, b, cc);
+                else { // tail tile whose cell count is not a multiple of 4: the last unit is short
+                    const uint32_t wds[3] = {a, b, cc};
+                    for (int b8 = 0; b8 < 3 * (n_flat - f0); b8++) out[12 * (int64_t)u + b8] = (uint8_t)(wds[b8 >> 2] >> (8 * (b8 & 3)));
+                }
+            }
+            return;
+        }
         for (int u = tid; u < n_u; u += 256) {
             const int f0 = 4 * u;
             int e = f0 / cells, c = f0 - e * cells;
@@ -886,6 +953,8 @@ hipError_t launch_sized(const StepParams &p, int mode, dim3 grid, dim3 block, si
     if (mode == 0) hipLaunchKernelGGL((k_step<CW, CH, 0, 7>), grid, block, shmem, st, p);
     else if (mode == 1) hipLaunchKernelGGL((k_step<CW, CH, 1, 7>), grid, block, shmem, st, p);
     else if (((CW && CH) ? CW * CH : p.W * p.H) % 4 == 0) hipLaunchKernelGGL((k_step_fulldirect<CW, CH>), dim3(p.n_tiles), dim3(256), 0, st, p);
+    else if (CW == 0 && !p.objaux && p.W == 19 && p.H == 19) hipLaunchKernelGGL((k_step_fulldirect<19, 19, true>), dim3(p.n_tiles), dim3(256), 0, st, p);
+    else if (CW == 0 && !p.objaux && p.W == 25 && p.H == 25) hipLaunchKernelGGL((k_step_fulldirect<25, 25, true>), dim3(p.n_tiles), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((k_step_fulldirect<CW, CH, true>), dim3(p.n_tiles), dim3(256), 0, st, p);
     return hipGetLastError();
 }
