@@ -747,7 +747,9 @@ __global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
     // FourRooms FullyObs ran at 2.7 TB/s), and divides by a run-time cell count per unit.
     constexpr int RCELLS = CW * CH;                                       // (0 for the run-time-size instance)
     constexpr int KPR = (RAGGED && RCELLS) ? (64 * RCELLS / 4 + 255) / 256 : 0; // units per thread of a full tile
-    uint32_t pr[KPR ? KPR : 1], pr2[KPR ? KPR : 1];
+    uint32_t pr[KPR ? KPR : 1];
+    __shared__ uint32_t s_first[64]; // (sized RAGGED) cells 0..3 of every env of the tile: the upper bytes of the one unit per env
+                                     // that straddles into the next env
     struct __attribute__((packed)) PU4 { uint32_t v; };
     if constexpr (KPR != 0) {
         const int n_flat_pf = (nv >= 64 ? 64 : (int)nv) * RCELLS;
@@ -758,9 +760,6 @@ __global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
             const bool in = f0 < n_flat_pf;
             const uint8_t *rowp = p.cells + (env0 + (in ? e : 0)) * S;
             pr[k] = reinterpret_cast<const PU4 *>(rowp + (in ? c : 0))->v; // c + 3 <= S - 1: inside the padded row
-            // a unit that straddles two envs takes its upper bytes from the next env's first cells
-            const bool straddle = in && c + 3 >= RCELLS && f0 + (RCELLS - c) < n_flat_pf;
-            pr2[k] = straddle ? *reinterpret_cast<const uint32_t *>(rowp + S) : 0u;
         }
     }
     s_lut[tid] = decode_triple_full(tid);
@@ -770,6 +769,9 @@ __global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
         const int64_t env = env0 + lane;
         const bool valid = env < p.n;
         Lane L = unpack_rec(p.agent[env], p.task);
+        uint32_t first = 0;
+        if constexpr (KPR != 0) first = *reinterpret_cast<const uint32_t *>(p.cells + env * S); // (rows are padded to whole tiles: readable
+                                                                                                // for every lane; the line is part of the prefetch)
         uint32_t act = 6;
         if (p.do_step && valid) act = __builtin_nontemporal_load(&p.actions[env]);
         const bool crash = p.task == MGX_TASK_DYNOBS && (act & 0x80u);
@@ -810,6 +812,7 @@ __global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
         }
         s_info[lane] = (uint32_t)(L.ax * H + L.ay) | ((uint32_t)L.dir << 16) | ((uint32_t)reset << 18) | (changed << 19);
         s_wr[lane] = wr;
+        if constexpr (KPR != 0) s_first[lane] = first; // (a reset env's consumer reads the snapshot instead)
     }
     __syncthreads();
 
@@ -847,10 +850,10 @@ __global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
                     if (d < 4u) w = (w & ~(0xFFu << (8u * d))) | (code << (8u * d));
                 }
                 if (n_lo < 4) { // the rest of the unit: the first 4 - n_lo cells of env e + 1 (or nothing past the tile's last cell)
-                    uint32_t w2 = pr2[k];
+                    uint32_t w2;
                     if (f0 + n_lo < n_flat) {
                         const uint32_t info = s_info[e + 1];
-                        if ((info >> 18) & 1u) w2 = *reinterpret_cast<const uint32_t *>(p.cells0 + (env0 + e + 1) * S);
+                        w2 = ((info >> 18) & 1u) ? *reinterpret_cast<const uint32_t *>(p.cells0 + (env0 + e + 1) * S) : s_first[e + 1];
                         if ((info >> 19) & 1u) {
                             const uint32_t x = s_wr[e + 1], d = x & 0xFFFFu;
                             if (d < 4u) w2 = (w2 & ~(0xFFu << (8u * d))) | ((x >> 16) << (8u * d));
