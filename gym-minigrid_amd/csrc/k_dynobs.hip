@@ -71,7 +71,19 @@ __global__ __launch_bounds__(256) void k_dynobs_init(const DynObsParams p)
 // window path; the in-kernel auto-reset of the step kernels raises regen[env], upon which the wave restores the
 // obstacle order, the RNG position and -- if it was touched -- the block from the episode-start snapshot
 // (ReseedWrapper: seed(s) + reset()).
+// Round 2, the DRAW TAPE: the first form rebuilt every env's 64-word window every step (64 coalesced loads + 192 ballots per
+// wave: ~1,700 of its 4,400 VALU instructions and 256 B/env of reads for the ~11 words a step consumes), and every env within
+// 64 words of its block's end (10 % of them, i.e. some lane of nearly every wave) fell through to one dependent global load
+// per draw.  Now each block has a tape: two bit planes (bit k of plane 0 / 1 = bit 0 / 1 of the tempered word k) over 848
+// stream positions -- the 624 words of the block and the first 224 of the NEXT one, which depend on the old block only
+// (new[k] = twist(old[k], old[k+1], old[k+397]) for k < 227).  It is built by the whole wave once per block (k_dynobs_tape at
+// reset, the service loop below when a block is finished or restored); a step reads its window as two unaligned 12-byte
+// loads per lane (and again for every further 64 positions a long placement needs).  Positions 624..847 are consumed from
+// the tape without touching the block; the service loop of the next
+// step then twists the whole block (bit 30 of the stored position says whether a lane already regenerated words in place).
 typedef unsigned long long dyn_u64;
+#define MGX_DYN_PLANE_DW (MGX_DYN_TAPE_DW / 2)
+#define MGX_DYN_POSITIONS 848 /* 624 + 224: the head of the next block depends on the old block only for k < 227 */
 
 // low two bits of genrand's tempering of y (checked against the full tempering on 1e6 random words)
 __device__ __forceinline__ uint32_t temper2(uint32_t y)
@@ -85,6 +97,7 @@ struct DynRng {
     uint32_t *A;           // the env's block in HBM
     uint32_t pos, c;       // window start, words of it consumed
     uint32_t p;            // absolute position once the window is used up (0xFFFFFFFF while inside it)
+    bool inplace;          // words [0, p - 624) of the next block have been generated in place (else the block is untouched)
     __device__ __forceinline__ int draw3() // _rand_int(t, t + 3) - t
     {
         if (p == 0xFFFFFFFFu) {
@@ -94,13 +107,18 @@ struct DynRng {
                 c = idx + 1u;
                 return (int)(((lo >> idx) & 1ull) | (((hi >> idx) & 1ull) << 1));
             }
-            p = pos + 64u < 624u || pos >= 624u ? pos + 64u : 624u; // first word behind the window
-            if (pos >= 624u) p = pos;                                 // (no window at all)
+            p = pos + 64u; // first word behind the window (a window always has 64 positions: the tape looks 224 words ahead)
+            if (p > 624u && !inplace) { // the tape supplied positions 624 .. p-1 without touching the block: catch the block up first
+#pragma nounroll
+                for (uint32_t k = 0; k < p - 624u; k++) A[k] = lg_twist_word(A[k], A[k + 1u], A[k + 397u]); // (k < 224 < 227)
+            }
+            if (p >= 624u) inplace = true;
         }
         for (;;) {
             uint32_t y;
             if (p < 624u) y = A[p];
             else {
+                inplace = true;
                 const uint32_t k = p % 624u, k1 = k + 1u == 624u ? 0u : k + 1u, km = k + 397u >= 624u ? k + 397u - 624u : k + 397u;
                 y = lg_twist_word(A[k], A[k1], A[km]);
                 A[k] = y;
@@ -112,6 +130,60 @@ struct DynRng {
     }
     __device__ __forceinline__ uint32_t end_pos() const { return p == 0xFFFFFFFFu ? pos + c : p; }
 };
+
+
+// The tape of a complete block `blk` (624 words in LDS) into `tp` (MGX_DYN_TAPE_DW dwords in LDS), by the whole wave:
+// 11 rounds of 64 stream positions, two ballots each.  Position k >= 624 is word k - 624 of the next block.
+__device__ __forceinline__ void dyn_build_tape(const uint32_t *blk, uint32_t *tp, int lane)
+{
+#pragma unroll
+    for (int r = 0; r < MGX_DYN_PLANE_DW / 2; r++) {
+        const int k = 64 * r + lane;
+        uint32_t y = 0;
+        if (k < 624) y = blk[k];
+        else if (k < MGX_DYN_POSITIONS) { const int j = k - 624; y = lg_twist_word(blk[j], blk[j + 1], blk[j + 397]); } // (j < 224 < 227: old words only)
+        const uint32_t v = temper2(y);
+        const dyn_u64 ml = __ballot((v & 1u) != 0u), mh = __ballot((v & 2u) != 0u);
+        if (lane == 0) { tp[2 * r] = (uint32_t)ml; tp[2 * r + 1] = (uint32_t)(ml >> 32); }
+        if (lane == 1) { tp[MGX_DYN_PLANE_DW + 2 * r] = (uint32_t)mh; tp[MGX_DYN_PLANE_DW + 2 * r + 1] = (uint32_t)(mh >> 32); }
+    }
+}
+
+// 64 positions of a tape starting at `pos` (< 624): unaligned 12-byte reads of the two planes -> (lo, hi)
+__device__ __forceinline__ void dyn_window(const uint32_t *tp, uint32_t pos, dyn_u64 &lo, dyn_u64 &hi)
+{
+    const uint32_t d = pos >> 5, sh = pos & 31u;
+    const uint32_t a0 = tp[d], a1 = tp[d + 1], a2 = tp[d + 2];
+    const uint32_t b0 = tp[MGX_DYN_PLANE_DW + d], b1 = tp[MGX_DYN_PLANE_DW + d + 1], b2 = tp[MGX_DYN_PLANE_DW + d + 2];
+    lo = (dyn_u64)__builtin_amdgcn_alignbit(a1, a0, sh) | ((dyn_u64)__builtin_amdgcn_alignbit(a2, a1, sh) << 32);
+    hi = (dyn_u64)__builtin_amdgcn_alignbit(b1, b0, sh) | ((dyn_u64)__builtin_amdgcn_alignbit(b2, b1, sh) << 32);
+}
+
+// Reset time: tapes (and their episode-start copies) of the envs a reset really re-seeded; one wave per 64 envs.
+__global__ __launch_bounds__(256) void k_dynobs_tape(const DynObsParams p)
+{
+    __shared__ uint32_t s_blk[4][624 + MGX_DYN_TAPE_DW];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t env0 = ((int64_t)blockIdx.x * 4 + wv) * 64;
+    if (env0 >= p.n) return; // wave-uniform
+    const int64_t env = env0 + lane;
+    const bool mine = env < p.n && (!p.mask_reset || p.mask_reset[env]) && (!p.mask || p.mask[env]);
+    uint32_t *blk = s_blk[wv], *tp = blk + 624;
+    for (dyn_u64 m = __ballot(mine); m; m &= m - 1) { // wave-uniform
+        const int64_t e = env0 + __builtin_ctzll(m);
+        const uint32_t *src = p.mt + e * 624;
+        uint32_t v[10];
+#pragma unroll
+        for (int i = 0; i < 10; i++) { const int k = lane + 64 * i; v[i] = k < 624 ? src[k] : 0u; }
+#pragma unroll
+        for (int i = 0; i < 10; i++) { const int k = lane + 64 * i; if (k < 624) blk[k] = v[i]; }
+        wave_sync();
+        dyn_build_tape(blk, tp, lane);
+        wave_sync();
+        if (lane < MGX_DYN_TAPE_DW) { p.tape[e * MGX_DYN_TAPE_DW + lane] = tp[lane]; p.tape0[e * MGX_DYN_TAPE_DW + lane] = tp[lane]; }
+        wave_sync();
+    }
+}
 
 template <int CW, int CH>
 __global__ __launch_bounds__(256) void k_dynobs(const DynObsParams p)
@@ -126,6 +198,7 @@ __global__ __launch_bounds__(256) void k_dynobs(const DynObsParams p)
     const int cells_bytes = 64 * LS > 2496 ? ((64 * LS + 15) & ~15) : 2496;
     uint32_t *blk = reinterpret_cast<uint32_t *>(lds); // 624 words: a block being restored / finished (before the cells arrive)
     uint32_t *ps = reinterpret_cast<uint32_t *>(lds + cells_bytes);
+    uint32_t *tp = ps + 64;                            // the tape of the block in `blk` (MGX_DYN_TAPE_DW dwords)
     const int64_t env0 = (int64_t)tile * 64, env = env0 + lane;
     const bool valid = env < p.n;
 
@@ -134,42 +207,40 @@ __global__ __launch_bounds__(256) void k_dynobs(const DynObsParams p)
     const bool regen = valid && p.regen[env];
     uint32_t a = valid ? p.actions[env] : 0u;
     const uint32_t rec = p.agent[env].x;
-    bool dirty = (pos >> 31) != 0u;
-    pos &= 0x7FFFFFFFu;
+    bool dirty = (pos >> 31) != 0u;          // the block in memory is no longer the episode-start block
+    bool inplace = ((pos >> 30) & 1u) != 0u; // words [0, pos - 624) of the next block were generated in place (window overrun)
+    pos &= 0x3FFFFFFFu;
     const bool need_restore = regen && dirty, need_finish = valid && !regen && pos >= 624u;
     if (regen) { // the previous step ended the episode: cells/agent are already the episode start
         ow = reinterpret_cast<const uint2 *>(p.obst0)[env];
         pos = p.pos0[env];
         dirty = false;
+        inplace = false;
         p.regen[env] = 0;
     }
-    ps[lane] = pos;
+    ps[lane] = pos | (inplace ? 0x40000000u : 0u);
     wave_sync();
 
-    dyn_u64 w_valid = 0, w_lo = 0, w_hi = 0;
-    // env e's window out of 64 consecutive words (this lane holds word `lane`, inb = it exists): three ballots
-    auto take = [&](int e, uint32_t y, bool inb) {
-        const uint32_t v = temper2(y);
-        const dyn_u64 mv = __ballot(inb && v != 3u), ml = __ballot((v & 1u) != 0u), mh = __ballot((v & 2u) != 0u);
-        if (lane == e) { w_valid = mv; w_lo = ml; w_hi = mh; }
-    };
-
+    dyn_u64 w_lo = 0, w_hi = 0;
     const dyn_u64 m_restore = __ballot(need_restore);
     const dyn_u64 m_serviced = m_restore | __ballot(need_finish);
     for (dyn_u64 m = m_serviced; m; m &= m - 1) { // wave-uniform: one env at a time, all 64 lanes on its block
         const int e = __builtin_ctzll(m);
         uint4 *dst4 = reinterpret_cast<uint4 *>(p.mt) + (env0 + e) * 156;
         uint4 *blk4 = reinterpret_cast<uint4 *>(blk);
+        uint32_t *tape_e = p.tape + (env0 + e) * MGX_DYN_TAPE_DW;
         uint32_t pe;
         if ((m_restore >> e) & 1ull) {
             const uint4 *src4 = reinterpret_cast<const uint4 *>(p.mt0) + (env0 + e) * 156;
-            for (int i = lane; i < 156; i += 64) { const uint4 v = src4[i]; dst4[i] = v; blk4[i] = v; }
-            pe = ps[e];
+            for (int i = lane; i < 156; i += 64) { const uint4 v = src4[i]; dst4[i] = v; }
+            if (lane < MGX_DYN_TAPE_DW) { const uint32_t v = p.tape0[(env0 + e) * MGX_DYN_TAPE_DW + lane]; tape_e[lane] = v; tp[lane] = v; }
+            pe = ps[e] & 0x3FFFFFFFu;
         } else {
             for (int i = lane; i < 156; i += 64) blk4[i] = dst4[i];
             wave_sync();
-            const uint32_t k0 = ps[e] % 624u; // words [0, k0) already belong to the new block
-            pe = k0;
+            const uint32_t pv = ps[e];
+            const uint32_t k0 = (pv & 0x40000000u) ? (pv & 0x3FFFFFFFu) % 624u : 0u; // words [0, k0) already belong to the new block
+            pe = (pv & 0x3FFFFFFFu) % 624u;
             uint32_t c0 = k0;
             while (c0 < 623u) { // chunks of <= 227 words: within one, nobody needs a word the chunk itself produces
                 const uint32_t c1 = c0 + 227u < 623u ? c0 + 227u : 623u;
@@ -192,33 +263,28 @@ __global__ __launch_bounds__(256) void k_dynobs(const DynObsParams p)
             if (lane == 0) blk[623] = lg_twist_word(blk[623], blk[0], blk[396]);
             wave_sync();
             for (int i = lane; i < 156; i += 64) dst4[i] = blk4[i];
+            dyn_build_tape(blk, tp, lane); // (reads blk only: the block is complete)
+            wave_sync();
+            if (lane < MGX_DYN_TAPE_DW) tape_e[lane] = tp[lane];
         }
         wave_sync();
-        const bool inb = pe + (uint32_t)lane < 624u; // the window comes from LDS: the global words were only just written
-        take(e, inb ? blk[pe + lane] : 0u, inb);
+        if (lane == e) dyn_window(tp, pe, w_lo, w_hi); // (from LDS: the global tape was only just written)
         wave_sync();
     }
-    if (need_finish) { pos %= 624u; dirty = true; }
-    if (m_serviced) { // blocks rewritten by the whole wave may be read word-wise by single lanes below: same CU, same L1,
-                      // so the stores only have to be complete (an agent-scope fence would write back the XCD's L2)
+    if (need_finish) { pos %= 624u; dirty = true; inplace = false; }
+    if (valid && !((m_serviced >> lane) & 1ull)) { // this lane's window straight from its tape: two unaligned 12-byte reads
+        struct __attribute__((packed, aligned(4))) T3 { uint32_t a, b, c; };
+        const uint32_t *tpe = p.tape + env * MGX_DYN_TAPE_DW;
+        const uint32_t d = pos >> 5, sh = pos & 31u;
+        const T3 x = *reinterpret_cast<const T3 *>(tpe + d), y = *reinterpret_cast<const T3 *>(tpe + MGX_DYN_PLANE_DW + d);
+        w_lo = (dyn_u64)__builtin_amdgcn_alignbit(x.b, x.a, sh) | ((dyn_u64)__builtin_amdgcn_alignbit(x.c, x.b, sh) << 32);
+        w_hi = (dyn_u64)__builtin_amdgcn_alignbit(y.b, y.a, sh) | ((dyn_u64)__builtin_amdgcn_alignbit(y.c, y.b, sh) << 32);
+    }
+    const dyn_u64 w_valid = ~(w_lo & w_hi); // masked rejection: the word is redrawn when its two bits are 3
+    if (m_serviced) { // blocks rewritten by the whole wave may be read word-wise by single lanes below (a window overrun): same
+                      // CU, same L1, so the stores only have to be complete (an agent-scope fence would write back the XCD's L2)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-    const uint32_t pos_w = valid ? pos : 0xFFFFFFFFu;
-    { // all 64 loads (one 256-B run per env) are issued before the first is consumed: one memory round trip, not 64
-        uint32_t y[64];
-#pragma unroll
-        for (int e = 0; e < 64; e++) {
-            const uint32_t pe = (uint32_t)__builtin_amdgcn_readlane((int)pos_w, e);
-            const bool inb = pe < 624u && pe + (uint32_t)lane < 624u && !((m_serviced >> e) & 1ull);
-            y[e] = inb ? p.mt[(env0 + e) * 624 + pe + lane] : 0u;
-        }
-#pragma unroll
-        for (int e = 0; e < 64; e++) {
-            const uint32_t pe = (uint32_t)__builtin_amdgcn_readlane((int)pos_w, e);
-            const bool inb = pe < 624u && pe + (uint32_t)lane < 624u;
-            if (!((m_serviced >> e) & 1ull)) take(e, y[e], inb);
-        }
     }
     stage_tile<CS>(p.cells, env0, S, LS, lds, lane);
     wave_sync();
@@ -235,29 +301,85 @@ __global__ __launch_bounds__(256) void k_dynobs(const DynObsParams p)
         const uint32_t k = g[fx * H + fy] & 15u;
         not_clear = k != MGX_K_EMPTY && k != MGX_K_GOAL;
     }
-    DynRng r = {w_valid, w_lo, w_hi, p.mt + env * 624, pos, 0u, 0xFFFFFFFFu};
-    for (int i = 0; i < p.n_obst; i++) {
+    DynRng r = {w_valid, w_lo, w_hi, p.mt + env * 624, pos, 0u, 0xFFFFFFFFu, inplace};
+    // The window as two 32-bit halves (fv/fl/fh: valid positions left / bit 0 / bit 1 of the current half): a draw is
+    // ffbl + clear-lowest-bit + two bit extracts, all 32-bit and branch-free but for the switch to the upper half.  The generic
+    // source `r` takes over behind the window (a step that needs more than its ~48 valid draws: rare).
+    uint32_t fv = (uint32_t)w_valid, fl = (uint32_t)w_lo, fh = (uint32_t)w_hi, fbase = 0u, flast = 0u;
+    uint32_t fv1 = (uint32_t)(w_valid >> 32), fl1 = (uint32_t)(w_lo >> 32), fh1 = (uint32_t)(w_hi >> 32);
+    uint32_t wstart = pos; // stream position of the window's first entry
+    const uint32_t *tape_l = p.tape + env * MGX_DYN_TAPE_DW;
+    // next half / next window; false once the tape of this block is used up (positions >= 624 + 64: the generic source goes on)
+    auto advance = [&]() -> bool {
+        if (fv1 != 0u) { fv = fv1; fl = fl1; fh = fh1; fv1 = 0u; fbase = 32u; return true; }
+        if (r.p != 0xFFFFFFFFu || wstart + 128u > MGX_DYN_POSITIONS) return false;
+        wstart += 64u; // a long placement (an obstacle with few free neighbours): the next 64 positions of the tape
+        struct __attribute__((packed, aligned(4))) T3 { uint32_t a, b, c; };
+        const uint32_t d = wstart >> 5, sh = wstart & 31u;
+        const T3 x = *reinterpret_cast<const T3 *>(tape_l + d), y = *reinterpret_cast<const T3 *>(tape_l + MGX_DYN_PLANE_DW + d);
+        fl = __builtin_amdgcn_alignbit(x.b, x.a, sh); fl1 = __builtin_amdgcn_alignbit(x.c, x.b, sh);
+        fh = __builtin_amdgcn_alignbit(y.b, y.a, sh); fh1 = __builtin_amdgcn_alignbit(y.c, y.b, sh);
+        fv = ~(fl & fh); fv1 = ~(fl1 & fh1);
+        fbase = 0u; flast = 0u;
+        r.pos = wstart; // (the generic source, should it take over, continues behind THIS window)
+        if (fv == 0u) { fv = fv1; fl = fl1; fh = fh1; fv1 = 0u; fbase = 32u; }
+        return fv != 0u;
+    };
+    auto draw3 = [&]() -> int {
+        if (fv == 0u && !advance()) { r.c = 64u; return r.draw3(); }
+        const uint32_t idx = (uint32_t)__builtin_ctz(fv);
+        fv &= fv - 1u;
+        flast = fbase + idx + 1u;
+        return (int)(((fl >> idx) & 1u) | (((fh >> idx) & 1u) << 1));
+    };
+    // n accepted draws whose values nobody looks at (a placement that cannot succeed still draws 2 x 101 times)
+    auto skip_draws = [&](int n) {
+        while (n > 0) {
+            if (fv == 0u && !advance()) { r.c = 64u; for (; n > 0; n--) (void)r.draw3(); return; }
+            const int have = __builtin_popcount(fv);
+            if (have <= n) { flast = fbase + 32u - (uint32_t)__builtin_clz(fv); fv = 0u; n -= have; } // the whole half
+            else { for (; n > 0; n--) { flast = fbase + (uint32_t)__builtin_ctz(fv) + 1u; fv &= fv - 1u; } }
+        }
+    };
+    // One loop over (obstacle, try) per lane, not a try loop per obstacle: with nested loops every lane waits, obstacle by
+    // obstacle, for the wave's unluckiest placement (an obstacle with one free neighbour needs ~9 samples, some lane's 30+),
+    // i.e. the sum over obstacles of the per-obstacle maxima; flattened, the wave runs for the lane with the most samples
+    // in total.  (SQ counters before: 21 of 64 lanes active on average.)
+    for (int i = 0, tries = 0; i < p.n_obst;) {
         const uint32_t o = (i < 4 ? ow.x >> (8 * i) : ow.y >> (8 * (i - 4))) & 255u; // x << 4 | y
         const int tx = (int)(o >> 4) - 1, ty = (int)(o & 15u) - 1; // top = old_pos + (-1, -1): interior, never clipped
-        int nx = -1, ny = -1;
-        for (int tries = 0; tries <= 100; tries++) { // num_tries > max_tries raises: 101 samples at most
-            const int x = tx + r.draw3(), y = ty + r.draw3();
-            if (g[x * H + y] != MGX_CODE_EMPTY) continue;
-            if (x == ax && y == ay) continue;
-            nx = x; ny = y;
-            break;
+        bool give_up = false;
+        if (tries == 8) { // eight misses: look at the 3x3 box once -- with no free cell in it the remaining 93 samples are
+                          // known to fail too, and all that is left of them is their 186 draws
+            bool any = false;
+#pragma unroll
+            for (int dxy = 0; dxy < 9; dxy++) {
+                const int x = tx + dxy / 3, y = ty + dxy % 3;
+                any = any || (g[x * H + y] == MGX_CODE_EMPTY && !(x == ax && y == ay));
+            }
+            if (!any) { skip_draws(2 * (101 - tries)); give_up = true; }
         }
-        if (nx < 0) continue; // RecursionError swallowed by the bare except: the obstacle stays
-        const int n8 = nx * H + ny, o8 = (tx + 1) * H + ty + 1;
-        g[n8] = (uint8_t)MGX_CODE_BALL_BLUE; gg[n8] = (uint8_t)MGX_CODE_BALL_BLUE;
-        g[o8] = (uint8_t)MGX_CODE_EMPTY; gg[o8] = (uint8_t)MGX_CODE_EMPTY;
-        const uint32_t nb = ((uint32_t)nx << 4) | (uint32_t)ny;
-        if (i < 4) ow.x = (ow.x & ~(255u << (8 * i))) | (nb << (8 * i));
-        else ow.y = (ow.y & ~(255u << (8 * (i - 4)))) | (nb << (8 * (i - 4)));
+        if (!give_up) {
+            const int x = tx + draw3(), y = ty + draw3();
+            if (g[x * H + y] == MGX_CODE_EMPTY && !(x == ax && y == ay)) {
+                const int n8 = x * H + y, o8 = (tx + 1) * H + ty + 1;
+                g[n8] = (uint8_t)MGX_CODE_BALL_BLUE; gg[n8] = (uint8_t)MGX_CODE_BALL_BLUE;
+                g[o8] = (uint8_t)MGX_CODE_EMPTY; gg[o8] = (uint8_t)MGX_CODE_EMPTY;
+                const uint32_t nb = ((uint32_t)x << 4) | (uint32_t)y;
+                if (i < 4) ow.x = (ow.x & ~(255u << (8 * i))) | (nb << (8 * i));
+                else ow.y = (ow.y & ~(255u << (8 * (i - 4)))) | (nb << (8 * (i - 4)));
+                i++; tries = 0;
+                continue;
+            }
+            give_up = ++tries > 100; // num_tries > max_tries raises (101 samples at most); the RecursionError is swallowed
+                                     // by the bare except: the obstacle stays
+        }
+        if (give_up) { i++; tries = 0; }
     }
+    if (r.p == 0xFFFFFFFFu) r.c = flast; // (else the generic source holds the position; r.pos = start of the last window)
     reinterpret_cast<uint2 *>(p.obst)[env] = ow;
-    const uint32_t pe = r.end_pos();
-    p.pos[env] = pe | ((dirty || pe > 624u) ? 0x80000000u : 0u);
+    const uint32_t pe = r.end_pos(); // (>= 624: the next step's service loop twists the block first)
+    p.pos[env] = pe | ((dirty || r.inplace) ? 0x80000000u : 0u) | (r.inplace ? 0x40000000u : 0u);
     p.act_out[env] = (uint8_t)(a | ((a == 2u && not_clear) ? 0x80u : 0u));
 }
 } // namespace
@@ -267,10 +389,11 @@ hipError_t mgx_launch_dynobs_init(const DynObsParams &p, hipStream_t st)
     const int64_t total = p.n * 156;
     if (total == 0) return hipSuccess;
     hipLaunchKernelGGL(k_dynobs_init, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(k_dynobs_tape, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, st, p); // tapes of the re-seeded envs' blocks
     return hipGetLastError();
 }
 
-int mgx_dynobs_wave_lds(int LS) { return (64 * LS > 2496 ? ((64 * LS + 15) & ~15) : 2496) + 64 * 4; }
+int mgx_dynobs_wave_lds(int LS) { return (64 * LS > 2496 ? ((64 * LS + 15) & ~15) : 2496) + 64 * 4 + ((MGX_DYN_TAPE_DW * 4 + 15) & ~15); }
 
 hipError_t mgx_launch_dynobs(const DynObsParams &p, hipStream_t st)
 {

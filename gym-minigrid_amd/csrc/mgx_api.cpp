@@ -83,7 +83,7 @@ struct mgx_env_s {
     uint8_t *obst_d = nullptr, *obst0_d = nullptr, *act_d = nullptr;
     uint8_t *restart_d = nullptr; // u8[n_pad]: the in-kernel auto-reset restarted this env's episode; the next k_dynobs restores obstacle
                                   // order + RNG position first (NOT regen_d: those flags mean "k_levelgen, make this env a new level")
-    uint32_t *mt0_d = nullptr, *pos0_d = nullptr;
+    uint32_t *mt0_d = nullptr, *pos0_d = nullptr, *tape_d = nullptr, *tape0_d = nullptr;
     // object_state: hidden Goal/Box planes (+ episode-start snapshots) and the carried object's pair
     uint8_t *objaux_d = nullptr, *objaux0_d = nullptr, *objcont_d = nullptr, *objcont0_d = nullptr;
     uint16_t *objcarry_d = nullptr;
@@ -234,6 +234,7 @@ DynObsParams dynobs_params(mgx_handle h)
     memset(&d, 0, sizeof d);
     d.cells = h->cells_d; d.cells0 = h->cells0_d; d.agent = h->agent_d; d.act_out = h->act_d; d.regen = h->restart_d;
     d.obst = h->obst_d; d.obst0 = h->obst0_d; d.mt = h->mt_d; d.mt0 = h->mt0_d; d.pos = h->mt_idx_d; d.pos0 = h->pos0_d;
+    d.tape = h->tape_d; d.tape0 = h->tape0_d;
     d.n = h->n; d.W = h->W; d.H = h->H; d.S = h->S; d.n_obst = h->cfg.level_arg0;
     d.n_tiles = (int)(h->n_pad / 64); d.LS = h->LS; d.wave_lds = mgx_dynobs_wave_lds(h->LS);
     return d;
@@ -472,6 +473,10 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
         CREATE_TRY(hipMemsetAsync(h->restart_d, 0, (size_t)h->n_pad, h->stream));
         CREATE_TRY(hipMalloc((void **)&h->mt0_d, (size_t)h->n_pad * 624 * sizeof(uint32_t)));
         CREATE_TRY(hipMalloc((void **)&h->pos0_d, (size_t)h->n_pad * sizeof(uint32_t)));
+        CREATE_TRY(hipMalloc((void **)&h->tape_d, (size_t)h->n_pad * MGX_DYN_TAPE_DW * sizeof(uint32_t)));
+        CREATE_TRY(hipMalloc((void **)&h->tape0_d, (size_t)h->n_pad * MGX_DYN_TAPE_DW * sizeof(uint32_t)));
+        CREATE_TRY(hipMemsetAsync(h->tape_d, 0, (size_t)h->n_pad * MGX_DYN_TAPE_DW * sizeof(uint32_t), h->stream));
+        CREATE_TRY(hipMemsetAsync(h->tape0_d, 0, (size_t)h->n_pad * MGX_DYN_TAPE_DW * sizeof(uint32_t), h->stream));
         CREATE_TRY(hipMemsetAsync(h->obst_d, 0, (size_t)h->n_pad * 8, h->stream));
         CREATE_TRY(hipMemsetAsync(h->obst0_d, 0, (size_t)h->n_pad * 8, h->stream));
         CREATE_TRY(hipMemsetAsync(h->mt0_d, 0, (size_t)h->n_pad * 624 * sizeof(uint32_t), h->stream));
@@ -503,7 +508,7 @@ extern "C" int mgx_destroy(mgx_handle h)
     (void)hipFree(h->seed0_d); (void)hipFree(h->has_seed_d); (void)hipFree(h->reseeded_d);
     if (h->roll_exec) (void)hipGraphExecDestroy(h->roll_exec);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
-    (void)hipFree(h->obst_d); (void)hipFree(h->obst0_d); (void)hipFree(h->act_d); (void)hipFree(h->restart_d); (void)hipFree(h->mt0_d); (void)hipFree(h->pos0_d);
+    (void)hipFree(h->obst_d); (void)hipFree(h->obst0_d); (void)hipFree(h->act_d); (void)hipFree(h->restart_d); (void)hipFree(h->mt0_d); (void)hipFree(h->pos0_d); (void)hipFree(h->tape_d); (void)hipFree(h->tape0_d);
     for (auto &s : h->st_in) if (s.dev) (void)hipFree(s.dev);
     for (auto &s : h->st_out) if (s.dev) (void)hipFree(s.dev);
     if (h->ev0) (void)hipEventDestroy(h->ev0);

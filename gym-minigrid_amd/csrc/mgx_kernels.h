@@ -96,10 +96,12 @@ struct DynObsParams {
     uint8_t *obst, *obst0;  // u8[n_pad][8] position x << 4 | y of obstacle i (placement order), and at episode start
     uint32_t *mt, *mt0;     // u32[n_pad][624] MT19937 words (lazily regenerated in place past the first block) + snapshot
     uint32_t *pos, *pos0;   // u32[n_pad] words drawn since the block in `mt0` was generated (= mt_idx right after reset)
+    uint32_t *tape, *tape0; // u32[n_pad][MGX_DYN_TAPE_DW] draw tape of the env's block (k_dynobs.hip) + its episode-start copy
     int64_t n;
     int W, H, S, n_obst;
     int n_tiles, LS, wave_lds; // k_dynobs: one wave per 64-env tile, cells + RNG windows staged in LDS
 };
+#define MGX_DYN_TAPE_DW 56 /* two bit planes of 848 stream positions (624 of the block + 224 of the next), 28 dwords each */
 int mgx_dynobs_wave_lds(int LS);
 hipError_t mgx_launch_dynobs_init(const DynObsParams &p, hipStream_t st);
 hipError_t mgx_launch_dynobs(const DynObsParams &p, hipStream_t st);
