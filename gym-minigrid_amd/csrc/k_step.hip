@@ -950,6 +950,117 @@ __global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// mgx_rollout, fused form: T consecutive steps in ONE launch.  The caller's `for t: env.step(a[t])` loop (run_tests.py:41-68,
+// benchmark.py:45-46) with the actions of all T steps given up front has no step-to-step dependency outside an env, so a wave
+// keeps its tile -- the 64 grids in LDS, the 64 agent records in registers -- across the whole loop: per env-step only the
+// action (1 B) comes in and the observation, reward and done flag (152 B) go out; cells and records are read once and written
+// back once per launch, and there is no launch boundary between steps (the per-step launches pay ~8 us each: DESIGN.md section 4).
+// The observation image gets LDS of its own behind the grid image (it overlays the grid in k_step).  Sized partial-view
+// handles only (7x7 view, default visibility, no hidden object state, no epilogue, no new_level_each_episode / Dynamic-Obstacles:
+// those interleave other kernels with the steps); everything else keeps the captured graph of per-step launches.
+struct RolloutParams {
+    const uint8_t *actions; // u8[T][n]
+    uint8_t *obs;           // u8[T][n][147] or null
+    float *reward;          // f32[T][n] or null
+    uint8_t *done;          // u8[T][n] or null
+    int64_t T;
+    int grid_lds;           // bytes of the grid image per wave (the observation image follows)
+};
+
+template <int CS>
+__device__ __forceinline__ void unstage_tile(uint8_t *__restrict__ cells, int64_t env0, int LS, const uint8_t *lds, int lane)
+{ // inverse of stage_tile: the LDS image (LS bytes per env) back to the tile's 64*CS contiguous bytes
+    constexpr int SD = CS >> 2;
+    const int LSD = LS >> 2;
+    uint4 *dst = reinterpret_cast<uint4 *>(cells + env0 * CS);
+    const uint32_t *l32 = reinterpret_cast<const uint32_t *>(lds);
+    constexpr int n_chunks = 4 * CS;
+    if constexpr ((SD & 1) != 0) {
+        const uint4 *l128 = reinterpret_cast<const uint4 *>(lds);
+#pragma unroll 4
+        for (int c = lane; c < n_chunks; c += 64) dst[c] = l128[c];
+        return;
+    }
+#pragma unroll 4
+    for (int c = lane; c < n_chunks; c += 64) {
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int dd = 4 * c + j, e = dd / SD;
+            w[j] = l32[e * LSD + (dd - e * SD)];
+        }
+        dst[c] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+template <int CW, int CH>
+__global__ __launch_bounds__(256) void k_rollout(const StepParams p, const RolloutParams q)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int tile = blockIdx.x * (blockDim.x >> 6) + wv;
+    if (tile >= p.n_tiles) return; // wave-uniform
+    constexpr int CS = (CW * CH + 3) & ~3;
+    constexpr int LS = CS + (((CS >> 2) & 1) ? 0 : 4);
+    uint8_t *lds = smem + (size_t)wv * p.wave_lds; // p.wave_lds = grid image + observation image (mgx_launch_rollout)
+    uint8_t *img = lds + q.grid_lds;
+    const int64_t env0 = (int64_t)tile * 64, env = env0 + lane;
+    const bool valid = env < p.n;
+    constexpr int B = 147;
+
+    stage_tile<CS>(p.cells, env0, CS, LS, lds, lane);
+    Lane L = unpack_rec(p.agent[env], p.task);
+    uint8_t *g = lds + lane * LS;
+    wave_sync();
+    bool wrote = false; // some cell of this lane's env differs from what p.cells holds
+    uint32_t act_next = valid ? (uint32_t)q.actions[env] : 6u;
+    for (int64_t t = 0; t < q.T; t++) {
+        uint32_t act = act_next;
+        if (t + 1 < q.T && valid) act_next = q.actions[(t + 1) * p.n + env]; // in flight during this step
+        if (p.task == MGX_TASK_MEMORY && act == 3u) act = 5u;
+        float reward = 0.f;
+        bool done = false, bad_act = false, oob = false;
+        const int fidx = transition_begin<CW, CH>(p, L, act, valid, bad_act, oob);
+        uint32_t fc = 0, nc = 0;
+        if (fidx >= 0) {
+            const uint32_t carry0 = L.carry;
+            fc = g[fidx];
+            const ObjRef obj = {nullptr, nullptr, nullptr};
+            nc = transition_apply<CH>(p, L, act, fc, reward, done, [&](int i) -> uint32_t { return g[i]; }, oob, fidx, obj);
+            if (nc != fc) g[fidx] = (uint8_t)nc;
+            if (valid && L.steps >= p.max_steps) done = true;
+            if (p.task) task_rule<CH>(p, L, act, reward, done, [&](int i) -> uint32_t { return (uint32_t)g[i]; }, fidx, fc, carry0, oob);
+            if (nc != fc && !(p.auto_reset && done)) { L.dirty = MGX_REC_DIRTY; wrote = true; }
+        } else if (valid && L.steps >= p.max_steps) done = true;
+        if (q.reward && valid) __builtin_nontemporal_store(reward, &q.reward[t * p.n + env]);
+        if (q.done && valid) __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), &q.done[t * p.n + env]);
+        wave_stats(p, valid, done, reward, bad_act, oob, lane, tile);
+        if (p.auto_reset && valid && done) {
+            if (L.dirty != 0u) { // back to the episode-start snapshot (LDS only: the tile goes home once, after the last step)
+                const uint32_t *s0 = reinterpret_cast<const uint32_t *>(p.cells0 + env * CS);
+                uint32_t *l32 = reinterpret_cast<uint32_t *>(g);
+                uint32_t v[CS / 4];
+#pragma unroll
+                for (int i = 0; i < CS / 4; i++) v[i] = s0[i];
+#pragma unroll
+                for (int i = 0; i < CS / 4; i++) l32[i] = v[i];
+                wrote = true;
+            } else if (nc != fc) g[fidx] = (uint8_t)fc;
+            L = unpack_rec(p.agent0[env], p.task);
+        }
+        if (q.obs) {
+            StepParams po = p;
+            po.obs = q.obs + t * p.n * B;
+            emit_partial_obs<CW, CH, 7, false>(po, L, img, g, env0, lane);
+            wave_sync(); // the image's readers are done before the next step's LDS writes (same wave: program order)
+        }
+    }
+    if (valid) p.agent[env] = pack_rec(L, p.task);
+    wave_sync();
+    if (__ballot(wrote)) unstage_tile<CS>(p.cells, env0, LS, lds, lane); // (wave-uniform; Empty / Crossing tiles never change)
+}
+
 template <int CW, int CH>
 hipError_t launch_sized(const StepParams &p, int mode, dim3 grid, dim3 block, size_t shmem, hipStream_t st)
 {
@@ -980,6 +1091,26 @@ hipError_t mgx_preload_step_kernels()
 {
     hipFuncAttributes a;
     return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k_step<0, 0, 0, 7>));
+}
+
+// Fused T-step rollout for sized partial-view handles; returns hipErrorNotSupported when the handle's grid has no sized instance.
+hipError_t mgx_launch_rollout(const StepParams &p0, const uint8_t *actions, uint8_t *obs, float *reward, uint8_t *done, int64_t T, hipStream_t st)
+{
+    StepParams p = p0;
+    const int CS = (p.W * p.H + 3) & ~3, LS = CS + (((CS >> 2) & 1) ? 0 : 4);
+    RolloutParams q;
+    q.actions = actions; q.obs = obs; q.reward = reward; q.done = done; q.T = T;
+    q.grid_lds = (64 * LS + 15) & ~15;
+    p.wave_lds = q.grid_lds + 32 * 147; // + the half-tile observation image (4,704 B)
+    int wpb = 65536 / p.wave_lds;
+    if (wpb > 4) wpb = 4;
+    if (wpb < 1) return hipErrorNotSupported;
+    const dim3 block(64 * wpb), grid((p.n_tiles + wpb - 1) / wpb);
+    const size_t shmem = (size_t)wpb * p.wave_lds;
+#define CASE(w, h) if (p.W == w && p.H == h) { hipLaunchKernelGGL((k_rollout<w, h>), grid, block, shmem, st, p, q); return hipGetLastError(); }
+    MGX_SIZED(CASE)
+#undef CASE
+    return hipErrorNotSupported;
 }
 
 hipError_t mgx_launch_step(const StepParams &p, int mode, int waves_per_block, hipStream_t st)

@@ -787,6 +787,24 @@ extern "C" int mgx_rollout(mgx_handle h, int64_t T, const uint8_t *actions, uint
     if (obs && (((uintptr_t)obs | (uintptr_t)((size_t)h->n * h->obs_bytes)) & 15u))
         return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_rollout: obs slices must stay 16-byte aligned (n_envs * obs_bytes = %lld)", (long long)(h->n * h->obs_bytes));
     if ((reward && ((uintptr_t)reward & 3u))) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_rollout: reward is not 4-byte aligned");
+    // Fused form: one launch for all T steps, the tile resident in LDS (k_rollout).  Handles whose steps interleave other kernels
+    // (k_levelgen, k_dynobs, one-hot / flat epilogues), other views / visibility / hidden object state and grids without a
+    // sized instance take the captured graph of per-step launches below.  MGX_ROLLOUT=graph forces that form (tests, tuning).
+    const char *rf = getenv("MGX_ROLLOUT");
+    const bool fused_ok = h->kernel_mode == 0 && h->view == 7 && !h->cfg.alt_visibility && !h->objaux_d && !h->stream_mode && !h->dynobs &&
+                          h->oh_nc < 0 && !h->flat && !(rf && !strcmp(rf, "graph"));
+    if (fused_ok) {
+        StepParams p = base_params(h);
+        p.do_step = 1;
+        const hipError_t e = mgx_launch_rollout(p, actions, obs, reward, done, T, h->stream);
+        if (e == hipSuccess) {
+            h->steps_total += T * h->n;
+            if (h->profiling) h->prof_launches += T;
+            return MGX_OK;
+        }
+        if (e != hipErrorNotSupported) return mgx_fail(MGX_ERR_HIP, "mgx_rollout: k_rollout launch failed: %s", hipGetErrorString(e));
+        (void)hipGetLastError();
+    }
     const bool cached = h->roll_exec && h->roll_T == T && !memcmp(h->roll_args, args, sizeof args);
     if (!cached) {
         if (h->roll_exec) { (void)hipGraphExecDestroy(h->roll_exec); h->roll_exec = nullptr; }

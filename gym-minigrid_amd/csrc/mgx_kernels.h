@@ -110,6 +110,7 @@ hipError_t mgx_launch_seed(const uint64_t *seeds, const uint8_t *mask, const uin
                            uint8_t *regen, uint64_t *seed0, uint8_t *has_seed, uint8_t *reseeded, int skip_same, int64_t n, hipStream_t st);
 hipError_t mgx_launch_consume(const ConsumeParams &p, hipStream_t st);
 hipError_t mgx_launch_step(const StepParams &p, int mode, int waves_per_block, hipStream_t st);
+hipError_t mgx_launch_rollout(const StepParams &p, const uint8_t *actions, uint8_t *obs, float *reward, uint8_t *done, int64_t T, hipStream_t st);
 hipError_t mgx_preload_step_kernels();
 // (every .hip file is a code object of its own; one lookup each loads it at mgx_create instead of inside the first reset / step)
 hipError_t mgx_preload_levelgen_kernels();

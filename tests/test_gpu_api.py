@@ -102,7 +102,7 @@ def test_two_handles_two_streams_and_stats():
                                         ("MiniGrid-Dynamic-Obstacles-6x6-v0", 512, 12)])
 def test_rollout_graph_equals_stepping(env_id, N, T):
     """mgx_rollout (T steps captured into one hipGraph, replayed) == T mgx_step calls, on every output byte; the replay
-    of the cached graph continues the episodes."""
+    of the cached graph continues the episodes.  (DoorKey takes the fused one-launch form here: see the next test.)"""
     seeds = np.arange(N, dtype=np.uint64)
     a_env = mg.VecMiniGrid(env_id, num_envs=N, seeds=seeds, backend="torch", new_level_each_episode=("Lava" in env_id))
     b_env = mg.VecMiniGrid(env_id, num_envs=N, seeds=seeds, backend="torch", new_level_each_episode=("Lava" in env_id))
@@ -123,6 +123,47 @@ def test_rollout_graph_equals_stepping(env_id, N, T):
     with pytest.raises(mg.MgxError):
         host = np.zeros((T, N), np.uint8)
         _lib.check(_lib.lib().mgx_rollout(a_env._h, T, host.ctypes.data, None, None, None))
+    a_env.close(); b_env.close()
+
+
+@pytest.mark.parametrize("form", ["fused", "graph"])
+@pytest.mark.parametrize("env_id,N,T,auto", [("MiniGrid-DoorKey-8x8-v0", 1008, 700, True),        # time-outs at 640: resets of dirty envs (N: multiples of 16, the API's obs alignment)
+                                             ("MiniGrid-LavaCrossingS9N1-v0", 1552, 90, True),     # resets every step, nothing dirty
+                                             ("MiniGrid-Fetch-8x8-N3-v0", 784, 60, True),          # task rule; the terminal pickup is undone
+                                             ("MiniGrid-Empty-16x16-v0", 208, 40, True),           # 3 waves per block
+                                             ("MiniGrid-KeyCorridorS3R3-v0", 336, 80, False),      # caller resets: cells keep changing
+                                             ("MiniGrid-Unlock-v0", 64, 50, True)])
+def test_rollout_fused_equals_stepping(env_id, N, T, auto, form, monkeypatch):
+    """k_rollout (all T steps in ONE launch, the tile resident in LDS) against T mgx_step calls: observations, rewards, dones of
+    every step, then state, task words and counters; a second rollout continues from the written-back state.  MGX_ROLLOUT=graph
+    runs the same check on the captured-graph form."""
+    if form == "graph":
+        monkeypatch.setenv("MGX_ROLLOUT", "graph")
+    seeds = np.arange(N, dtype=np.uint64) * 3 + 1
+    a_env = mg.VecMiniGrid(env_id, num_envs=N, seeds=seeds, backend="torch", auto_reset=auto)
+    b_env = mg.VecMiniGrid(env_id, num_envs=N, seeds=seeds, backend="torch", auto_reset=auto)
+    a_env.reset(); b_env.reset()
+    chunk = 64 if T > 200 else T
+    done_total = 0
+    for rep, t0 in enumerate(range(0, 2 * T, chunk)):
+        n = min(chunk, 2 * T - t0)
+        acts = a_env.fill_actions(21, t0, n)
+        obs, rew, done = a_env.rollout(acts)
+        for t in range(n):
+            o, r, d, _ = b_env.step(acts[t])
+            assert torch.equal(obs[t], o), (rep, t)
+            assert torch.equal(rew[t], r) and torch.equal(done[t], d), (rep, t)
+        done_total += int(done.sum())
+        if rep % 4 == 0:
+            sa, sb = a_env.get_state(), b_env.get_state()
+            for k in sa:
+                assert np.array_equal(sa[k], sb[k]), (k, rep)
+    assert done_total > 0 or "16x16" in env_id             # (Empty-16x16 times out after 1,024 steps)
+    assert a_env.stats() == b_env.stats()
+    if a_env.cfg.task_kind:
+        assert np.array_equal(a_env.get_task(), b_env.get_task())
+    o2, _, _ = a_env.rollout(acts[:1], with_obs=False)      # reward / done only: no observation stream at all
+    assert o2 is None
     a_env.close(); b_env.close()
 
 
