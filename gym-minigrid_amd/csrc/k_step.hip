@@ -418,17 +418,31 @@ __device__ __forceinline__ void emit_partial_obs(const StepParams &p, const Lane
     // the agent's own cell shows what it carries, after occlusion; always visible (minigrid.py:1349-1356)
     code[V / 2][V - 1] = L.carry;
 
-    // pack 49 triples (image[vx][vy][c], vx-major) into 37 dwords; v_perm_b32 picks 4 of the 8 bytes {S0,S1}
+    // 49 codes -> 49 (type, color, state) triples (image[vx][vy][c], vx-major) in 37 dwords, FOUR CELLS PER INSTRUCTION: the codes
+    // of 4 consecutive cells are packed into one dword and decoded byte-parallel with the instructions that issue at full rate
+    // on this chip (and / or / xor / add / sub / lshr: tools/ubench/issue_rate.hip; v_perm, v_cndmask, v_cmp, v_bfe, v_lshl*, SDWA run
+    // at half rate, and the cell-by-cell decode was made of them: ~15 issue slots per cell, now ~8 with the packing and the
+    // interleave):   k = c & 15;  col = (c >> 4) & 7;  shut = k >= 11  (k + 0x75 carries into bit 7; k <= 15: no carry between
+    // bytes);  type = shut ? 4 : k;  state = shut ? (k + 2) & 3 : 0   (11 -> 1 closed, 12 -> 2 locked).
     uint32_t D[NDW];
 #pragma unroll
     for (int q = 0; q < NQ; q++) {
-        const uint32_t c0 = decode_triple(code[(4 * q) / V][(4 * q) % V]);
-        const uint32_t c1 = decode_triple(code[(4 * q + 1) / V][(4 * q + 1) % V]);
-        const uint32_t c2 = decode_triple(code[(4 * q + 2) / V][(4 * q + 2) % V]);
-        const uint32_t c3 = decode_triple(code[(4 * q + 3) / V][(4 * q + 3) % V]);
-        D[3 * q + 0] = __builtin_amdgcn_perm(c1, c0, 0x04020100u); // c0.b0 c0.b1 c0.b2 c1.b0
-        D[3 * q + 1] = __builtin_amdgcn_perm(c2, c1, 0x05040201u); // c1.b1 c1.b2 c2.b0 c2.b1
-        D[3 * q + 2] = __builtin_amdgcn_perm(c3, c2, 0x06050402u); // c2.b2 c3.b0 c3.b1 c3.b2
+        const uint32_t c0 = code[(4 * q) / V][(4 * q) % V], c1 = code[(4 * q + 1) / V][(4 * q + 1) % V];
+        const uint32_t c2 = code[(4 * q + 2) / V][(4 * q + 2) % V], c3 = code[(4 * q + 3) / V][(4 * q + 3) % V];
+        const uint32_t P = __builtin_amdgcn_perm(c1, c0, 0x0C0C0400u) | __builtin_amdgcn_perm(c3, c2, 0x04000C0Cu); // c0 c1 c2 c3
+        const uint32_t k4 = P & 0x0F0F0F0Fu;
+        const uint32_t col4 = (P >> 4) & 0x07070707u;
+        const uint32_t m80 = (k4 + 0x75757575u) & 0x80808080u;      // 0x80 in the bytes of closed / locked doors
+        const uint32_t m1 = m80 >> 7;                                // 0x01 there
+        const uint32_t mFF = (m80 - m1) | m80;                       // 0xFF there
+        const uint32_t T4 = k4 ^ ((k4 ^ 0x04040404u) & mFF);         // type: 4 for doors of any state
+        const uint32_t S4 = (k4 + 0x02020202u) & 0x03030303u & mFF;  // state
+        // interleave the three byte planes: t0 c0 s0 t1 | c1 s1 t2 c2 | s2 t3 c3 s3
+        const uint32_t X0 = __builtin_amdgcn_perm(col4, T4, 0x010C0400u), X1 = __builtin_amdgcn_perm(col4, T4, 0x06020C05u),
+                       X2 = __builtin_amdgcn_perm(col4, T4, 0x0C07030Cu);
+        D[3 * q + 0] = __builtin_amdgcn_perm(S4, X0, 0x03040100u);
+        D[3 * q + 1] = __builtin_amdgcn_perm(S4, X1, 0x03020500u);
+        D[3 * q + 2] = __builtin_amdgcn_perm(S4, X2, 0x07020106u);
     }
     D[NDW - 1] = decode_triple(code[V - 1][V - 1]); // 3 bytes
 
