@@ -77,3 +77,36 @@ def test_shard_b_matches_the_oracle_directly():
         assert np.array_equal(obs.cpu().numpy(), want), t
         assert np.array_equal(done.cpu().numpy(), o_done) and np.array_equal(rew.cpu().numpy(), o_rew.astype(np.float32))
     B.close()
+
+
+def test_config4_eight_shards_equal_one_handle():
+    """BASELINE configs[3] at its stated size: MiniGrid-LavaCrossingS9N1-v0, 4,194,304 envs as 8 shards of 524,288 (here all on
+    one GPU, one handle per shard with its global env_offset) against ONE handle of 4,194,304 envs: the concatenated per-env
+    done / reward vectors -- what the RCCL all-gather of the 8-GPU run delivers, rank-major -- and the observations equal the
+    single handle's on every step checked, and the counters add up.  (The collective itself needs 8 processes: tests/test_dist_gloo.py
+    and tests/test_bench_launcher.py cover its order on CPU.)"""
+    env_id, G, n, T = "MiniGrid-LavaCrossingS9N1-v0", 8, 524288, 48
+    kw = dict(seeds=0, auto_reset=True, backend="torch")
+    shards = [mg.VecMiniGrid(env_id, num_envs=n, env_offset=r * n, **kw) for r in range(G)]
+    assert [mdist.shard(G * n, r, G) for r in range(G)] == [(r * n, n) for r in range(G)]
+    C = mg.VecMiniGrid(env_id, num_envs=G * n, env_offset=0, **kw)
+    oc = C.reset()
+    for r, e in enumerate(shards):
+        assert torch.equal(e.reset(), oc[r * n:(r + 1) * n])
+    acts_c = C.fill_actions(2, 0, T)
+    acts = [e.fill_actions(2, 0, T) for e in shards]
+    episodes = 0
+    for t in range(T):
+        oc, rc, dc, _ = C.step(acts_c[t])
+        outs = [e.step(a[t]) for e, a in zip(shards, acts)]
+        assert torch.equal(torch.cat([o[2] for o in outs]), dc) and torch.equal(torch.cat([o[1] for o in outs]), rc), t
+        if t % 8 == 7 or t < 2:
+            for r, o in enumerate(outs):
+                assert torch.equal(o[0], oc[r * n:(r + 1) * n]), (t, r)
+        episodes += int(dc.sum())
+    assert episodes > 100000
+    st = [e.stats() for e in shards]
+    assert sum(s["episodes"] for s in st) == C.stats()["episodes"] == episodes
+    assert abs(sum(s["reward_sum"] for s in st) - C.stats()["reward_sum"]) < 1e-6
+    for e in shards + [C]:
+        e.close()
