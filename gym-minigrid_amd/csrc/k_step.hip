@@ -580,7 +580,9 @@ __device__ __forceinline__ void emit_full_obs(const StepParams &p, const Lane &L
 
 
 
-template <int CW, int CH, int MODE, int V, bool ALT = false>
+// OBJ: the handle keeps hidden Goal/Box state (object_state planes).  Always on for the run-time-size instances, and for the two
+// sized ones ObstructedMaze needs (11x6, 16x16: round 2); pruned from every other sized instance.
+template <int CW, int CH, int MODE, int V, bool ALT = false, bool OBJ = (CW == 0)>
 __global__ __launch_bounds__(256) void k_step(const StepParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -625,7 +627,7 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
             const uint32_t carry0 = L.carry;
             fc = row[fidx];
             // hidden object state rides only on the run-time-size kernels (mgx_launch_step routes there): pruned from the sized ones
-            const bool has_obj = CW == 0 && p.objaux != nullptr;
+            const bool has_obj = OBJ && p.objaux != nullptr;
             const ObjRef obj = {has_obj ? p.objaux + env * S : nullptr, has_obj ? p.objcont + env * S : nullptr, has_obj ? p.objcarry + env : nullptr};
             nc = transition_apply<CH>(p, L, act, fc, reward, done, [&](int i) -> uint32_t { return row[i]; }, oob, fidx, obj);
             if constexpr (!GATHER) { if (nc != fc) g[fidx] = (uint8_t)nc; }
@@ -658,7 +660,7 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
                 pidx = -1;
             } else if (needs_copy) restore_own<CS>(p, env, g);
             else if (nc != fc) g[fidx] = (uint8_t)fc; // a terminal step that changed a cell (Fetch's pickup): only the LDS image saw it
-            if (CW == 0) restore_objstate(p, env);
+            if (OBJ) restore_objstate(p, env);
             L = unpack_rec(p.agent0[env], p.task);
             if (p.regen) p.regen[env] = 1; // the next-level buffer was consumed: k_levelgen refills it after this launch
         }
@@ -1150,6 +1152,10 @@ hipError_t mgx_launch_step(const StepParams &p, int mode, int waves_per_block, h
         MGX_VIEWS(VCASE)
 #undef VCASE
         return hipErrorInvalidValue;
+    }
+    if (p.objaux && mode == 0 && p.view == 7) { // ObstructedMaze's grids with their boxed keys: sized instances that keep the plane accesses
+        if (p.W == 11 && p.H == 6) { hipLaunchKernelGGL((k_step<11, 6, 0, 7, false, true>), grid, block, shmem, st, p); return hipGetLastError(); }
+        if (p.W == 16 && p.H == 16) { hipLaunchKernelGGL((k_step<16, 16, 0, 7, false, true>), grid, block, shmem, st, p); return hipGetLastError(); }
     }
     if (p.objaux) return launch_sized<0, 0>(p, mode, grid, block, shmem, st);
 #define CASE(w, h) if (p.W == w && p.H == h) return launch_sized<w, h>(p, mode, grid, block, shmem, st);

@@ -21,7 +21,8 @@ FAMILIES = ["MiniGrid-Empty-8x8-v0", "MiniGrid-DoorKey-8x8-v0", "MiniGrid-LavaCr
             "MiniGrid-LavaGapS7-v1", "MiniGrid-MultiRoom-N4-S5-v0", "MiniGrid-FourRooms-v0", "MiniGrid-Fetch-8x8-N3-v0",
             "MiniGrid-GoToDoor-8x8-v0", "MiniGrid-GoToObject-8x8-N2-v0", "MiniGrid-PutNear-8x8-N3-v0", "MiniGrid-RedBlueDoors-8x8-v0",
             "MiniGrid-MemoryS13Random-v0", "MiniGrid-UnlockPickup-v0", "MiniGrid-BlockedUnlockPickup-v0", "MiniGrid-KeyCorridorS4R3-v0",
-            "MiniGrid-LockedRoom-v0", "MiniGrid-Playground-v0", "MiniGrid-TwoGoals-8x8-v0", "MiniGrid-TwoGoals-Random-16x16-v0"]
+            "MiniGrid-LockedRoom-v0", "MiniGrid-Playground-v0", "MiniGrid-TwoGoals-8x8-v0", "MiniGrid-TwoGoals-Random-16x16-v0",
+            "MiniGrid-ObstructedMaze-1Dlhb-v0", "MiniGrid-ObstructedMaze-2Dlh-v0", "MiniGrid-ObstructedMaze-Full-v0"]
 
 
 def main():
@@ -34,11 +35,13 @@ def main():
         seeds = np.arange(N, dtype=np.uint64) * 11 + 3
         env = mg.VecMiniGrid(env_id, num_envs=N, seeds=seeds, auto_reset=True, backend="torch", obs_mode="full" if full else "partial")
         obs = env.reset().cpu().numpy()
-        grid, agent, task = mg.generate_levels(env_id, seeds, with_task=True)
+        grid, agent, task, contains = mg.generate_levels(env_id, seeds, with_task=True, with_contains=True)
         cfg = mg.env_config(env_id)
         orc = OracleEnvs(cfg.width, cfg.height, cfg.max_steps, cfg.see_through_walls, cfg.lava_v1, task=cfg.task_kind)
         orc.set_state(grid, agent)
         orc.task = task.copy()
+        if cfg.object_state:          # ObstructedMaze: keys hidden in boxes
+            orc.set_contains(contains)
         assert np.array_equal(obs, orc.observe(True)[int(full)]), env_id
         rs = np.random.RandomState(5)
         episodes = 0
