@@ -103,7 +103,7 @@ def test_golden_trace_autoreset(name):
     (the reference's recorded `reset()` observation), state is the episode start."""
     meta, z = load_case(name)
     if not meta.get("reseed", True):
-        pytest.skip("recorded without re-seeding (a new level per episode): the in-kernel reset of those is test_stream_mode's")
+        pytest.skip("recorded without re-seeding (a new level per episode): tests/test_gpu_stream.py::test_reference_stream_traces replays it")
     K, T = z["actions"].shape
     N = 64 + K
     sel = np.arange(N) % K
