@@ -733,7 +733,9 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
 //              the same stream of 12-byte records.  (Before this form these sizes went through the LDS tile image:
 //              3.0-3.7 TB/s for the sized kernels, 0.8-1.2 for 19x19 / 25x25.)
 template <int CW, int CH, bool RAGGED = false>
-__global__ __launch_bounds__(256) void k_step_fulldirect(const StepParams p)
+// (19x19: 64 VGPRs = 8 resident blocks per CU, so that 131,072 envs = 2,048 blocks are ONE round: 46.7 -> 40.2 us, at the price
+// of six spilled dwords)
+__global__ __launch_bounds__(256, (RAGGED && CW == 19) ? 8 : 1) void k_step_fulldirect(const StepParams p)
 {
     __shared__ uint32_t s_info[64]; // per env: agent idx | dir<<16 | reset<<18 | (1<<19 if a cell changed)
     __shared__ uint32_t s_wr[64];   // changed cell: idx | code<<16
