@@ -10,13 +10,11 @@
 // ------------------------------------------------------------------------------------------------
 // Dynamic-Obstacles (envs/dynamicobstacles.py:60-89).  The obstacle walk draws from the env's own MT19937 stream
 // inside step(), so it cannot live in the streaming step kernel: k_dynobs runs before it, one lane per env.
-//   RNG   : the per-env block `mt` is the one k_seed/k_levelgen left behind (words [pos, 624) not drawn yet).  Past
-//           the block the next words are produced ONE AT A TIME in place -- new[k] = f(old[k], old[k+1], old[k+397] or
-//           new[k-227]) is exactly the order genrand's bulk twist uses, so the stream is numpy's -- which costs three
-//           loads and a store per draw instead of a 2.5 KB twist per lane.
-//   reset : the in-kernel auto-reset of the step kernels raises regen[env]; the walk then first restores the obstacle
-//           order and the RNG position of the episode start (ReseedWrapper: seed(s) + reset()), and the block itself
-//           only if the episode ran past it (pos > 624), which random-action episodes (~6 steps) never do.
+//   RNG   : the per-env block `mt` is the one k_seed/k_levelgen left behind (words [pos, 624) not drawn yet); `tape` holds the
+//           low two bits of its tempered words and of the first 224 words of the next block (see "the draw tape" below).
+//   reset : the in-kernel auto-reset of the step kernels raises restart[env] (DynObsParams.regen); the walk then first restores
+//           the obstacle order and the RNG position of the episode start (ReseedWrapper: seed(s) + reset()), and block + tape
+//           only if the episode twisted or touched the block (bit 31 of the stored position).
 namespace {
 __global__ __launch_bounds__(256) void k_dynobs_init(const DynObsParams p)
 {
@@ -51,36 +49,28 @@ __global__ __launch_bounds__(256) void k_dynobs_init(const DynObsParams p)
     p.regen[t] = 0;
 }
 
-// One wave per tile of 64 envs, lane per env, like k_step.  The walk is a chain of draw -> look at a cell -> maybe draw
-// again, every link depending on the one before and diverging between lanes.  Three forms were measured at 1 Mi 8x8 envs:
-// lane-per-env straight from HBM 0.55-1.9 ms per step (a memory round trip per link); cells + a byte-wide window of
-// tempered words staged in LDS 0.28 ms (bound by VALU issue: the per-draw rejection loops and the try loops run for the
-// slowest lane of the wave, ~4.5 k instructions per wave); this one:
-//   * every draw of the walk is `bounded(2)` (a 3-wide range: obstacles live in the interior, so the 3x3 box never
-//     clips): masked rejection on the low two bits of the tempered word.  The accepted draws are therefore simply the
-//     words whose two bits are not 3, in order.  The wave loads the next 64 words of env e with ONE coalesced 256-B
-//     load (lane = word), computes the two bits (a 6-op shortcut of the tempering) and takes three BALLOTS -- valid,
-//     bit 0, bit 1 -- which are exactly env e's window as three 64-bit masks; lane e keeps them in registers.  A draw is
-//     then `ctz(valid >> cursor)` + two bit extracts: no loop, no memory access.
+// One wave per tile of 64 envs, lane per env, like k_step.  The walk is a chain of draw -> look at a cell -> maybe draw again,
+// every link depending on the one before and diverging between lanes.
+//   * every draw of the walk is `bounded(2)` (a 3-wide range: obstacles live in the interior, so the 3x3 box never clips):
+//     masked rejection on the low two bits of the tempered word.  The accepted draws are therefore simply the words whose
+//     two bits are not 3, in order: a window of 64 stream positions is three 64-bit masks (valid, bit 0, bit 1), and a draw
+//     is ffbl + clear-lowest-bit + two bit extracts: no loop, no memory access.
+//   * THE DRAW TAPE.  Each block has a tape: two bit planes (bit k of plane 0 / 1 = bit 0 / 1 of tempered word k) over 848
+//     stream positions -- the 624 words of the block and the first 224 of the NEXT one, which depend on the old block only
+//     (new[k] = twist(old[k], old[k+1], old[k+397]) for k < 227).  The whole wave builds it once per block (k_dynobs_tape at
+//     reset; the service loop of k_dynobs when a block is finished or restored: 14 rounds of 64 positions, two ballots
+//     each); a step reads its window as two unaligned 12-byte loads per lane, and again for every further 64 positions a
+//     long placement needs.  (Round 1 rebuilt every env's window every step with 64 coalesced loads + 192 ballots per wave --
+//     ~1,700 of its 4,400 VALU instructions and 256 B/env of reads for the ~11 words a step consumes -- and every env within 64
+//     words of its block's end, i.e. some lane of nearly every wave, fell through to one dependent global load per draw.)
+//   * positions 624..847 are consumed from the tape WITHOUT touching the block; the stored position then is >= 624 and the next
+//     step's service loop twists the whole block (in LDS, chunks of <= 227 independent words), rebuilds the tape and takes
+//     624 off the position.  Only a lane that runs off the tape altogether falls back to DynRng's word-by-word source, which
+//     first catches the block up in place (bit 30 of the stored position: words [0, pos - 624) already belong to the new block).
 //   * the tile's cells are staged in LDS as k_step stages them; moved obstacles are written through to HBM.
-// RNG bookkeeping: `pos` counts the words drawn since the block in memory was complete (bit 31: the block is no longer
-// the episode-start block).  A lane that exhausts its 64-word window reads the global words, and past the block it
-// produces the next block's words one at a time in place (new[k] from old[k], old[k+1], old[k+397] or new[k-227]: the
-// order of genrand's bulk twist, so the stream is numpy's).  At the start of the next step the whole wave finishes such
-// a half-regenerated block (words k..623, in LDS, in chunks of <= 227 independent words) so that the env is back on the
-// window path; the in-kernel auto-reset of the step kernels raises regen[env], upon which the wave restores the
-// obstacle order, the RNG position and -- if it was touched -- the block from the episode-start snapshot
-// (ReseedWrapper: seed(s) + reset()).
-// Round 2, the DRAW TAPE: the first form rebuilt every env's 64-word window every step (64 coalesced loads + 192 ballots per
-// wave: ~1,700 of its 4,400 VALU instructions and 256 B/env of reads for the ~11 words a step consumes), and every env within
-// 64 words of its block's end (10 % of them, i.e. some lane of nearly every wave) fell through to one dependent global load
-// per draw.  Now each block has a tape: two bit planes (bit k of plane 0 / 1 = bit 0 / 1 of the tempered word k) over 848
-// stream positions -- the 624 words of the block and the first 224 of the NEXT one, which depend on the old block only
-// (new[k] = twist(old[k], old[k+1], old[k+397]) for k < 227).  It is built by the whole wave once per block (k_dynobs_tape at
-// reset, the service loop below when a block is finished or restored); a step reads its window as two unaligned 12-byte
-// loads per lane (and again for every further 64 positions a long placement needs).  Positions 624..847 are consumed from
-// the tape without touching the block; the service loop of the next
-// step then twists the whole block (bit 30 of the stored position says whether a lane already regenerated words in place).
+//   * history (1 Mi 8x8 envs, us per launch): lane-per-env straight from HBM 550-1,900; byte-wide windows in LDS 280; ballot-built
+//     register windows 254 (round 1); the tape 186; + look-ahead 224, further windows, the hopeless-box skip, one flat
+//     (obstacle, try) loop per lane: 143.
 typedef unsigned long long dyn_u64;
 #define MGX_DYN_PLANE_DW (MGX_DYN_TAPE_DW / 2)
 #define MGX_DYN_POSITIONS 848 /* 624 + 224: the head of the next block depends on the old block only for k < 227 */
