@@ -962,7 +962,7 @@ extern "C" int mgx_reset(mgx_handle h, const uint64_t *seeds, const uint8_t *mas
         const void *ds = nullptr, *dm = nullptr;
         if ((rc = dev_in(h, 4, seeds, n * sizeof(uint64_t), &ds, 8))) return rc;
         if ((rc = dev_in(h, 5, mask, n, &dm))) return rc;
-        // (k_seed clears the regeneration flags of every env before it raises those of the envs it seeds)
+        // (k_seed clears the regeneration flags of the envs being reset before it raises those of the envs it really seeds)
         // (an env that keeps its seed keeps its level: with the snapshot still holding it -- not in stream mode, where the
         // buffer holds the NEXT level -- seeding and generation are skipped for it and k_consume alone restores it)
         HIP_TRY(mgx_launch_seed((const uint64_t *)ds, (const uint8_t *)dm, h->mt_init_d, h->mt_d, h->mt_idx_d, h->regen_d, h->seed0_d, h->has_seed_d,
