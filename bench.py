@@ -27,7 +27,7 @@ ranks; rank 0 prints ONE JSON line.
 Extra objects on the line:
   roofline     the step kernel (k_step / k_step_fulldirect) against the HBM roof: algorithmic bytes per launch / the
                kernel's average duration, measured with HIP events on the launch stream inside the timed region two ways:
-               `event_pair_us` = event pairs around every 8th launch of THAT kernel (mgx_profile_kernel; includes the ~2 us
+               `event_pair_us` = event pairs around every 16th launch of THAT kernel (mgx_profile_kernel; includes the ~2 us
                the two markers take), `span_us_per_step` = the whole stream span / steps (includes launch gaps and, where a
                workload has them, k_dynobs / epilogues / k_levelgen).  Both bound the kernel from above; `avg_kernel_us` is
                the smaller one, rocprofv3's per-dispatch average under profiles/ reads just below it.
@@ -317,7 +317,7 @@ def main():
     read_stats(stats0)
     barrier()
     if not dry:
-        env.profile_begin(stride=8)
+        env.profile_begin(stride=16)   # an event pair around every 16th launch of the step kernel (each pair costs the stream ~2 us)
     t0 = time.perf_counter()
     for t in range(Wm, Wm + K):
         step(t)
