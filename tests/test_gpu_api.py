@@ -378,3 +378,25 @@ def test_reset_of_a_random_family_beyond_64x64_runs_on_the_host_generator():
     m = (np.arange(N) % 2).astype(bool)
     assert np.array_equal(st2["agent"][m], agent[m]) and (st2["steps"][m] == 0).all() and (st2["steps"][~m] == 5).all()
     env.close()
+
+
+def test_profile_span_and_per_launch_samples():
+    """mgx_profile_*: one event pair around the span + one around every n-th launch of the step kernel alone."""
+    env = mg.VecMiniGrid("MiniGrid-DoorKey-8x8-v0", num_envs=65536, seeds=0, backend="torch")
+    env.reset()
+    acts = env.fill_actions(1, 0, 12)
+    env.profile_begin(stride=3)
+    for t in range(12):
+        env.step(acts[t])
+    launches, span_ms = env.profile_end()
+    samples, kernel_ms = env.profile_kernel()
+    assert launches == 12 and samples == 4                       # launches 0, 3, 6, 9
+    assert 0 < kernel_ms / samples < 1.0 and span_ms > 0         # a 65,536-env step is ~10 us
+    assert kernel_ms / samples < 3 * span_ms / launches + 0.05   # same order: both bound the kernel from above
+    with pytest.raises(mg.MgxError):
+        env.profile_end()                                        # not running any more
+    env.profile_begin()                                          # default stride 8; rollouts count launches but are not sampled
+    env.rollout(acts)
+    launches, _ = env.profile_end()
+    assert launches == 12 and env.profile_kernel()[0] == 0
+    env.close()
