@@ -59,6 +59,7 @@ struct StepParams {
     int n_tiles;
     int W, H, S, LS, wave_lds, view;
     int max_steps, see_through, lava_v1, auto_reset, do_step, extended, alt_vis, task;
+    int tail_block0;       // blocks from this index on (the last two per CU of the grid: mgx_launch_step) run at wave priority 3
 };
 
 struct PackParams {

@@ -1,0 +1,75 @@
+// Micro-benchmark (tuning aid, not product): the memory skeleton of k_step with no compute.  One wave per 64-env tile reads RB bytes
+// per env (state: re-read every launch, so cache-resident where it fits) and writes WB bytes per env (observation: non-temporal,
+// dependent on the loads), in k_step's launch shape.  Prints the span per launch over back-to-back launches.
+//   hipcc --offload-arch=gfx950 -O3 -o stream_mix stream_mix.hip && ./stream_mix
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+
+// RQ / WQ: 16-byte quads per tile read / written.  NT: 0 plain stores, 1 non-temporal.  WAVES: waves per block.
+template <int RQ, int WQ, int NT>
+__global__ __launch_bounds__(256) void k(const u4 *__restrict__ in, u4 *__restrict__ out, int n_tiles)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int tile = blockIdx.x * (blockDim.x >> 6) + wv;
+    if (tile >= n_tiles) return;
+    const u4 *src = in + (size_t)tile * RQ;
+    u4 *dst = out + (size_t)tile * WQ;
+    u4 acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < (RQ + 63) / 64; i++) {
+        const int q = i * 64 + lane;
+        if (q < RQ) acc ^= src[q];
+    }
+    // every lane's stores depend on every lane's loads, as the view gather does
+    acc.x ^= __shfl_xor(acc.x, 1); acc.y ^= __shfl_xor(acc.y, 2); acc.z ^= __shfl_xor(acc.z, 4); acc.w ^= __shfl_xor(acc.w, 8);
+#pragma unroll
+    for (int i = 0; i < (WQ + 63) / 64; i++) {
+        const int q = i * 64 + lane;
+        if (q < WQ) {
+            u4 v = acc; v.x += i;
+            if (NT) __builtin_nontemporal_store(v, &dst[q]); else dst[q] = v;
+        }
+    }
+}
+
+template <int RQ, int WQ, int NT>
+static void run(const char *name, int n_envs, int wpb, u4 *in, u4 *out)
+{
+    const int n_tiles = n_envs / 64, iters = 300;
+    dim3 grid((n_tiles + wpb - 1) / wpb), block(wpb * 64);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 30; i++) hipLaunchKernelGGL((k<RQ, WQ, NT>), grid, block, 0, 0, in, out, n_tiles);
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; i++) hipLaunchKernelGGL((k<RQ, WQ, NT>), grid, block, 0, 0, in, out, n_tiles);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / iters, bytes = (double)n_tiles * (RQ + WQ) * 16;
+    printf("%-34s envs %8d  wpb %d  %7.2f us/launch  %6.0f GB/s (R %5.1f MB + W %5.1f MB)\n", name, n_envs, wpb, us, bytes / us * 1e-3,
+           n_tiles * RQ * 16e-6, n_tiles * WQ * 16e-6);
+    fflush(stdout);
+}
+
+int main()
+{
+    const size_t cap = (size_t)4 << 30;
+    u4 *in, *out;
+    CK(hipMalloc(&in, cap)); CK(hipMalloc(&out, cap));
+    CK(hipMemset(in, 1, cap)); CK(hipMemset(out, 0, cap));
+    // LavaCrossing 9x9: read 84 (cells, padded) + 8 (record) + 1 (action) ~ 92 B/env = 368 quads per tile; write 147 + 8 + 4 + 1 = 160 B/env = 640 quads
+    const int sizes[] = {262144, 524288, 1048576, 2097152, 4194304};
+    for (int n : sizes) {
+        run<368, 640, 1>("lava 9x9 skeleton, nt stores", n, 4, in, out);
+        run<368, 640, 0>("lava 9x9 skeleton, plain stores", n, 4, in, out);
+        run<368, 640, 1>("lava 9x9 skeleton, nt, 1 wave/blk", n, 1, in, out);
+        run<0, 640, 1>("writes only (160 B/env), nt", n, 4, in, out);
+        run<368, 4, 1>("reads only (92 B/env)", n, 4, in, out);
+        run<1008, 1008, 1>("copy 252 B/env each way, nt", n, 4, in, out);
+    }
+    return 0;
+}
