@@ -25,6 +25,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#ifdef MGX_TIMELINE
+#include <stdio.h>
+#include <vector>
+#endif
 
 #include "mgx_internal.h"
 #include "mgx_kernels.h"
@@ -302,7 +306,7 @@ __device__ __forceinline__ void wave_stats(const StepParams &p, bool valid, bool
 // B = 3*V*V bytes per env is always 3 mod 4 for odd V, so the byte-phase logic below is the same for every V.
 template <int CW, int CH, int V, bool ALT, bool GATHER = false>
 __device__ __forceinline__ void emit_partial_obs(const StepParams &p, const Lane &L, uint8_t *lds, const uint8_t *g,
-                                                 int64_t env0, int lane, int pidx = -1, uint32_t pcode = 0)
+                                                 int64_t env0, int lane, int pidx = -1, uint32_t pcode = 0, unsigned long long *tlv = nullptr)
 {
     constexpr int B = V * V * 3;       // bytes per observation (147 for V = 7)
     constexpr int NDW = (B + 1) / 4;   // dwords holding one observation, the last with 3 valid bytes (37)
@@ -467,6 +471,9 @@ __device__ __forceinline__ void emit_partial_obs(const StepParams &p, const Lane
     const int lim_all = nv >= 64 ? 64 * B : (int)nv * B;
     uint32_t *o32 = reinterpret_cast<uint32_t *>(lds) + (((uint32_t)B * (uint32_t)(lane & 31)) >> 2);
     const uint4 *l128 = reinterpret_cast<const uint4 *>(lds);
+#ifdef MGX_TIMELINE
+    if (tlv) tlv[3] = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         wave_sync(); // every lane is done reading what this image overlays (grid image / previous half)
@@ -602,7 +609,20 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
     // The grid's last blocks are dispatched into a chip that is draining: at the default (equal) priority they share their SIMDs'
     // issue slots with the waves still finishing, and the launch ends one contended wave lifetime after they start.  At priority 3
     // they run through first; worth 1.6 us of 26.5 at 524,288 LavaCrossing envs and 1.1 of 39.4 at 1 Mi Empty-8x8.
+#ifdef MGX_TIMELINE
+    unsigned long long tlv[5];
+    tlv[0] = __builtin_amdgcn_s_memrealtime();
+#endif
     if ((int)blockIdx.x >= p.tail_block0) __builtin_amdgcn_s_setprio(3);
+    // ... and the FIRST round of blocks starts all at once: every wave's loads queue behind everyone else's, then 7 waves per SIMD
+    // compute at the same time, and nothing is stored until the first of them is through (wave timelines, profiles/r02_timeline_*:
+    // no store before 7 us of a 24 us launch).  The waves of the first round therefore start one after the other per SIMD: slot k of
+    // a SIMD sleeps k * stagger * 256 clocks before its first load.  LavaCrossing 524,288 envs 25.0 -> 22.6 us, 1 Mi 45.3 -> 43.6.
+    if (p.stagger && (int)blockIdx.x < p.round_blocks) {
+        uint32_t slot;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(slot));
+        for (uint32_t i = (slot < 7u ? slot : 7u) * (uint32_t)p.stagger; i; i--) __builtin_amdgcn_s_sleep(4);
+    }
     const uint2 rec = p.agent[env]; // agent/cells arrays are padded to whole tiles
     uint32_t act = 6;
     if (p.do_step && valid) act = __builtin_nontemporal_load(&p.actions[env]);
@@ -616,6 +636,9 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
         stage_tile<CS>(p.cells, env0, S, LS, lds, lane);
         wave_sync();
     }
+#ifdef MGX_TIMELINE
+    tlv[1] = __builtin_amdgcn_s_memrealtime();
+#endif
 
     Lane L = unpack_rec(rec, p.task);
     uint8_t *g = lds + lane * LS;                       // (staged modes) this env's cells in LDS
@@ -711,7 +734,24 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
                 Lw.ax = L.ax - x0; Lw.ay = L.ay - y0;
                 emit_partial_obs<7, 8, V, ALT, false>(p, Lw, lds, win, env0, lane);
             } else emit_partial_obs<CW, CH, V, ALT, true>(p, L, lds, row, env0, lane, pidx, pcode);
-        } else if (MODE == 0) emit_partial_obs<CW, CH, V, ALT>(p, L, lds, g, env0, lane);
+        }
+#ifdef MGX_TIMELINE
+        else if (MODE == 0) {
+            tlv[2] = __builtin_amdgcn_s_memrealtime();
+            emit_partial_obs<CW, CH, V, ALT>(p, L, lds, g, env0, lane, -1, 0, tlv);
+            tlv[4] = __builtin_amdgcn_s_memrealtime();
+            if (p.timeline && lane == 0) {
+                uint32_t hw, xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                unsigned long long *o = p.timeline + (size_t)tile * 8;
+                for (int i = 0; i < 5; i++) o[i] = tlv[i];
+                o[5] = hw; o[6] = xcc; o[7] = blockIdx.x;
+            }
+        }
+#else
+        else if (MODE == 0) emit_partial_obs<CW, CH, V, ALT>(p, L, lds, g, env0, lane);
+#endif
         else emit_full_obs<CW, CH>(p, L, valid, lds, g, LS, env0, lane);
     }
 }
@@ -1084,23 +1124,22 @@ __global__ __launch_bounds__(256) void k_rollout(const StepParams p, const Rollo
     if (__ballot(wrote)) unstage_tile<CS>(p.cells, env0, LS, lds, lane); // (wave-uniform; Empty / Crossing tiles never change)
 }
 
-template <int CW, int CH>
-hipError_t launch_sized(const StepParams &p, int mode, dim3 grid, dim3 block, size_t shmem, hipStream_t st)
-{
-    if (mode == 0) hipLaunchKernelGGL((k_step<CW, CH, 0, 7>), grid, block, shmem, st, p);
-    else if (mode == 1) hipLaunchKernelGGL((k_step<CW, CH, 1, 7>), grid, block, shmem, st, p);
-    else if (((CW && CH) ? CW * CH : p.W * p.H) % 4 == 0) hipLaunchKernelGGL((k_step_fulldirect<CW, CH>), dim3(p.n_tiles), dim3(256), 0, st, p);
-    else if (CW == 0 && !p.objaux && p.W == 19 && p.H == 19) hipLaunchKernelGGL((k_step_fulldirect<19, 19, true>), dim3(p.n_tiles), dim3(256), 0, st, p);
-    else if (CW == 0 && !p.objaux && p.W == 25 && p.H == 25) hipLaunchKernelGGL((k_step_fulldirect<25, 25, true>), dim3(p.n_tiles), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((k_step_fulldirect<CW, CH, true>), dim3(p.n_tiles), dim3(256), 0, st, p);
-    return hipGetLastError();
-}
+// ---- which instantiation runs a handle's step: one selector for the launch, the LDS limit and the residency query ----------------
+using StepKernel = void (*)(const StepParams);
+struct StepChoice {
+    StepKernel fn;
+    bool block_per_tile; // the FullyObs direct forms: a 256-thread block per tile, no dynamic LDS
+};
 
 template <int CW, int CH>
-hipError_t raise_lds_limit(int mode, int bytes)
+StepChoice choose_sized(const StepParams &p, int mode)
 {
-    if (mode == 0) return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<CW, CH, 0, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<CW, CH, 1, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (mode == 0) return {k_step<CW, CH, 0, 7>, false};
+    if (mode == 1) return {k_step<CW, CH, 1, 7>, false};
+    if (((CW && CH) ? CW * CH : p.W * p.H) % 4 == 0) return {k_step_fulldirect<CW, CH>, true};
+    if (CW == 0 && !p.objaux && p.W == 19 && p.H == 19) return {k_step_fulldirect<19, 19, true>, true};
+    if (CW == 0 && !p.objaux && p.W == 25 && p.H == 25) return {k_step_fulldirect<25, 25, true>, true};
+    return {k_step_fulldirect<CW, CH, true>, true};
 }
 
 } // namespace
@@ -1136,6 +1175,60 @@ hipError_t mgx_launch_rollout(const StepParams &p0, const uint8_t *actions, uint
     return hipErrorNotSupported;
 }
 
+static StepChoice choose_step_kernel(const StepParams &p, int mode)
+{
+    const StepChoice none = {nullptr, false};
+    if (mode == 3) { // large grids: gather form (the default view and visibility by the size rule, anything else when the tile image cannot fit the LDS)
+#define VCASE(v) if (p.view == v) return p.alt_vis ? StepChoice{k_step<0, 0, 3, v, true>, false} : StepChoice{k_step<0, 0, 3, v>, false};
+        MGX_VIEWS(VCASE) VCASE(7)
+#undef VCASE
+        return none;
+    }
+    if (mode == 0 && p.alt_vis) { // default_vis=False: run-time grid size only
+#define VCASE(v) if (p.view == v) return {k_step<0, 0, 0, v, true>, false};
+        MGX_VIEWS(VCASE) VCASE(7)
+#undef VCASE
+        return none;
+    }
+    if (mode == 0 && p.view != 7) {
+#define VCASE(v) if (p.view == v) return {k_step<0, 0, 0, v>, false};
+        MGX_VIEWS(VCASE)
+#undef VCASE
+        return none;
+    }
+    if (p.objaux && mode == 0 && p.view == 7) { // ObstructedMaze's grids with their boxed keys: sized instances that keep the plane accesses
+        if (p.W == 11 && p.H == 6) return {k_step<11, 6, 0, 7, false, true>, false};
+        if (p.W == 16 && p.H == 16) return {k_step<16, 16, 0, 7, false, true>, false};
+    }
+    if (p.objaux) return choose_sized<0, 0>(p, mode);
+#define CASE(w, h) if (p.W == w && p.H == h) return choose_sized<w, h>(p, mode);
+    MGX_SIZED(CASE)
+#undef CASE
+    return choose_sized<0, 0>(p, mode);
+}
+
+struct StepShape { dim3 grid, block; size_t shmem; };
+static StepShape step_shape(const StepParams &p, const StepChoice &c, int waves_per_block)
+{
+    if (c.block_per_tile) return {dim3(p.n_tiles), dim3(256), 0};
+    return {dim3((p.n_tiles + waves_per_block - 1) / waves_per_block), dim3(64 * waves_per_block), (size_t)waves_per_block * p.wave_lds};
+}
+
+// Blocks of this handle's step kernel that are resident at once on the whole chip (one "round" of the grid).
+hipError_t mgx_step_round_blocks(const StepParams &p, int mode, int waves_per_block, int *blocks)
+{
+    const StepChoice c = choose_step_kernel(p, mode);
+    if (!c.fn) return hipErrorInvalidValue;
+    const StepShape sh = step_shape(p, c, waves_per_block);
+    int dev = 0, cus = 0, per_cu = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(c.fn), (int)sh.block.x, sh.shmem);
+    if (e != hipSuccess) return e;
+    *blocks = per_cu * cus;
+    return hipSuccess;
+}
+
 // How many of a grid's last blocks run at raised wave priority: two per CU (measured best of 0.5 / 2 / 3.5 / 7 per CU and "the last
 // partial round"); MGX_TAIL_BLOCKS overrides it for tuning runs (0 = off).
 static int tail_blocks()
@@ -1149,66 +1242,51 @@ static int tail_blocks()
     }
     return n;
 }
+// First-round stagger per SIMD wave slot, in units of `s_sleep 4` (256 clocks); MGX_STAGGER overrides it for tuning runs (0 = off).
+static int stagger_units()
+{
+    static int n = -1;
+    if (n < 0) { const char *e = getenv("MGX_STAGGER"); n = e ? atoi(e) : 5; }
+    return n;
+}
 
 hipError_t mgx_launch_step(const StepParams &p0, int mode, int waves_per_block, hipStream_t st)
 {
-    const dim3 block(64 * waves_per_block);
-    const dim3 grid((p0.n_tiles + waves_per_block - 1) / waves_per_block);
+    const StepChoice c = choose_step_kernel(p0, mode);
+    if (!c.fn) return hipErrorInvalidValue;
+    const StepShape sh = step_shape(p0, c, waves_per_block);
     StepParams p = p0;
-    {
-        const int blocks = (mode == 0 || mode == 1 || mode == 3) ? (int)grid.x : p.n_tiles; // (the FullyObs direct forms: a block per tile)
-        const int tb = tail_blocks();
-        p.tail_block0 = (tb > 0 && blocks > tb) ? blocks - tb : 0x7fffffff;
+    const int blocks = (int)sh.grid.x, tb = tail_blocks();
+    p.tail_block0 = (tb > 0 && blocks > tb) ? blocks - tb : 0x7fffffff;
+    static const int stagger_min = getenv("MGX_STAGGER_MIN") ? atoi(getenv("MGX_STAGGER_MIN")) : -1; // (tuning runs: the smallest grid that staggers)
+    p.stagger = (!c.block_per_tile && p.round_blocks > 0 && blocks > (stagger_min >= 0 ? stagger_min : p.round_blocks)) ? stagger_units() : 0;
+#ifdef MGX_TIMELINE
+    {   // launch number MGX_TL_LAUNCH (default 300) of the process records its waves; the next launch writes them to MGX_TL_FILE
+        static unsigned long long *tl = nullptr;
+        static int launches = 0;
+        const char *f = getenv("MGX_TL_FILE");
+        const int at = getenv("MGX_TL_LAUNCH") ? atoi(getenv("MGX_TL_LAUNCH")) : 300;
+        if (f && !tl) { if (hipMalloc(&tl, (size_t)p.n_tiles * 64) != hipSuccess) return hipErrorOutOfMemory; (void)hipMemset(tl, 0, (size_t)p.n_tiles * 64); }
+        p.timeline = (f && launches == at) ? tl : nullptr;
+        if (f && launches == at + 1) {
+            (void)hipStreamSynchronize(st);
+            std::vector<unsigned long long> hbuf((size_t)p.n_tiles * 8);
+            (void)hipMemcpy(hbuf.data(), tl, hbuf.size() * 8, hipMemcpyDeviceToHost);
+            FILE *fp = fopen(f, "wb");
+            if (fp) { fwrite(hbuf.data(), 8, hbuf.size(), fp); fclose(fp); }
+        }
+        launches++;
     }
-    const size_t shmem = (size_t)waves_per_block * p.wave_lds;
-    if (mode == 3) { // large grids: gather form (the default view and visibility by the size rule, anything else when the tile image cannot fit the LDS)
-#define VCASE(v) if (p.view == v) { if (p.alt_vis) hipLaunchKernelGGL((k_step<0, 0, 3, v, true>), grid, block, shmem, st, p); \
-                                    else hipLaunchKernelGGL((k_step<0, 0, 3, v>), grid, block, shmem, st, p); return hipGetLastError(); }
-        MGX_VIEWS(VCASE) VCASE(7)
-#undef VCASE
-        return hipErrorInvalidValue;
-    }
-    if (mode == 0 && p.alt_vis) { // default_vis=False: run-time grid size only
-#define VCASE(v) if (p.view == v) { hipLaunchKernelGGL((k_step<0, 0, 0, v, true>), grid, block, shmem, st, p); return hipGetLastError(); }
-        MGX_VIEWS(VCASE) VCASE(7)
-#undef VCASE
-        return hipErrorInvalidValue;
-    }
-    if (mode == 0 && p.view != 7) {
-#define VCASE(v) if (p.view == v) { hipLaunchKernelGGL((k_step<0, 0, 0, v>), grid, block, shmem, st, p); return hipGetLastError(); }
-        MGX_VIEWS(VCASE)
-#undef VCASE
-        return hipErrorInvalidValue;
-    }
-    if (p.objaux && mode == 0 && p.view == 7) { // ObstructedMaze's grids with their boxed keys: sized instances that keep the plane accesses
-        if (p.W == 11 && p.H == 6) { hipLaunchKernelGGL((k_step<11, 6, 0, 7, false, true>), grid, block, shmem, st, p); return hipGetLastError(); }
-        if (p.W == 16 && p.H == 16) { hipLaunchKernelGGL((k_step<16, 16, 0, 7, false, true>), grid, block, shmem, st, p); return hipGetLastError(); }
-    }
-    if (p.objaux) return launch_sized<0, 0>(p, mode, grid, block, shmem, st);
-#define CASE(w, h) if (p.W == w && p.H == h) return launch_sized<w, h>(p, mode, grid, block, shmem, st);
-    MGX_SIZED(CASE)
-#undef CASE
-    return launch_sized<0, 0>(p, mode, grid, block, shmem, st);
+#endif
+    hipLaunchKernelGGL(c.fn, sh.grid, sh.block, sh.shmem, st, p);
+    return hipGetLastError();
 }
 
-hipError_t mgx_raise_lds_limit(int W, int H, int mode, int bytes, int view, int alt_vis, int object_state)
+hipError_t mgx_raise_lds_limit(const StepParams &p, int mode, int bytes)
 {
-    if (object_state) W = H = 0;
-    if (mode == 0 && alt_vis) {
-#define VCASE(v) if (view == v) return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<0, 0, 0, v, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        MGX_VIEWS(VCASE) VCASE(7)
-#undef VCASE
-        return hipErrorInvalidValue;
-    }
-    if (mode == 0 && view != 7) {
-#define VCASE(v) if (view == v) return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_step<0, 0, 0, v>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        MGX_VIEWS(VCASE)
-#undef VCASE
-        return hipErrorInvalidValue;
-    }
-#define CASE(w, h) if (W == w && H == h) return raise_lds_limit<w, h>(mode, bytes);
-    MGX_SIZED(CASE)
-#undef CASE
-    return raise_lds_limit<0, 0>(mode, bytes);
+    const StepChoice c = choose_step_kernel(p, mode);
+    if (!c.fn) return hipErrorInvalidValue;
+    if (c.block_per_tile) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(c.fn), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 

@@ -50,6 +50,7 @@ struct mgx_env_s {
     int64_t n = 0, n_pad = 0;
     int device = 0;
     int W = 0, H = 0, cells = 0, S = 0, LS = 0, wave_lds = 0, wpb = 4, view = 7;
+    int round_blocks = 0; // blocks of the step kernel resident at once on the chip (first-round stagger, k_step)
     bool partial = true;   // the simulator emits the VxV view (else the full grid)
     int oh_nc = -1, oh_ns = 0; // one-hot epilogue channels (oh_nc < 0: none)
     uint8_t *tri_d = nullptr;  // triples scratch feeding the one-hot / flat epilogue
@@ -192,6 +193,7 @@ StepParams base_params(mgx_handle h)
     p.ctr = h->ctr_d;
     p.n = h->n; p.n_tiles = (int)(h->n_pad / 64);
     p.W = h->W; p.H = h->H; p.S = h->S; p.LS = h->LS; p.wave_lds = h->wave_lds; p.view = h->view;
+    p.round_blocks = h->round_blocks;
     p.max_steps = h->cfg.max_steps; p.see_through = h->cfg.see_through_walls; p.lava_v1 = h->cfg.lava_v1;
     p.auto_reset = h->cfg.auto_reset;
     p.extended = h->cfg.extended_actions ? 1 : 0;
@@ -364,15 +366,8 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     }
     h->wpb = LDS_DEFAULT / h->wave_lds;
     if (h->wpb > 4) h->wpb = 4;
-    if (h->wpb < 1) {
-        h->wpb = 1;
-        hipError_t e2 = mgx_raise_lds_limit(h->W, h->H, h->kernel_mode == 0 ? 0 : 1, h->wave_lds, h->view, h->cfg.alt_visibility ? 1 : 0, h->cfg.object_state ? 1 : 0);
-        if (e2 != hipSuccess) {
-            int rc = mgx_fail(MGX_ERR_HIP, "mgx_create: cannot raise dynamic LDS to %d B: %s", h->wave_lds, hipGetErrorString(e2));
-            delete h;
-            return rc;
-        }
-    }
+    const bool raise_lds = h->wpb < 1; // (done below, once the buffers that select the kernel instantiation exist)
+    if (raise_lds) h->wpb = 1;
 #define CREATE_TRY(expr)                                                                     \
     do {                                                                                     \
         hipError_t e_ = (expr);                                                              \
@@ -483,6 +478,18 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
         CREATE_TRY(hipMemsetAsync(h->pos0_d, 0, (size_t)h->n_pad * sizeof(uint32_t), h->stream));
     }
     CREATE_TRY(mgx_preload_step_kernels());
+    {
+        const StepParams sp = base_params(h);
+        if (raise_lds) {
+            hipError_t e2 = mgx_raise_lds_limit(sp, h->kernel_mode, h->wave_lds);
+            if (e2 != hipSuccess) {
+                int rc = mgx_fail(MGX_ERR_HIP, "mgx_create: cannot raise dynamic LDS to %d B: %s", h->wave_lds, hipGetErrorString(e2));
+                mgx_destroy(h);
+                return rc;
+            }
+        }
+        CREATE_TRY(mgx_step_round_blocks(sp, h->kernel_mode, h->wpb, &h->round_blocks));
+    }
     CREATE_TRY(mgx_preload_state_kernels());
     if (h->device_levels || h->one_level) CREATE_TRY(mgx_preload_levelgen_kernels());
     if (h->oh_nc >= 0 || h->flat) CREATE_TRY(mgx_preload_epilogue_kernels());

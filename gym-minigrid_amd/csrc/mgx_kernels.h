@@ -59,7 +59,12 @@ struct StepParams {
     int n_tiles;
     int W, H, S, LS, wave_lds, view;
     int max_steps, see_through, lava_v1, auto_reset, do_step, extended, alt_vis, task;
+#ifdef MGX_TIMELINE     // profiling build only (tools/build_variant.sh tl -DMGX_TIMELINE=1): per-wave phase timestamps
+    unsigned long long *timeline; // [n_tiles][8]: s_memrealtime at entry / tile staged / transition done / obs computed / stores issued, HW_ID, XCC_ID, block
+#endif
     int tail_block0;       // blocks from this index on (the last two per CU of the grid: mgx_launch_step) run at wave priority 3
+    int round_blocks;      // blocks of this kernel resident at once on the chip (mgx_step_round_blocks, at create); 0 = unknown
+    int stagger;           // first-round waves sleep slot * stagger * 256 clocks before their loads (set per launch; 0 = off)
 };
 
 struct PackParams {
@@ -118,7 +123,8 @@ hipError_t mgx_preload_levelgen_kernels();
 hipError_t mgx_preload_state_kernels();
 hipError_t mgx_preload_epilogue_kernels();
 hipError_t mgx_preload_dynobs_kernels();
-hipError_t mgx_raise_lds_limit(int W, int H, int mode, int bytes, int view, int alt_vis, int object_state);
+hipError_t mgx_raise_lds_limit(const StepParams &p, int mode, int bytes);
+hipError_t mgx_step_round_blocks(const StepParams &p, int mode, int waves_per_block, int *blocks);
 #define MGX_FLAT_MISSION (96 * 27) /* FlatObsWrapper: maxStrLen x numCharCodes (wrappers.py:534-537) */
 // How the per-env task word selects the mission (a row of k_flat's pattern table), per family.  One definition for the
 // host (which fills the rows from mgx_mission) and the kernel.
