@@ -688,6 +688,8 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
             } else if (needs_copy) restore_own<CS>(p, env, g);
             else if (nc != fc) g[fidx] = (uint8_t)fc; // a terminal step that changed a cell (Fetch's pickup): only the LDS image saw it
             if (OBJ) restore_objstate(p, env);
+            // (loaded here, by the waves that need it: fetching agent0 with the record up front takes a 3-6 us round trip under load
+            // out of 40 % of LavaCrossing's waves and still measured +0.6 ... +1.5 us per launch -- 8 B per env of extra requests)
             L = unpack_rec(p.agent0[env], p.task);
             if (p.regen) p.regen[env] = 1; // the next-level buffer was consumed: k_levelgen refills it after this launch
         }
@@ -1256,7 +1258,7 @@ hipError_t mgx_launch_step(const StepParams &p0, int mode, int waves_per_block, 
     if (!c.fn) return hipErrorInvalidValue;
     const StepShape sh = step_shape(p0, c, waves_per_block);
     StepParams p = p0;
-    const int blocks = (int)sh.grid.x, tb = tail_blocks();
+    const int blocks = (int)sh.grid.x, tb = tail_blocks() * 4 / (c.block_per_tile ? 4 : waves_per_block); // (counted in 4-wave blocks)
     p.tail_block0 = (tb > 0 && blocks > tb) ? blocks - tb : 0x7fffffff;
     static const int stagger_min = getenv("MGX_STAGGER_MIN") ? atoi(getenv("MGX_STAGGER_MIN")) : -1; // (tuning runs: the smallest grid that staggers)
     p.stagger = (!c.block_per_tile && p.round_blocks > 0 && blocks > (stagger_min >= 0 ? stagger_min : p.round_blocks)) ? stagger_units() : 0;

@@ -366,6 +366,7 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     }
     h->wpb = LDS_DEFAULT / h->wave_lds;
     if (h->wpb > 4) h->wpb = 4;
+    if (const char *e = getenv("MGX_WPB")) { const int w = atoi(e); if (w >= 1 && w < h->wpb) h->wpb = w; } // (tuning runs: waves per block of k_step)
     const bool raise_lds = h->wpb < 1; // (done below, once the buffers that select the kernel instantiation exist)
     if (raise_lds) h->wpb = 1;
 #define CREATE_TRY(expr)                                                                     \
