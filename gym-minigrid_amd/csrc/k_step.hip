@@ -180,37 +180,51 @@ __device__ __forceinline__ uint32_t transition_apply(const StepParams &p, Lane &
         if (k == MGX_K_LAVA) done = true; // no 'v1' special case on the strafe path (minigrid.py:1304-1305,1313-1314)
         return fc;
     }
+    // The action switch in straight-line form: a wave of 64 independent agents takes every branch of an `if (act == ...)` chain on
+    // every step, so the chain cost the sum of its arms plus an exec-mask region each (0.7 us of a lone wave's 5.5 us: wave
+    // timelines, profiles/).  Each outcome is a predicate; the few results are selected at the end.  Only the rare arms that need
+    // memory or f64 (hidden object state, the goal's reward) stay branches.
     const int dx = (dir == 0) - (dir == 2), dy = (dir == 1) - (dir == 3);
     const uint32_t k = fc & 15u;
-    uint32_t nc = fc;
-    if (act == 0) L.dir = (dir + 3) & 3;
-    else if (act == 1) L.dir = (dir + 1) & 3;
-    else if (act == 2) {
-        // None, Floor, open Door, Goal, Lava can be walked onto (minigrid.py:93,164-166,192,211,245-247)
-        const uint32_t OVERLAP = (1u << MGX_K_EMPTY) | (1u << MGX_K_FLOOR) | (1u << MGX_K_DOOR_OPEN) | (1u << MGX_K_GOAL) | (1u << MGX_K_LAVA);
-        if (((OVERLAP >> k) & 1u) || (k == MGX_K_BOX && box_overlappable(o, tidx, fc))) { L.ax += dx; L.ay += dy; }
-        if (k == MGX_K_GOAL && (fc & 0x80u)) { // goal.overlap (minigrid.py:1259-1261)
-            done = true;
-            // _reward(): 1 - 0.9*(step_count/max_steps) in Python doubles (minigrid.py:933-937), then f32
-            reward = (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps));
-        }
-        if (k == MGX_K_LAVA) { // minigrid.py:1262-1268
-            if (p.lava_v1) { done = false; reward = -1.f; }
-            else done = true;
-        }
-    } else if (act == 3) {
-        const uint32_t PICK = (1u << MGX_K_KEY) | (1u << MGX_K_BALL) | (1u << MGX_K_BOX);
-        if (((PICK >> k) & 1u) && L.carry == MGX_CODE_EMPTY) {
-            L.carry = fc; nc = MGX_CODE_EMPTY;
-            if (o.aux) { *o.carry = (uint16_t)(o.aux[tidx] | (o.cont[tidx] << 8)); o.aux[tidx] = 0; o.cont[tidx] = MGX_CODE_EMPTY; }
-        }
-    } else if (act == 4) {
-        if (k == MGX_K_EMPTY && L.carry != MGX_CODE_EMPTY) {
-            nc = L.carry; L.carry = MGX_CODE_EMPTY;
-            if (o.aux) { o.aux[tidx] = (uint8_t)*o.carry; o.cont[tidx] = (uint8_t)(*o.carry >> 8); *o.carry = (uint16_t)(MGX_CODE_EMPTY << 8); }
-        }
-    } else if (act == 5 && o.aux && (k == MGX_K_GOAL || k == MGX_K_BOX)) {
+    const uint32_t carry = L.carry;
+    L.dir = act == 0 ? (dir + 3) & 3 : (act == 1 ? (dir + 1) & 3 : dir);
+    // act 2: None, Floor, open Door, Goal, Lava can be walked onto (minigrid.py:93,164-166,192,211,245-247)
+    const uint32_t OVERLAP = (1u << MGX_K_EMPTY) | (1u << MGX_K_FLOOR) | (1u << MGX_K_DOOR_OPEN) | (1u << MGX_K_GOAL) | (1u << MGX_K_LAVA);
+    const bool fwd = act == 2;
+    bool ovl = ((OVERLAP >> k) & 1u) != 0u;
+    if (o.aux && fwd && k == MGX_K_BOX) ovl = box_overlappable(o, tidx, fc);
+    const bool move = fwd && ovl;
+    L.ax += move ? dx : 0;
+    L.ay += move ? dy : 0;
+    if (fwd && k == MGX_K_GOAL && (fc & 0x80u)) { // goal.overlap (minigrid.py:1259-1261)
+        done = true;
+        // _reward(): 1 - 0.9*(step_count/max_steps) in Python doubles (minigrid.py:933-937), then f32
+        reward = (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps));
+    }
+    const bool lava = fwd && k == MGX_K_LAVA; // minigrid.py:1262-1268 ('v1' classes: reward -1, no done)
+    done = lava ? !p.lava_v1 : done;
+    reward = (lava && p.lava_v1) ? -1.f : reward;
+    // act 3 / 4: pickup, drop
+    const uint32_t PICK = (1u << MGX_K_KEY) | (1u << MGX_K_BALL) | (1u << MGX_K_BOX);
+    const bool pick = act == 3 && ((PICK >> k) & 1u) && carry == MGX_CODE_EMPTY;
+    const bool drop = act == 4 && k == MGX_K_EMPTY && carry != MGX_CODE_EMPTY;
+    if (o.aux) {
+        if (pick) { *o.carry = (uint16_t)(o.aux[tidx] | (o.cont[tidx] << 8)); o.aux[tidx] = 0; o.cont[tidx] = MGX_CODE_EMPTY; }
+        if (drop) { o.aux[tidx] = (uint8_t)*o.carry; o.cont[tidx] = (uint8_t)(*o.carry >> 8); *o.carry = (uint16_t)(MGX_CODE_EMPTY << 8); }
+    }
+    // act 5: toggle.  Door.toggle (minigrid.py:252-262): locked opens with a key of its colour, open <-> closed; Goal.toggle with
+    // toggletimes=1 (minigrid.py:171-181) removes a goal that is not an `overlap` one; Box.toggle with contains=None (minigrid.py:355-364)
+    const bool keyfits = (carry & 15u) == MGX_K_KEY && ((carry >> 4) & 7u) == ((fc >> 4) & 7u);
+    const uint32_t opened = (fc & 0xF0u) | MGX_K_DOOR_OPEN, closed = (fc & 0xF0u) | MGX_K_DOOR_CLOSED;
+    uint32_t tog = fc;
+    tog = k == MGX_K_DOOR_LOCKED ? (keyfits ? opened : fc) : tog;
+    tog = k == MGX_K_DOOR_OPEN ? closed : tog;
+    tog = k == MGX_K_DOOR_CLOSED ? opened : tog;
+    tog = (k == MGX_K_GOAL && !(fc & 0x80u)) ? (uint32_t)MGX_CODE_EMPTY : tog;
+    tog = k == MGX_K_BOX ? (uint32_t)MGX_CODE_EMPTY : tog;
+    if (act == 5 && o.aux && (k == MGX_K_GOAL || k == MGX_K_BOX)) {
         // Goal.toggle / Box.toggle with their hidden state (minigrid.py:171-181,355-364)
+        tog = fc;
         uint32_t a = o.aux[tidx];
         int tt = (int)(((a >> 4) + 1u) & 15u);
         const uint32_t tri = (a >> 1) & 7u;
@@ -219,21 +233,16 @@ __device__ __forceinline__ uint32_t transition_apply(const StepParams &p, Lane &
             tt = tt > 0 ? tt - 1 : 0; // Box counts below zero in Python; every value <= 0 behaves the same
             a = (a & 0x0Fu) | ((uint32_t)((tt - 1) & 15) << 4);
             if (tt <= 0 && tri == 0u) { // Goal: removed; Box: replaced by its contents
-                nc = goal ? (uint32_t)MGX_CODE_EMPTY : (uint32_t)o.cont[tidx];
+                tog = goal ? (uint32_t)MGX_CODE_EMPTY : (uint32_t)o.cont[tidx];
                 o.cont[tidx] = MGX_CODE_EMPTY;
                 a = 0;
-            } else if (tt <= 0) nc = (fc & 0x8Fu) | ((tri - 1u) << 4); // self.color = self.triage_color
+            } else if (tt <= 0) tog = (fc & 0x8Fu) | ((tri - 1u) << 4); // self.color = self.triage_color
             o.aux[tidx] = (uint8_t)a;
         }
-    } else if (act == 5) {
-        if (k == MGX_K_DOOR_LOCKED) { // Door.toggle (minigrid.py:252-262)
-            if ((L.carry & 15u) == MGX_K_KEY && ((L.carry >> 4) & 7u) == ((fc >> 4) & 7u)) nc = (fc & 0xF0u) | MGX_K_DOOR_OPEN;
-        } else if (k == MGX_K_DOOR_OPEN) nc = (fc & 0xF0u) | MGX_K_DOOR_CLOSED;
-        else if (k == MGX_K_DOOR_CLOSED) nc = (fc & 0xF0u) | MGX_K_DOOR_OPEN;
-        else if (k == MGX_K_GOAL) { if (!(fc & 0x80u)) nc = MGX_CODE_EMPTY; } // Goal.toggle, toggletimes=1 (minigrid.py:171-181)
-        else if (k == MGX_K_BOX) nc = MGX_CODE_EMPTY;                         // Box.toggle, contains=None (minigrid.py:355-364)
-    } // act == 6 ("done"): pass (minigrid.py:1291-1293)
-    return nc;
+    }
+    L.carry = pick ? fc : (drop ? (uint32_t)MGX_CODE_EMPTY : carry);
+    // act == 6 ("done"): pass (minigrid.py:1291-1293)
+    return pick ? (uint32_t)MGX_CODE_EMPTY : (drop ? carry : (act == 5 ? tog : fc));
 }
 
 // auto-reset of the hidden object state: planes back to the snapshot, nothing carried
@@ -340,6 +349,9 @@ __device__ __forceinline__ void emit_partial_obs(const StepParams &p, const Lane
         }
     }
 
+#ifdef MGX_TIMELINE
+    if (tlv) tlv[7] = __builtin_amdgcn_s_memrealtime();
+#endif
     if (ALT && !p.see_through) {
         // the fork's alternative visibility model, default_vis=False (minigrid.py:649-709), per lane on column bit
         // masks (bit j of m[i] = view cell (i, j) visible): its data-dependent `break`s become per-lane alive flags.
@@ -419,6 +431,9 @@ __device__ __forceinline__ void emit_partial_obs(const StepParams &p, const Lane
             }
         }
     }
+#ifdef MGX_TIMELINE
+    if (tlv) tlv[8] = __builtin_amdgcn_s_memrealtime();
+#endif
     // the agent's own cell shows what it carries, after occlusion; always visible (minigrid.py:1349-1356)
     code[V / 2][V - 1] = L.carry;
 
@@ -450,6 +465,9 @@ __device__ __forceinline__ void emit_partial_obs(const StepParams &p, const Lane
     }
     D[NDW - 1] = decode_triple(code[V - 1][V - 1]); // 3 bytes
 
+#ifdef MGX_TIMELINE
+    if (tlv) tlv[9] = __builtin_amdgcn_s_memrealtime();
+#endif
     // byte phase of this env inside the tile's contiguous output: B*lane = 4*P + s.  Q = D delayed by s bytes:
     // Q[k] = bytes (4-s)..(7-s) of {D[k], D[k-1]}  -> one v_perm_b32 with a per-lane selector
     const uint32_t s = (3u * (uint32_t)lane) & 3u;
@@ -610,7 +628,7 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
     // issue slots with the waves still finishing, and the launch ends one contended wave lifetime after they start.  At priority 3
     // they run through first; worth 1.6 us of 26.5 at 524,288 LavaCrossing envs and 1.1 of 39.4 at 1 Mi Empty-8x8.
 #ifdef MGX_TIMELINE
-    unsigned long long tlv[5];
+    unsigned long long tlv[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     tlv[0] = __builtin_amdgcn_s_memrealtime();
 #endif
     if ((int)blockIdx.x >= p.tail_block0) __builtin_amdgcn_s_setprio(3);
@@ -650,6 +668,9 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
     if (p.do_step) {
         const int fidx = transition_begin<CW, CH>(p, L, act, valid, bad_act, oob);
         uint32_t fc = 0, nc = 0; // forward cell before / after the transition
+#ifdef MGX_TIMELINE
+        tlv[5] = __builtin_amdgcn_s_memrealtime();
+#endif
         if (fidx >= 0) {
             const uint32_t carry0 = L.carry;
             fc = row[fidx];
@@ -664,6 +685,9 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
             if (nc != fc && !(p.auto_reset && done)) { p.cells[env * S + fidx] = (uint8_t)nc; pidx = fidx; pcode = nc; L.dirty = MGX_REC_DIRTY; }
         } else if (valid && L.steps >= p.max_steps) done = true;
         if (crash) { reward = -1.f; done = true; } // envs/dynamicobstacles.py:83-86
+#ifdef MGX_TIMELINE
+        tlv[6] = __builtin_amdgcn_s_memrealtime();
+#endif
         if (p.reward && valid) __builtin_nontemporal_store(reward, &p.reward[env]);
         if (p.done && valid) __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), &p.done[env]);
         wave_stats(p, valid, done, reward, bad_act, oob, lane, tile);
@@ -748,7 +772,8 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
                 asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
                 unsigned long long *o = p.timeline + (size_t)tile * 8;
                 for (int i = 0; i < 5; i++) o[i] = tlv[i];
-                o[5] = hw; o[6] = xcc; o[7] = blockIdx.x;
+                o[5] = hw | ((unsigned long long)xcc << 32); o[6] = (tlv[5] - tlv[1]) | ((tlv[6] - tlv[1]) << 20) | ((unsigned long long)blockIdx.x << 40);
+                o[7] = (tlv[7] - tlv[2]) | ((tlv[8] - tlv[2]) << 20) | ((tlv[9] - tlv[2]) << 40); // inside the observation: gathered / occluded / decoded
             }
         }
 #else
