@@ -342,7 +342,9 @@ __device__ __forceinline__ void emit_partial_obs(const StepParams &p, const Lane
 #pragma unroll
         for (int vx = 0; vx < V; vx++) {
             const bool inb = vf[V - 1 - vy] && vl[vx];
-            const int idx = inb ? rowbase + (vx - V / 2) * sr : base;
+            // (LDS forms: a cell outside the grid is read where its index points -- a neighbouring env's row or the guard band,
+            // StepParams.lds_guard -- and replaced by the wall below; only the global-memory form has to clamp the index)
+            const int idx = (GATHER && !inb) ? base : rowbase + (vx - V / 2) * sr;
             uint32_t c = g[idx];
             if constexpr (GATHER) c = idx == pidx ? pcode : c; // the cell this step changed is not in HBM yet for this lane's reads
             code[vx][vy] = inb ? c : (uint32_t)MGX_CODE_WALL_GREY;
@@ -618,7 +620,7 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
     const int S = CS ? CS : p.S;
     constexpr int CLS = CS + (((CS >> 2) & 1) ? 0 : 4); // the host's rule (mgx_create): odd dword stride per env in LDS
     const int LS = CS ? CLS : p.LS;
-    uint8_t *lds = smem + (size_t)wv * p.wave_lds;
+    uint8_t *lds = smem + p.lds_guard + (size_t)wv * p.wave_lds;
     const int64_t env0 = (int64_t)tile * 64;
     const int64_t env = env0 + lane;
     const bool valid = env < p.n;
@@ -1093,7 +1095,7 @@ __global__ __launch_bounds__(256) void k_rollout(const StepParams p, const Rollo
     if (tile >= p.n_tiles) return; // wave-uniform
     constexpr int CS = (CW * CH + 3) & ~3;
     constexpr int LS = CS + (((CS >> 2) & 1) ? 0 : 4);
-    uint8_t *lds = smem + (size_t)wv * p.wave_lds; // p.wave_lds = grid image + observation image (mgx_launch_rollout)
+    uint8_t *lds = smem + p.lds_guard + (size_t)wv * p.wave_lds; // p.wave_lds = grid image + observation image (mgx_launch_rollout)
     uint8_t *img = lds + q.grid_lds;
     const int64_t env0 = (int64_t)tile * 64, env = env0 + lane;
     const bool valid = env < p.n;
@@ -1191,11 +1193,11 @@ hipError_t mgx_launch_rollout(const StepParams &p0, const uint8_t *actions, uint
     q.actions = actions; q.obs = obs; q.reward = reward; q.done = done; q.T = T;
     q.grid_lds = (64 * LS + 15) & ~15;
     p.wave_lds = q.grid_lds + 32 * 147; // + the half-tile observation image (4,704 B)
-    int wpb = 65536 / p.wave_lds;
+    int wpb = (65536 - p.lds_guard) / p.wave_lds;
     if (wpb > 4) wpb = 4;
     if (wpb < 1) return hipErrorNotSupported;
     const dim3 block(64 * wpb), grid((p.n_tiles + wpb - 1) / wpb);
-    const size_t shmem = (size_t)wpb * p.wave_lds;
+    const size_t shmem = (size_t)wpb * p.wave_lds + p.lds_guard; // (guard in front; behind the last grid image lies its observation image)
 #define CASE(w, h) if (p.W == w && p.H == h) { hipLaunchKernelGGL((k_rollout<w, h>), grid, block, shmem, st, p, q); return hipGetLastError(); }
     MGX_SIZED(CASE)
 #undef CASE
@@ -1238,7 +1240,7 @@ struct StepShape { dim3 grid, block; size_t shmem; };
 static StepShape step_shape(const StepParams &p, const StepChoice &c, int waves_per_block)
 {
     if (c.block_per_tile) return {dim3(p.n_tiles), dim3(256), 0};
-    return {dim3((p.n_tiles + waves_per_block - 1) / waves_per_block), dim3(64 * waves_per_block), (size_t)waves_per_block * p.wave_lds};
+    return {dim3((p.n_tiles + waves_per_block - 1) / waves_per_block), dim3(64 * waves_per_block), (size_t)waves_per_block * p.wave_lds + 2 * (size_t)p.lds_guard};
 }
 
 // Blocks of this handle's step kernel that are resident at once on the whole chip (one "round" of the grid).

@@ -50,6 +50,7 @@ struct mgx_env_s {
     int64_t n = 0, n_pad = 0;
     int device = 0;
     int W = 0, H = 0, cells = 0, S = 0, LS = 0, wave_lds = 0, wpb = 4, view = 7;
+    int lds_guard = 0;    // StepParams.lds_guard
     int round_blocks = 0; // blocks of the step kernel resident at once on the chip (first-round stagger, k_step)
     bool partial = true;   // the simulator emits the VxV view (else the full grid)
     int oh_nc = -1, oh_ns = 0; // one-hot epilogue channels (oh_nc < 0: none)
@@ -193,7 +194,7 @@ StepParams base_params(mgx_handle h)
     p.ctr = h->ctr_d;
     p.n = h->n; p.n_tiles = (int)(h->n_pad / 64);
     p.W = h->W; p.H = h->H; p.S = h->S; p.LS = h->LS; p.wave_lds = h->wave_lds; p.view = h->view;
-    p.round_blocks = h->round_blocks;
+    p.round_blocks = h->round_blocks; p.lds_guard = h->lds_guard;
     p.max_steps = h->cfg.max_steps; p.see_through = h->cfg.see_through_walls; p.lava_v1 = h->cfg.lava_v1;
     p.auto_reset = h->cfg.auto_reset;
     p.extended = h->cfg.extended_actions ? 1 : 0;
@@ -347,7 +348,9 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     const bool gather_ok = h->partial && view == 7 && !cfg->alt_visibility && !cfg->object_state;
     if (gather_ok && (force ? !strcmp(force, "gather") : h->S > 256)) { h->kernel_mode = 3; need = obs_img; }
     // any other partial view whose tile image cannot fit the LDS (past ~50x50) takes the gather form too, with byte loads
-    if (h->partial && h->kernel_mode == 0 && need > 160 * 1024) { h->kernel_mode = 3; need = obs_img; }
+    const int guard = ((view - 1) * h->H + view / 2 + 15) & ~15; // StepParams.lds_guard (staged partial form only)
+    if (h->partial && h->kernel_mode == 0 && need + 2 * guard > 160 * 1024) { h->kernel_mode = 3; need = obs_img; }
+    h->lds_guard = h->kernel_mode == 0 ? guard : 0;
     h->wave_lds = (need + 15) & ~15;
     // a family that draws no random numbers (Empty with a fixed start) has only one level: nothing to generate
     const bool uses_rng = cfg->level_kind != MGX_LEVEL_NONE && cfg->level_kind != MGX_LEVEL_DISTSHIFT &&
@@ -359,12 +362,12 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     h->obs_bytes = h->oh_nc < 0 ? h->tri_bytes : h->tri_bytes / 3 * (11 + h->oh_nc + h->oh_ns);
     if (h->flat) h->obs_bytes = (h->tri_bytes + MGX_FLAT_MISSION) * (int64_t)sizeof(float);
     const int LDS_DEFAULT = 64 * 1024, LDS_MAX = 160 * 1024;
-    if (h->wave_lds > LDS_MAX) {
+    if (h->wave_lds + 2 * h->lds_guard > LDS_MAX) {
         int rc = mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_create: a %dx%d tile (64 envs) needs %d B of LDS > %d", h->W, h->H, h->wave_lds, LDS_MAX);
         delete h;
         return rc;
     }
-    h->wpb = LDS_DEFAULT / h->wave_lds;
+    h->wpb = (LDS_DEFAULT - 2 * h->lds_guard) / h->wave_lds;
     if (h->wpb > 4) h->wpb = 4;
     if (const char *e = getenv("MGX_WPB")) { const int w = atoi(e); if (w >= 1 && w < h->wpb) h->wpb = w; } // (tuning runs: waves per block of k_step)
     const bool raise_lds = h->wpb < 1; // (done below, once the buffers that select the kernel instantiation exist)
@@ -482,7 +485,7 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     {
         const StepParams sp = base_params(h);
         if (raise_lds) {
-            hipError_t e2 = mgx_raise_lds_limit(sp, h->kernel_mode, h->wave_lds);
+            hipError_t e2 = mgx_raise_lds_limit(sp, h->kernel_mode, h->wave_lds + 2 * h->lds_guard);
             if (e2 != hipSuccess) {
                 int rc = mgx_fail(MGX_ERR_HIP, "mgx_create: cannot raise dynamic LDS to %d B: %s", h->wave_lds, hipGetErrorString(e2));
                 mgx_destroy(h);

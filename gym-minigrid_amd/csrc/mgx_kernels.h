@@ -62,6 +62,9 @@ struct StepParams {
 #ifdef MGX_TIMELINE     // profiling build only (tools/build_variant.sh tl -DMGX_TIMELINE=1): per-wave phase timestamps
     unsigned long long *timeline; // [n_tiles][8]: s_memrealtime at entry / tile staged / transition done / obs computed / stores issued, HW_ID, XCC_ID, block
 #endif
+    int lds_guard;         // bytes kept free in front of and behind the block's tile images (staged partial form): the view gather
+                           // reads cells outside the grid where their index points -- up to (V-1)*H + V/2 bytes off the env's row --
+                           // and replaces them by the wall afterwards; the guard keeps those reads inside the allocation
     int tail_block0;       // blocks from this index on (the last two per CU of the grid: mgx_launch_step) run at wave priority 3
     int round_blocks;      // blocks of this kernel resident at once on the chip (mgx_step_round_blocks, at create); 0 = unknown
     int stagger;           // first-round waves sleep slot * stagger * 256 clocks before their loads (set per launch; 0 = off)
