@@ -36,6 +36,40 @@ __global__ __launch_bounds__(256) void k(const u4 *__restrict__ in, u4 *__restri
     }
 }
 
+// the FullyObs direct form's shape: a 256-thread block per tile
+template <int RQ, int WQ>
+__global__ __launch_bounds__(256) void kb(const u4 *__restrict__ in, u4 *__restrict__ out, int n_tiles)
+{
+    const int tile = blockIdx.x, t = threadIdx.x;
+    const u4 *src = in + (size_t)tile * RQ;
+    u4 *dst = out + (size_t)tile * WQ;
+    u4 acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < (RQ + 255) / 256; i++) { const int q = i * 256 + t; if (q < RQ) acc ^= src[q]; }
+    __shared__ uint32_t sh[4];
+    if ((t & 63) == 0) sh[t >> 6] = acc.x;
+    __syncthreads();
+    acc.y ^= sh[0]; // phase B depends on phase A (wave 0)
+#pragma unroll
+    for (int i = 0; i < (WQ + 255) / 256; i++) { const int q = i * 256 + t; if (q < WQ) { u4 v = acc; v.x += i; __builtin_nontemporal_store(v, &dst[q]); } }
+}
+template <int RQ, int WQ>
+static void runb(const char *name, int n_envs, u4 *in, u4 *out)
+{
+    const int n_tiles = n_envs / 64, iters = 200;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 20; i++) hipLaunchKernelGGL((kb<RQ, WQ>), dim3(n_tiles), dim3(256), 0, 0, in, out, n_tiles);
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; i++) hipLaunchKernelGGL((kb<RQ, WQ>), dim3(n_tiles), dim3(256), 0, 0, in, out, n_tiles);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / iters, bytes = (double)n_tiles * (RQ + WQ) * 16;
+    printf("%-34s envs %8d  block/tile  %7.2f us/launch  %6.0f GB/s (R %5.1f MB + W %5.1f MB)\n", name, n_envs, us, bytes / us * 1e-3, n_tiles * RQ * 16e-6, n_tiles * WQ * 16e-6);
+    fflush(stdout);
+}
+
 template <int RQ, int WQ, int NT>
 static void run(const char *name, int n_envs, int wpb, u4 *in, u4 *out)
 {
@@ -62,7 +96,7 @@ int main()
     CK(hipMalloc(&in, cap)); CK(hipMalloc(&out, cap));
     CK(hipMemset(in, 1, cap)); CK(hipMemset(out, 0, cap));
     // LavaCrossing 9x9: read 84 (cells, padded) + 8 (record) + 1 (action) ~ 92 B/env = 368 quads per tile; write 147 + 8 + 4 + 1 = 160 B/env = 640 quads
-    const int sizes[] = {262144, 524288, 1048576, 2097152, 4194304};
+    const int sizes[] = {524288, 1048576};
     for (int n : sizes) {
         run<368, 640, 1>("lava 9x9 skeleton, nt stores", n, 4, in, out);
         run<368, 640, 0>("lava 9x9 skeleton, plain stores", n, 4, in, out);
@@ -71,5 +105,11 @@ int main()
         run<368, 4, 1>("reads only (92 B/env)", n, 4, in, out);
         run<1008, 1008, 1>("copy 252 B/env each way, nt", n, 4, in, out);
     }
+    // FullyObs 16x16: read 256 + 8 + 1 B/env ~ 272 B = 1088 quads per tile; write 768 + 8 + 5 ~ 784 B = 3136 quads
+    for (int n : {262144, 1048576}) runb<1088, 3136>("FullyObs 16x16 skeleton", n, in, out);
+    // FullyObs 19x19: read 364 + 9, write 1083 + 13
+    for (int n : {131072, 524288}) runb<1492, 4384>("FullyObs 19x19 skeleton", n, in, out);
+    // Empty-8x8 partial: read 64 + 8 + 1 = 73 B/env ~ 292 quads, write 640
+    for (int n : {524288, 1048576}) run<292, 640, 1>("empty 8x8 skeleton, nt stores", n, 4, in, out);
     return 0;
 }
