@@ -293,7 +293,7 @@ def main():
         sync()
         if world > 1:
             dist.barrier()
-        sync()
+            sync()
 
     logger = mdist.GatherLogger(n_local, dev, world) if (world > 1 and args.log == "gather") else None
     if dry:
