@@ -166,7 +166,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
-                    help="REHEARSAL ONLY: every rank uses cuda:0 (with --backend gloo) to exercise the multi-rank code "
+                    help="REHEARSAL ONLY: every rank uses cuda:0 (backend gloo: RCCL refuses two ranks on one GPU) to exercise the multi-rank code "
                          "path on a one-GPU box; the numbers it prints are meaningless")
     ap.add_argument("--dry-run-ranks", action="store_true",
                     help="PLUMBING TEST ONLY (no GPU, gloo): launcher -> ranks -> rendezvous -> sharding -> logging gather -> "
@@ -265,7 +265,7 @@ def main():
     import torch.distributed as dist
 
     dry = args.dry_run_ranks
-    rank, local_rank, world = mdist.init_process_group("gloo" if dry else args.backend)
+    rank, local_rank, world = mdist.init_process_group("gloo" if (dry or (args.rehearse_on_one_gpu and not args.backend)) else args.backend)
     if args.rehearse_on_one_gpu:
         local_rank = 0
     if world != args.gpus:
@@ -405,7 +405,7 @@ def main():
         obs_desc = ("float32 (N,%d) FlatObs" % (obs_cells(cfg.width, cfg.height, args.obs_mode, args.view) * 3 + FLAT_MISSION) if args.obs_mode.endswith("flat")
                     else "uint8 (N,%d,%d,%d)" % (args.view, args.view, OBS_CHANNELS[args.obs_mode]) if args.obs_mode.startswith("partial")
                     else "uint8 (N,W,H,%d) FullyObs" % OBS_CHANNELS[args.obs_mode])
-        exchange = "none" if world == 1 else ("RCCL all-gather of done u8 + reward f32 (%d B per rank) every %d steps on a side stream" % (5 * n_local, args.log_every)
+        exchange = "none" if world == 1 else ("%s all-gather of done u8 + reward f32 (%d B per rank) every %d steps on a side stream" % ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend(), 5 * n_local, args.log_every)
                                               if logger is not None else ("all-reduce of (episodes, reward_sum) every %d steps" % args.log_every if args.log == "allreduce" else "none"))
         out = {
             "metric": "env-steps/sec", "value": n_total * K / dt, "unit": "env-steps/s", "n_gpus": world,
