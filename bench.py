@@ -317,7 +317,8 @@ def main():
     read_stats(stats0)
     barrier()
     if not dry:
-        env.profile_begin(stride=16)   # an event pair around every 16th launch of the step kernel (each pair costs the stream ~2 us)
+        # an event pair around every 16th launch of the step kernel (each pair costs the stream ~2-5 us: short runs sample the first launch only)
+        env.profile_begin(stride=16 if K >= 256 else K + 1)
     t0 = time.perf_counter()
     for t in range(Wm, Wm + K):
         step(t)
@@ -327,11 +328,13 @@ def main():
             elif args.log == "allreduce":
                 read_stats(stats2)
                 mdist.allreduce_log(stats2)      # 16 bytes
-    launches, span_ms = (K, 0.0) if dry else env.profile_end()  # HIP events on the launch stream
+    if not dry:
+        env.profile_stop()             # the span's end marker, enqueued behind the K-th step (no wait here)
     if logger is not None:
         logger.wait()
     barrier()
     dt = time.perf_counter() - t0
+    launches, span_ms = (K, 0.0) if dry else env.profile_end()  # HIP events on the launch stream (already complete)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

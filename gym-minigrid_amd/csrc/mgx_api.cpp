@@ -91,7 +91,7 @@ struct mgx_env_s {
     uint16_t *objcarry_d = nullptr;
     Staging st_in[6], st_out[4];
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool profiling = false;
+    bool profiling = false, prof_stopped = false;
     int64_t prof_launches = 0, steps_total = 0;
     // per-launch samples of the step kernel alone (mgx_profile_begin_sampled): event pairs around every stride-th launch
     std::vector<hipEvent_t> prof_ev;   // 2 per sample, created on first use
@@ -1077,6 +1077,7 @@ extern "C" int mgx_profile_begin_sampled(mgx_handle h, int stride)
     if (rc) return rc;
     if (stride < 1) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_profile_begin_sampled: stride must be >= 1");
     h->profiling = true;
+    h->prof_stopped = false;
     h->prof_launches = 0;
     h->prof_stride = stride;
     h->prof_samples = 0;
@@ -1088,13 +1089,26 @@ extern "C" int mgx_profile_begin_sampled(mgx_handle h, int stride)
 
 extern "C" int mgx_profile_begin(mgx_handle h) { return mgx_profile_begin_sampled(h, 8); }
 
+extern "C" int mgx_profile_stop(mgx_handle h)
+{
+    DeviceGuard dev_guard;
+    int rc = dev_guard.enter(h, "mgx_profile_stop");
+    if (rc) return rc;
+    if (!h->profiling) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_profile_stop without mgx_profile_begin");
+    if (h->prof_stopped) return mgx_fail(MGX_ERR_INVALID_STATE, "mgx_profile_stop: already stopped");
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    h->prof_stopped = true;
+    return MGX_OK;
+}
+
 extern "C" int mgx_profile_end(mgx_handle h, int64_t *launches, double *span_ms)
 {
     DeviceGuard dev_guard;
     int rc = dev_guard.enter(h, "mgx_profile_end");
     if (rc) return rc;
     if (!h->profiling) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_profile_end without mgx_profile_begin");
-    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    if (!h->prof_stopped) HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    h->prof_stopped = false;
     HIP_TRY(hipEventSynchronize(h->ev1));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));

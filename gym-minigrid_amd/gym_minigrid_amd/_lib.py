@@ -83,6 +83,7 @@ SIGNATURES = {
     "mgx_action_at": (ctypes.c_uint32, [ctypes.c_uint64, _i64, _i64]),
     "mgx_profile_begin": (_int, [_vp]),
     "mgx_profile_begin_sampled": (_int, [_vp, _int]),
+    "mgx_profile_stop": (_int, [_vp]),
     "mgx_profile_end": (_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double)]),
     "mgx_profile_kernel": (_int, [_vp, ctypes.POINTER(_i64), ctypes.POINTER(ctypes.c_double)]),
 }

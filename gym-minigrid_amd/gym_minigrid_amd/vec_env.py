@@ -338,6 +338,10 @@ class VecMiniGrid:
         """Start timing (include/mgx.h): the stream span + every `stride`-th step-kernel launch on its own."""
         _lib.check(_lib.lib().mgx_profile_begin_sampled(self._h, int(stride)))
 
+    def profile_stop(self):
+        """Enqueue the span's end marker now, without waiting (profile_end() after the caller's own synchronise reads the times)."""
+        _lib.check(_lib.lib().mgx_profile_stop(self._h))
+
     def profile_end(self):
         """-> (step-kernel launches in the span, span ms).  profile_kernel() then gives the per-launch samples."""
         n, ms = ctypes.c_int64(), ctypes.c_double()

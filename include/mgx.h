@@ -327,9 +327,12 @@ uint32_t mgx_action_at(uint64_t seed, int64_t env, int64_t t);
  *    bracketed by its own event pair, up to 256 pairs per span (later launches are not sampled).  mgx_profile_kernel()
  *    returns how many were sampled and the sum of their durations; valid after mgx_profile_end().  Launches recorded
  *    into mgx_rollout's graph are counted in `launches` but not sampled.
- * mgx_profile_begin(h) == mgx_profile_begin_sampled(h, 8). */
+ * mgx_profile_begin(h) == mgx_profile_begin_sampled(h, 8).  stride > the number of launches samples the first launch only.
+ * mgx_profile_stop() (optional) enqueues the span's end marker without waiting, so that a caller who synchronises the stream anyway
+ * (bench.py's timed region) pays for one wait instead of two; mgx_profile_end() then only reads the times. */
 int mgx_profile_begin(mgx_handle h);
 int mgx_profile_begin_sampled(mgx_handle h, int stride);
+int mgx_profile_stop(mgx_handle h);
 int mgx_profile_end(mgx_handle h, int64_t *launches, double *span_ms);
 int mgx_profile_kernel(mgx_handle h, int64_t *samples, double *sum_ms);
 
