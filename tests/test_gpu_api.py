@@ -399,4 +399,21 @@ def test_profile_span_and_per_launch_samples():
     env.rollout(acts)
     launches, _ = env.profile_end()
     assert launches == 12 and env.profile_kernel()[0] == 0
+    # profile_stop: the end marker goes out without a wait; work enqueued after it is outside the span
+    env.profile_begin(stride=100)
+    for t in range(4):
+        env.step(acts[t])
+    env.profile_stop()
+    with pytest.raises(mg.MgxError):
+        env.profile_stop()                                       # one end marker per span
+    for t in range(4, 12):
+        env.step(acts[t])                                        # (counted as launches, not timed)
+    torch.cuda.synchronize()
+    launches, span4 = env.profile_end()
+    assert launches == 12 and env.profile_kernel()[0] == 1      # stride > launches: the first launch only
+    env.profile_begin(stride=100)
+    for t in range(12):
+        env.step(acts[t])
+    _, span12 = env.profile_end()
+    assert 0 < span4 < span12
     env.close()
