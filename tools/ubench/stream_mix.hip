@@ -70,6 +70,53 @@ static void runb(const char *name, int n_envs, u4 *in, u4 *out)
     fflush(stdout);
 }
 
+// k_step's real streams for an 8x8 / 9x9 tile: reads = cells (CQ quads, 16 B per lane) + record (8 B per lane) + action (1 B per lane);
+// writes = observation (588 quads, non-temporal) + reward (4 B per lane, nt) + done (1 B per lane, nt) + record (8 B per lane, plain)
+template <int CQ>
+__global__ __launch_bounds__(256) void ks(const u4 *__restrict__ cells, const uint2 *__restrict__ rec_in, const uint8_t *__restrict__ act,
+                                          u4 *__restrict__ obs, float *__restrict__ reward, uint8_t *__restrict__ done, uint2 *__restrict__ rec_out, int n_tiles)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int tile = blockIdx.x * (blockDim.x >> 6) + wv;
+    if (tile >= n_tiles) return;
+    const size_t env = (size_t)tile * 64 + lane;
+    uint2 r = rec_in[env];
+    uint32_t a = __builtin_nontemporal_load(&act[env]);
+    const u4 *src = cells + (size_t)tile * CQ;
+    u4 acc = {r.x, r.y, a, 0};
+#pragma unroll
+    for (int i = 0; i < (CQ + 63) / 64; i++) { const int q = i * 64 + lane; if (q < CQ) acc ^= src[q]; }
+    acc.x ^= __shfl_xor(acc.x, 1); acc.y ^= __shfl_xor(acc.y, 2);
+    __builtin_nontemporal_store(__uint_as_float(acc.x & 0x3fffffffu), &reward[env]);
+    __builtin_nontemporal_store((uint8_t)(acc.y & 1u), &done[env]);
+    rec_out[env] = make_uint2(acc.x, acc.y);
+    u4 *dst = obs + (size_t)tile * 588;
+#pragma unroll
+    for (int i = 0; i < 10; i++) { const int q = i * 64 + lane; if (q < 588) { u4 v = acc; v.x += i; __builtin_nontemporal_store(v, &dst[q]); } }
+}
+template <int CQ>
+static void runs(const char *name, int n_envs, u4 *in, u4 *out)
+{
+    const int n_tiles = n_envs / 64, iters = 300;
+    // carve the streams out of the two big buffers
+    const u4 *cells = in; const uint2 *rec_in = reinterpret_cast<const uint2 *>(in + (size_t)n_tiles * CQ + 64);
+    const uint8_t *act = reinterpret_cast<const uint8_t *>(rec_in + (size_t)n_envs + 64);
+    u4 *obs = out; float *reward = reinterpret_cast<float *>(out + (size_t)n_tiles * 588 + 64);
+    uint8_t *done = reinterpret_cast<uint8_t *>(reward + (size_t)n_envs + 64);
+    uint2 *rec_out = const_cast<uint2 *>(rec_in); // the record is updated in place, as in k_step
+    dim3 grid((n_tiles + 3) / 4), block(256);
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 30; i++) hipLaunchKernelGGL((ks<CQ>), grid, block, 0, 0, cells, rec_in, act, obs, reward, done, rec_out, n_tiles);
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; i++) hipLaunchKernelGGL((ks<CQ>), grid, block, 0, 0, cells, rec_in, act, obs, reward, done, rec_out, n_tiles);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-34s envs %8d  k_step's own streams  %7.2f us/launch\n", name, n_envs, ms * 1e3 / iters);
+    fflush(stdout);
+}
+
 template <int RQ, int WQ, int NT>
 static void run(const char *name, int n_envs, int wpb, u4 *in, u4 *out)
 {
@@ -111,5 +158,7 @@ int main()
     for (int n : {131072, 524288}) runb<1492, 4384>("FullyObs 19x19 skeleton", n, in, out);
     // Empty-8x8 partial: read 64 + 8 + 1 = 73 B/env ~ 292 quads, write 640
     for (int n : {524288, 1048576}) run<292, 640, 1>("empty 8x8 skeleton, nt stores", n, 4, in, out);
+    // the same bytes as k_step moves, in k_step's own seven streams (3 in, 4 out; 147-B observations: a tile's 9,408 B straddle lines)
+    for (int n : {524288, 1048576}) { runs<256>("8x8 tile, real streams", n, in, out); runs<336>("9x9 tile, real streams", n, in, out); }
     return 0;
 }
