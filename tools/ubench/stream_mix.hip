@@ -72,7 +72,8 @@ static void runb(const char *name, int n_envs, u4 *in, u4 *out)
 
 // k_step's real streams for an 8x8 / 9x9 tile: reads = cells (CQ quads, 16 B per lane) + record (8 B per lane) + action (1 B per lane);
 // writes = observation (588 quads, non-temporal) + reward (4 B per lane, nt) + done (1 B per lane, nt) + record (8 B per lane, plain)
-template <int CQ>
+// VAR: 0 as k_step; 1 done stored plain (not nt); 2 no done stream; 3 no reward stream; 4 no record write; 5 reward + done plain
+template <int CQ, int VAR = 0>
 __global__ __launch_bounds__(256) void ks(const u4 *__restrict__ cells, const uint2 *__restrict__ rec_in, const uint8_t *__restrict__ act,
                                           u4 *__restrict__ obs, float *__restrict__ reward, uint8_t *__restrict__ done, uint2 *__restrict__ rec_out, int n_tiles)
 {
@@ -87,14 +88,16 @@ __global__ __launch_bounds__(256) void ks(const u4 *__restrict__ cells, const ui
 #pragma unroll
     for (int i = 0; i < (CQ + 63) / 64; i++) { const int q = i * 64 + lane; if (q < CQ) acc ^= src[q]; }
     acc.x ^= __shfl_xor(acc.x, 1); acc.y ^= __shfl_xor(acc.y, 2);
-    __builtin_nontemporal_store(__uint_as_float(acc.x & 0x3fffffffu), &reward[env]);
-    __builtin_nontemporal_store((uint8_t)(acc.y & 1u), &done[env]);
-    rec_out[env] = make_uint2(acc.x, acc.y);
+    if (VAR == 5) reward[env] = __uint_as_float(acc.x & 0x3fffffffu);
+    else if (VAR != 3) __builtin_nontemporal_store(__uint_as_float(acc.x & 0x3fffffffu), &reward[env]);
+    if (VAR == 1 || VAR == 5) done[env] = (uint8_t)(acc.y & 1u);
+    else if (VAR != 2) __builtin_nontemporal_store((uint8_t)(acc.y & 1u), &done[env]);
+    if (VAR != 4) rec_out[env] = make_uint2(acc.x, acc.y);
     u4 *dst = obs + (size_t)tile * 588;
 #pragma unroll
     for (int i = 0; i < 10; i++) { const int q = i * 64 + lane; if (q < 588) { u4 v = acc; v.x += i; __builtin_nontemporal_store(v, &dst[q]); } }
 }
-template <int CQ>
+template <int CQ, int VAR = 0>
 static void runs(const char *name, int n_envs, u4 *in, u4 *out)
 {
     const int n_tiles = n_envs / 64, iters = 300;
@@ -107,9 +110,9 @@ static void runs(const char *name, int n_envs, u4 *in, u4 *out)
     dim3 grid((n_tiles + 3) / 4), block(256);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 30; i++) hipLaunchKernelGGL((ks<CQ>), grid, block, 0, 0, cells, rec_in, act, obs, reward, done, rec_out, n_tiles);
+    for (int i = 0; i < 30; i++) hipLaunchKernelGGL((ks<CQ, VAR>), grid, block, 0, 0, cells, rec_in, act, obs, reward, done, rec_out, n_tiles);
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < iters; i++) hipLaunchKernelGGL((ks<CQ>), grid, block, 0, 0, cells, rec_in, act, obs, reward, done, rec_out, n_tiles);
+    for (int i = 0; i < iters; i++) hipLaunchKernelGGL((ks<CQ, VAR>), grid, block, 0, 0, cells, rec_in, act, obs, reward, done, rec_out, n_tiles);
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -160,5 +163,11 @@ int main()
     for (int n : {524288, 1048576}) run<292, 640, 1>("empty 8x8 skeleton, nt stores", n, 4, in, out);
     // the same bytes as k_step moves, in k_step's own seven streams (3 in, 4 out; 147-B observations: a tile's 9,408 B straddle lines)
     for (int n : {524288, 1048576}) { runs<256>("8x8 tile, real streams", n, in, out); runs<336>("9x9 tile, real streams", n, in, out); }
+    runs<256, 1>("8x8, done stored plain", 1048576, in, out);
+    runs<256, 2>("8x8, no done stream", 1048576, in, out);
+    runs<256, 3>("8x8, no reward stream", 1048576, in, out);
+    runs<256, 4>("8x8, no record write", 1048576, in, out);
+    runs<256, 5>("8x8, reward + done plain", 1048576, in, out);
+    runs<256, 0>("8x8 tile, real streams (again)", 1048576, in, out);
     return 0;
 }
