@@ -31,7 +31,7 @@ int mgx_fail(int status, const char *fmt, ...)
 }
 
 extern "C" const char *mgx_last_error(void) { return g_err; }
-extern "C" const char *mgx_version(void) { return "mgx 0.1 (gfx950)"; }
+extern "C" const char *mgx_version(void) { return "mgx 0.2 (gfx950)"; }
 
 #define HIP_TRY(expr)                                                                                         \
     do {                                                                                                      \
