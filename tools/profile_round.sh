@@ -43,6 +43,7 @@ pmc() { # name, counter, bench args...: per-dispatch counter values of one pass
 if [ $PART = stats ] || [ $PART = all ]; then
   stats warmup --steps 64 --warmup 8      # a fresh box: first profiled process (kept like the rest)
   stats empty8x8_1M --config empty8 --steps 1024 --warmup 64
+  stats empty8x8_1M_k20 --gpus 1 --steps 20 --warmup 5   # the driver's own command line (BENCH_rNN.json)
   stats doorkey8x8_1M --config doorkey8 --steps 1024 --warmup 64
   stats lavacrossing_512k --config lava4m --steps 1024 --warmup 64
   stats empty16x16_full_256k --config empty16full --steps 1024 --warmup 64
