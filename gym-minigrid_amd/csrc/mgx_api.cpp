@@ -275,6 +275,7 @@ int read_counters(mgx_handle h, MgxCounters *c)
 {
     HIP_TRY(hipMemcpyAsync(c, h->ctr_d, sizeof *c, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < MGX_CTR_SHARDS; i++) { c->invalid_actions += c->shard[i].invalid_actions; c->out_of_bounds += c->shard[i].out_of_bounds; }
     return MGX_OK;
 }
 

@@ -17,11 +17,13 @@
 struct MgxCounterShard {
     unsigned long long episodes;
     double reward_sum;
-    unsigned long long pad[6]; // one 64-byte line per shard
+    unsigned long long invalid_actions, out_of_bounds; // sharded as well: TwoGoals refuses pickup / drop, two actions in seven of a random
+                                                       // policy -- every wave of every step then hit ONE word (524,288 envs: 208 us per step)
+    unsigned long long pad[4]; // one 64-byte line per shard
 };
 struct MgxCounters {
     MgxCounterShard shard[MGX_CTR_SHARDS];
-    unsigned long long invalid_actions, out_of_bounds, invalid_state;
+    unsigned long long invalid_actions, out_of_bounds, invalid_state; // (the first two: filled by the host from the shards, read_counters)
 };
 
 // on-device level generation (new level each episode)
