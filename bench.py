@@ -18,19 +18,25 @@ of the rank.  Workloads are BASELINE.json's configs:
   empty16full  configs[4]  MiniGrid-Empty-16x16-v0 + FullyObsWrapper encode, 262,144 envs per GPU
 Weak scaling: per-GPU work is fixed as N grows; envs shard by global index (seeds and synthetic actions are keyed by the
 GLOBAL env index), no data-path collective.  For N > 1 the logging exchange (north_star: "RCCL ... to gather the
-done/reward scalars") runs every --log-every steps: an all-gather of done u8 + reward f32 of every rank, issued on a
-side stream behind a snapshot of the step's outputs, so the step stream never waits for it.
+done/reward scalars") runs every --log-every steps (default min(256, --steps): at least one exchange lands INSIDE the timed
+region whatever K is): an all-gather of done u8 + reward f32 of every rank, issued on a side stream behind a snapshot of
+the step's outputs into one of two snapshot buffers; the step stream waits for it only if a gather is still running when
+its buffer comes round again, and the line says whether that happened (`rccl.step_stream_wait_us_total`).
 Inputs (synthetic counter-based actions for all K+W steps, env state) are resident in HBM before the timed region.
 The timed region is bracketed by barrier + torch.cuda.synchronize() on both sides; the reported time is the MAX over
 ranks; rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline     the step kernel (k_step / k_step_fulldirect) against the HBM roof: algorithmic bytes per launch / the
-               kernel's average duration, measured with HIP events on the launch stream inside the timed region two ways:
-               `event_pair_us` = event pairs around every 16th launch of THAT kernel (mgx_profile_kernel; includes the ~2 us
-               the two markers take), `span_us_per_step` = the whole stream span / steps (includes launch gaps and, where a
-               workload has them, k_dynobs / epilogues / k_levelgen).  Both bound the kernel from above; `avg_kernel_us` is
-               the smaller one, rocprofv3's per-dispatch average under profiles/ reads just below it.
+  roofline     the step kernel (`kernel` = the instantiation the library's selector launches, mgx_step_kernel_name) against the
+               HBM roof: algorithmic bytes per launch / the kernel's average duration, measured with HIP events on the launch
+               stream inside the timed region: `span_us_per_step` = the whole stream span / steps (kernel + launch gaps and,
+               where a workload has them, k_dynobs / epilogues / k_levelgen) -- an upper bound of the kernel's mean duration,
+               and what `avg_kernel_us`, `achieved` and `frac` are derived from; `event_pair_us` = event pairs around every
+               16th launch of THAT kernel alone (mgx_profile_kernel; includes the ~2 us the two markers take), reported when
+               the run is long enough for >= 8 pairs (K >= 128) and used instead of the span only for workloads whose step is
+               several kernels.  rocprofv3's per-dispatch average under profiles/ reads just below both.
+               `achieved` uses the bytes the kernel ALGORITHMICALLY touches: the gather form of large grids (S > 256) reads its
+               7x7 window, not the grid (`algorithmic_bytes_per_env_step` then says so).
                The bytes are those of THIS layout (233 B/env-step for 8x8 + 7x7 view) -- smaller
                than SURVEY.md section 8d's 372 B, which assumed 3-byte cells; the survey-basis rate is given beside it.
                `traffic` = HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2
@@ -38,6 +44,9 @@ Extra objects on the line:
                the top-level achieved/frac is the SLOWEST rank's.
   cpu_baseline the CPU oracle (C restatement of the reference, oracle/minigrid_oracle.c; kind "port") timed on
                one host core of this box on a bounded sample of the same workload (rank 0, N = 1 only).
+  rccl         (N > 1) backend, world size, the device identity (UUID / PCI address) every rank reported -- ranks sharing a GPU
+               fail the run unless --rehearse-on-one-gpu -- and the exchange's own timing: exchanges inside the timed region,
+               mean / max duration on the side stream, time the step stream waited for it.
   episodes_in_timed_region   episodes that ended (and were auto-reset) inside the K timed steps, over all ranks: a short
                window on a time-out-only workload (Empty-8x8: every 256 steps) honestly shows 0 here.
 """
@@ -95,10 +104,27 @@ def layout_bytes_per_step(W, H, obs_mode, view=7):
     return cells + 8 + 8 + 1 + obs + 4 + 1
 
 
-def step_kernel_bytes_per_step(W, H, obs_mode, view=7):
-    """What the STEP KERNEL alone streams (the one-hot / flat epilogues are kernels of their own): its output is the triples."""
+def step_kernel_bytes_per_step(W, H, obs_mode, view=7, kernel=""):
+    """What the STEP KERNEL alone streams (the one-hot / flat epilogues are kernels of their own): its output is the triples.
+    The gather form (k_step<0,0,3,V>: partial view on grids past 16x16) never reads the grid: per env-step it touches the
+    V x V window (V columns of 8 bytes for V = 7) and the forward cell, so that is what its roofline is priced on."""
     cells = (W * H + 3) // 4 * 4
+    if kernel.startswith("k_step<0,0,3,"):
+        cells = (view * 8 if view == 7 else view * view) + 1
     return cells + 8 + 8 + 1 + obs_cells(W, H, obs_mode, view) * 3 + 4 + 1
+
+
+def reference_cpu_note(env_id, obs_mode):
+    """The reference's own Python path timed by oracle/time_reference.py in the build container (profiles/reference_cpu.json):
+    quoted beside the port's number, never measured here (the reference does not travel to the GPU box)."""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "reference_cpu.json")))
+        key = env_id + ("+FullyObsWrapper" if obs_mode.startswith("full") else "")
+        r = j["envs"][key]
+        return "reference Python %.0f steps/s on 1 core of %s (%d logical CPUs; %d steps, profiles/reference_cpu.json, oracle/time_reference.py)" % (
+            r["steps_per_s"], j["cpu_model"], j["nproc"], r["steps"])
+    except Exception:
+        return "reference Python: profiles/reference_cpu.json has no entry for this workload"
 
 
 def cpu_baseline(env_id, obs_mode, target_seconds=10.0):
@@ -139,8 +165,8 @@ def cpu_baseline(env_id, obs_mode, target_seconds=10.0):
     T = int(max(64, min(100000, 64 * target_seconds / max(dt, 1e-6))))
     steps1, dt1 = run(T, 1)
     out = {"value": steps1 / dt1, "unit": "env-steps/s", "cores": 1, "kind": "port",
-           "sample": "%s, %d envs x %d steps (%.1f s), oracle/minigrid_oracle.c single thread, same action stream; "
-                     "reference Python measured at 6.7e3 steps/s/core in the build container (BASELINE.md)" % (env_id, n, T, dt1)}
+           "sample": "%s, %d envs x %d steps (%.1f s), oracle/minigrid_oracle.c single thread, same action stream; %s"
+                     % (env_id, n, T, dt1, reference_cpu_note(env_id, obs_mode))}
     if cores > 1:
         stepsC, dtC = run(T * min(cores, 4), cores)
         out["all_cores"] = {"value": stepsC / dtC, "cores": cores, "seconds": dtC}
@@ -160,7 +186,8 @@ def parse_args(argv=None):
     ap.add_argument("--log", default="gather", choices=("gather", "allreduce", "none"),
                     help="N > 1 logging exchange every --log-every steps: all-gather of per-env done/reward on a side stream "
                          "(default), all-reduce of (episodes, reward_sum), or none")
-    ap.add_argument("--log-every", type=int, default=256)
+    ap.add_argument("--log-every", type=int, default=None,
+                    help="steps between two logging exchanges (default min(256, --steps): never fewer than one inside the timed region)")
     ap.add_argument("--new-level-each-episode", action="store_true",
                     help="plain reference episode boundary: every reset draws a new level on the GPU (k_levelgen)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -178,6 +205,8 @@ def parse_args(argv=None):
     args.env = args.env or c["env"]
     args.envs_per_gpu = args.envs_per_gpu or c["envs_per_gpu"]
     args.obs_mode = args.obs_mode or c["obs_mode"]
+    if args.log_every is None:
+        args.log_every = max(1, min(256, args.steps))
     return args
 
 
@@ -265,7 +294,7 @@ def main():
     import torch.distributed as dist
 
     dry = args.dry_run_ranks
-    rank, local_rank, world = mdist.init_process_group("gloo" if (dry or (args.rehearse_on_one_gpu and not args.backend)) else args.backend)
+    rank, local_rank, world = mdist.env_rank_info()
     if args.rehearse_on_one_gpu:
         local_rank = 0
     if world != args.gpus:
@@ -275,8 +304,23 @@ def main():
     if dry:
         dev = torch.device("cpu")
     else:
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(local_rank)          # before the process group: RCCL's communicator is bound to THIS device
         dev = torch.device("cuda", local_rank)
+    backend = "gloo" if (dry or (args.rehearse_on_one_gpu and not args.backend)) else args.backend
+    mdist.init_process_group(backend, device=None if dry else dev)
+    # who is here: every rank's device identity, all-gathered (N ranks must be N distinct GPUs)
+    rccl = None
+    if world > 1:
+        ident = {"rank": rank, "local_rank": local_rank, "host": socket.gethostname(), "pid": os.getpid()}
+        ident.update({"key": "cpu|pid-%d" % os.getpid()} if dry else mdist.device_identity(local_rank))
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+        keys = [i["host"] + "|" + i["key"] for i in idents]
+        distinct = len(set(keys)) == world
+        rccl = {"backend": dist.get_backend(), "world": world, "distinct_devices": distinct,
+                "devices": [{k: v for k, v in i.items() if k in ("rank", "local_rank", "index", "name", "uuid", "pci", "host")} for i in idents]}
+        if not distinct and not (args.rehearse_on_one_gpu or dry):
+            raise SystemExit("bench.py: %d ranks but only %d distinct GPUs (%s); one rank per GPU, or --rehearse-on-one-gpu" % (world, len(set(keys)), sorted(set(keys))))
 
     n_local = args.envs_per_gpu
     n_total = n_local * world
@@ -317,12 +361,15 @@ def main():
     read_stats(stats0)
     barrier()
     if not dry:
-        # an event pair around every 16th launch of the step kernel (each pair costs the stream ~2-5 us: short runs sample the first launch only)
-        env.profile_begin(stride=16 if K >= 256 else K + 1)
+        # an event pair around every 16th launch of the step kernel (each pair costs the stream ~2-5 us, so short runs take none
+        # that count: below 128 steps only the first launch is bracketed and the figure is left off the line)
+        env.profile_begin(stride=16 if K >= 128 else K + 1)
+    exchanges_timed = 0
     t0 = time.perf_counter()
     for t in range(Wm, Wm + K):
         step(t)
         if world > 1 and args.log_every > 0 and (t - Wm + 1) % args.log_every == 0:
+            exchanges_timed += 1
             if logger is not None:
                 logger.submit(*outputs())        # RCCL all-gather of done/reward over xGMI, on the side stream
             elif args.log == "allreduce":
@@ -350,7 +397,7 @@ def main():
     ep0 = float(stats0.tolist()[0])
     gather_checked = None
     if logger is not None:
-        if logger.submitted == 0:            # a short run: exercise the exchange once, outside the timed region
+        if logger.submitted == 0:            # (--log-every larger than --steps was asked for: exercise the exchange once, outside the timed region)
             logger.submit(*outputs())
         gd, gr = logger.wait()
         sync()
@@ -370,12 +417,16 @@ def main():
             raise SystemExit("bench.py: the gathered done/reward vectors do not match the shards")
     k_n, k_ms = (0, 0.0) if dry else env.profile_kernel()
     span_s = span_ms * 1e-3 / max(launches, 1)
-    sampled_s = (k_ms * 1e-3 / k_n) if k_n else span_s
-    # Two upper bounds of the step kernel's mean duration: the per-launch event pairs (kernel + the ~2 us the two event
-    # markers themselves take in the queue) and the stream span / launches (kernel + inter-kernel gap + whatever else the
-    # workload enqueues per step).  The smaller of the two is still an upper bound, so the rate derived from it is a lower
-    # bound; rocprofv3's per-dispatch duration (profiles/) is the tie-breaker and reads slightly below both.
-    avg_kernel_s = min(sampled_s, span_s)
+    sampled_s = (k_ms * 1e-3 / k_n) if k_n >= 8 else 0.0   # fewer than 8 pairs say nothing about the mean (one pair = the first launch after a barrier)
+    kernel_name = "dry-run" if dry else env.step_kernel_name()
+    # The step kernel's mean duration is bounded from above by the stream span / launches (kernel + inter-kernel gap + whatever
+    # else the workload enqueues per step): the roofline figure is derived from THAT, so the rate is a lower bound.  Only a
+    # workload whose step is several kernels (k_dynobs in front, an epilogue or k_levelgen behind) uses the per-launch event
+    # pairs instead -- kernel + the ~2 us the two markers take -- and only with >= 8 of them.  rocprofv3's per-dispatch
+    # average (profiles/) reads slightly below both.
+    multi_kernel = (not dry) and (args.new_level_each_episode or args.obs_mode.endswith("onehot") or args.obs_mode.endswith("nocolor")
+                                  or args.obs_mode.endswith("flat") or "Dynamic-Obstacles" in args.env)
+    avg_kernel_s = sampled_s if (multi_kernel and sampled_s > 0.0) else span_s
     mine = torch.tensor([avg_kernel_s, span_s, float(local_totals[0]), sampled_s], dtype=torch.float64, device=dev)
     per = [torch.zeros_like(mine) for _ in range(world)]
     if world > 1:
@@ -386,7 +437,7 @@ def main():
 
     if rank == 0:
         cfg = mg.env_config(args.env)
-        bps = step_kernel_bytes_per_step(cfg.width, cfg.height, args.obs_mode, args.view)
+        bps = step_kernel_bytes_per_step(cfg.width, cfg.height, args.obs_mode, args.view, kernel_name)
         lbps = layout_bytes_per_step(cfg.width, cfg.height, args.obs_mode, args.view)
         sbps = survey_bytes_per_step(cfg.width, cfg.height, args.obs_mode, args.view)
         traffic = None
@@ -402,13 +453,13 @@ def main():
         for r, v in enumerate(per):
             ks, ss, ep, es = [float(x) for x in v.tolist()]
             ach = bps * n_local / ks / 1e9 if ks > 0 else 0.0
-            per_rank.append({"rank": r, "avg_kernel_us": ks * 1e6, "span_us_per_step": ss * 1e6, "event_pair_us": es * 1e6, "achieved": ach,
+            per_rank.append({"rank": r, "avg_kernel_us": ks * 1e6, "span_us_per_step": ss * 1e6, "event_pair_us": (es * 1e6) if es > 0 else None, "achieved": ach,
                              "frac": ach / HBM_PEAK_GBS, "episodes": ep})
         slow = min(per_rank, key=lambda x: x["achieved"])
         obs_desc = ("float32 (N,%d) FlatObs" % (obs_cells(cfg.width, cfg.height, args.obs_mode, args.view) * 3 + FLAT_MISSION) if args.obs_mode.endswith("flat")
                     else "uint8 (N,%d,%d,%d)" % (args.view, args.view, OBS_CHANNELS[args.obs_mode]) if args.obs_mode.startswith("partial")
                     else "uint8 (N,W,H,%d) FullyObs" % OBS_CHANNELS[args.obs_mode])
-        exchange = "none" if world == 1 else ("%s all-gather of done u8 + reward f32 (%d B per rank) every %d steps on a side stream" % ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend(), 5 * n_local, args.log_every)
+        exchange = "none" if world == 1 else ("%s all-gather of done u8 + reward f32 (%d B per rank) every %d steps on a side stream, %d inside the timed region" % ("RCCL" if dist.get_backend() == "nccl" else dist.get_backend(), 5 * n_local, args.log_every, exchanges_timed)
                                               if logger is not None else ("all-reduce of (episodes, reward_sum) every %d steps" % args.log_every if args.log == "allreduce" else "none"))
         out = {
             "metric": "env-steps/sec", "value": n_total * K / dt, "unit": "env-steps/s", "n_gpus": world,
@@ -423,7 +474,7 @@ def main():
             "episodes": episodes, "reward_sum": reward_sum, "episodes_in_timed_region": episodes - ep0,
             "roofline": {"bound": "hbm", "achieved": slow["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": slow["frac"], "traffic": traffic,
-                         "kernel": "k_step_fulldirect" if (args.obs_mode.startswith("full") and (cfg.width * cfg.height) % 4 == 0) else "k_step",
+                         "kernel": kernel_name, "avg_kernel_from": "event pairs" if (multi_kernel and sampled_s > 0.0) else "span / launches",
                          "avg_kernel_us": slow["avg_kernel_us"], "kernel_samples": k_n, "launches": launches,
                          "span_us_per_step": slow["span_us_per_step"], "event_pair_us": slow["event_pair_us"],
                          "algorithmic_bytes_per_env_step": bps, "layout_bytes_per_env_step_all_kernels": lbps,
@@ -431,6 +482,13 @@ def main():
                          "survey_bytes_per_env_step": sbps, "achieved_on_survey_bytes": sbps * n_local / (slow["avg_kernel_us"] * 1e-6) / 1e9 if slow["avg_kernel_us"] > 0 else 0.0,
                          "per_rank": per_rank},
         }
+        if rccl is not None:
+            rccl["exchanges_in_timed_region"] = exchanges_timed
+            rccl["log_every"] = args.log_every
+            rccl["bytes_per_rank_per_exchange"] = 5 * n_local if logger is not None else (16 if args.log == "allreduce" else 0)
+            if logger is not None:
+                rccl.update(logger.stats())   # rank 0's side stream: collective_us_mean / max, step-stream waits
+            out["rccl"] = rccl
         if gather_checked is not None:
             out["gather_checked"] = gather_checked
         if dry:

@@ -74,6 +74,8 @@ __global__ __launch_bounds__(256) void k_dynobs_init(const DynObsParams p)
 typedef unsigned long long dyn_u64;
 #define MGX_DYN_PLANE_DW (MGX_DYN_TAPE_DW / 2)
 #define MGX_DYN_POSITIONS 848 /* 624 + 224: the head of the next block depends on the old block only for k < 227 */
+static_assert(MGX_DYN_POSITIONS <= 32 * MGX_DYN_PLANE_DW && (MGX_DYN_POSITIONS - 64) / 32 + 2 < MGX_DYN_PLANE_DW,
+              "the last window advance() may take starts at 848 - 64 and reads three dwords of each plane: they must lie inside the plane");
 
 // low two bits of genrand's tempering of y (checked against the full tempering on 1e6 random words)
 __device__ __forceinline__ uint32_t temper2(uint32_t y)
@@ -123,7 +125,9 @@ struct DynRng {
 
 
 // The tape of a complete block `blk` (624 words in LDS) into `tp` (MGX_DYN_TAPE_DW dwords in LDS), by the whole wave:
-// 11 rounds of 64 stream positions, two ballots each.  Position k >= 624 is word k - 624 of the next block.
+// MGX_DYN_PLANE_DW / 2 = 14 rounds of 64 stream positions, two ballots each.  Position k >= 624 is word k - 624 of the next block;
+// the plane's last 48 positions (848 .. 895) do not exist and are marked as rejected draws (both bits set), so a window that
+// reached them would skip them instead of reading zeros as draws (advance() stops at 848 anyway).
 __device__ __forceinline__ void dyn_build_tape(const uint32_t *blk, uint32_t *tp, int lane)
 {
 #pragma unroll
@@ -132,7 +136,7 @@ __device__ __forceinline__ void dyn_build_tape(const uint32_t *blk, uint32_t *tp
         uint32_t y = 0;
         if (k < 624) y = blk[k];
         else if (k < MGX_DYN_POSITIONS) { const int j = k - 624; y = lg_twist_word(blk[j], blk[j + 1], blk[j + 397]); } // (j < 224 < 227: old words only)
-        const uint32_t v = temper2(y);
+        const uint32_t v = k < MGX_DYN_POSITIONS ? temper2(y) : 3u;
         const dyn_u64 ml = __ballot((v & 1u) != 0u), mh = __ballot((v & 2u) != 0u);
         if (lane == 0) { tp[2 * r] = (uint32_t)ml; tp[2 * r + 1] = (uint32_t)(ml >> 32); }
         if (lane == 1) { tp[MGX_DYN_PLANE_DW + 2 * r] = (uint32_t)mh; tp[MGX_DYN_PLANE_DW + 2 * r + 1] = (uint32_t)(mh >> 32); }

@@ -24,9 +24,9 @@
 //   * auto-reset restores the episode-start snapshot for the (rare) done lanes inside the same launch.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #ifdef MGX_TIMELINE
-#include <stdio.h>
 #include <vector>
 #endif
 
@@ -1165,17 +1165,32 @@ using StepKernel = void (*)(const StepParams);
 struct StepChoice {
     StepKernel fn;
     bool block_per_tile; // the FullyObs direct forms: a 256-thread block per tile, no dynamic LDS
+    const char *name;    // the instantiation, as rocprofv3 prints it (mgx_step_kernel_name: bench.py's roofline.kernel)
 };
+#define MGX_STR_(x) #x
+#define MGX_STR(x) MGX_STR_(x)
 
 template <int CW, int CH>
 StepChoice choose_sized(const StepParams &p, int mode)
 {
-    if (mode == 0) return {k_step<CW, CH, 0, 7>, false};
-    if (mode == 1) return {k_step<CW, CH, 1, 7>, false};
-    if (((CW && CH) ? CW * CH : p.W * p.H) % 4 == 0) return {k_step_fulldirect<CW, CH>, true};
-    if (CW == 0 && !p.objaux && p.W == 19 && p.H == 19) return {k_step_fulldirect<19, 19, true>, true};
-    if (CW == 0 && !p.objaux && p.W == 25 && p.H == 25) return {k_step_fulldirect<25, 25, true>, true};
-    return {k_step_fulldirect<CW, CH, true>, true};
+    struct Names { // (one per <CW, CH>, written once: a function-local static is initialised under the language's own lock)
+        char n0[48], n1[48], n2[48], n3[48];
+        Names()
+        {
+            snprintf(n0, sizeof n0, "k_step<%d,%d,0,7>", CW, CH);
+            snprintf(n1, sizeof n1, "k_step<%d,%d,1,7>", CW, CH);
+            snprintf(n2, sizeof n2, "k_step_fulldirect<%d,%d>", CW, CH);
+            snprintf(n3, sizeof n3, "k_step_fulldirect<%d,%d,ragged>", CW, CH);
+        }
+    };
+    static const Names nm;
+    const char *n0 = nm.n0, *n1 = nm.n1, *n2 = nm.n2, *n3 = nm.n3;
+    if (mode == 0) return {k_step<CW, CH, 0, 7>, false, n0};
+    if (mode == 1) return {k_step<CW, CH, 1, 7>, false, n1};
+    if (((CW && CH) ? CW * CH : p.W * p.H) % 4 == 0) return {k_step_fulldirect<CW, CH>, true, n2};
+    if (CW == 0 && !p.objaux && p.W == 19 && p.H == 19) return {k_step_fulldirect<19, 19, true>, true, "k_step_fulldirect<19,19,ragged>"};
+    if (CW == 0 && !p.objaux && p.W == 25 && p.H == 25) return {k_step_fulldirect<25, 25, true>, true, "k_step_fulldirect<25,25,ragged>"};
+    return {k_step_fulldirect<CW, CH, true>, true, n3};
 }
 
 } // namespace
@@ -1213,28 +1228,28 @@ hipError_t mgx_launch_rollout(const StepParams &p0, const uint8_t *actions, uint
 
 static StepChoice choose_step_kernel(const StepParams &p, int mode)
 {
-    const StepChoice none = {nullptr, false};
+    const StepChoice none = {nullptr, false, "none"};
     if (mode == 3) { // large grids: gather form (the default view and visibility by the size rule, anything else when the tile image cannot fit the LDS)
-#define VCASE(v) if (p.view == v) return p.alt_vis ? StepChoice{k_step<0, 0, 3, v, true>, false} : StepChoice{k_step<0, 0, 3, v>, false};
+#define VCASE(v) if (p.view == v) return p.alt_vis ? StepChoice{k_step<0, 0, 3, v, true>, false, "k_step<0,0,3," MGX_STR(v) ",alt>"} : StepChoice{k_step<0, 0, 3, v>, false, "k_step<0,0,3," MGX_STR(v) ">"};
         MGX_VIEWS(VCASE) VCASE(7)
 #undef VCASE
         return none;
     }
     if (mode == 0 && p.alt_vis) { // default_vis=False: run-time grid size only
-#define VCASE(v) if (p.view == v) return {k_step<0, 0, 0, v, true>, false};
+#define VCASE(v) if (p.view == v) return {k_step<0, 0, 0, v, true>, false, "k_step<0,0,0," MGX_STR(v) ",alt>"};
         MGX_VIEWS(VCASE) VCASE(7)
 #undef VCASE
         return none;
     }
     if (mode == 0 && p.view != 7) {
-#define VCASE(v) if (p.view == v) return {k_step<0, 0, 0, v>, false};
+#define VCASE(v) if (p.view == v) return {k_step<0, 0, 0, v>, false, "k_step<0,0,0," MGX_STR(v) ">"};
         MGX_VIEWS(VCASE)
 #undef VCASE
         return none;
     }
     if (p.objaux && mode == 0 && p.view == 7) { // ObstructedMaze's grids with their boxed keys: sized instances that keep the plane accesses
-        if (p.W == 11 && p.H == 6) return {k_step<11, 6, 0, 7, false, true>, false};
-        if (p.W == 16 && p.H == 16) return {k_step<16, 16, 0, 7, false, true>, false};
+        if (p.W == 11 && p.H == 6) return {k_step<11, 6, 0, 7, false, true>, false, "k_step<11,6,0,7,obj>"};
+        if (p.W == 16 && p.H == 16) return {k_step<16, 16, 0, 7, false, true>, false, "k_step<16,16,0,7,obj>"};
     }
     if (p.objaux) return choose_sized<0, 0>(p, mode);
 #define CASE(w, h) if (p.W == w && p.H == h) return choose_sized<w, h>(p, mode);
@@ -1265,37 +1280,31 @@ hipError_t mgx_step_round_blocks(const StepParams &p, int mode, int waves_per_bl
     return hipSuccess;
 }
 
-// How many of a grid's last blocks run at raised wave priority: two per CU (measured best of 0.5 / 2 / 3.5 / 7 per CU and "the last
-// partial round"); MGX_TAIL_BLOCKS overrides it for tuning runs (0 = off).
-static int tail_blocks()
+// Launch shaping of a handle, fixed at mgx_create from the handle's OWN device: how many of a grid's last blocks
+// run at raised wave priority -- two per CU (measured best of 0.5 / 2 / 3.5 / 7 per CU and "the last partial round") -- and the
+// first-round stagger per SIMD wave slot in units of `s_sleep 4` (256 clocks).  MGX_TAIL_BLOCKS / MGX_STAGGER / MGX_STAGGER_MIN override
+// them for tuning runs (0 = off; read once per handle, never needed for correctness).
+hipError_t mgx_step_launch_cfg(int device, StepLaunchCfg *out)
 {
-    static int n = -1;
-    if (n < 0) {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-        const char *e = getenv("MGX_TAIL_BLOCKS");
-        n = e ? atoi(e) : 2 * cus;
-    }
-    return n;
-}
-// First-round stagger per SIMD wave slot, in units of `s_sleep 4` (256 clocks); MGX_STAGGER overrides it for tuning runs (0 = off).
-static int stagger_units()
-{
-    static int n = -1;
-    if (n < 0) { const char *e = getenv("MGX_STAGGER"); n = e ? atoi(e) : 5; }
-    return n;
+    int cus = 256;
+    hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    if (e != hipSuccess) return e;
+    const char *t = getenv("MGX_TAIL_BLOCKS"), *s = getenv("MGX_STAGGER"), *m = getenv("MGX_STAGGER_MIN");
+    out->tail_blocks = t ? atoi(t) : 2 * cus;
+    out->stagger_units = s ? atoi(s) : 5;
+    out->stagger_min = m ? atoi(m) : -1; // (tuning runs: the smallest grid that staggers; default: one round of resident blocks)
+    return hipSuccess;
 }
 
-hipError_t mgx_launch_step(const StepParams &p0, int mode, int waves_per_block, hipStream_t st)
+hipError_t mgx_launch_step(const StepParams &p0, int mode, int waves_per_block, const StepLaunchCfg &lc, hipStream_t st)
 {
     const StepChoice c = choose_step_kernel(p0, mode);
     if (!c.fn) return hipErrorInvalidValue;
     const StepShape sh = step_shape(p0, c, waves_per_block);
     StepParams p = p0;
-    const int blocks = (int)sh.grid.x, tb = tail_blocks() * 4 / (c.block_per_tile ? 4 : waves_per_block); // (counted in 4-wave blocks)
+    const int blocks = (int)sh.grid.x, tb = lc.tail_blocks * 4 / (c.block_per_tile ? 4 : waves_per_block); // (counted in 4-wave blocks)
     p.tail_block0 = (tb > 0 && blocks > tb) ? blocks - tb : 0x7fffffff;
-    static const int stagger_min = getenv("MGX_STAGGER_MIN") ? atoi(getenv("MGX_STAGGER_MIN")) : -1; // (tuning runs: the smallest grid that staggers)
-    p.stagger = (!c.block_per_tile && p.round_blocks > 0 && blocks > (stagger_min >= 0 ? stagger_min : p.round_blocks)) ? stagger_units() : 0;
+    p.stagger = (!c.block_per_tile && p.round_blocks > 0 && blocks > (lc.stagger_min >= 0 ? lc.stagger_min : p.round_blocks)) ? lc.stagger_units : 0;
 #ifdef MGX_TIMELINE
     {   // launch number MGX_TL_LAUNCH (default 300) of the process records its waves; the next launch writes them to MGX_TL_FILE
         static unsigned long long *tl = nullptr;
@@ -1317,6 +1326,8 @@ hipError_t mgx_launch_step(const StepParams &p0, int mode, int waves_per_block, 
     hipLaunchKernelGGL(c.fn, sh.grid, sh.block, sh.shmem, st, p);
     return hipGetLastError();
 }
+
+const char *mgx_step_kernel_label(const StepParams &p, int mode) { return choose_step_kernel(p, mode).name; }
 
 hipError_t mgx_raise_lds_limit(const StepParams &p, int mode, int bytes)
 {

@@ -52,6 +52,7 @@ struct mgx_env_s {
     int W = 0, H = 0, cells = 0, S = 0, LS = 0, wave_lds = 0, wpb = 4, view = 7;
     int lds_guard = 0;    // StepParams.lds_guard
     int round_blocks = 0; // blocks of the step kernel resident at once on the chip (first-round stagger, k_step)
+    StepLaunchCfg launch_cfg = {0, 0, -1}; // raised-priority tail / stagger of THIS handle's device (mgx_step_launch_cfg, at create)
     bool partial = true;   // the simulator emits the VxV view (else the full grid)
     int oh_nc = -1, oh_ns = 0; // one-hot epilogue channels (oh_nc < 0: none)
     uint8_t *tri_d = nullptr;  // triples scratch feeding the one-hot / flat epilogue
@@ -494,6 +495,7 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
             }
         }
         CREATE_TRY(mgx_step_round_blocks(sp, h->kernel_mode, h->wpb, &h->round_blocks));
+        CREATE_TRY(mgx_step_launch_cfg(device, &h->launch_cfg));
     }
     CREATE_TRY(mgx_preload_state_kernels());
     if (h->device_levels || h->one_level) CREATE_TRY(mgx_preload_levelgen_kernels());
@@ -750,7 +752,7 @@ static int run_step(mgx_handle h, bool do_step, const uint8_t *actions, uint8_t 
         }
         HIP_TRY(hipEventRecord(h->prof_ev[2 * h->prof_samples], h->stream));
     }
-    HIP_TRY(mgx_launch_step(p, h->kernel_mode, h->wpb, h->stream));
+    HIP_TRY(mgx_launch_step(p, h->kernel_mode, h->wpb, h->launch_cfg, h->stream));
     if (sample) {
         HIP_TRY(hipEventRecord(h->prof_ev[2 * h->prof_samples + 1], h->stream));
         h->prof_samples++;
@@ -1070,6 +1072,16 @@ extern "C" int mgx_fill_actions(mgx_handle h, uint64_t seed, int64_t env0, int64
 }
 
 extern "C" uint32_t mgx_action_at(uint64_t seed, int64_t env, int64_t t) { return mgx_action_of(seed, (uint64_t)env, (uint64_t)t); }
+
+extern "C" int mgx_step_kernel_name(mgx_handle h, char *out, int cap)
+{
+    if (!h || !out || cap < 1) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_step_kernel_name: null argument");
+    const char *name = mgx_step_kernel_label(base_params(h), h->kernel_mode); // (host-side table lookup: no device call)
+    const int len = (int)strlen(name);
+    if (len + 1 > cap) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_step_kernel_name: need %d bytes", len + 1);
+    memcpy(out, name, (size_t)len + 1);
+    return len;
+}
 
 extern "C" int mgx_profile_begin_sampled(mgx_handle h, int stride)
 {

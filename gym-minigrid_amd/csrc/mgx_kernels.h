@@ -120,7 +120,11 @@ hipError_t mgx_launch_levelgen(const LevelGenParams &p, hipStream_t st);
 hipError_t mgx_launch_seed(const uint64_t *seeds, const uint8_t *mask, const uint32_t *init, uint32_t *mt, uint32_t *mt_idx,
                            uint8_t *regen, uint64_t *seed0, uint8_t *has_seed, uint8_t *reseeded, int skip_same, int64_t n, hipStream_t st);
 hipError_t mgx_launch_consume(const ConsumeParams &p, hipStream_t st);
-hipError_t mgx_launch_step(const StepParams &p, int mode, int waves_per_block, hipStream_t st);
+// launch shaping of one handle on its own device (k_step.hip: raised-priority tail blocks, first-round stagger)
+struct StepLaunchCfg { int tail_blocks, stagger_units, stagger_min; };
+hipError_t mgx_step_launch_cfg(int device, StepLaunchCfg *out);
+hipError_t mgx_launch_step(const StepParams &p, int mode, int waves_per_block, const StepLaunchCfg &lc, hipStream_t st);
+const char *mgx_step_kernel_label(const StepParams &p, int mode); // the instantiation the selector picks, e.g. "k_step<8,8,0,7>"
 hipError_t mgx_launch_rollout(const StepParams &p, const uint8_t *actions, uint8_t *obs, float *reward, uint8_t *done, int64_t T, hipStream_t st);
 hipError_t mgx_preload_step_kernels();
 // (every .hip file is a code object of its own; one lookup each loads it at mgx_create instead of inside the first reset / step)

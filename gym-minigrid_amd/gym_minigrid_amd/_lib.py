@@ -5,7 +5,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
-SO_PATH = os.path.join(CSRC, "libmgx.so")
+# MGX_LIB: another build of the same library (tuning / instrumented variants, tools/ab.sh); never a different implementation
+SO_PATH = os.environ.get("MGX_LIB") or os.path.join(CSRC, "libmgx.so")
 
 MGX_OK = 0
 ERR_NAMES = {-1: "INVALID_ARG", -2: "INVALID_STATE", -3: "INVALID_ACTION", -4: "OUT_OF_BOUNDS",
@@ -81,6 +82,7 @@ SIGNATURES = {
     "mgx_read_stats_async": (_int, [_vp, _vp]),
     "mgx_fill_actions": (_int, [_vp, ctypes.c_uint64, _i64, _i64, _i64, _vp]),
     "mgx_action_at": (ctypes.c_uint32, [ctypes.c_uint64, _i64, _i64]),
+    "mgx_step_kernel_name": (_int, [_vp, ctypes.c_char_p, _int]),
     "mgx_profile_begin": (_int, [_vp]),
     "mgx_profile_begin_sampled": (_int, [_vp, _int]),
     "mgx_profile_stop": (_int, [_vp]),

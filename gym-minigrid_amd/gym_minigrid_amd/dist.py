@@ -20,8 +20,11 @@ def env_rank_info():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init_process_group(backend=None):
-    """Rendezvous from RANK/WORLD_SIZE/MASTER_* (torchrun).  backend: 'nccl' (RCCL) on GPUs, 'gloo' on CPU."""
+def init_process_group(backend=None, device=None):
+    """Rendezvous from RANK/WORLD_SIZE/MASTER_* (torchrun).  backend: 'nccl' (RCCL) on GPUs, 'gloo' on CPU.
+    `device` (a cuda torch.device, already made current by the caller) binds the RCCL communicator to that GPU up front
+    (init_process_group(device_id=...)): the communicator is then created eagerly on the right device instead of on whatever
+    device is current at the first collective."""
     import torch
     import torch.distributed as dist
     rank, local_rank, world = env_rank_info()
@@ -31,8 +34,27 @@ def init_process_group(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs between processes on this pool
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if backend == "nccl" and device is not None:
+            kw["device_id"] = device
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world
+
+
+def device_identity(index):
+    """What distinguishes the physical GPU behind cuda:<index> from every other GPU of the node: its UUID where the
+    runtime reports one, else its PCI address.  bench.py all-gathers these to prove that N ranks drove N distinct GPUs."""
+    import torch
+    p = torch.cuda.get_device_properties(index)
+    ident = {"index": int(index), "name": p.name}
+    u = getattr(p, "uuid", None)
+    if u is not None:
+        ident["uuid"] = str(u)
+    if hasattr(p, "pci_bus_id"):
+        ident["pci"] = "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, getattr(p, "pci_device_id", 0))
+    # (both: a runtime that reports one constant UUID for every GPU must not make distinct GPUs look like one)
+    ident["key"] = "%s|%s" % (ident.get("uuid", "-"), ident.get("pci", "index-%d" % index))
+    return ident
 
 
 def allreduce_log(stats2):
@@ -78,54 +100,120 @@ def gather_done_reward(done, reward, sizes=None):
 class GatherLogger:
     """The logging exchange of BASELINE config 4 ("RCCL gather of done/reward"), off the step stream.
 
-    submit(done, reward) snapshots the step's per-env done (u8) / reward (f32) vectors into private buffers on the
-    caller's stream (the env overwrites its own on the next step), then all-gathers the snapshots of every rank on a
-    SIDE stream: RCCL's work is ordered behind the snapshot by an event, not behind later steps, and the step stream
-    never waits for it.  wait() joins the side stream and returns the gathered (done, reward) in global env order.
-    Equal shards only (n_local envs on every rank).  CPU tensors (gloo) take the same calls without streams."""
+    submit(done, reward) snapshots the step's per-env done (u8) / reward (f32) vectors into one of `buffers` (2) private
+    snapshot buffers on the caller's stream (the env overwrites its own on the next step), then all-gathers the snapshots
+    of every rank on a SIDE stream: RCCL's work is ordered behind the snapshot by an event, not behind later steps.  The
+    step stream waits for the side stream only when it comes back to a snapshot buffer whose previous gather has not
+    finished -- with two buffers that takes a gather longer than a whole logging interval -- and that wait is bracketed by
+    its own event pair, so stats() can say how long the step stream really stood still.  Every exchange is bracketed by
+    an event pair on the side stream (`collective_us`).  wait() joins the side stream and returns the gathered
+    (done, reward) of the LAST submit in global env order.  Equal shards only (n_local envs on every rank).
+    CPU tensors (gloo) take the same calls without streams."""
 
-    def __init__(self, n_local, device, world):
+    MAX_TIMED = 512  # exchanges that get their own timing events (later ones run untimed)
+
+    def __init__(self, n_local, device, world, buffers=2):
         import torch
         self.torch = torch
         self.world = int(world)
         self.n = int(n_local)
+        self.nbuf = max(1, int(buffers))
         self.cuda = torch.device(device).type == "cuda"
-        self.done = torch.zeros(self.n, dtype=torch.uint8, device=device)
-        self.reward = torch.zeros(self.n, dtype=torch.float32, device=device)
-        self.all_done = torch.zeros(self.world * self.n, dtype=torch.uint8, device=device)
-        self.all_reward = torch.zeros(self.world * self.n, dtype=torch.float32, device=device)
+        self.snap_done = [torch.zeros(self.n, dtype=torch.uint8, device=device) for _ in range(self.nbuf)]
+        self.snap_reward = [torch.zeros(self.n, dtype=torch.float32, device=device) for _ in range(self.nbuf)]
+        self.gath_done = [torch.zeros(self.world * self.n, dtype=torch.uint8, device=device) for _ in range(self.nbuf)]
+        self.gath_reward = [torch.zeros(self.world * self.n, dtype=torch.float32, device=device) for _ in range(self.nbuf)]
         self.side = torch.cuda.Stream(device=device) if self.cuda else None
-        self.ready = torch.cuda.Event() if self.cuda else None
+        self.ready = [torch.cuda.Event() for _ in range(self.nbuf)] if self.cuda else None
+        self.consumed = [torch.cuda.Event() for _ in range(self.nbuf)] if self.cuda else None
+        self.in_use = [False] * self.nbuf
         self.submitted = 0
+        self.last = 0
+        self._coll = []        # (start, end) events on the side stream, or host seconds (gloo)
+        self._waits = []       # (before, after) events around a step-stream wait
+        self.not_ready_at_submit = 0
+
+    # the snapshot the last submit took (bench.py checks its own shard inside the gathered vectors against it)
+    @property
+    def done(self):
+        return self.snap_done[self.last]
+
+    @property
+    def reward(self):
+        return self.snap_reward[self.last]
 
     def submit(self, done, reward):
+        import time
         import torch.distributed as dist
         torch = self.torch
-        if self.cuda:
-            cur = torch.cuda.current_stream(self.done.device)
-            cur.wait_stream(self.side)          # the previous gather has read the snapshot buffers
-        self.done.copy_(done, non_blocking=True)
-        self.reward.copy_(reward, non_blocking=True)
+        b = self.submitted % self.nbuf
         many = self.world > 1 and dist.is_initialized()
         if self.cuda:
-            self.ready.record(cur)
-            with torch.cuda.stream(self.side):
-                self.side.wait_event(self.ready)
-                if many:
-                    dist.all_gather_into_tensor(self.all_done, self.done)
-                    dist.all_gather_into_tensor(self.all_reward, self.reward)
+            cur = torch.cuda.current_stream(self.snap_done[b].device)
+            if self.in_use[b]:
+                # the gather that last read this snapshot buffer must be through before it is overwritten
+                if not self.consumed[b].query():
+                    self.not_ready_at_submit += 1
+                if len(self._waits) < self.MAX_TIMED:
+                    w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    w0.record(cur)
+                    cur.wait_event(self.consumed[b])
+                    w1.record(cur)
+                    self._waits.append((w0, w1))
                 else:
-                    self.all_done.copy_(self.done, non_blocking=True)
-                    self.all_reward.copy_(self.reward, non_blocking=True)
-        elif many:
-            dist.all_gather_into_tensor(self.all_done, self.done)
-            dist.all_gather_into_tensor(self.all_reward, self.reward)
+                    cur.wait_event(self.consumed[b])
+            self.snap_done[b].copy_(done, non_blocking=True)
+            self.snap_reward[b].copy_(reward, non_blocking=True)
+            self.ready[b].record(cur)
+            timed = len(self._coll) < self.MAX_TIMED
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self.ready[b])
+                if timed:
+                    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    t0.record(self.side)
+                if many:
+                    dist.all_gather_into_tensor(self.gath_done[b], self.snap_done[b])
+                    dist.all_gather_into_tensor(self.gath_reward[b], self.snap_reward[b])
+                else:
+                    self.gath_done[b].copy_(self.snap_done[b], non_blocking=True)
+                    self.gath_reward[b].copy_(self.snap_reward[b], non_blocking=True)
+                if timed:
+                    t1.record(self.side)
+                    self._coll.append((t0, t1))
+                self.consumed[b].record(self.side)
+            self.in_use[b] = True
         else:
-            self.all_done.copy_(self.done)
-            self.all_reward.copy_(self.reward)
+            self.snap_done[b].copy_(done)
+            self.snap_reward[b].copy_(reward)
+            t0 = time.perf_counter()
+            if many:
+                dist.all_gather_into_tensor(self.gath_done[b], self.snap_done[b])
+                dist.all_gather_into_tensor(self.gath_reward[b], self.snap_reward[b])
+            else:
+                self.gath_done[b].copy_(self.snap_done[b])
+                self.gath_reward[b].copy_(self.snap_reward[b])
+            if len(self._coll) < self.MAX_TIMED:
+                self._coll.append(time.perf_counter() - t0)
+        self.last = b
         self.submitted += 1
 
     def wait(self):
         if self.cuda:
-            self.torch.cuda.current_stream(self.done.device).wait_stream(self.side)
-        return self.all_done, self.all_reward
+            self.torch.cuda.current_stream(self.snap_done[0].device).wait_stream(self.side)
+        return self.gath_done[self.last], self.gath_reward[self.last]
+
+    def stats(self):
+        """Call after a synchronise: per-exchange duration on the side stream and what the step stream waited for it."""
+        if self.cuda:
+            self.side.synchronize()
+            coll = [a.elapsed_time(b) * 1e3 for a, b in self._coll]
+            waits = [a.elapsed_time(b) * 1e3 for a, b in self._waits]
+        else:
+            coll = [c * 1e6 for c in self._coll]
+            waits = []
+        return {"exchanges": self.submitted, "buffers": self.nbuf,
+                "collective_us_mean": (sum(coll) / len(coll)) if coll else None,
+                "collective_us_max": max(coll) if coll else None,
+                "step_stream_waits": len(waits), "step_stream_wait_us_total": sum(waits),
+                "gather_unfinished_when_buffer_reused": self.not_ready_at_submit,
+                "timed_on": "side stream (HIP events)" if self.cuda else "host clock (blocking gloo collective)"}

@@ -334,6 +334,14 @@ class VecMiniGrid:
         _lib.check(_lib.lib().mgx_fill_actions(self._h, ctypes.c_uint64(seed), self.env_offset, int(t0), int(T), _ptr(out)))
         return out
 
+    def step_kernel_name(self):
+        """The step-kernel instantiation this handle launches, e.g. 'k_step<8,8,0,7>' (include/mgx.h)."""
+        buf = ctypes.create_string_buffer(64)
+        n = _lib.lib().mgx_step_kernel_name(self._h, buf, 64)
+        if n < 0:
+            _lib.check(n)
+        return buf.value.decode()
+
     def profile_begin(self, stride=8):
         """Start timing (include/mgx.h): the stream span + every `stride`-th step-kernel launch on its own."""
         _lib.check(_lib.lib().mgx_profile_begin_sampled(self._h, int(stride)))

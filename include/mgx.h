@@ -330,6 +330,11 @@ uint32_t mgx_action_at(uint64_t seed, int64_t env, int64_t t);
  * mgx_profile_begin(h) == mgx_profile_begin_sampled(h, 8).  stride > the number of launches samples the first launch only.
  * mgx_profile_stop() (optional) enqueues the span's end marker without waiting, so that a caller who synchronises the stream anyway
  * (bench.py's timed region) pays for one wait instead of two; mgx_profile_end() then only reads the times. */
+/* Name of the step-kernel instantiation this handle launches, as a profiler prints it without the argument list
+ * ("k_step<8,8,0,7>", "k_step_fulldirect<19,19,ragged>", "k_step<0,0,3,7>" = the gather form of large grids, ...): lets a
+ * bench line and a rocprofv3 row be matched by name.  Writes a NUL-terminated string, returns its length or a negative status. */
+int mgx_step_kernel_name(mgx_handle h, char *out, int cap);
+
 int mgx_profile_begin(mgx_handle h);
 int mgx_profile_begin_sampled(mgx_handle h, int stride);
 int mgx_profile_stop(mgx_handle h);

@@ -41,7 +41,12 @@ def test_launcher_two_gloo_ranks_one_json_line():
     assert j["n_gpus"] == 2 and j["steps"] == 40 and j["warmup"] == 3 and j["scaling"] == "weak"
     assert j["gather_checked"] is True and j["dry_run"] is True
     assert j["config"]["env_id"] == "MiniGrid-LavaCrossingS9N1-v0" and j["config"]["envs_per_gpu"] == 1001
-    assert "all-gather" in j["config"]["logging_exchange"]
+    assert "all-gather" in j["config"]["logging_exchange"] and "gloo" in j["config"]["logging_exchange"]
+    # the line proves who took part and what the exchange cost: backend, world, one identity per rank, exchanges inside the timed region
+    r = j["rccl"]
+    assert r["backend"] == "gloo" and r["world"] == 2 and [d["rank"] for d in r["devices"]] == [0, 1] and r["distinct_devices"] is True
+    assert r["exchanges_in_timed_region"] == 2 and r["exchanges"] == 2 and r["log_every"] == 16 and r["collective_us_mean"] > 0
+    assert r["bytes_per_rank_per_exchange"] == 5 * 1001
     assert [r["rank"] for r in j["roofline"]["per_rank"]] == [0, 1]
     assert j["episodes_in_timed_region"] == sum(r["episodes"] for r in j["roofline"]["per_rank"]) > 0
     # the N = 1 line has the same shape (plus what only one rank can have: no exchange, no gather check)
@@ -49,7 +54,7 @@ def test_launcher_two_gloo_ranks_one_json_line():
                                 "--steps", "40", "--warmup", "3", "--no-cpu-baseline")
     assert rc1 == 0, err1[-2000:]
     j1 = json.loads(out1.strip())
-    assert keys_of(j) - keys_of(j1) == {"gather_checked"} and keys_of(j1) <= keys_of(j)
+    assert {k for k in keys_of(j) - keys_of(j1) if not k.startswith("rccl")} == {"gather_checked"} and keys_of(j1) <= keys_of(j)
     assert j1["config"]["logging_exchange"] == "none"
     # global indexing: 2 ranks x 1001 envs saw the same (env, t) pairs as 1 rank x 2002 envs
     rc2, out2, err2 = run_bench("--gpus", "1", "--dry-run-ranks", "--config", "lava4m", "--envs-per-gpu", "2002",
@@ -57,6 +62,20 @@ def test_launcher_two_gloo_ranks_one_json_line():
     assert rc2 == 0, err2[-2000:]
     j2 = json.loads(out2.strip())
     assert j2["episodes"] == j["episodes"] and abs(j2["reward_sum"] - j["reward_sum"]) < 1e-6
+
+
+@pytest.mark.timeout(600)
+def test_drivers_own_command_shape_times_the_exchange():
+    """`bench.py --gpus N --steps 20 --warmup W` (what the driver runs): --log-every defaults to min(256, steps), so the one
+    exchange of a 20-step run lands INSIDE the timed region and is reported with its own duration."""
+    rc, out, err = run_bench("--gpus", "2", "--dry-run-ranks", "--steps", "20", "--warmup", "5", "--envs-per-gpu", "777")
+    assert rc == 0, err[-2000:]
+    j = json.loads(out.strip())
+    r = j["rccl"]
+    assert r["log_every"] == 20 and r["exchanges_in_timed_region"] == 1 and r["exchanges"] == 1
+    assert r["collective_us_mean"] > 0 and r["step_stream_wait_us_total"] == 0
+    assert j["gather_checked"] is True and "1 inside the timed region" in j["config"]["logging_exchange"]
+    assert len(r["devices"]) == 2 and r["devices"][0]["host"]
 
 
 @pytest.mark.timeout(600)

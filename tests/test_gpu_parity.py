@@ -295,24 +295,51 @@ def test_task_families_on_device_vs_oracle(env_id):
 @pytest.mark.parametrize("env_id", ["MiniGrid-PutNear-8x8-N3-v0", "MiniGrid-RedBlueDoors-6x6-v0", "MiniGrid-TwoGoals-Random-6x6-v0", "MiniGrid-MemoryS9-v0",
                                     "MiniGrid-KeyCorridorS5R3-v0", "MiniGrid-GoToObject-6x6-N2-v0", "MiniGrid-Dynamic-Obstacles-6x6-v0"])
 def test_task_families_fully_observable(env_id):
-    """The task rules also run inside the FullyObs kernels (direct, ragged direct and LDS form, by grid size)."""
+    """The task rules also run inside the FullyObs kernels (direct, ragged direct and LDS form, by grid size): the FullyObs
+    handle against the ORACLE running the same task rule with full=True (oracle/minigrid_oracle.c: mgo_step_batch writes
+    FullyObsWrapper.observation, wrappers.py:326-338, of the post-step state) on the host-generated levels -- every image,
+    reward and done byte, across in-kernel auto-resets; the partial handle of the same seeds must agree on reward / done too."""
     N, T = 200, 60
     seeds = np.arange(N, dtype=np.uint64) + 50
     full = mg.VecMiniGrid(env_id, num_envs=N, seeds=seeds, auto_reset=True, backend="torch", obs_mode="full")
     part = mg.VecMiniGrid(env_id, num_envs=N, seeds=seeds, auto_reset=True, backend="torch")
-    full.reset(); part.reset()
+    cfg = mg.env_config(env_id)
+    dyn = "Dynamic-Obstacles" in env_id
+    if dyn:
+        from oracle.dynobs_oracle import DynObsOracle
+        orc = DynObsOracle(cfg.width, cfg.level_arg0, bool(cfg.level_arg1), seeds)
+        base = orc.base
+    else:
+        grid, agent, task = mg.generate_levels(env_id, seeds, with_task=True)
+        orc = base = OracleEnvs(cfg.width, cfg.height, cfg.max_steps, cfg.see_through_walls, cfg.lava_v1, task=cfg.task_kind)
+        orc.set_state(grid, agent)
+        orc.task = task.copy()
+    fo0 = full.reset(); part.reset()
+    assert np.array_equal(to_np(fo0), base.observe(full=True)[1])
     rs = np.random.RandomState(4)
     import torch
+    dones = 0
     for t in range(T):
-        a = torch.from_numpy(rs.randint(0, 7, size=N).astype(np.uint8)).cuda()
+        a_np = rs.randint(0, 7, size=N).astype(np.uint8)
+        a = torch.from_numpy(a_np).cuda()
         fo, fr, fd, _ = full.step(a)
         po, pr, pd, _ = part.step(a)
         assert torch.equal(fr, pr) and torch.equal(fd, pd), (env_id, t)
-        st = part.get_state()                                  # FullyObsWrapper.observation of the same state
-        want = st["grid"].copy()
-        want[np.arange(N), st["agent"][:, 0], st["agent"][:, 1]] = np.stack([np.full(N, 10), np.zeros(N, int), st["agent"][:, 2]], 1)
-        assert np.array_equal(fo.cpu().numpy(), want), (env_id, t)
-    assert full.stats() == part.stats()
+        if dyn:
+            _, orew, odone = orc.step(a_np)
+            want = base.observe(full=True)[1]            # FullyObsWrapper.observation of the post-step state
+        else:
+            _, want, orew, odone = orc.step(a_np, full=True)
+        orc.reset_where(odone)
+        d = odone.astype(bool)
+        if d.any():
+            want = want.copy()
+            want[d] = base.observe(full=True)[1][d]      # auto-reset: the first image of the new episode
+        assert np.array_equal(to_np(fd), odone), (env_id, t)
+        assert np.array_equal(to_np(fr), np.asarray(orew).astype(np.float32)), (env_id, t)
+        assert np.array_equal(to_np(fo), want), (env_id, t)
+        dones += int(odone.sum())
+    assert (dones > 0 or "KeyCorridor" in env_id) and full.stats() == part.stats() and full.stats()["episodes"] == dones  # (no random walk solves KeyCorridorS5R3 in 60 steps)
     full.close(); part.close()
 
 

@@ -93,9 +93,20 @@ def test_config4_eight_shards_equal_one_handle():
     oc = C.reset()
     for r, e in enumerate(shards):
         assert torch.equal(e.reset(), oc[r * n:(r + 1) * n])
+    # ... and the single 4,194,304-env handle itself against the CPU oracle, so that the comparison above is not HIP against HIP
+    # only: 1,600 envs of it (every shard's first and last tile, tile boundaries, a random spread) followed on every step from
+    # host-generated levels of their GLOBAL seeds under the GLOBAL action stream -- observation, reward, done, across the resets.
+    rs = np.random.RandomState(11)
+    edges = np.concatenate([[r * n + k for k in (0, 1, 63, 64, n - 65, n - 64, n - 1)] for r in range(G)])
+    sample = np.unique(np.concatenate([edges, rs.randint(0, G * n, size=1600 - len(edges))])).astype(np.int64)
+    cfg = mg.env_config(env_id)
+    grid, agent = mg.generate_levels(env_id, sample.astype(np.uint64))          # seeds=0: env i is seeded with i
+    orc = make_oracle(cfg.width, cfg.height, cfg.max_steps, cfg.see_through_walls, cfg.lava_v1, grid, np.zeros(grid.shape[:3], np.uint8), agent)
+    sample_d = torch.from_numpy(sample).cuda()
+    assert np.array_equal(oc[sample_d].cpu().numpy(), orc.observe())
     acts_c = C.fill_actions(2, 0, T)
     acts = [e.fill_actions(2, 0, T) for e in shards]
-    episodes = 0
+    episodes = sampled_episodes = 0
     for t in range(T):
         oc, rc, dc, _ = C.step(acts_c[t])
         outs = [e.step(a[t]) for e, a in zip(shards, acts)]
@@ -103,8 +114,16 @@ def test_config4_eight_shards_equal_one_handle():
         if t % 8 == 7 or t < 2:
             for r, o in enumerate(outs):
                 assert torch.equal(o[0], oc[r * n:(r + 1) * n]), (t, r)
+        a = mg.action_stream(2, sample, t)
+        assert np.array_equal(acts_c[t][sample_d].cpu().numpy(), a)
+        o_obs, o_rew, o_done = orc.step(a)
+        orc.reset_where(o_done)
+        want = np.where(o_done.astype(bool)[:, None, None, None], orc.observe(), o_obs)
+        assert np.array_equal(oc[sample_d].cpu().numpy(), want), t
+        assert np.array_equal(dc[sample_d].cpu().numpy(), o_done) and np.array_equal(rc[sample_d].cpu().numpy(), o_rew.astype(np.float32)), t
         episodes += int(dc.sum())
-    assert episodes > 100000
+        sampled_episodes += int(o_done.sum())
+    assert episodes > 100000 and sampled_episodes > 100 and len(sample) >= 1500
     st = [e.stats() for e in shards]
     assert sum(s["episodes"] for s in st) == C.stats()["episodes"] == episodes
     assert abs(sum(s["reward_sum"] for s in st) - C.stats()["reward_sum"]) < 1e-6

@@ -5,6 +5,8 @@ TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
+PY=$(readlink -f "$(command -v python3)")   # the real interpreter binary must follow `--` directly: the profiler's preloaded
+                                            # library has initialised the GPU before the program starts, and no hop may exec after that
 cd /tmp && export TMPDIR=/tmp
 i=0
 for grp in \
@@ -13,6 +15,6 @@ for grp in \
  "SQ_IFETCH SQ_IFETCH_LEVEL SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_BUSY_CU_CYCLES SQ_INSTS_BRANCH" \
  "GRBM_GUI_ACTIVE SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_FLAT SQ_INSTS_SMEM SQ_CYCLES SQ_LDS_DATA_FIFO_FULL" ; do
   i=$((i+1))
-  timeout -k 10 240 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/p$i -- python $R/bench.py --steps 24 --warmup 4 --no-cpu-baseline "$@" > $OUT/p$i.log 2>&1 || echo "pass $i failed (see $OUT/p$i.log)"
+  timeout -k 10 240 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/p$i -- $PY $R/bench.py --steps 24 --warmup 4 --no-cpu-baseline "$@" > $OUT/p$i.log 2>&1 || echo "pass $i failed (see $OUT/p$i.log)"
 done
 echo "done $TAG"

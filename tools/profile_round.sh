@@ -5,16 +5,17 @@
 # collected in passes of their own (--pmc with --kernel-trace only).  Nothing is re-measured silently: a run whose slowest
 # launch of the top kernel took > 100x its fastest is KEPT and listed in <tag>_outliers.txt with that launch's duration.
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 PART=${2:-all}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
+PY=$(readlink -f "$(command -v python3)")   # the real interpreter binary directly after `--` (no shim, no env hop)
 cd /tmp && export TMPDIR=/tmp
 stats() { # name, bench args...
   local name=$1; shift
   rm -rf $OUT/tmp_$name
-  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tmp_$name -- python3 $R/bench.py --no-cpu-baseline "$@" > $OUT/$name.log 2>&1 || { echo "stats $name failed"; return 0; }
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tmp_$name -- $PY $R/bench.py --no-cpu-baseline "$@" > $OUT/$name.log 2>&1 || { echo "stats $name failed"; return 0; }
   local f=$(find $OUT/tmp_$name -name "*kernel_stats.csv" | head -n 1)
   [ -n "$f" ] && cp $f $OUT/${TAG}_kernel_stats_$name.csv
   grep "^{\"metric\"" $OUT/$name.log | tail -n 1 > $OUT/${TAG}_bench_$name.json
@@ -32,7 +33,7 @@ PY
 pmc() { # name, counter, bench args...: per-dispatch counter values of one pass
   local name=$1 c=$2; shift; shift
   rm -rf $OUT/tmp_pmc
-  timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/tmp_pmc -- python3 $R/bench.py --steps 24 --warmup 8 --no-cpu-baseline "$@" > $OUT/pmc_${name}_$c.log 2>&1 || { echo "pmc $name $c failed"; return 0; }
+  timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/tmp_pmc -- $PY $R/bench.py --steps 24 --warmup 8 --no-cpu-baseline "$@" > $OUT/pmc_${name}_$c.log 2>&1 || { echo "pmc $name $c failed"; return 0; }
   local f=$(find $OUT/tmp_pmc -name "*counter_collection.csv" | head -n 1)
   # keep the step kernels' rows only (the files are per dispatch: ~100 bytes each)
   [ -n "$f" ] && { head -n 1 $f > $OUT/${TAG}_pmc_${name}_$c.csv; grep -E "k_step|k_dynobs|k_levelgen" $f >> $OUT/${TAG}_pmc_${name}_$c.csv || true; }
@@ -56,6 +57,9 @@ if [ $PART = stats ] || [ $PART = all ]; then
   stats fourrooms_full_512k --env MiniGrid-FourRooms-v0 --envs-per-gpu 524288 --obs-mode full --steps 256
   stats multiroom_n6_full_128k --env MiniGrid-MultiRoom-N6-v0 --envs-per-gpu 131072 --obs-mode full --steps 256
   stats multiroom_n6_256k --env MiniGrid-MultiRoom-N6-v0 --envs-per-gpu 262144 --steps 256
+  stats fourrooms_1M --env MiniGrid-FourRooms-v0 --envs-per-gpu 1048576 --steps 256
+  stats empty16x16_512k --env MiniGrid-Empty-16x16-v0 --envs-per-gpu 524288 --steps 256
+  stats keycorridor_s6r3_512k --env MiniGrid-KeyCorridorS6R3-v0 --envs-per-gpu 524288 --steps 256
   stats obstructedmaze_2dlhb_256k --env MiniGrid-ObstructedMaze-2Dlhb-v0 --envs-per-gpu 262144 --steps 256
   stats empty8x8_1M_partial_onehot --obs-mode partial_onehot --steps 256
 fi
@@ -68,10 +72,15 @@ if [ $PART = pmc ] || [ $PART = all ]; then
     pmc empty8x8_4M $c --config empty8 --envs-per-gpu 4194304
     pmc lavacrossing_4M $c --config lava4m --envs-per-gpu 4194304
     pmc lavacrossing_1M $c --config lava4m --envs-per-gpu 1048576
+    pmc multiroom_n6_256k $c --env MiniGrid-MultiRoom-N6-v0 --envs-per-gpu 262144     # the gather form k_step<0,0,3,7>
+    pmc fourrooms_1M $c --env MiniGrid-FourRooms-v0 --envs-per-gpu 1048576
   done
 fi
 if [ $PART = sq ] || [ $PART = all ]; then
-  for w in "lava512k --config lava4m" "lava1m --config lava4m --envs-per-gpu 1048576" "empty8 --config empty8" "dyn1m --env MiniGrid-Dynamic-Obstacles-8x8-v0"; do
+  for w in "lava512k --config lava4m" "lava1m --config lava4m --envs-per-gpu 1048576" "empty8 --config empty8" "dyn1m --env MiniGrid-Dynamic-Obstacles-8x8-v0" \
+           "empty16 --env MiniGrid-Empty-16x16-v0 --envs-per-gpu 524288" "keycorridor_s6r3 --env MiniGrid-KeyCorridorS6R3-v0 --envs-per-gpu 524288" \
+           "obstructed_2dlhb --env MiniGrid-ObstructedMaze-2Dlhb-v0 --envs-per-gpu 262144" "fourrooms1m --env MiniGrid-FourRooms-v0 --envs-per-gpu 1048576" \
+           "multiroom_n6 --env MiniGrid-MultiRoom-N6-v0 --envs-per-gpu 262144"; do
     set -- $w; n=$1; shift
     (cd $R && tools/pmc_quick2.sh ${TAG}_$n "$@" > /dev/null && python3 tools/pmc_summary.py ${TAG}_$n k_ > $OUT/${TAG}_sq_counters_$n.txt) || echo "sq $n failed"
     echo "sq $n ok"

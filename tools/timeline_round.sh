@@ -3,8 +3,7 @@
 # 524,288 and 1 Mi envs, with the launch-shaping rules off / tail priority only / tail priority + first-round stagger.
 set -e
 mkdir -p gpurun_out
-cp gym-minigrid_amd/csrc/libmgx.so /tmp/libmgx.keep.so
-cp ab/tl.so gym-minigrid_amd/csrc/libmgx.so
+export MGX_LIB=$PWD/ab/tl.so   # the instrumented build is selected by path (gym_minigrid_amd/_lib.py); csrc/libmgx.so stays the product build
 for n in 524288 1048576; do
   for mode in "0 0 plain" "512 0 tail" "512 5 tail_stagger"; do
     set -- $mode
@@ -12,4 +11,3 @@ for n in 524288 1048576; do
     python tools/timeline_report.py /tmp/tl.bin > gpurun_out/timeline_lava_${n}_$3.txt
   done
 done
-cp /tmp/libmgx.keep.so gym-minigrid_amd/csrc/libmgx.so

@@ -22,6 +22,9 @@ WORKLOADS = {  # name -> (traffic.json key, layout bytes per env-step, envs)
     "empty16x16_full_256k": ("MiniGrid-Empty-16x16-v0/full/262144", 1046, 262144),
     "empty8x8_4M": ("MiniGrid-Empty-8x8-v0/partial/4194304", 233, 4194304),
     "lavacrossing_4M": ("MiniGrid-LavaCrossingS9N1-v0/partial/4194304", 253, 4194304),
+    # the gather form (k_step<0,0,3,7>) reads its 7 x 8-byte window + the forward cell, not the grid: 57 + 16 + 1 + 147 + 5 = 226 B
+    "multiroom_n6_256k": ("MiniGrid-MultiRoom-N6-v0/partial/262144", 226, 262144),
+    "fourrooms_1M": ("MiniGrid-FourRooms-v0/partial/1048576", 226, 1048576),
 }
 
 
