@@ -53,6 +53,7 @@ Extra objects on the line:
 import argparse
 import json
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -109,7 +110,7 @@ def step_kernel_bytes_per_step(W, H, obs_mode, view=7, kernel=""):
     The gather form (k_step<0,0,3,V>: partial view on grids past 16x16) never reads the grid: per env-step it touches the
     V x V window (V columns of 8 bytes for V = 7) and the forward cell, so that is what its roofline is priced on."""
     cells = (W * H + 3) // 4 * 4
-    if kernel.startswith("k_step<0,0,3,"):
+    if re.match(r"k_step<\d+,\d+,3,", kernel):
         cells = (view * 8 if view == 7 else view * view) + 1
     return cells + 8 + 8 + 1 + obs_cells(W, H, obs_mode, view) * 3 + 4 + 1
 

@@ -616,8 +616,17 @@ __device__ __forceinline__ void emit_full_obs(const StepParams &p, const Lane &L
 
 // OBJ: the handle keeps hidden Goal/Box state (object_state planes).  Always on for the run-time-size instances, and for the two
 // sized ones ObstructedMaze needs (11x6, 16x16: round 2); pruned from every other sized instance.
+// The gather form (MODE 3) lives on memory latency: record -> transition -> 7 scattered window loads -> observation.  Holding its
+// instances to 64 / 72 VGPRs (8 / 7 waves per SIMD instead of the 5 the compiler's 88 VGPRs give) was measured and is NOT done: with the
+// window loads all in flight at once 5, 6 and "no cap" run within 1 % of each other and 8 waves per SIMD 3 % slower (FourRooms, 1 Mi
+// envs: 83.9 / 84.0 / 84.1 / 86.8 us) -- more waves in flight only deepen the queue in front of a memory system that is already busy.
+#ifdef MGX_GATHER_WAVES_ALL /* (tuning builds: tools/build_variant.sh x -DMGX_GATHER_WAVES_ALL=n) */
+#define MGX_GATHER_WAVES(CW) MGX_GATHER_WAVES_ALL
+#else
+#define MGX_GATHER_WAVES(CW) 1
+#endif
 template <int CW, int CH, int MODE, int V, bool ALT = false, bool OBJ = (CW == 0)>
-__global__ __launch_bounds__(256) void k_step(const StepParams p)
+__global__ __launch_bounds__(256, (MODE == 3 && V == 7 && !ALT && !OBJ) ? MGX_GATHER_WAVES(CW) : 1) void k_step(const StepParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -656,6 +665,11 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
     const bool crash = p.task == MGX_TASK_DYNOBS && (act & 0x80u); // k_dynobs' verdict rides on the folded action
     if (p.task == MGX_TASK_DYNOBS) act &= 0x7Fu;
     if (p.task == MGX_TASK_MEMORY && act == 3u) act = 5u; // `if action == pickup: action = toggle` (envs/memory.py:89-90)
+    // (gather form) the code of the cell in front of the agent as the LAST observation pass of this env saw it, 0 = unknown: a
+    // coalesced byte per env instead of a dependent one-byte gather whose 128-byte line is fetched, evicted under the launch's
+    // own traffic and fetched again for the view (FETCH_SIZE: 428 B per env-step at 1 Mi FourRooms envs, 633 at MultiRoom-N6)
+    uint32_t front0 = 0;
+    if constexpr (MODE == 3) { if (p.front && p.do_step) front0 = p.front[env]; }
     // MODE 3 (large grids): no tile image in LDS -- at 25x25 it would be 40 KB per wave and leave 4 waves per CU; each
     // lane gathers its forward cell and its VxV view straight from its row in HBM/L2 instead (50 byte loads).
     constexpr bool GATHER = MODE == 3;
@@ -682,7 +696,8 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
 #endif
         if (fidx >= 0) {
             const uint32_t carry0 = L.carry;
-            fc = row[fidx];
+            if (GATHER && front0 != 0u && act < 7u) fc = front0; // (strafe targets are the left / right cell: read from the row)
+            else fc = row[fidx];
             // hidden object state rides only on the run-time-size kernels (mgx_launch_step routes there): pruned from the sized ones
             const bool has_obj = OBJ && p.objaux != nullptr;
             const ObjRef obj = {has_obj ? p.objaux + env * S : nullptr, has_obj ? p.objcont + env * S : nullptr, has_obj ? p.objcarry + env : nullptr};
@@ -712,6 +727,11 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
                 const uint32_t *s = reinterpret_cast<const uint32_t *>(p.cells0 + e * S);
                 uint32_t *d = reinterpret_cast<uint32_t *>(p.cells + e * S);
                 for (int i = lane; i < (S >> 2); i += 64) d[i] = s[i];
+                if (OBJ && p.objaux) { // the hidden planes ride along (a lane copying its own 2 x S bytes dword by dword: ObstructedMaze's lock-step time-outs)
+                    const uint32_t *a0 = reinterpret_cast<const uint32_t *>(p.objaux0 + e * S), *c0 = reinterpret_cast<const uint32_t *>(p.objcont0 + e * S);
+                    uint32_t *a = reinterpret_cast<uint32_t *>(p.objaux + e * S), *c = reinterpret_cast<uint32_t *>(p.objcont + e * S);
+                    for (int i = lane; i < (S >> 2); i += 64) { a[i] = a0[i]; c[i] = c0[i]; }
+                }
             }
         }
         if (p.auto_reset && valid && done) {
@@ -720,7 +740,7 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
                 pidx = -1;
             } else if (needs_copy) restore_own<CS>(p, env, g);
             else if (nc != fc) g[fidx] = (uint8_t)fc; // a terminal step that changed a cell (Fetch's pickup): only the LDS image saw it
-            if (OBJ) restore_objstate(p, env, needs_copy);
+            if (OBJ) restore_objstate(p, env, needs_copy && !GATHER); // (gather form: the planes were copied by the whole wave above)
             // (loaded here, by the waves that need it: fetching agent0 with the record up front takes a 3-6 us round trip under load
             // out of 40 % of LavaCrossing's waves and still measured +0.6 ... +1.5 us per launch -- 8 B per env of extra requests)
             L = unpack_rec(p.agent0[env], p.task);
@@ -728,34 +748,41 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
         }
         if (valid) p.agent[env] = pack_rec(L, p.task);
     }
+    if constexpr (GATHER) { if (!p.obs && p.front && p.do_step && valid) p.front[env] = 0; } // (no observation pass: nothing to remember)
     if (p.obs) {
         if constexpr (GATHER && V != 7) {
             // other view sizes reach this form only when the tile image cannot fit the LDS (grids past ~50x50): V*V byte loads
+            if (p.front && valid) p.front[env] = 0;
             emit_partial_obs<CW, CH, V, ALT, true>(p, L, lds, row, env0, lane, pidx, pcode);
         } else if constexpr (GATHER) {
-            if (p.H >= 8) {
+            if ((CH ? CH : p.H) >= 8) {
                 // The VxV view always lies inside a world-aligned VxV window whose columns (fixed world x) are V contiguous
                 // bytes: V unaligned 8-byte loads per lane instead of V*V byte loads.  The window goes to this lane's
                 // LDS slot as a tiny 7x8 "grid" (cells outside the real grid = grey wall, which is what Grid.slice pads
                 // with) and the ordinary closed-form gather runs on it.
-                const int H = p.H, W = p.W;
+                const int H = CH ? CH : p.H, W = CW ? CW : p.W;
                 const int x0 = L.dir == 0 ? L.ax : (L.dir == 2 ? L.ax - 6 : L.ax - 3);
                 const int y0 = L.dir == 1 ? L.ay : (L.dir == 3 ? L.ay - 6 : L.ay - 3);
                 const int yc = y0 < 0 ? 0 : (y0 > H - 8 ? H - 8 : y0), sh = y0 - yc; // loaded bytes start at yc
                 const u64 wall = 0x0101010101010101ull * MGX_CODE_WALL_GREY;
                 const u64 keep = sh >= 0 ? (sh == 0 ? ~0ull : ((1ull << (8 * (8 - sh))) - 1ull)) : ~((1ull << (8 * -sh)) - 1ull);
                 struct __attribute__((packed)) U8 { uint32_t a, b; };
+                // All seven loads are issued before the first use, on a column index clamped into the grid: a load inside
+                // `if (x in the grid)` is not hoisted out of its branch, and seven conditional loads were seven dependent round
+                // trips (an s_waitcnt vmcnt(0) behind each one: 22 us wave lifetime, 6.6 L2 requests per env instead of 2.2 because the
+                // vector cache had long lost the line when the next column asked for it).
+                u64 raw[7];
+#pragma unroll
+                for (int k = 0; k < 7; k++) {
+                    const int x = x0 + k, xc = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);
+                    const U8 v = *reinterpret_cast<const U8 *>(row + xc * H + yc); // (yc + 8 <= H: inside the row for every column)
+                    raw[k] = (u64)v.a | ((u64)v.b << 32);
+                }
                 u64 w[7];
 #pragma unroll
                 for (int k = 0; k < 7; k++) {
-                    const int x = x0 + k;
-                    w[k] = wall;
-                    if (x >= 0 && x < W) {
-                        const U8 v = *reinterpret_cast<const U8 *>(row + x * H + yc);
-                        const u64 v64 = (u64)v.a | ((u64)v.b << 32);
-                        const u64 sv = sh >= 0 ? v64 >> (8 * sh) : v64 << (8 * -sh);
-                        w[k] = (sv & keep) | (wall & ~keep);
-                    }
+                    const u64 sv = sh >= 0 ? raw[k] >> (8 * sh) : raw[k] << (8 * -sh);
+                    w[k] = (unsigned)(x0 + k) < (unsigned)W ? (sv & keep) | (wall & ~keep) : wall;
                 }
                 uint32_t *win32 = reinterpret_cast<uint32_t *>(lds) + lane * 15; // 60 B per lane: odd dword stride
 #pragma unroll
@@ -767,8 +794,13 @@ __global__ __launch_bounds__(256) void k_step(const StepParams p)
                 }
                 Lane Lw = L;
                 Lw.ax = L.ax - x0; Lw.ay = L.ay - y0;
+                // the cell in front of the (new) pose lies inside the window for every direction: remembered for the next step
+                if (p.front && valid) p.front[env] = win[(Lw.ax + (L.dir == 0) - (L.dir == 2)) * 8 + Lw.ay + (L.dir == 1) - (L.dir == 3)];
                 emit_partial_obs<7, 8, V, ALT, false>(p, Lw, lds, win, env0, lane);
-            } else emit_partial_obs<CW, CH, V, ALT, true>(p, L, lds, row, env0, lane, pidx, pcode);
+            } else {
+                if (p.front && valid) p.front[env] = 0;
+                emit_partial_obs<CW, CH, V, ALT, true>(p, L, lds, row, env0, lane, pidx, pcode);
+            }
         }
 #ifdef MGX_TIMELINE
         else if (MODE == 0) {
@@ -1230,7 +1262,17 @@ static StepChoice choose_step_kernel(const StepParams &p, int mode)
 {
     const StepChoice none = {nullptr, false, "none"};
     if (mode == 3) { // large grids: gather form (the default view and visibility by the size rule, anything else when the tile image cannot fit the LDS)
-#define VCASE(v) if (p.view == v) return p.alt_vis ? StepChoice{k_step<0, 0, 3, v, true>, false, "k_step<0,0,3," MGX_STR(v) ",alt>"} : StepChoice{k_step<0, 0, 3, v>, false, "k_step<0,0,3," MGX_STR(v) ">"};
+        if (p.view == 7 && !p.alt_vis && !p.objaux) { // the default view: 13x13 Memory, every 16x16 id, 17x17 Memory, FourRooms / LockedRoom / Playground 19x19, MultiRoom 25x25, any other size
+#define GCASE(w, h) if (p.W == w && p.H == h) return {k_step<w, h, 3, 7, false, false>, false, "k_step<" #w "," #h ",3,7>"};
+            GCASE(13, 13) GCASE(16, 16) GCASE(17, 17) GCASE(19, 19) GCASE(25, 25)
+#undef GCASE
+            return {k_step<0, 0, 3, 7, false, false>, false, "k_step<0,0,3,7>"};
+        }
+        if (p.view == 7 && !p.alt_vis) { // ... with the hidden Goal / Box planes (ObstructedMaze 2Dl / 2Dlh / 2Dlhb / 1Q / 2Q / Full are 16x16)
+            if (p.W == 16 && p.H == 16) return {k_step<16, 16, 3, 7, false, true>, false, "k_step<16,16,3,7,obj>"};
+            return {k_step<0, 0, 3, 7, false, true>, false, "k_step<0,0,3,7,obj>"};
+        }
+#define VCASE(v) if (p.view == v) return p.alt_vis ? StepChoice{k_step<0, 0, 3, v, true>, false, "k_step<0,0,3," MGX_STR(v) ",alt>"} : StepChoice{k_step<0, 0, 3, v>, false, "k_step<0,0,3," MGX_STR(v) ",obj>"};
         MGX_VIEWS(VCASE) VCASE(7)
 #undef VCASE
         return none;

@@ -51,6 +51,7 @@ struct mgx_env_s {
     int device = 0;
     int W = 0, H = 0, cells = 0, S = 0, LS = 0, wave_lds = 0, wpb = 4, view = 7;
     int lds_guard = 0;    // StepParams.lds_guard
+    int staged_guard = 0; // ... as the staged partial form needs it (k_rollout keeps the tile in LDS whatever form the single step takes)
     int round_blocks = 0; // blocks of the step kernel resident at once on the chip (first-round stagger, k_step)
     StepLaunchCfg launch_cfg = {0, 0, -1}; // raised-priority tail / stagger of THIS handle's device (mgx_step_launch_cfg, at create)
     bool partial = true;   // the simulator emits the VxV view (else the full grid)
@@ -64,6 +65,7 @@ struct mgx_env_s {
     int64_t obs_bytes = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     uint8_t *cells_d = nullptr, *cells0_d = nullptr;
+    uint8_t *front_d = nullptr; // StepParams.front (gather form: kernel_mode 3)
     uint2 *agent_d = nullptr, *agent0_d = nullptr;
     MgxCounters *ctr_d = nullptr;
     // new level each episode: per-env MT19937 block + read index, regeneration flags
@@ -203,7 +205,16 @@ StepParams base_params(mgx_handle h)
     p.task = h->cfg.task_kind;
     p.regen = h->dynobs ? h->restart_d : (h->stream_mode ? h->regen_d : nullptr);
     p.objaux = h->objaux_d; p.objcont = h->objcont_d; p.objaux0 = h->objaux0_d; p.objcont0 = h->objcont0_d; p.objcarry = h->objcarry_d;
+    p.front = h->dynobs ? nullptr : h->front_d; // (k_dynobs moves cells between two steps)
     return p;
+}
+
+// The gather form's per-env "cell in front" cache describes the state the last observation pass saw: whoever changes cells or
+// poses behind the step kernel's back (set_state, reset, set_task's snapshot, ...) marks every entry unknown.
+int forget_front(mgx_handle h)
+{
+    if (h->front_d) HIP_TRY(hipMemsetAsync(h->front_d, 0, (size_t)h->n_pad, h->stream));
+    return MGX_OK;
 }
 
 // which of the families of mgx_mission_row (mgx_kernels.h) the handle's missions belong to
@@ -347,12 +358,17 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     h->kernel_mode = h->partial ? 0 : (direct ? 2 : 1);
     if (h->kernel_mode == 2) need = 16; // k_step_fulldirect keeps no tile image in LDS
     const char *force = getenv("MGX_PARTIAL_KERNEL"); // "staged" / "gather": override the size rule (tests, tuning)
-    const bool gather_ok = h->partial && view == 7 && !cfg->alt_visibility && !cfg->object_state;
-    if (gather_ok && (force ? !strcmp(force, "gather") : h->S > 256)) { h->kernel_mode = 3; need = obs_img; }
+    // Default view and visibility: from 13x13 up each lane gathers its 7x8-byte window straight from its row (k_step MODE 3) instead of
+    // the wave staging the whole tile in LDS.  Measured with all seven window loads in flight at once (round 3): 8x8 41.7 vs 39.6 us
+    // staged, 9x9 48.3 vs 43.2, 11x11 50.9 vs 50.0, 16x8 32.9 vs 28.7 -- but 13x13 32.3 vs 34.3, 16x16 32.0 vs 43.7 (the 16.6 KB tile
+    // image left two waves per SIMD), and past 16x16 the image does not pay at all.
+    const bool gather_ok = h->partial && view == 7 && !cfg->alt_visibility;
+    if (gather_ok && (force ? !strcmp(force, "gather") : h->S >= 160)) { h->kernel_mode = 3; need = obs_img; }
     // any other partial view whose tile image cannot fit the LDS (past ~50x50) takes the gather form too, with byte loads
     const int guard = ((view - 1) * h->H + view / 2 + 15) & ~15; // StepParams.lds_guard (staged partial form only)
     if (h->partial && h->kernel_mode == 0 && need + 2 * guard > 160 * 1024) { h->kernel_mode = 3; need = obs_img; }
     h->lds_guard = h->kernel_mode == 0 ? guard : 0;
+    h->staged_guard = guard;
     h->wave_lds = (need + 15) & ~15;
     // a family that draws no random numbers (Empty with a fixed start) has only one level: nothing to generate
     const bool uses_rng = cfg->level_kind != MGX_LEVEL_NONE && cfg->level_kind != MGX_LEVEL_DISTSHIFT &&
@@ -446,6 +462,10 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     CREATE_TRY(hipMemsetAsync(h->agent_d, 0, ab, h->stream));
     CREATE_TRY(hipMemsetAsync(h->agent0_d, 0, ab, h->stream));
     CREATE_TRY(hipMemsetAsync(h->ctr_d, 0, sizeof(MgxCounters), h->stream));
+    if (h->kernel_mode == 3) {
+        CREATE_TRY(hipMalloc((void **)&h->front_d, (size_t)h->n_pad));
+        CREATE_TRY(hipMemsetAsync(h->front_d, 0, (size_t)h->n_pad, h->stream));
+    }
     if (h->device_levels) {
         uint32_t init[624];
         mgx_mt_init_table(init);
@@ -516,7 +536,7 @@ extern "C" int mgx_destroy(mgx_handle h)
     (void)dev_guard.enter_device(h->device, "mgx_destroy");
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->cells_d); (void)hipFree(h->cells0_d); (void)hipFree(h->agent_d); (void)hipFree(h->agent0_d);
-    (void)hipFree(h->ctr_d); (void)hipFree(h->tri_d); (void)hipFree(h->mission_d);
+    (void)hipFree(h->ctr_d); (void)hipFree(h->tri_d); (void)hipFree(h->mission_d); (void)hipFree(h->front_d);
     (void)hipFree(h->objaux_d); (void)hipFree(h->objaux0_d); (void)hipFree(h->objcont_d); (void)hipFree(h->objcont0_d); (void)hipFree(h->objcarry_d);
     (void)hipFree(h->mt_d); (void)hipFree(h->mt_idx_d); (void)hipFree(h->regen_d); (void)hipFree(h->mt_init_d);
     (void)hipFree(h->seed0_d); (void)hipFree(h->has_seed_d); (void)hipFree(h->reseeded_d);
@@ -635,6 +655,7 @@ static int set_state_impl(mgx_handle h, const uint8_t *grid, const uint8_t *aux,
     const void *d;
     int rc;
     h->snapshot_is_level = false;
+    if ((rc = forget_front(h))) return rc;
     p.bcast = bcast ? 1 : 0;
     if ((rc = dev_in(h, 0, grid, n_src * cells * 3, &d))) return rc;
     p.grid = (const uint8_t *)d;
@@ -805,11 +826,13 @@ extern "C" int mgx_rollout(mgx_handle h, int64_t T, const uint8_t *actions, uint
     // (k_levelgen, k_dynobs, one-hot / flat epilogues), other views / visibility / hidden object state and grids without a
     // sized instance take the captured graph of per-step launches below.  MGX_ROLLOUT=graph forces that form (tests, tuning).
     const char *rf = getenv("MGX_ROLLOUT");
-    const bool fused_ok = h->kernel_mode == 0 && h->view == 7 && !h->cfg.alt_visibility && !h->objaux_d && !h->stream_mode && !h->dynobs &&
-                          h->oh_nc < 0 && !h->flat && !(rf && !strcmp(rf, "graph"));
+    const bool fused_ok = (h->kernel_mode == 0 || h->kernel_mode == 3) && h->partial && h->view == 7 && !h->cfg.alt_visibility && !h->objaux_d && !h->stream_mode &&
+                          !h->dynobs && h->oh_nc < 0 && !h->flat && !(rf && !strcmp(rf, "graph"));
     if (fused_ok) {
         StepParams p = base_params(h);
         p.do_step = 1;
+        p.lds_guard = h->staged_guard; // (k_rollout stages the tile in LDS even where the single step gathers: sized grids up to 16x16)
+        if (h->front_d) { int rc2 = forget_front(h); if (rc2) return rc2; } // k_rollout moves agents and cells without keeping the gather form's "cell in front"
         const hipError_t e = mgx_launch_rollout(p, actions, obs, reward, done, T, h->stream);
         if (e == hipSuccess) {
             h->steps_total += T * h->n;
@@ -987,6 +1010,7 @@ extern "C" int mgx_reset(mgx_handle h, const uint64_t *seeds, const uint8_t *mas
         c.mask = (const uint8_t *)dm;
         c.cells = h->cells_d; c.cells0 = h->cells0_d; c.agent = h->agent_d; c.agent0 = h->agent0_d; c.regen = h->regen_d;
         c.objaux = h->objaux_d; c.objaux0 = h->objaux0_d; c.objcont = h->objcont_d; c.objcont0 = h->objcont0_d; c.objcarry = h->objcarry_d;
+        c.front = h->front_d; // (the reset envs' "cell in front" is unknown until their next observation pass)
         c.n = h->n; c.S = h->S; c.flag_regen = h->stream_mode ? 1 : 0;
         HIP_TRY(mgx_launch_consume(c, h->stream));
         if (h->stream_mode && (rc = launch_levelgen(h))) return rc;
@@ -1026,7 +1050,8 @@ extern "C" int mgx_reset(mgx_handle h, const uint64_t *seeds, const uint8_t *mas
             c.mask = (const uint8_t *)dm;
             c.cells = h->cells_d; c.cells0 = h->cells0_d; c.agent = h->agent_d; c.agent0 = h->agent0_d; c.regen = nullptr;
             c.objaux = h->objaux_d; c.objaux0 = h->objaux0_d; c.objcont = h->objcont_d; c.objcont0 = h->objcont0_d; c.objcarry = h->objcarry_d;
-            c.n = h->n; c.S = h->S; c.flag_regen = 0;
+            c.front = h->front_d; // (the reset envs' "cell in front" is unknown until their next observation pass)
+        c.n = h->n; c.S = h->S; c.flag_regen = 0;
             HIP_TRY(mgx_launch_consume(c, h->stream));
         }
         if (obs) return run_step(h, false, nullptr, obs, nullptr, nullptr, (dm && is_device_ptr(obs)) ? (const uint8_t *)dm : nullptr);

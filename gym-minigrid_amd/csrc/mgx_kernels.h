@@ -56,6 +56,8 @@ struct StepParams {
     uint16_t *objcarry;
     uint8_t *regen;        // stream mode: set to 1 for every env that consumed its next-level buffer; Dynamic-Obstacles: the
                            // handle's own `restart` flags for k_dynobs (else null)
+    uint8_t *front;        // gather form only (else null): u8[n_pad], cell code in front of the agent as of the env's last observation pass;
+                           // 0 = unknown (every entry point that changes cells or poses outside the step kernel clears it)
     const uint8_t *obs_mask; // observe after a masked reset: 64-env tiles without a masked env are skipped (else null)
     int64_t n;
     int n_tiles;
@@ -92,6 +94,7 @@ struct ConsumeParams {
     uint8_t *cells; const uint8_t *cells0; uint2 *agent; const uint2 *agent0; uint8_t *regen;
     uint8_t *objaux, *objaux0, *objcont, *objcont0; uint16_t *objcarry; // object_state handles (else null): aux planes to 0,
                                                                         // contains <- the generated level's (objcont0), nothing carried
+    uint8_t *front;     // StepParams.front of gather-form handles (else null): cleared for every env consumed here
     int64_t n;
     int S, flag_regen;
 };
