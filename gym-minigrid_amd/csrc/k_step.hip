@@ -320,9 +320,12 @@ __device__ __forceinline__ void wave_stats(const StepParams &p, bool valid, bool
 // ------------------------------------------------------------------------------------------------
 // Partial (VxVx3, V = agent_view_size, odd) observation of lane's env -> wave's LDS image of the tile's output -> HBM.
 // B = 3*V*V bytes per env is always 3 mod 4 for odd V, so the byte-phase logic below is the same for every V.
-template <int CW, int CH, int V, bool ALT, bool GATHER = false>
+// WIN (the gather form's window): `g` is not the env's grid but a raw 7-column x 8-row excerpt of it (column stride 8 bytes) whose
+// cell (0, 0) is world cell (wx0, wy0); indices are taken relative to that origin while the in-grid tests still use the real W x H.
+template <int CW, int CH, int V, bool ALT, bool GATHER = false, bool WIN = false>
 __device__ __forceinline__ void emit_partial_obs(const StepParams &p, const Lane &L, uint8_t *lds, const uint8_t *g,
-                                                 int64_t env0, int lane, int pidx = -1, uint32_t pcode = 0, unsigned long long *tlv = nullptr)
+                                                 int64_t env0, int lane, int pidx = -1, uint32_t pcode = 0, unsigned long long *tlv = nullptr,
+                                                 int wx0 = 0, int wy0 = 0)
 {
     constexpr int B = V * V * 3;       // bytes per observation (147 for V = 7)
     constexpr int NDW = (B + 1) / 4;   // dwords holding one observation, the last with 3 valid bytes (37)
@@ -331,8 +334,9 @@ __device__ __forceinline__ void emit_partial_obs(const StepParams &p, const Lane
     const int dir = L.dir;
     const int dx = (dir == 0) - (dir == 2), dy = (dir == 1) - (dir == 3);
     const int rx = -dy, ry = dx; // right_vec (minigrid.py:1102-1109)
-    const int base = L.ax * H + L.ay;
-    const int sf = dx * H + dy, sr = rx * H + ry;
+    const int HS = WIN ? 8 : H; // byte stride between columns of `g`
+    const int base = WIN ? (L.ax - wx0) * 8 + (L.ay - wy0) : L.ax * H + L.ay;
+    const int sf = dx * HS + dy, sr = rx * HS + ry;
 
     // in-bounds is separable: the forward coordinate depends on d = 6-vy only, the lateral one on l = vx-3 only
     bool vf[V], vl[V];
@@ -763,40 +767,32 @@ __global__ __launch_bounds__(256, (MODE == 3 && V == 7 && !ALT && !OBJ) ? MGX_GA
                 const int H = CH ? CH : p.H, W = CW ? CW : p.W;
                 const int x0 = L.dir == 0 ? L.ax : (L.dir == 2 ? L.ax - 6 : L.ax - 3);
                 const int y0 = L.dir == 1 ? L.ay : (L.dir == 3 ? L.ay - 6 : L.ay - 3);
-                const int yc = y0 < 0 ? 0 : (y0 > H - 8 ? H - 8 : y0), sh = y0 - yc; // loaded bytes start at yc
-                const u64 wall = 0x0101010101010101ull * MGX_CODE_WALL_GREY;
-                const u64 keep = sh >= 0 ? (sh == 0 ? ~0ull : ((1ull << (8 * (8 - sh))) - 1ull)) : ~((1ull << (8 * -sh)) - 1ull);
+                const int yc = y0 < 0 ? 0 : (y0 > H - 8 ? H - 8 : y0); // the 8 loaded rows start at yc: every in-grid row of the view is among them
                 struct __attribute__((packed)) U8 { uint32_t a, b; };
                 // All seven loads are issued before the first use, on a column index clamped into the grid: a load inside
                 // `if (x in the grid)` is not hoisted out of its branch, and seven conditional loads were seven dependent round
                 // trips (an s_waitcnt vmcnt(0) behind each one: 22 us wave lifetime, 6.6 L2 requests per env instead of 2.2 because the
-                // vector cache had long lost the line when the next column asked for it).
-                u64 raw[7];
+                // vector cache had long lost the line when the next column asked for it).  The excerpt goes to LDS as it is -- columns
+                // outside the grid hold a copy of the border column, rows outside it are not there at all -- and the observation's own
+                // in-grid tests (on the real W x H) turn exactly those cells into the grey wall Grid.slice pads with.
+                U8 raw[7];
 #pragma unroll
                 for (int k = 0; k < 7; k++) {
                     const int x = x0 + k, xc = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);
-                    const U8 v = *reinterpret_cast<const U8 *>(row + xc * H + yc); // (yc + 8 <= H: inside the row for every column)
-                    raw[k] = (u64)v.a | ((u64)v.b << 32);
-                }
-                u64 w[7];
-#pragma unroll
-                for (int k = 0; k < 7; k++) {
-                    const u64 sv = sh >= 0 ? raw[k] >> (8 * sh) : raw[k] << (8 * -sh);
-                    w[k] = (unsigned)(x0 + k) < (unsigned)W ? (sv & keep) | (wall & ~keep) : wall;
+                    raw[k] = *reinterpret_cast<const U8 *>(row + xc * H + yc); // (yc + 8 <= H: inside the row for every column)
                 }
                 uint32_t *win32 = reinterpret_cast<uint32_t *>(lds) + lane * 15; // 60 B per lane: odd dword stride
 #pragma unroll
-                for (int k = 0; k < 7; k++) { win32[2 * k] = (uint32_t)w[k]; win32[2 * k + 1] = (uint32_t)(w[k] >> 32); }
+                for (int k = 0; k < 7; k++) { win32[2 * k] = raw[k].a; win32[2 * k + 1] = raw[k].b; }
                 uint8_t *win = reinterpret_cast<uint8_t *>(win32);
-                if (pidx >= 0) { // the front cell this step changed (the agent did not move then)
-                    const int px = L.ax + (L.dir == 0) - (L.dir == 2) - x0, py = L.ay + (L.dir == 1) - (L.dir == 3) - y0;
-                    win[px * 8 + py] = (uint8_t)pcode;
+                const int fdx = (L.dir == 0) - (L.dir == 2), fdy = (L.dir == 1) - (L.dir == 3);
+                if (pidx >= 0) win[(L.ax + fdx - x0) * 8 + L.ay + fdy - yc] = (uint8_t)pcode; // the front cell this step changed (the agent did not move then)
+                // the cell in front of the (new) pose lies inside the excerpt whenever it lies inside the grid: remembered for the next step
+                if (p.front && valid) {
+                    const int fx = L.ax + fdx, fy = L.ay + fdy;
+                    p.front[env] = ((unsigned)fx < (unsigned)W && (unsigned)fy < (unsigned)H) ? win[(fx - x0) * 8 + fy - yc] : (uint8_t)0;
                 }
-                Lane Lw = L;
-                Lw.ax = L.ax - x0; Lw.ay = L.ay - y0;
-                // the cell in front of the (new) pose lies inside the window for every direction: remembered for the next step
-                if (p.front && valid) p.front[env] = win[(Lw.ax + (L.dir == 0) - (L.dir == 2)) * 8 + Lw.ay + (L.dir == 1) - (L.dir == 3)];
-                emit_partial_obs<7, 8, V, ALT, false>(p, Lw, lds, win, env0, lane);
+                emit_partial_obs<CW, CH, V, ALT, false, true>(p, L, lds, win, env0, lane, -1, 0, nullptr, x0, yc);
             } else {
                 if (p.front && valid) p.front[env] = 0;
                 emit_partial_obs<CW, CH, V, ALT, true>(p, L, lds, row, env0, lane, pidx, pcode);
