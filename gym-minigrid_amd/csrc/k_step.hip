@@ -356,7 +356,12 @@ __device__ __forceinline__ void emit_partial_obs(const StepParams &p, const Lane
             // (LDS forms: a cell outside the grid is read where its index points -- a neighbouring env's row or the guard band,
             // StepParams.lds_guard -- and replaced by the wall below; only the global-memory form has to clamp the index)
             const int idx = (GATHER && !inb) ? base : rowbase + (vx - V / 2) * sr;
+#ifdef MGX_EXP_FIXED_GATHER /* timing / counter experiment only (wrong observations): every lane reads the same offset of its own row, which is
+                               conflict-free under the odd dword stride -- what the view gather would cost without LDS bank conflicts */
+            uint32_t c = g[(vx * V + vy) & 63];
+#else
             uint32_t c = g[idx];
+#endif
             if constexpr (GATHER) c = idx == pidx ? pcode : c; // the cell this step changed is not in HBM yet for this lane's reads
             code[vx][vy] = inb ? c : (uint32_t)MGX_CODE_WALL_GREY;
         }
