@@ -1101,14 +1101,15 @@ struct RolloutParams {
 };
 
 template <int CS>
-__device__ __forceinline__ void unstage_tile(uint8_t *__restrict__ cells, int64_t env0, int LS, const uint8_t *lds, int lane)
-{ // inverse of stage_tile: the LDS image (LS bytes per env) back to the tile's 64*CS contiguous bytes
-    constexpr int SD = CS >> 2;
+__device__ __forceinline__ void unstage_tile(uint8_t *__restrict__ cells, int64_t env0, int S_rt, int LS, const uint8_t *lds, int lane)
+{ // inverse of stage_tile: the LDS image (LS bytes per env) back to the tile's 64*S contiguous bytes
+    const int S = CS ? CS : S_rt;
+    const int SD = S >> 2;
     const int LSD = LS >> 2;
-    uint4 *dst = reinterpret_cast<uint4 *>(cells + env0 * CS);
+    uint4 *dst = reinterpret_cast<uint4 *>(cells + env0 * S);
     const uint32_t *l32 = reinterpret_cast<const uint32_t *>(lds);
-    constexpr int n_chunks = 4 * CS;
-    if constexpr ((SD & 1) != 0) {
+    const int n_chunks = 4 * S;
+    if constexpr (CS != 0 && ((CS >> 2) & 1) != 0) {
         const uint4 *l128 = reinterpret_cast<const uint4 *>(lds);
 #pragma unroll 4
         for (int c = lane; c < n_chunks; c += 64) dst[c] = l128[c];
@@ -1126,7 +1127,9 @@ __device__ __forceinline__ void unstage_tile(uint8_t *__restrict__ cells, int64_
     }
 }
 
-template <int CW, int CH>
+// CW = CH = 0: run-time grid size (any size whose tile image + observation image fit the LDS); V: agent_view_size (7 for the sized
+// instances, 3 / 5 / 9 / 11 on the run-time-size one: round 3 -- those handles took the captured graph before).
+template <int CW, int CH, int V>
 __global__ __launch_bounds__(256) void k_rollout(const StepParams p, const RolloutParams q)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1134,14 +1137,15 @@ __global__ __launch_bounds__(256) void k_rollout(const StepParams p, const Rollo
     const int tile = blockIdx.x * (blockDim.x >> 6) + wv;
     if (tile >= p.n_tiles) return; // wave-uniform
     constexpr int CS = (CW * CH + 3) & ~3;
-    constexpr int LS = CS + (((CS >> 2) & 1) ? 0 : 4);
+    constexpr int CLS = CS + (((CS >> 2) & 1) ? 0 : 4);
+    const int S = CS ? CS : p.S, LS = CS ? CLS : p.LS;
     uint8_t *lds = smem + p.lds_guard + (size_t)wv * p.wave_lds; // p.wave_lds = grid image + observation image (mgx_launch_rollout)
     uint8_t *img = lds + q.grid_lds;
     const int64_t env0 = (int64_t)tile * 64, env = env0 + lane;
     const bool valid = env < p.n;
-    constexpr int B = 147;
+    constexpr int B = 3 * V * V;
 
-    stage_tile<CS>(p.cells, env0, CS, LS, lds, lane);
+    stage_tile<CS>(p.cells, env0, S, LS, lds, lane);
     Lane L = unpack_rec(p.agent[env], p.task);
     uint8_t *g = lds + lane * LS;
     wave_sync();
@@ -1170,13 +1174,18 @@ __global__ __launch_bounds__(256) void k_rollout(const StepParams p, const Rollo
         wave_stats(p, valid, done, reward, bad_act, oob, lane, tile);
         if (p.auto_reset && valid && done) {
             if (L.dirty != 0u) { // back to the episode-start snapshot (LDS only: the tile goes home once, after the last step)
-                const uint32_t *s0 = reinterpret_cast<const uint32_t *>(p.cells0 + env * CS);
+                const uint32_t *s0 = reinterpret_cast<const uint32_t *>(p.cells0 + env * S);
                 uint32_t *l32 = reinterpret_cast<uint32_t *>(g);
-                uint32_t v[CS / 4];
+                if constexpr (CS != 0) {
+                    uint32_t v[CS ? CS / 4 : 1];
 #pragma unroll
-                for (int i = 0; i < CS / 4; i++) v[i] = s0[i];
+                    for (int i = 0; i < CS / 4; i++) v[i] = s0[i];
 #pragma unroll
-                for (int i = 0; i < CS / 4; i++) l32[i] = v[i];
+                    for (int i = 0; i < CS / 4; i++) l32[i] = v[i];
+                } else {
+#pragma unroll 8
+                    for (int i = 0; i < (S >> 2); i++) l32[i] = s0[i];
+                }
                 wrote = true;
             } else if (nc != fc) g[fidx] = (uint8_t)fc;
             L = unpack_rec(p.agent0[env], p.task);
@@ -1184,13 +1193,13 @@ __global__ __launch_bounds__(256) void k_rollout(const StepParams p, const Rollo
         if (q.obs) {
             StepParams po = p;
             po.obs = q.obs + t * p.n * B;
-            emit_partial_obs<CW, CH, 7, false>(po, L, img, g, env0, lane);
+            emit_partial_obs<CW, CH, V, false>(po, L, img, g, env0, lane);
             wave_sync(); // the image's readers are done before the next step's LDS writes (same wave: program order)
         }
     }
     if (valid) p.agent[env] = pack_rec(L, p.task);
     wave_sync();
-    if (__ballot(wrote)) unstage_tile<CS>(p.cells, env0, LS, lds, lane); // (wave-uniform; Empty / Crossing tiles never change)
+    if (__ballot(wrote)) unstage_tile<CS>(p.cells, env0, S, LS, lds, lane); // (wave-uniform; Empty / Crossing tiles never change)
 }
 
 // ---- which instantiation runs a handle's step: one selector for the launch, the LDS limit and the residency query ----------------
@@ -1239,7 +1248,16 @@ hipError_t mgx_preload_step_kernels()
     return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k_step<0, 0, 0, 7>));
 }
 
-// Fused T-step rollout for sized partial-view handles; returns hipErrorNotSupported when the handle's grid has no sized instance.
+bool mgx_rollout_has_sized(int W, int H)
+{
+#define CASE(w, h) if (W == w && H == h) return true;
+    MGX_SIZED(CASE)
+#undef CASE
+    return false;
+}
+
+// Fused T-step rollout for partial-view handles with the default visibility: sized instances for the 7x7 view, the run-time-size one
+// for every other grid and for agent_view_size 3 / 5 / 9 / 11; returns hipErrorNotSupported when the two LDS images of a wave do not fit.
 hipError_t mgx_launch_rollout(const StepParams &p0, const uint8_t *actions, uint8_t *obs, float *reward, uint8_t *done, int64_t T, hipStream_t st)
 {
     StepParams p = p0;
@@ -1247,15 +1265,33 @@ hipError_t mgx_launch_rollout(const StepParams &p0, const uint8_t *actions, uint
     RolloutParams q;
     q.actions = actions; q.obs = obs; q.reward = reward; q.done = done; q.T = T;
     q.grid_lds = (64 * LS + 15) & ~15;
-    p.wave_lds = q.grid_lds + 32 * 147; // + the half-tile observation image (4,704 B)
-    int wpb = (65536 - p.lds_guard) / p.wave_lds;
+    p.wave_lds = (q.grid_lds + 32 * 3 * p.view * p.view + 15) & ~15; // + the half-tile observation image (4,704 B for the 7x7 view)
+    const int LDS_DEFAULT = 64 * 1024, LDS_MAX = 160 * 1024;
+    int wpb = (LDS_DEFAULT - p.lds_guard) / p.wave_lds;
     if (wpb > 4) wpb = 4;
-    if (wpb < 1) return hipErrorNotSupported;
+    const bool raise = wpb < 1;
+    if (raise) { wpb = 1; if (p.wave_lds + p.lds_guard > LDS_MAX) return hipErrorNotSupported; }
     const dim3 block(64 * wpb), grid((p.n_tiles + wpb - 1) / wpb);
     const size_t shmem = (size_t)wpb * p.wave_lds + p.lds_guard; // (guard in front; behind the last grid image lies its observation image)
-#define CASE(w, h) if (p.W == w && p.H == h) { hipLaunchKernelGGL((k_rollout<w, h>), grid, block, shmem, st, p, q); return hipGetLastError(); }
-    MGX_SIZED(CASE)
+#define LAUNCH(KERN)                                                                                                                       \
+    do {                                                                                                                                   \
+        if (raise) {                                                                                                                       \
+            const hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&KERN), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+            if (e_ != hipSuccess) return e_;                                                                                               \
+        }                                                                                                                                  \
+        hipLaunchKernelGGL(KERN, grid, block, shmem, st, p, q);                                                                            \
+        return hipGetLastError();                                                                                                          \
+    } while (0)
+    if (p.view == 7) {
+#define CASE(w, h) if (p.W == w && p.H == h) LAUNCH((k_rollout<w, h, 7>));
+        MGX_SIZED(CASE)
 #undef CASE
+        LAUNCH((k_rollout<0, 0, 7>));
+    }
+#define VCASE(v) if (p.view == v) LAUNCH((k_rollout<0, 0, v>));
+    MGX_VIEWS(VCASE)
+#undef VCASE
+#undef LAUNCH
     return hipErrorNotSupported;
 }
 

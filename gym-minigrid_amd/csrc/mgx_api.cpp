@@ -826,7 +826,11 @@ extern "C" int mgx_rollout(mgx_handle h, int64_t T, const uint8_t *actions, uint
     // (k_levelgen, k_dynobs, one-hot / flat epilogues), other views / visibility / hidden object state and grids without a
     // sized instance take the captured graph of per-step launches below.  MGX_ROLLOUT=graph forces that form (tests, tuning).
     const char *rf = getenv("MGX_ROLLOUT");
-    const bool fused_ok = (h->kernel_mode == 0 || h->kernel_mode == 3) && h->partial && h->view == 7 && !h->cfg.alt_visibility && !h->objaux_d && !h->stream_mode &&
+    // (grids whose single step takes the gather form stay on the graph unless a sized k_rollout exists -- 13x13, 16x16: measured at 262,144
+    // envs, T = 64, the run-time-size k_rollout runs FourRooms 19x19 at 20.7 us per step against 19.6 for the graph of gather steps and
+    // MultiRoom 25x25 at 27.5 against 21.8: a 23-40 KB tile image leaves one or two waves per block)
+    const bool fused_ok = (h->kernel_mode == 0 || (h->kernel_mode == 3 && h->view == 7 && mgx_rollout_has_sized(h->W, h->H))) && h->partial &&
+                          !h->cfg.alt_visibility && !h->objaux_d && !h->stream_mode &&
                           !h->dynobs && h->oh_nc < 0 && !h->flat && !(rf && !strcmp(rf, "graph"));
     if (fused_ok) {
         StepParams p = base_params(h);
