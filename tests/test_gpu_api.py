@@ -429,3 +429,22 @@ def test_profile_span_and_per_launch_samples():
     _, span12 = env.profile_end()
     assert 0 < span4 < span12
     env.close()
+
+
+def test_step_kernel_name_follows_the_selector():
+    """mgx_step_kernel_name: the instantiation the handle launches (what bench.py prints as roofline.kernel and rocprofv3 as the kernel)."""
+    want = {("MiniGrid-Empty-8x8-v0", "partial", 7): "k_step<8,8,0,7>",
+            ("MiniGrid-LavaCrossingS9N1-v0", "partial", 7): "k_step<9,9,0,7>",
+            ("MiniGrid-Empty-16x16-v0", "partial", 7): "k_step<16,16,3,7>",          # from 13x13 up the view is gathered, not staged
+            ("MiniGrid-MemoryS13-v0", "partial", 7): "k_step<13,13,3,7>",
+            ("MiniGrid-FourRooms-v0", "partial", 7): "k_step<19,19,3,7>",
+            ("MiniGrid-ObstructedMaze-2Dlhb-v0", "partial", 7): "k_step<16,16,3,7,obj>",
+            ("MiniGrid-ObstructedMaze-1Dlhb-v0", "partial", 7): "k_step<11,6,0,7,obj>",
+            ("MiniGrid-DoorKey-8x8-v0", "partial", 5): "k_step<0,0,0,5>",
+            ("MiniGrid-Empty-16x16-v0", "full", 7): "k_step_fulldirect<16,16>",
+            ("MiniGrid-FourRooms-v0", "full", 7): "k_step_fulldirect<19,19,ragged>",
+            ("MiniGrid-LavaCrossingS9N1-v0", "full", 7): "k_step<9,9,1,7>"}
+    for (env_id, mode, view), name in want.items():
+        env = mg.VecMiniGrid(env_id, num_envs=64, obs_mode=mode, agent_view_size=view, backend="numpy")
+        assert env.step_kernel_name() == name, (env_id, mode, view, env.step_kernel_name())
+        env.close()

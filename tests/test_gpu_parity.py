@@ -159,8 +159,8 @@ def test_random_batch_vs_oracle(W, H, auto_reset, mode):
     _random_batch_vs_oracle(W, H, auto_reset, mode)
 
 
-@pytest.mark.parametrize("form,W,H", [("gather", 8, 8), ("gather", 9, 9), ("gather", 7, 11), ("gather", 16, 16), ("gather", 5, 5),
-                                      ("staged", 19, 19), ("staged", 25, 25), ("staged", 40, 33)])
+@pytest.mark.parametrize("form,W,H", [("gather", 8, 8), ("gather", 9, 9), ("gather", 7, 11), ("gather", 16, 16), ("gather", 5, 5), ("gather", 13, 13), ("gather", 11, 6),
+                                      ("staged", 19, 19), ("staged", 25, 25), ("staged", 40, 33), ("staged", 16, 16), ("staged", 13, 13), ("staged", 17, 17)])
 @pytest.mark.parametrize("auto_reset", [False, True])
 def test_partial_kernel_forms(monkeypatch, form, W, H, auto_reset):
     """Both forms of the partial-view kernel (tile staged in LDS / view gathered from HBM) on both sides of the size
@@ -533,9 +533,14 @@ def test_largest_grids():
     big.close()
 
 
-@pytest.mark.parametrize("W,H,extended,mode", [(8, 8, False, "partial"), (9, 7, True, "partial"), (6, 11, True, "full")])
-def test_object_state_random_batch_vs_oracle(W, H, extended, mode):
+@pytest.mark.parametrize("W,H,extended,mode,form", [(8, 8, False, "partial", None), (9, 7, True, "partial", None), (6, 11, True, "full", None),
+                                                    # round 3: the gather form carries the planes too (16x16 = ObstructedMaze's grid: sized instance; 14x15: run-time size)
+                                                    (16, 16, False, "partial", None), (16, 16, True, "partial", "staged"), (14, 15, True, "partial", None),
+                                                    (8, 8, False, "partial", "gather")])
+def test_object_state_random_batch_vs_oracle(W, H, extended, mode, form, monkeypatch):
     """Hidden Goal/Box state (toggletimes, triage_color, Box.contains; minigrid.py:156-181,332-364) on random rooms."""
+    if form:
+        monkeypatch.setenv("MGX_PARTIAL_KERNEL", form)
     N, T, max_steps = 3000, 60, 25
     grid, _, agent, _, _ = random_states(N, W, H, seed=W * 7 + H, density=0.45)
     aux, contains = random_object_state(grid, seed=W + H)
