@@ -271,14 +271,33 @@ __device__ __forceinline__ void restore_own(const StepParams &p, int64_t env, ui
 {
     const int S = CS ? CS : p.S;
     uint32_t *l32 = reinterpret_cast<uint32_t *>(g);
-    if constexpr (CS != 0 && (CS % 16) == 0) {
+    if constexpr (CS != 0 && (CS % 16) == 0 && CS <= 128) {
+        // (every load before the first store: written as one loop -- load, store, load, ... -- the stores may alias the next load as far
+        // as the compiler knows, and the ISA was four dependent round trips: s_waitcnt vmcnt(0) behind each load.  Dynamic-Obstacles and
+        // new_level_each_episode handles restore every finished env, i.e. some lane of nearly every wave on every step.)
         const uint4 *s = reinterpret_cast<const uint4 *>(p.cells0 + env * S);
         uint4 *d = reinterpret_cast<uint4 *>(p.cells + env * S);
+        uint4 v[CS / 16];
+#pragma unroll
+        for (int i = 0; i < CS / 16; i++) v[i] = s[i];
 #pragma unroll
         for (int i = 0; i < CS / 16; i++) {
-            const uint4 v = s[i];
-            l32[4 * i + 0] = v.x; l32[4 * i + 1] = v.y; l32[4 * i + 2] = v.z; l32[4 * i + 3] = v.w;
-            d[i] = v;
+            l32[4 * i + 0] = v[i].x; l32[4 * i + 1] = v[i].y; l32[4 * i + 2] = v[i].z; l32[4 * i + 3] = v[i].w;
+            d[i] = v[i];
+        }
+    } else if constexpr (CS != 0 && (CS % 16) == 0) { // (16x16: 64 registers would not pay; four at a time)
+        const uint4 *s = reinterpret_cast<const uint4 *>(p.cells0 + env * S);
+        uint4 *d = reinterpret_cast<uint4 *>(p.cells + env * S);
+#pragma unroll 1
+        for (int i0 = 0; i0 < CS / 16; i0 += 4) {
+            uint4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[i] = s[i0 + i];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                l32[4 * (i0 + i) + 0] = v[i].x; l32[4 * (i0 + i) + 1] = v[i].y; l32[4 * (i0 + i) + 2] = v[i].z; l32[4 * (i0 + i) + 3] = v[i].w;
+                d[i0 + i] = v[i];
+            }
         }
     } else {
         const uint32_t *s = reinterpret_cast<const uint32_t *>(p.cells0 + env * S);
