@@ -18,8 +18,9 @@ of the rank.  Workloads are BASELINE.json's configs:
   empty16full  configs[4]  MiniGrid-Empty-16x16-v0 + FullyObsWrapper encode, 262,144 envs per GPU
 Weak scaling: per-GPU work is fixed as N grows; envs shard by global index (seeds and synthetic actions are keyed by the
 GLOBAL env index), no data-path collective.  For N > 1 the logging exchange (north_star: "RCCL ... to gather the
-done/reward scalars") runs every --log-every steps (default min(256, --steps): at least one exchange lands INSIDE the timed
-region whatever K is): an all-gather of done u8 + reward f32 of every rank, issued on a side stream behind a snapshot of
+done/reward scalars") runs every --log-every steps (default min(256, --steps // 2 + 1): a short run exchanges once, half-way through, so
+the timed region holds the exchange AND steps enqueued behind it; one more, untimed, runs with the warm-up steps because a
+communicator's first collective sets up its channels): an all-gather of done u8 + reward f32 of every rank, issued on a side stream behind a snapshot of
 the step's outputs into one of two snapshot buffers; the step stream waits for it only if a gather is still running when
 its buffer comes round again, and the line says whether that happened (`rccl.step_stream_wait_us_total`).
 Inputs (synthetic counter-based actions for all K+W steps, env state) are resident in HBM before the timed region.
@@ -207,7 +208,9 @@ def parse_args(argv=None):
     args.envs_per_gpu = args.envs_per_gpu or c["envs_per_gpu"]
     args.obs_mode = args.obs_mode or c["obs_mode"]
     if args.log_every is None:
-        args.log_every = max(1, min(256, args.steps))
+        # a short run (the driver's --steps 20) exchanges once, half-way through, so that the timed region holds both the exchange and
+        # steps that overlap it; from 512 steps on the interval is the 256 steps a training loop would log at
+        args.log_every = max(1, min(256, args.steps // 2 + 1))
     return args
 
 
@@ -359,6 +362,17 @@ def main():
 
     for t in range(Wm):
         step(t)
+    warmup_exchanges = 0
+    if world > 1 and (Wm > 0 or dry):
+        # one untimed exchange with the warm-up steps: the first collective of a communicator sets up its channels (RCCL: tens of
+        # milliseconds), which is start-up cost, not a per-step cost
+        if logger is not None:
+            logger.submit(*outputs())
+            logger.wait()
+            warmup_exchanges = 1
+        elif args.log == "allreduce":
+            read_stats(stats2)
+            mdist.allreduce_log(stats2)
     read_stats(stats0)
     barrier()
     if not dry:
@@ -485,6 +499,8 @@ def main():
         }
         if rccl is not None:
             rccl["exchanges_in_timed_region"] = exchanges_timed
+            rccl["warmup_exchanges"] = warmup_exchanges
+            rccl["steps_enqueued_behind_the_last_exchange"] = (K - (K // args.log_every) * args.log_every) if args.log_every <= K else 0
             rccl["log_every"] = args.log_every
             rccl["bytes_per_rank_per_exchange"] = 5 * n_local if logger is not None else (16 if args.log == "allreduce" else 0)
             if logger is not None:

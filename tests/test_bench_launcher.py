@@ -45,7 +45,7 @@ def test_launcher_two_gloo_ranks_one_json_line():
     # the line proves who took part and what the exchange cost: backend, world, one identity per rank, exchanges inside the timed region
     r = j["rccl"]
     assert r["backend"] == "gloo" and r["world"] == 2 and [d["rank"] for d in r["devices"]] == [0, 1] and r["distinct_devices"] is True
-    assert r["exchanges_in_timed_region"] == 2 and r["exchanges"] == 2 and r["log_every"] == 16 and r["collective_us_mean"] > 0
+    assert r["exchanges_in_timed_region"] == 2 and r["exchanges"] == 3 and r["warmup_exchanges"] == 1 and r["log_every"] == 16 and r["collective_us_mean"] > 0
     assert r["bytes_per_rank_per_exchange"] == 5 * 1001
     assert [r["rank"] for r in j["roofline"]["per_rank"]] == [0, 1]
     assert j["episodes_in_timed_region"] == sum(r["episodes"] for r in j["roofline"]["per_rank"]) > 0
@@ -66,14 +66,14 @@ def test_launcher_two_gloo_ranks_one_json_line():
 
 @pytest.mark.timeout(600)
 def test_drivers_own_command_shape_times_the_exchange():
-    """`bench.py --gpus N --steps 20 --warmup W` (what the driver runs): --log-every defaults to min(256, steps), so the one
-    exchange of a 20-step run lands INSIDE the timed region and is reported with its own duration."""
+    """`bench.py --gpus N --steps 20 --warmup W` (what the driver runs): --log-every defaults to min(256, steps // 2 + 1), so the one
+    exchange of a 20-step run lands INSIDE the timed region, with nine steps enqueued behind it, and is reported with its own duration."""
     rc, out, err = run_bench("--gpus", "2", "--dry-run-ranks", "--steps", "20", "--warmup", "5", "--envs-per-gpu", "777")
     assert rc == 0, err[-2000:]
     j = json.loads(out.strip())
     r = j["rccl"]
-    assert r["log_every"] == 20 and r["exchanges_in_timed_region"] == 1 and r["exchanges"] == 1
-    assert r["collective_us_mean"] > 0 and r["step_stream_wait_us_total"] == 0
+    assert r["log_every"] == 11 and r["exchanges_in_timed_region"] == 1 and r["exchanges"] == 2 and r["warmup_exchanges"] == 1
+    assert r["collective_us_mean"] > 0 and r["steps_enqueued_behind_the_last_exchange"] == 9
     assert j["gather_checked"] is True and "1 inside the timed region" in j["config"]["logging_exchange"]
     assert len(r["devices"]) == 2 and r["devices"][0]["host"]
 
