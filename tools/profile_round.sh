@@ -74,6 +74,7 @@ if [ $PART = pmc ] || [ $PART = all ]; then
     pmc lavacrossing_1M $c --config lava4m --envs-per-gpu 1048576
     pmc multiroom_n6_256k $c --env MiniGrid-MultiRoom-N6-v0 --envs-per-gpu 262144     # the gather form k_step<0,0,3,7>
     pmc fourrooms_1M $c --env MiniGrid-FourRooms-v0 --envs-per-gpu 1048576
+    pmc empty16x16_512k $c --env MiniGrid-Empty-16x16-v0 --envs-per-gpu 524288
   done
 fi
 if [ $PART = sq ] || [ $PART = all ]; then

@@ -25,6 +25,7 @@ WORKLOADS = {  # name -> (traffic.json key, layout bytes per env-step, envs)
     # the gather form (k_step<0,0,3,7>) reads its 7 x 8-byte window + the forward cell, not the grid: 57 + 16 + 1 + 147 + 5 = 226 B
     "multiroom_n6_256k": ("MiniGrid-MultiRoom-N6-v0/partial/262144", 226, 262144),
     "fourrooms_1M": ("MiniGrid-FourRooms-v0/partial/1048576", 226, 1048576),
+    "empty16x16_512k": ("MiniGrid-Empty-16x16-v0/partial/524288", 226, 524288),
 }
 
 
