@@ -114,6 +114,11 @@ class VecMiniGrid:
         self._obs = self._new((self.num_envs,) + self.obs_shape, self.obs_dtype)
         self._reward = self._new((self.num_envs,), "float32")
         self._done = self._new((self.num_envs,), "uint8")
+        # step()'s output pointers never change (the buffers belong to this object): looked up once, passed as plain integers.
+        # Below ~200 k envs a step is bound by the host side of the call, of which these lookups were a fifth.
+        self._out_ptrs = tuple(_ptr(x).value for x in (self._obs, self._reward, self._done))
+        self._step_fn = L.mgx_step
+        self._act_shape = (self.num_envs,)
         self.seed(seeds)
 
     # ------------------------------------------------------------------ plumbing
@@ -190,10 +195,22 @@ class VecMiniGrid:
         return self._obs
 
     def step(self, actions):
-        if self._torch is not None:
+        t = self._torch
+        if t is not None:
             self._bind_stream()
-        a = self._actions(actions)
-        _lib.check(_lib.lib().mgx_step(self._h, _ptr(a), _ptr(self._obs), _ptr(self._reward), _ptr(self._done)))
+            # the common case -- a contiguous uint8 tensor of the right shape on the handle's device -- skips the conversions
+            if (type(actions) is t.Tensor and actions.dtype is t.uint8 and actions.device == self._dev and tuple(actions.shape) == self._act_shape
+                    and actions.is_contiguous() and not self.check_actions):
+                a = actions
+            else:
+                a = self._actions(actions)
+            ap = a.data_ptr()
+        else:
+            a = self._actions(actions)
+            ap = a.ctypes.data
+        rc = self._step_fn(self._h, ap, *self._out_ptrs)
+        if rc:
+            _lib.check(rc)
         self._last_actions = a  # keep alive until the async kernel has consumed it
         return self._obs, self._reward, self._done, {}
 

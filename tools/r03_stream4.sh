@@ -1,0 +1,15 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O; cd $R
+b() { timeout -k 10 200 python bench.py --no-cpu-baseline --env $1 --envs-per-gpu ${2:-262144} --new-level-each-episode --steps 600 --warmup 32 2>/dev/null | grep "^{" | python -c "import sys,json,os; j=json.loads(sys.stdin.read()); print('%-34s n=%-8d lanes=%-4s fast_waves=%-4s span=%-5s %.3g steps/s %.1f us/step' % (j['config']['env_id'], j['config']['envs_per_gpu'], os.environ.get('MGX_LG_LANES','rule'), os.environ.get('MGX_LG_FAST_WAVES','rule'), os.environ.get('MGX_LG_SPAN','rule'), j['value'], j['ms_per_step']*1e3))"; }
+{
+for e in MiniGrid-MultiRoom-N6-v0 MiniGrid-KeyCorridorS3R3-v0 MiniGrid-MultiRoom-N4-S5-v0; do
+  for sp in 64 128 256 512; do MGX_LG_FAST_WAVES=0 MGX_LG_SPAN=$sp b $e; done
+  MGX_LG_LANES=16 MGX_LG_SPAN=64 b $e
+  MGX_LG_LANES=16 MGX_LG_SPAN=256 b $e
+done
+for e in MiniGrid-LockedRoom-v0 MiniGrid-Fetch-8x8-N3-v0 MiniGrid-ObstructedMaze-2Dlhb-v0 MiniGrid-Playground-v0; do
+  b $e
+  MGX_LG_SPAN=128 b $e
+  MGX_LG_SPAN=256 b $e
+done
+} 2>&1 | tee $O/stream4.txt
