@@ -257,7 +257,15 @@ __device__ __forceinline__ void restore_objstate(const StepParams &p, int64_t en
     if (planes) {
         const uint32_t *a0 = reinterpret_cast<const uint32_t *>(p.objaux0 + env * p.S), *c0 = reinterpret_cast<const uint32_t *>(p.objcont0 + env * p.S);
         uint32_t *a = reinterpret_cast<uint32_t *>(p.objaux + env * p.S), *c = reinterpret_cast<uint32_t *>(p.objcont + env * p.S);
-        for (int i = 0; i < (p.S >> 2); i++) { a[i] = a0[i]; c[i] = c0[i]; }
+        const int SD = p.S >> 2;
+        for (int i0 = 0; i0 < SD; i0 += 4) { // (loads first, clamped; then the stores)
+            uint32_t va[4], vc[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const int i = i0 + k < SD ? i0 + k : SD - 1; va[k] = a0[i]; vc[k] = c0[i]; }
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (i0 + k < SD) { a[i0 + k] = va[k]; c[i0 + k] = vc[k]; }
+        }
     }
     p.objcarry[env] = (uint16_t)(MGX_CODE_EMPTY << 8);
 }
@@ -309,12 +317,15 @@ __device__ __forceinline__ void restore_own(const StepParams &p, int64_t env, ui
 #pragma unroll
             for (int i = 0; i < CS / 4; i++) { l32[i] = v[i]; d[i] = v[i]; }
         } else {
+            // (eight loads in flight, then eight stores: one load / store pair per trip compiled to a round trip per dword -- see above)
             const int SD = S >> 2;
-#pragma unroll 8
-            for (int i = 0; i < SD; i++) {
-                const uint32_t v = s[i];
-                l32[i] = v;
-                d[i] = v;
+            for (int i0 = 0; i0 < SD; i0 += 8) {
+                uint32_t v[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) v[k] = s[i0 + k < SD ? i0 + k : SD - 1]; // (clamped, not conditional: a load in a branch is not hoisted)
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    if (i0 + k < SD) { l32[i0 + k] = v[k]; d[i0 + k] = v[k]; }
             }
         }
     }

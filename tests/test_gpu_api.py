@@ -137,7 +137,8 @@ def test_rollout_graph_equals_stepping(env_id, N, T):
     # round 3: the run-time-size instance (grids without a sized one) and the other view sizes
     ("MiniGrid-FourRooms-v0", 400, 260, True, 7),            # 19x19 (time-outs at 500): the gather form's graph either way
     ("MiniGrid-MultiRoom-N6-v0", 144, 130, True, 7),         # 25x25
-    ("MiniGrid-DistShift1-v0", 336, 300, True, 7),           # 9x7: no sized instance -> k_rollout<0,0,7> (lava ends episodes, time-outs at 252)
+    ("MiniGrid-KeyCorridorS3R2-v0", 336, 300, True, 7),      # 7x5: no sized instance -> k_rollout<0,0,7> (time-outs at 270)
+    ("MiniGrid-DistShift1-v0", 336, 300, True, 7),           # (lava ends episodes, time-outs)
     ("MiniGrid-DoorKey-8x8-v0", 1008, 90, True, 3),
     ("MiniGrid-LavaCrossingS9N1-v0", 1552, 90, True, 5),
     ("MiniGrid-DoorKey-16x16-v0", 208, 60, True, 9),
