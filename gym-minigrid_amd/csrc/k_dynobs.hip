@@ -226,11 +226,23 @@ __global__ __launch_bounds__(256) void k_dynobs(const DynObsParams p)
         uint32_t pe;
         if ((m_restore >> e) & 1ull) {
             const uint4 *src4 = reinterpret_cast<const uint4 *>(p.mt0) + (env0 + e) * 156;
-            for (int i = lane; i < 156; i += 64) { const uint4 v = src4[i]; dst4[i] = v; }
+            { // (the three loads together, on clamped indices: a load / store pair per trip compiled to three dependent round trips)
+                uint4 v[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) { const int i = lane + 64 * k; v[k] = src4[i < 156 ? i : 155]; }
+#pragma unroll
+                for (int k = 0; k < 3; k++) { const int i = lane + 64 * k; if (i < 156) dst4[i] = v[k]; }
+            }
             if (lane < MGX_DYN_TAPE_DW) { const uint32_t v = p.tape0[(env0 + e) * MGX_DYN_TAPE_DW + lane]; tape_e[lane] = v; tp[lane] = v; }
             pe = ps[e] & 0x3FFFFFFFu;
         } else {
-            for (int i = lane; i < 156; i += 64) blk4[i] = dst4[i];
+            {
+                uint4 v[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) { const int i = lane + 64 * k; v[k] = dst4[i < 156 ? i : 155]; }
+#pragma unroll
+                for (int k = 0; k < 3; k++) { const int i = lane + 64 * k; if (i < 156) blk4[i] = v[k]; }
+            }
             wave_sync();
             const uint32_t pv = ps[e];
             const uint32_t k0 = (pv & 0x40000000u) ? (pv & 0x3FFFFFFFu) % 624u : 0u; // words [0, k0) already belong to the new block
