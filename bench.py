@@ -494,6 +494,7 @@ def main():
                          "span_us_per_step": slow["span_us_per_step"], "event_pair_us": slow["event_pair_us"],
                          "algorithmic_bytes_per_env_step": bps, "layout_bytes_per_env_step_all_kernels": lbps,
                          "measured_streaming_ceiling": 6290.0,
+                         "achieved_on_layout_bytes": lbps * n_local / (slow["avg_kernel_us"] * 1e-6) / 1e9 if (slow["avg_kernel_us"] > 0 and lbps != bps and not multi_kernel) else None,
                          "survey_bytes_per_env_step": sbps, "achieved_on_survey_bytes": sbps * n_local / (slow["avg_kernel_us"] * 1e-6) / 1e9 if slow["avg_kernel_us"] > 0 else 0.0,
                          "per_rank": per_rank},
         }
