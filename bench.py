@@ -109,10 +109,10 @@ def layout_bytes_per_step(W, H, obs_mode, view=7):
 def step_kernel_bytes_per_step(W, H, obs_mode, view=7, kernel=""):
     """What the STEP KERNEL alone streams (the one-hot / flat epilogues are kernels of their own): its output is the triples.
     The gather form (k_step<0,0,3,V>: partial view on grids past 16x16) never reads the grid: per env-step it touches the
-    V x V window (V columns of 8 bytes for V = 7) and the forward cell, so that is what its roofline is priced on."""
+    window excerpt (V columns of 4 / 8 / 12 bytes for V = 3 / 5, 7 / 9, 11) and the forward cell, so that is what its roofline is priced on."""
     cells = (W * H + 3) // 4 * 4
     if re.match(r"k_step<\d+,\d+,3,", kernel):
-        cells = (view * 8 if view == 7 else view * view) + 1
+        cells = view * (4 if view <= 3 else 8 if view <= 7 else 12) + 1   # V columns of 4 / 8 / 12 bytes + the forward cell
     return cells + 8 + 8 + 1 + obs_cells(W, H, obs_mode, view) * 3 + 4 + 1
 
 

@@ -350,9 +350,9 @@ __device__ __forceinline__ void wave_stats(const StepParams &p, bool valid, bool
 // ------------------------------------------------------------------------------------------------
 // Partial (VxVx3, V = agent_view_size, odd) observation of lane's env -> wave's LDS image of the tile's output -> HBM.
 // B = 3*V*V bytes per env is always 3 mod 4 for odd V, so the byte-phase logic below is the same for every V.
-// WIN (the gather form's window): `g` is not the env's grid but a raw 7-column x 8-row excerpt of it (column stride 8 bytes) whose
+// WIN != 0 (the gather form's window): `g` is not the env's grid but a raw V-column x WIN-row excerpt of it (column stride WIN bytes) whose
 // cell (0, 0) is world cell (wx0, wy0); indices are taken relative to that origin while the in-grid tests still use the real W x H.
-template <int CW, int CH, int V, bool ALT, bool GATHER = false, bool WIN = false>
+template <int CW, int CH, int V, bool ALT, bool GATHER = false, int WIN = 0>
 __device__ __forceinline__ void emit_partial_obs(const StepParams &p, const Lane &L, uint8_t *lds, const uint8_t *g,
                                                  int64_t env0, int lane, int pidx = -1, uint32_t pcode = 0, unsigned long long *tlv = nullptr,
                                                  int wx0 = 0, int wy0 = 0)
@@ -364,8 +364,8 @@ __device__ __forceinline__ void emit_partial_obs(const StepParams &p, const Lane
     const int dir = L.dir;
     const int dx = (dir == 0) - (dir == 2), dy = (dir == 1) - (dir == 3);
     const int rx = -dy, ry = dx; // right_vec (minigrid.py:1102-1109)
-    const int HS = WIN ? 8 : H; // byte stride between columns of `g`
-    const int base = WIN ? (L.ax - wx0) * 8 + (L.ay - wy0) : L.ax * H + L.ay;
+    const int HS = WIN ? WIN : H; // byte stride between columns of `g`
+    const int base = WIN ? (L.ax - wx0) * WIN + (L.ay - wy0) : L.ax * H + L.ay;
     const int sf = dx * HS + dy, sr = rx * HS + ry;
 
     // in-bounds is separable: the forward coordinate depends on d = 6-vy only, the lateral one on l = vx-3 only
@@ -789,46 +789,46 @@ __global__ __launch_bounds__(256, (MODE == 3 && V == 7 && !ALT && !OBJ) ? MGX_GA
     }
     if constexpr (GATHER) { if (!p.obs && p.front && p.do_step && valid) p.front[env] = 0; } // (no observation pass: nothing to remember)
     if (p.obs) {
-        if constexpr (GATHER && V != 7) {
-            // other view sizes reach this form only when the tile image cannot fit the LDS (grids past ~50x50): V*V byte loads
-            if (p.front && valid) p.front[env] = 0;
-            emit_partial_obs<CW, CH, V, ALT, true>(p, L, lds, row, env0, lane, pidx, pcode);
-        } else if constexpr (GATHER) {
-            if ((CH ? CH : p.H) >= 8) {
-                // The VxV view always lies inside a world-aligned VxV window whose columns (fixed world x) are V contiguous
-                // bytes: V unaligned 8-byte loads per lane instead of V*V byte loads.  The window goes to this lane's
-                // LDS slot as a tiny 7x8 "grid" (cells outside the real grid = grey wall, which is what Grid.slice pads
-                // with) and the ordinary closed-form gather runs on it.
+        if constexpr (GATHER) {
+            // The VxV view always lies inside a world-aligned VxV window whose columns (fixed world x) are V contiguous bytes: V unaligned
+            // loads of RS = 4 / 8 / 12 bytes per lane (V = 3 / 5, 7 / 9, 11) instead of V*V byte loads.  The excerpt goes to this lane's LDS
+            // slot as a tiny V x RS "grid" and the ordinary closed-form gather runs on it, with indices relative to the excerpt's origin
+            // and the in-grid tests on the real W x H (cells outside the grid = grey wall, which is what Grid.slice pads with).
+            constexpr int RS = V <= 3 ? 4 : (V <= 7 ? 8 : 12);  // rows loaded per column
+            constexpr int SLOT = (V * RS / 4) | 1;               // dwords per lane, odd: 3, 11, 15, 27, 33
+            if ((CH ? CH : p.H) >= RS) {
                 const int H = CH ? CH : p.H, W = CW ? CW : p.W;
-                const int x0 = L.dir == 0 ? L.ax : (L.dir == 2 ? L.ax - 6 : L.ax - 3);
-                const int y0 = L.dir == 1 ? L.ay : (L.dir == 3 ? L.ay - 6 : L.ay - 3);
-                const int yc = y0 < 0 ? 0 : (y0 > H - 8 ? H - 8 : y0); // the 8 loaded rows start at yc: every in-grid row of the view is among them
-                struct __attribute__((packed)) U8 { uint32_t a, b; };
-                // All seven loads are issued before the first use, on a column index clamped into the grid: a load inside
+                const int x0 = L.dir == 0 ? L.ax : (L.dir == 2 ? L.ax - (V - 1) : L.ax - V / 2);
+                const int y0 = L.dir == 1 ? L.ay : (L.dir == 3 ? L.ay - (V - 1) : L.ay - V / 2);
+                const int yc = y0 < 0 ? 0 : (y0 > H - RS ? H - RS : y0); // the RS loaded rows start at yc: every in-grid row of the view is among them
+                struct __attribute__((packed)) UR { uint32_t w[RS / 4]; };
+                // All V loads are issued before the first use, on a column index clamped into the grid: a load inside
                 // `if (x in the grid)` is not hoisted out of its branch, and seven conditional loads were seven dependent round
                 // trips (an s_waitcnt vmcnt(0) behind each one: 22 us wave lifetime, 6.6 L2 requests per env instead of 2.2 because the
                 // vector cache had long lost the line when the next column asked for it).  The excerpt goes to LDS as it is -- columns
                 // outside the grid hold a copy of the border column, rows outside it are not there at all -- and the observation's own
                 // in-grid tests (on the real W x H) turn exactly those cells into the grey wall Grid.slice pads with.
-                U8 raw[7];
+                UR raw[V];
 #pragma unroll
-                for (int k = 0; k < 7; k++) {
+                for (int k = 0; k < V; k++) {
                     const int x = x0 + k, xc = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);
-                    raw[k] = *reinterpret_cast<const U8 *>(row + xc * H + yc); // (yc + 8 <= H: inside the row for every column)
+                    raw[k] = *reinterpret_cast<const UR *>(row + xc * H + yc); // (yc + RS <= H: inside the row for every column)
                 }
-                uint32_t *win32 = reinterpret_cast<uint32_t *>(lds) + lane * 15; // 60 B per lane: odd dword stride
+                uint32_t *win32 = reinterpret_cast<uint32_t *>(lds) + lane * SLOT; // odd dword stride per lane
 #pragma unroll
-                for (int k = 0; k < 7; k++) { win32[2 * k] = raw[k].a; win32[2 * k + 1] = raw[k].b; }
+                for (int k = 0; k < V; k++)
+#pragma unroll
+                    for (int q = 0; q < RS / 4; q++) win32[(RS / 4) * k + q] = raw[k].w[q];
                 uint8_t *win = reinterpret_cast<uint8_t *>(win32);
                 const int fdx = (L.dir == 0) - (L.dir == 2), fdy = (L.dir == 1) - (L.dir == 3);
-                if (pidx >= 0) win[(L.ax + fdx - x0) * 8 + L.ay + fdy - yc] = (uint8_t)pcode; // the front cell this step changed (the agent did not move then)
+                if (pidx >= 0) win[(L.ax + fdx - x0) * RS + L.ay + fdy - yc] = (uint8_t)pcode; // the front cell this step changed (the agent did not move then)
                 // the cell in front of the (new) pose lies inside the excerpt whenever it lies inside the grid: remembered for the next step
                 if (p.front && valid) {
                     const int fx = L.ax + fdx, fy = L.ay + fdy;
-                    p.front[env] = ((unsigned)fx < (unsigned)W && (unsigned)fy < (unsigned)H) ? win[(fx - x0) * 8 + fy - yc] : (uint8_t)0;
+                    p.front[env] = ((unsigned)fx < (unsigned)W && (unsigned)fy < (unsigned)H) ? win[(fx - x0) * RS + fy - yc] : (uint8_t)0;
                 }
-                emit_partial_obs<CW, CH, V, ALT, false, true>(p, L, lds, win, env0, lane, -1, 0, nullptr, x0, yc);
-            } else {
+                emit_partial_obs<CW, CH, V, ALT, false, RS>(p, L, lds, win, env0, lane, -1, 0, nullptr, x0, yc);
+            } else { // (a grid lower than the excerpt: V*V byte loads)
                 if (p.front && valid) p.front[env] = 0;
                 emit_partial_obs<CW, CH, V, ALT, true>(p, L, lds, row, env0, lane, pidx, pcode);
             }
@@ -1276,14 +1276,6 @@ hipError_t mgx_preload_step_kernels()
 {
     hipFuncAttributes a;
     return hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&k_step<0, 0, 0, 7>));
-}
-
-bool mgx_rollout_has_sized(int W, int H)
-{
-#define CASE(w, h) if (W == w && H == h) return true;
-    MGX_SIZED(CASE)
-#undef CASE
-    return false;
 }
 
 // Fused T-step rollout for partial-view handles with the default visibility: sized instances for the 7x7 view, the run-time-size one

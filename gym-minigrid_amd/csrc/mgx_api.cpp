@@ -358,15 +358,19 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     h->kernel_mode = h->partial ? 0 : (direct ? 2 : 1);
     if (h->kernel_mode == 2) need = 16; // k_step_fulldirect keeps no tile image in LDS
     const char *force = getenv("MGX_PARTIAL_KERNEL"); // "staged" / "gather": override the size rule (tests, tuning)
-    // Default view and visibility: from 13x13 up each lane gathers its 7x8-byte window straight from its row (k_step MODE 3) instead of
+    // From 13x13 up each lane gathers its V x 4 / 8 / 12-byte window straight from its row (k_step MODE 3; V = 7 in the figures) instead of
     // the wave staging the whole tile in LDS.  Measured with all seven window loads in flight at once (round 3): 8x8 41.7 vs 39.6 us
     // staged, 9x9 48.3 vs 43.2, 11x11 50.9 vs 50.0, 16x8 32.9 vs 28.7 -- but 13x13 32.3 vs 34.3, 16x16 32.0 vs 43.7 (the 16.6 KB tile
     // image left two waves per SIMD), and past 16x16 the image does not pay at all.
-    const bool gather_ok = h->partial && view == 7 && !cfg->alt_visibility;
+    const bool gather_ok = h->partial; // (every view size, both visibility rules, with or without the hidden-object planes)
     if (gather_ok && (force ? !strcmp(force, "gather") : h->S >= 160)) { h->kernel_mode = 3; need = obs_img; }
-    // any other partial view whose tile image cannot fit the LDS (past ~50x50) takes the gather form too, with byte loads
     const int guard = ((view - 1) * h->H + view / 2 + 15) & ~15; // StepParams.lds_guard (staged partial form only)
+    // (a forced staged form whose tile image cannot fit the LDS -- past ~50x50 -- gathers after all)
     if (h->partial && h->kernel_mode == 0 && need + 2 * guard > 160 * 1024) { h->kernel_mode = 3; need = obs_img; }
+    if (h->kernel_mode == 3) { // the lanes' window excerpts (V columns x 4 / 8 / 12 rows, odd dword stride): read before the output image overlays them
+        const int rs = view <= 3 ? 4 : (view <= 7 ? 8 : 12), slot = ((view * rs / 4) | 1) * 4;
+        if (64 * slot > need) need = 64 * slot;
+    }
     h->lds_guard = h->kernel_mode == 0 ? guard : 0;
     h->staged_guard = guard;
     h->wave_lds = (need + 15) & ~15;
@@ -826,10 +830,11 @@ extern "C" int mgx_rollout(mgx_handle h, int64_t T, const uint8_t *actions, uint
     // (k_levelgen, k_dynobs, one-hot / flat epilogues), other views / visibility / hidden object state and grids without a
     // sized instance take the captured graph of per-step launches below.  MGX_ROLLOUT=graph forces that form (tests, tuning).
     const char *rf = getenv("MGX_ROLLOUT");
-    // (grids whose single step takes the gather form stay on the graph unless a sized k_rollout exists -- 13x13, 16x16: measured at 262,144
-    // envs, T = 64, the run-time-size k_rollout runs FourRooms 19x19 at 20.7 us per step against 19.6 for the graph of gather steps and
-    // MultiRoom 25x25 at 27.5 against 21.8: a 23-40 KB tile image leaves one or two waves per block)
-    const bool fused_ok = (h->kernel_mode == 0 || (h->kernel_mode == 3 && h->view == 7 && mgx_rollout_has_sized(h->W, h->H))) && h->partial &&
+    // (grids whose single step takes the gather form: fused while the tile is no larger than 16x16 -- sized k_rollout instances exist for
+    // 13x13 and 16x16 -- and the graph beyond: measured at 262,144 envs, T = 64, the run-time-size k_rollout runs FourRooms 19x19 at
+    // 20.7 us per step against 19.6 for the graph of gather steps and MultiRoom 25x25 at 27.5 against 21.8: a 23-40 KB tile image
+    // leaves one or two waves per block)
+    const bool fused_ok = (h->kernel_mode == 0 || (h->kernel_mode == 3 && h->S <= 256)) && h->partial &&
                           !h->cfg.alt_visibility && !h->objaux_d && !h->stream_mode &&
                           !h->dynobs && h->oh_nc < 0 && !h->flat && !(rf && !strcmp(rf, "graph"));
     if (fused_ok) {

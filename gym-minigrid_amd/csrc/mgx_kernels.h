@@ -129,7 +129,6 @@ hipError_t mgx_step_launch_cfg(int device, StepLaunchCfg *out);
 hipError_t mgx_launch_step(const StepParams &p, int mode, int waves_per_block, const StepLaunchCfg &lc, hipStream_t st);
 const char *mgx_step_kernel_label(const StepParams &p, int mode); // the instantiation the selector picks, e.g. "k_step<8,8,0,7>"
 hipError_t mgx_launch_rollout(const StepParams &p, const uint8_t *actions, uint8_t *obs, float *reward, uint8_t *done, int64_t T, hipStream_t st);
-bool mgx_rollout_has_sized(int W, int H); // a k_rollout<W,H,7> instance exists
 hipError_t mgx_preload_step_kernels();
 // (every .hip file is a code object of its own; one lookup each loads it at mgx_create instead of inside the first reset / step)
 hipError_t mgx_preload_levelgen_kernels();

@@ -442,6 +442,7 @@ def test_step_kernel_name_follows_the_selector():
             ("MiniGrid-ObstructedMaze-2Dlhb-v0", "partial", 7): "k_step<16,16,3,7,obj>",
             ("MiniGrid-ObstructedMaze-1Dlhb-v0", "partial", 7): "k_step<11,6,0,7,obj>",
             ("MiniGrid-DoorKey-8x8-v0", "partial", 5): "k_step<0,0,0,5>",
+            ("MiniGrid-FourRooms-v0", "partial", 5): "k_step<0,0,3,5,obj>",     # (the run-time-size instance carries the object-plane code)
             ("MiniGrid-Empty-16x16-v0", "full", 7): "k_step_fulldirect<16,16>",
             ("MiniGrid-FourRooms-v0", "full", 7): "k_step_fulldirect<19,19,ragged>",
             ("MiniGrid-LavaCrossingS9N1-v0", "full", 7): "k_step<9,9,1,7>"}

@@ -388,9 +388,14 @@ def test_faults_and_errors():
 
 
 @pytest.mark.parametrize("view", [3, 5, 9, 11])
-@pytest.mark.parametrize("W,H", [(8, 8), (9, 9), (13, 6), (25, 25)])
-def test_view_sizes_vs_oracle(W, H, view):
+@pytest.mark.parametrize("W,H,form", [(8, 8, None), (9, 9, None), (13, 6, None), (25, 25, None),
+                                      # round 3: the gather form's window excerpt for every view size (13x13 up by rule; forced on both sides of it;
+                                      # 14x9 / 9x14: fewer rows than the 12-row excerpt of views 9 / 11 on one axis)
+                                      (16, 16, None), (13, 13, "staged"), (9, 9, "gather"), (14, 9, "gather"), (9, 14, "gather"), (25, 25, "staged")])
+def test_view_sizes_vs_oracle(W, H, form, view, monkeypatch):
     """ViewSizeWrapper (wrappers.py:579-608): agent_view_size 3/5/9/11, random states, HIP vs CPU oracle."""
+    if form:
+        monkeypatch.setenv("MGX_PARTIAL_KERNEL", form)
     N, T, max_steps = 64 * 5 + 9, 40, 17
     see = (W + view) % 3 == 0
     grid, aux, agent, carry, steps = random_states(N, W, H, seed=W * 31 + view)
@@ -448,9 +453,12 @@ def test_strafe_vs_oracle_and_refbug():
 
 
 @pytest.mark.parametrize("view", [3, 5, 7, 9, 11])
-def test_alt_visibility_vs_oracle(view):
-    """default_vis=False (minigrid.py:649-709) on random states, every view size."""
-    W, H, N, T, max_steps = 10, 9, 64 * 5 + 3, 40, 21
+@pytest.mark.parametrize("W,H,form", [(10, 9, None), (10, 9, "gather"), (17, 15, None), (17, 15, "staged")])
+def test_alt_visibility_vs_oracle(W, H, form, view, monkeypatch):
+    """default_vis=False (minigrid.py:649-709) on random states, every view size, both kernel forms."""
+    if form:
+        monkeypatch.setenv("MGX_PARTIAL_KERNEL", form)
+    N, T, max_steps = 64 * 5 + 3, 40, 21
     grid, aux, agent, carry, steps = random_states(N, W, H, seed=view + 40, density=0.35)
     orc = make_oracle(W, H, max_steps, False, False, grid, aux, agent, carry, steps)
     orc.cfg.view, orc.V, orc.cfg.alt_vis = view, view, 1

@@ -32,7 +32,7 @@ def one(rs, trial):
     max_steps = int(rs.randint(4, 40))
     T = 40
     forms = {}
-    if mode == "partial" and view == 7 and not alt and not objstate and rs.uniform() < 0.4:
+    if mode == "partial" and rs.uniform() < 0.4:   # (round 3: every view size / visibility rule / object-state handle has both forms)
         forms["MGX_PARTIAL_KERNEL"] = str(rs.choice(["staged", "gather"]))
     if mode == "full" and rs.uniform() < 0.4:
         forms["MGX_FULL_KERNEL"] = str(rs.choice(["lds", "direct"]))
