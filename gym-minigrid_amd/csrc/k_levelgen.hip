@@ -20,26 +20,42 @@ namespace {
 // next one.  (One form with a run-time slide cost the crossing generator 10-20 %: it sits in a dozen call sites.)
 template <bool SLIDE>
 struct WinRng {
-    uint32_t *win;       // this lane's LDS window: MGX_LGF_WIN words starting at block position `base`
-    const uint32_t *mt;  // the env's block in HBM
-    int base, idx, limit;
+    uint32_t *win;       // this lane's LDS window: MGX_LGF_WIN words starting at stream position `base`
+    const uint32_t *mt;  // the env's block in HBM: stream positions 0 .. 623
+    const uint32_t *mt2; // the block after it (positions 624 .. 1247) or null (LevelGenParams.mt2)
+    int base, idx, limit, end; // end: 624, or 1248 with a second block
     bool overflow;
 
     __device__ __forceinline__ bool alive() const { return !overflow; }
+    // word at stream position w (clamped into what exists): ONE load on a selected address, never a load inside a branch
+    __device__ __forceinline__ uint32_t word(int w) const
+    {
+        w = w < end ? w : end - 1;
+        const uint32_t *src = (mt2 && w >= 624) ? mt2 + (w - 624) : mt + w;
+        return *src;
+    }
+    __device__ __forceinline__ void fill(int from)
+    {
+        // Eight loads at a time before their LDS writes (four round trips per refill).  As a rolled loop of single words -- load,
+        // s_waitcnt vmcnt(0), ds_write, next -- the refill was 32 dependent global round trips (the ISA had 173 inlined copies of that
+        // loop), paid every 32 draws by every draw-heavy generator: MultiRoom-N6 draws 287 words per level on average, KeyCorridorS3R3
+        // 158.  (All 32 at once cost the kernel its registers: 256 VGPRs + scratch, one wave per SIMD.)
+#pragma nounroll
+        for (int q = 0; q < MGX_LGF_WIN; q += 8) {
+            uint32_t t[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) t[k] = word(from + q + k);
+#pragma unroll
+            for (int k = 0; k < 8; k++) win[q + k] = t[k];
+        }
+    }
     __device__ __forceinline__ uint32_t next32()
     {
         if (idx >= limit) {
-            if (!SLIDE || idx >= 624) { overflow = true; return 0u; } // masked draws end on 0; place_obj-style loops test alive()
+            if (!SLIDE || idx >= end) { overflow = true; return 0u; } // masked draws end on 0; place_obj-style loops test alive()
             base = idx;
-            limit = base + MGX_LGF_WIN < 624 ? base + MGX_LGF_WIN : 624;
-            // All 32 loads before the first LDS write, on indices clamped into the block.  As a rolled loop -- load, s_waitcnt vmcnt(0),
-            // ds_write, next -- the refill was 32 dependent global round trips (the ISA had 173 inlined copies of that loop), paid every
-            // 32 draws by every draw-heavy generator: MultiRoom-N6 draws 287 words per level on average, KeyCorridorS3R3 158.
-            uint32_t t[MGX_LGF_WIN];
-#pragma unroll
-            for (int k = 0; k < MGX_LGF_WIN; k++) t[k] = mt[base + k < 624 ? base + k : 623];
-#pragma unroll
-            for (int k = 0; k < MGX_LGF_WIN; k++) win[k] = t[k];
+            limit = base + MGX_LGF_WIN < end ? base + MGX_LGF_WIN : end;
+            fill(base);
         }
         return lg_temper(win[idx++ - base]);
     }
@@ -74,6 +90,44 @@ struct DevRng {
     }
 };
 
+// nxt = the MT19937 block after cur (both 624 words in LDS), by the whole wave: the recurrence is 3 data-parallel phases + 1 word
+__device__ __forceinline__ void twist_to(const uint32_t *cur, uint32_t *nxt, int lane)
+{
+    for (int k = lane; k < 227; k += 64) nxt[k] = lg_twist_word(cur[k], cur[k + 1], cur[k + 397]);
+    wave_sync();
+    for (int k = 227 + lane; k < 454; k += 64) nxt[k] = lg_twist_word(cur[k], cur[k + 1], nxt[k - 227]);
+    wave_sync();
+    for (int k = 454 + lane; k < 623; k += 64) nxt[k] = lg_twist_word(cur[k], cur[k + 1], nxt[k - 227]);
+    wave_sync();
+    if (lane == 0) nxt[623] = lg_twist_word(cur[623], nxt[0], nxt[396]);
+    wave_sync();
+}
+// one env's 624-word row: HBM -> LDS / LDS -> HBM by the whole wave (all ten loads in flight before the first LDS write)
+__device__ __forceinline__ void block_load(const uint32_t *g, uint32_t *l, int lane)
+{
+    uint32_t v[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) { const int k = lane + 64 * i; v[i] = g[k < 624 ? k : 623]; }
+#pragma unroll
+    for (int i = 0; i < 10; i++) { const int k = lane + 64 * i; if (k < 624) l[k] = v[i]; }
+}
+__device__ __forceinline__ void block_store(uint32_t *g, const uint32_t *l, int lane)
+{
+    for (int k = lane; k < 624; k += 64) g[k] = l[k];
+}
+
+// An env whose level (made on the lane path) ended inside its second block moves one block on: mt <- mt2, mt2 <- twist(mt2).
+__device__ __forceinline__ void advance_env(const LevelGenParams &p, int64_t env, uint8_t *base, int lane)
+{
+    uint32_t *cur = reinterpret_cast<uint32_t *>(base), *nxt = cur + 624;
+    block_load(p.mt2 + env * 624, cur, lane);
+    wave_sync();
+    block_store(p.mt + env * 624, cur, lane);
+    twist_to(cur, nxt, lane);
+    block_store(p.mt2 + env * 624, nxt, lane);
+    wave_sync();
+}
+
 // One level, generated by one wave into its LDS workspace and written back coalesced.
 __device__ __forceinline__ void levelgen_one(const LevelGenParams &p, int64_t env, uint8_t *base, int lane)
 {
@@ -82,28 +136,14 @@ __device__ __forceinline__ void levelgen_one(const LevelGenParams &p, int64_t en
     int16_t *ws = reinterpret_cast<int16_t *>(res + 4);
     LgCmd *cmds = reinterpret_cast<LgCmd *>(ws + MGX_LG_WS_WORDS);
     uint32_t *mt = p.mt + env * 624;
-    { // all ten loads of the block in flight before the first LDS write (a rolled loop pays one latency per trip)
-        uint32_t v[10];
-#pragma unroll
-        for (int i = 0; i < 10; i++) { const int k = lane + 64 * i; v[i] = k < 624 ? mt[k] : 0u; }
-#pragma unroll
-        for (int i = 0; i < 10; i++) { const int k = lane + 64 * i; if (k < 624) cur[k] = v[i]; }
-    }
+    block_load(mt, cur, lane);
     const int idx0 = (int)p.mt_idx[env];
     wave_sync();
-    // If the read index is within 64 words of the end of the block the level will probably run into the next block:
-    // the whole wave builds it first (the recurrence is 3 data-parallel phases + 1 word).
-    const bool pre = idx0 + 64 > 624;
-    if (pre) {
-        for (int k = lane; k < 227; k += 64) nxt[k] = lg_twist_word(cur[k], cur[k + 1], cur[k + 397]);
-        wave_sync();
-        for (int k = 227 + lane; k < 454; k += 64) nxt[k] = lg_twist_word(cur[k], cur[k + 1], nxt[k - 227]);
-        wave_sync();
-        for (int k = 454 + lane; k < 623; k += 64) nxt[k] = lg_twist_word(cur[k], cur[k + 1], nxt[k - 227]);
-        wave_sync();
-        if (lane == 0) nxt[623] = lg_twist_word(cur[623], nxt[0], nxt[396]);
-        wave_sync();
-    }
+    // The block after this one: kept in HBM by new_level_each_episode handles (p.mt2); otherwise, if the read index is within 64 words
+    // of the end of the block the level will probably run into the next one and the whole wave builds it first.
+    const bool pre = p.mt2 != nullptr || idx0 + 64 > 624;
+    if (p.mt2) { block_load(p.mt2 + env * 624, nxt, lane); wave_sync(); }
+    else if (pre) twist_to(cur, nxt, lane);
     if (lane == 0) {
         DevRng r;
         r.a = cur; r.b = nxt; r.idx = idx0; r.have_b = pre; r.advanced = 0;
@@ -145,9 +185,13 @@ __device__ __forceinline__ void levelgen_one(const LevelGenParams &p, int64_t en
             }
         }
     }
-    if (res[2]) { // moved into a later block: it becomes the env's state
-        const uint32_t *blk = res[2] == 1 ? cur : nxt;
-        for (int k = lane; k < 624; k += 64) mt[k] = blk[k];
+    if (res[2]) { // moved into a later block: it becomes the env's state (and the one after it is made ready, where the handle keeps one)
+        uint32_t *blk = res[2] == 1 ? cur : nxt, *other = res[2] == 1 ? nxt : cur;
+        block_store(mt, blk, lane);
+        if (p.mt2) {
+            twist_to(blk, other, lane);
+            block_store(p.mt2 + env * 624, other, lane);
+        }
     }
     if (lane == 0) {
         p.mt_idx[env] = (uint32_t)idx1;
@@ -190,22 +234,17 @@ static_assert(MGX_LG_LDS_PER_WAVE == MGX_LG_LDS_PER_WAVE_BYTES, "keep mgx_kernel
 struct FastLayout { int cmd_cap, river_cap, img_dw, slice_dw, n_fast_waves, span, lanes; }; // lanes: generating lanes per fast wave (64, or fewer for the long-tailed generators)
 
 template <bool SLIDE>
-__device__ __forceinline__ bool fast_level(const LevelGenParams &p, const FastLayout &fl, int64_t env, uint32_t *slice, int W, int H, int cells)
+__device__ __forceinline__ bool fast_level(const LevelGenParams &p, const FastLayout &fl, int64_t env, uint32_t *slice, int W, int H, int cells, bool &crossed)
 {
+    crossed = false;
     const int idx0 = (int)p.mt_idx[env];
-    if (SLIDE ? idx0 >= 624 : (idx0 + MGX_LGF_WIN > 624 || fl.img_dw == 0)) return false;
-    const uint32_t *mt = p.mt + env * 624;
-    { // (32 loads in flight, on clamped indices -- `idx0 + k < 624 ? mt[idx0 + k] : 0` compiled to 32 branches with a load and an
-      // s_waitcnt vmcnt(0) each: 32 dependent round trips in front of every level; words past the block's end are never drawn)
-        uint32_t t[MGX_LGF_WIN];
-#pragma unroll
-        for (int k = 0; k < MGX_LGF_WIN; k++) t[k] = mt[idx0 + k < 624 ? idx0 + k : 623];
-#pragma unroll
-        for (int k = 0; k < MGX_LGF_WIN; k++) slice[k] = t[k];
-    }
+    const int end = p.mt2 ? 1248 : 624; // stream positions this env has ready: its block, and the next one where the handle keeps it
+    if (idx0 >= 624 || (!SLIDE && (idx0 + MGX_LGF_WIN > end || fl.img_dw == 0))) return false;
     WinRng<SLIDE> r;
-    r.win = slice; r.mt = mt; r.base = idx0; r.idx = idx0; r.overflow = false;
-    r.limit = idx0 + MGX_LGF_WIN < 624 ? idx0 + MGX_LGF_WIN : 624;
+    r.win = slice; r.mt = p.mt + env * 624; r.mt2 = p.mt2 ? p.mt2 + env * 624 : nullptr; r.end = end;
+    r.base = idx0; r.idx = idx0; r.overflow = false;
+    r.limit = idx0 + MGX_LGF_WIN < end ? idx0 + MGX_LGF_WIN : end;
+    r.fill(idx0);
     LgLevel L;
     L.cmds = reinterpret_cast<LgCmd *>(slice + MGX_LGF_WIN); L.ncmd = 0; L.max_cmds = fl.cmd_cap;
     L.ws = reinterpret_cast<int16_t *>(slice + MGX_LGF_WIN + 2 * fl.cmd_cap); L.max_rivers = fl.river_cap;
@@ -246,7 +285,11 @@ __device__ __forceinline__ bool fast_level(const LevelGenParams &p, const FastLa
             if (c.x0 == c.x1 && c.y0 == c.y1) dcb[c.x0 * H + c.y0] = c.cont ? c.cont : (uint8_t)MGX_CODE_EMPTY; // (a later command over a box empties the cell's entry)
         }
     }
-    p.mt_idx[env] = (uint32_t)r.idx;
+    // (a level that ended in the second block: the position is stored relative to it; the caller moves the env one block on)
+    // (without a second block a level that used exactly the last word of its block leaves idx == 624 = "exhausted", as ever: the fuzz
+    // found the first version of this line treating that as a crossing and dereferencing the null mt2)
+    crossed = p.mt2 != nullptr && r.idx >= 624;
+    p.mt_idx[env] = (uint32_t)(crossed ? r.idx - 624 : r.idx);
     p.agent0[env] = make_uint2((uint32_t)((L.ax & 255) | ((L.ay & 255) << 8) | ((L.adir & 3) << 16)) | ((uint32_t)MGX_CODE_EMPTY << 24), L.task << 16);
     return true;
 }
@@ -293,8 +336,12 @@ __global__ __launch_bounds__(256) void k_levelgen(const LevelGenParams p, const 
         for (int i = wv * fl.lanes + lane; i < ((count + stride - 1) / stride) * stride; i += stride) {
             if (i >= count) continue;
             const int64_t env = env_base + s_queue[i];
-            const bool ok = slide ? fast_level<true>(p, fl, env, slice, W, H, cells) : fast_level<false>(p, fl, env, slice, W, H, cells);
+            bool crossed;
+            const bool ok = slide ? fast_level<true>(p, fl, env, slice, W, H, cells, crossed) : fast_level<false>(p, fl, env, slice, W, H, cells, crossed);
+            // (the second queue holds both kinds of whole-wave work: levels the lane path gave up on, and -- bit 15 -- envs whose level is
+            // done but ended in their second MT19937 block)
             if (!ok) s_slow[atomicAdd(&s_nslow, 1)] = s_queue[i];
+            else if (crossed) s_slow[atomicAdd(&s_nslow, 1)] = (uint16_t)(s_queue[i] | 0x8000u);
         }
     }
     __syncthreads();
@@ -306,7 +353,9 @@ __global__ __launch_bounds__(256) void k_levelgen(const LevelGenParams p, const 
         if (lane == 0) i = atomicAdd(&s_head, 1);
         i = __builtin_amdgcn_readfirstlane(i);
         if (i >= nslow) break;
-        levelgen_one(p, env_base + s_slow[i], base, lane);
+        const uint32_t job = s_slow[i];
+        if (job & 0x8000u) advance_env(p, env_base + (job & 0x7FFFu), base, lane);
+        else levelgen_one(p, env_base + job, base, lane);
     }
 }
 
@@ -469,7 +518,21 @@ __device__ __forceinline__ void twist_to_lds(uint32_t *s, const uint32_t r[10], 
     for (int j = 0; j < 10; j++) if (lane + 64 * j < 624) s[lane + 64 * j] = r[j];
     wave_sync();
 }
-__device__ __forceinline__ void twist_block_wave(uint32_t *m, uint32_t *s, int lane)
+// m2 (or null): the block after that one as well (new_level_each_episode handles keep it ready: LevelGenParams.mt2)
+__device__ __forceinline__ void twist_rounds(uint32_t *s, int lane);
+__device__ __forceinline__ void twist_block_wave(uint32_t *m, uint32_t *m2, uint32_t *s, int lane)
+{
+    twist_rounds(s, lane);
+#pragma unroll
+    for (int j = 0; j < 10; j++) if (lane + 64 * j < 624) m[lane + 64 * j] = s[lane + 64 * j];
+    if (m2) {
+        twist_rounds(s, lane);
+#pragma unroll
+        for (int j = 0; j < 10; j++) if (lane + 64 * j < 624) m2[lane + 64 * j] = s[lane + 64 * j];
+    }
+    wave_sync();
+}
+__device__ __forceinline__ void twist_rounds(uint32_t *s, int lane)
 {
     uint32_t v[4];
     // k in [0, 227): old[k], old[k+1], old[k+397]
@@ -495,13 +558,10 @@ __device__ __forceinline__ void twist_block_wave(uint32_t *m, uint32_t *s, int l
     wave_sync();
     if (lane == 0) s[623] = lg_twist_word(s[623], s[0], s[396]);
     wave_sync();
-#pragma unroll
-    for (int j = 0; j < 10; j++) if (lane + 64 * j < 624) m[lane + 64 * j] = s[lane + 64 * j];
-    wave_sync();
 }
 
 // up to 64 queued envs of a span by one wave: the two passes lane-per-env, then the block twists together
-__device__ __forceinline__ void seed_queue_wave(const uint64_t *__restrict__ seeds, const uint32_t *__restrict__ init, uint32_t *mt, uint32_t *mt_idx,
+__device__ __forceinline__ void seed_queue_wave(const uint64_t *__restrict__ seeds, const uint32_t *__restrict__ init, uint32_t *mt, uint32_t *mt2, uint32_t *mt_idx,
                                                 uint8_t *regen, const SeedBook &book, int64_t base, const uint16_t *s_queue, int q0, int count,
                                                 uint32_t *s_blk, int lane)
 {
@@ -518,7 +578,7 @@ __device__ __forceinline__ void seed_queue_wave(const uint64_t *__restrict__ see
     for (int l = 0; l < nq; l++) {
         twist_to_lds(s_blk, r, lane);
         if (l + 1 < nq) twist_load(mt + (base + s_queue[q0 + l + 1]) * 624, r, lane); // in flight during the rounds below
-        twist_block_wave(mt + (base + s_queue[q0 + l]) * 624, s_blk, lane);
+        twist_block_wave(mt + (base + s_queue[q0 + l]) * 624, mt2 ? mt2 + (base + s_queue[q0 + l]) * 624 : nullptr, s_blk, lane);
     }
     if (have) {
         mt_idx[env] = 0; // the first block is ready
@@ -529,7 +589,7 @@ __device__ __forceinline__ void seed_queue_wave(const uint64_t *__restrict__ see
 }
 
 __global__ __launch_bounds__(256) void k_seed(const uint64_t *__restrict__ seeds, const uint8_t *__restrict__ mask,
-                                              const uint32_t *__restrict__ init, uint32_t *mt, uint32_t *mt_idx,
+                                              const uint32_t *__restrict__ init, uint32_t *mt, uint32_t *mt2, uint32_t *mt_idx,
                                               uint8_t *regen, SeedBook book, int64_t n)
 {
     __shared__ uint16_t s_queue[MGX_SEED_SPAN];
@@ -549,7 +609,7 @@ __global__ __launch_bounds__(256) void k_seed(const uint64_t *__restrict__ seeds
     }
     __syncthreads();
     const int count = s_count;
-    for (int q0 = wv * 64; q0 < count; q0 += 256) seed_queue_wave(seeds, init, mt, mt_idx, regen, book, base, s_queue, q0, count, s_blk[wv], lane); // wave-uniform trip count
+    for (int q0 = wv * 64; q0 < count; q0 += 256) seed_queue_wave(seeds, init, mt, mt2, mt_idx, regen, book, base, s_queue, q0, count, s_blk[wv], lane); // wave-uniform trip count
 }
 
 // Masked form (caller-side `reset(mask = done)`: ~1 % of the envs): one wave per 512-env span compacts the masked envs
@@ -560,7 +620,7 @@ __global__ __launch_bounds__(256) void k_seed(const uint64_t *__restrict__ seeds
 // four waves per span.)
 #define MGX_SEEDM_SPAN 512
 __global__ __launch_bounds__(64) void k_seed_masked(const uint64_t *__restrict__ seeds, const uint8_t *__restrict__ mask,
-                                                    const uint32_t *__restrict__ init, uint32_t *mt, uint32_t *mt_idx,
+                                                    const uint32_t *__restrict__ init, uint32_t *mt, uint32_t *mt2, uint32_t *mt_idx,
                                                     uint8_t *regen, SeedBook book, int64_t n)
 {
     __shared__ uint32_t s_blk[624];
@@ -600,7 +660,7 @@ __global__ __launch_bounds__(64) void k_seed_masked(const uint64_t *__restrict__
     wave_sync();
     const int count = s_count;
     if (count == 0) return;
-    for (int q0 = 0; q0 < count; q0 += 64) seed_queue_wave(seeds, init, mt, mt_idx, regen, book, base, s_queue, q0, count, s_blk, lane);
+    for (int q0 = 0; q0 < count; q0 += 64) seed_queue_wave(seeds, init, mt, mt2, mt_idx, regen, book, base, s_queue, q0, count, s_blk, lane);
 }
 
 } // namespace
@@ -637,12 +697,13 @@ hipError_t mgx_launch_levelgen(const LevelGenParams &p, hipStream_t st)
     const bool heavy = kind == MGX_LEVEL_MULTIROOM || kind == MGX_LEVEL_KEYCORRIDOR;
     fl.lanes = 64;
     if (kind == MGX_LEVEL_MULTIROOM) fl.lanes = 16;
+    if (kind == MGX_LEVEL_KEYCORRIDOR && p.mt2) fl.lanes = 32; // (with the second block: 162 us per step against 178 for a wave per level)
     if (const char *e = getenv("MGX_LG_LANES")) { const int v = atoi(e); if (heavy && v >= 1 && v <= 64) fl.lanes = v; } // (tuning runs)
     const int slice_bytes = fl.lanes * fl.slice_dw * 4;
     fl.n_fast_waves = 60 * 1024 / slice_bytes; // with the two queues (8 KB) a block stays under 64 KB of LDS
     if (fl.n_fast_waves > 4) fl.n_fast_waves = 4;
     if (fl.n_fast_waves < 1) fl.n_fast_waves = 1;
-    if (kind == MGX_LEVEL_KEYCORRIDOR) fl.n_fast_waves = 0; // a wave per level
+    if (kind == MGX_LEVEL_KEYCORRIDOR && !p.mt2) fl.n_fast_waves = 0; // a wave per level
     if (const char *e = getenv("MGX_LG_FAST_WAVES")) fl.n_fast_waves = atoi(e); // (tuning runs; 0 = every level takes the wave-per-level path)
     size_t shmem = (size_t)(fl.n_fast_waves > 0 ? fl.n_fast_waves : 1) * slice_bytes;
     if (shmem < (size_t)slow_bytes) shmem = slow_bytes;
@@ -656,19 +717,19 @@ hipError_t mgx_launch_levelgen(const LevelGenParams &p, hipStream_t st)
             raised[dev] = true;
         }
     }
-    fl.span = kind == MGX_LEVEL_MULTIROOM ? 64 : (heavy ? 128 : 512);
+    fl.span = heavy ? 128 : 512;
     while (fl.span < MGX_LGF_ENVS && (p.n + fl.span - 1) / fl.span > (heavy ? 8192 : 512)) fl.span *= 2;
     if (const char *e = getenv("MGX_LG_SPAN")) { const int v = atoi(e); if (v >= 64 && v <= MGX_LGF_ENVS && (v & 63) == 0) fl.span = v; } // (tuning runs)
     hipLaunchKernelGGL(k_levelgen, dim3((unsigned)((p.n + fl.span - 1) / fl.span)), dim3(256), shmem, st, p, fl);
     return hipGetLastError();
 }
 
-hipError_t mgx_launch_seed(const uint64_t *seeds, const uint8_t *mask, const uint32_t *init, uint32_t *mt, uint32_t *mt_idx,
+hipError_t mgx_launch_seed(const uint64_t *seeds, const uint8_t *mask, const uint32_t *init, uint32_t *mt, uint32_t *mt2, uint32_t *mt_idx,
                            uint8_t *regen, uint64_t *seed0, uint8_t *has_seed, uint8_t *reseeded, int skip_same, int64_t n, hipStream_t st)
 {
     const SeedBook book = {seed0, has_seed, reseeded, skip_same};
-    if (mask) hipLaunchKernelGGL(k_seed_masked, dim3((unsigned)((n + MGX_SEEDM_SPAN - 1) / MGX_SEEDM_SPAN)), dim3(64), 0, st, seeds, mask, init, mt, mt_idx, regen, book, n);
-    else hipLaunchKernelGGL(k_seed, dim3((unsigned)((n + MGX_SEED_SPAN - 1) / MGX_SEED_SPAN)), dim3(256), 0, st, seeds, mask, init, mt, mt_idx, regen, book, n);
+    if (mask) hipLaunchKernelGGL(k_seed_masked, dim3((unsigned)((n + MGX_SEEDM_SPAN - 1) / MGX_SEEDM_SPAN)), dim3(64), 0, st, seeds, mask, init, mt, mt2, mt_idx, regen, book, n);
+    else hipLaunchKernelGGL(k_seed, dim3((unsigned)((n + MGX_SEED_SPAN - 1) / MGX_SEED_SPAN)), dim3(256), 0, st, seeds, mask, init, mt, mt2, mt_idx, regen, book, n);
     return hipGetLastError();
 }
 

@@ -74,6 +74,7 @@ struct mgx_env_s {
     bool one_level = false;          // the family draws none (Empty with a fixed start, DistShift, fixed TwoGoals): its level does not depend on the seed
     bool snapshot_is_level = false;  // ... and every env's episode-start snapshot holds it: mgx_reset is a restore (k_consume)
     uint32_t *mt_d = nullptr, *mt_idx_d = nullptr, *mt_init_d = nullptr;
+    uint32_t *mt2_d = nullptr; // LevelGenParams.mt2 (new_level_each_episode handles)
     uint8_t *regen_d = nullptr;
     uint64_t *seed0_d = nullptr;                  // seed of the level the episode-start snapshot holds ...
     uint8_t *has_seed_d = nullptr, *reseeded_d = nullptr; // ... if any; envs the last mgx_reset really re-seeded
@@ -236,7 +237,7 @@ LevelGenParams levelgen_params(mgx_handle h)
     LevelGenParams g;
     memset(&g, 0, sizeof g);
     g.cfg = h->cfg;
-    g.mt = h->mt_d; g.mt_idx = h->mt_idx_d; g.regen = h->regen_d; g.cells0 = h->cells0_d; g.agent0 = h->agent0_d;
+    g.mt = h->mt_d; g.mt2 = h->mt2_d; g.mt_idx = h->mt_idx_d; g.regen = h->regen_d; g.cells0 = h->cells0_d; g.agent0 = h->agent0_d;
     g.objaux0 = h->objaux0_d; g.objcont0 = h->objcont0_d;
     g.ctr = h->ctr_d;
     g.n = h->n; g.n_tiles = (int)(h->n_pad / 64); g.S = h->S;
@@ -480,6 +481,16 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
         CREATE_TRY(hipMalloc((void **)&h->mt_idx_d, (size_t)h->n_pad * sizeof(uint32_t)));
         CREATE_TRY(hipMalloc((void **)&h->regen_d, (size_t)h->n_pad));
         CREATE_TRY(hipMemsetAsync(h->mt_d, 0, (size_t)h->n_pad * 624 * sizeof(uint32_t), h->stream));
+        // new_level_each_episode handles of the draw-heavy families keep the NEXT block ready as well (LevelGenParams.mt2): a level may then
+        // run across the end of its block on the lane-per-level path instead of being generated again by a whole wave (MultiRoom-N6 uses
+        // 287 of a block's 624 words per level: every second level crossed).  The cheap families (tens of words per level) cross rarely
+        // and measured 5 % slower with the second block's upkeep (LavaCrossing, 1 Mi envs: 60.0 -> 63.1 us per step).
+        const bool cheap_draws = cfg->level_kind == MGX_LEVEL_EMPTY || cfg->level_kind == MGX_LEVEL_DOORKEY || cfg->level_kind == MGX_LEVEL_CROSSING ||
+                                 cfg->level_kind == MGX_LEVEL_LAVAGAP || cfg->level_kind == MGX_LEVEL_DISTSHIFT;
+        if (h->stream_mode && !(cfg->task_kind == MGX_TASK_DYNOBS) && !cheap_draws) {
+            CREATE_TRY(hipMalloc((void **)&h->mt2_d, (size_t)h->n_pad * 624 * sizeof(uint32_t)));
+            CREATE_TRY(hipMemsetAsync(h->mt2_d, 0, (size_t)h->n_pad * 624 * sizeof(uint32_t), h->stream));
+        }
         CREATE_TRY(hipMemsetAsync(h->mt_idx_d, 0, (size_t)h->n_pad * sizeof(uint32_t), h->stream));
         CREATE_TRY(hipMemsetAsync(h->regen_d, 0, (size_t)h->n_pad, h->stream));
         CREATE_TRY(hipMalloc((void **)&h->seed0_d, (size_t)h->n_pad * sizeof(uint64_t)));
@@ -542,7 +553,7 @@ extern "C" int mgx_destroy(mgx_handle h)
     (void)hipFree(h->cells_d); (void)hipFree(h->cells0_d); (void)hipFree(h->agent_d); (void)hipFree(h->agent0_d);
     (void)hipFree(h->ctr_d); (void)hipFree(h->tri_d); (void)hipFree(h->mission_d); (void)hipFree(h->front_d);
     (void)hipFree(h->objaux_d); (void)hipFree(h->objaux0_d); (void)hipFree(h->objcont_d); (void)hipFree(h->objcont0_d); (void)hipFree(h->objcarry_d);
-    (void)hipFree(h->mt_d); (void)hipFree(h->mt_idx_d); (void)hipFree(h->regen_d); (void)hipFree(h->mt_init_d);
+    (void)hipFree(h->mt_d); (void)hipFree(h->mt2_d); (void)hipFree(h->mt_idx_d); (void)hipFree(h->regen_d); (void)hipFree(h->mt_init_d);
     (void)hipFree(h->seed0_d); (void)hipFree(h->has_seed_d); (void)hipFree(h->reseeded_d);
     if (h->roll_exec) (void)hipGraphExecDestroy(h->roll_exec);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
@@ -1011,7 +1022,7 @@ extern "C" int mgx_reset(mgx_handle h, const uint64_t *seeds, const uint8_t *mas
         // (k_seed clears the regeneration flags of the envs being reset before it raises those of the envs it really seeds)
         // (an env that keeps its seed keeps its level: with the snapshot still holding it -- not in stream mode, where the
         // buffer holds the NEXT level -- seeding and generation are skipped for it and k_consume alone restores it)
-        HIP_TRY(mgx_launch_seed((const uint64_t *)ds, (const uint8_t *)dm, h->mt_init_d, h->mt_d, h->mt_idx_d, h->regen_d, h->seed0_d, h->has_seed_d,
+        HIP_TRY(mgx_launch_seed((const uint64_t *)ds, (const uint8_t *)dm, h->mt_init_d, h->mt_d, h->mt2_d, h->mt_idx_d, h->regen_d, h->seed0_d, h->has_seed_d,
                                 h->reseeded_d, h->stream_mode ? 0 : 1, h->n, h->stream));
         if ((rc = launch_levelgen(h))) return rc;
         ConsumeParams c;

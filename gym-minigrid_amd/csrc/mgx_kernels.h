@@ -30,6 +30,8 @@ struct MgxCounters {
 struct LevelGenParams {
     mgx_config cfg;
     uint32_t *mt;      // u32[n_pad][624]  per-env MT19937 block
+    uint32_t *mt2;     // new_level_each_episode handles (else null): u32[n_pad][624], always twist(mt) = the block AFTER `mt`, kept ready by
+                       // whoever advances an env's block, so that a level may run across the end of `mt` on the lane-per-level path
     uint32_t *mt_idx;  // u32[n_pad]       next unread word of the block (624 = exhausted / freshly seeded)
     uint8_t *regen;    // u8[n_pad]        work flags, cleared here
     uint8_t *cells0;   // next-level buffer (codes) and its agent record
@@ -120,7 +122,7 @@ int mgx_dynobs_wave_lds(int LS);
 hipError_t mgx_launch_dynobs_init(const DynObsParams &p, hipStream_t st);
 hipError_t mgx_launch_dynobs(const DynObsParams &p, hipStream_t st);
 hipError_t mgx_launch_levelgen(const LevelGenParams &p, hipStream_t st);
-hipError_t mgx_launch_seed(const uint64_t *seeds, const uint8_t *mask, const uint32_t *init, uint32_t *mt, uint32_t *mt_idx,
+hipError_t mgx_launch_seed(const uint64_t *seeds, const uint8_t *mask, const uint32_t *init, uint32_t *mt, uint32_t *mt2, uint32_t *mt_idx,
                            uint8_t *regen, uint64_t *seed0, uint8_t *has_seed, uint8_t *reseeded, int skip_same, int64_t n, hipStream_t st);
 hipError_t mgx_launch_consume(const ConsumeParams &p, hipStream_t st);
 // launch shaping of one handle on its own device (k_step.hip: raised-priority tail blocks, first-round stagger)

@@ -250,6 +250,20 @@ def test_seeded_reset_on_device(env_id):
     env.close()
 
 
+@pytest.mark.parametrize("env_id", ["MiniGrid-MultiRoom-N6-v0", "MiniGrid-KeyCorridorS6R3-v0", "MiniGrid-ObstructedMaze-Full-v0"])
+def test_seeded_reset_many_levels_including_ones_that_end_on_the_block_boundary(env_id):
+    """Draw-heavy families at 24,000 seeds: among them are levels whose last draw is word 623 of the env's MT19937 block
+    (position 624 afterwards, no second block on a handle outside stream mode) and levels that run past it (slow path).
+    tools/fuzz_ids.py found the first: k_levelgen took position 624 for a crossing into a second block that was not there."""
+    N = 24000
+    env = mg.VecMiniGrid(env_id, num_envs=N, seeds=77, auto_reset=True, backend="torch")
+    env.reset()
+    grid, agent = mg.generate_levels(env_id, 77 + np.arange(N, dtype=np.uint64))
+    st = env.get_state()
+    assert np.array_equal(st["grid"], grid) and np.array_equal(st["agent"], agent)
+    env.close()
+
+
 @pytest.mark.parametrize("env_id", ["MiniGrid-Fetch-8x8-N3-v0", "MiniGrid-GoToDoor-6x6-v0", "MiniGrid-GoToObject-8x8-N2-v0", "MiniGrid-PutNear-8x8-N3-v0",
                                     "MiniGrid-RedBlueDoors-6x6-v0", "MiniGrid-MemoryS9-v0", "MiniGrid-MemoryS17Random-v0", "MiniGrid-Unlock-v0",
                                     "MiniGrid-BlockedUnlockPickup-v0", "MiniGrid-KeyCorridorS3R2-v0", "MiniGrid-KeyCorridorS5R3-v0",

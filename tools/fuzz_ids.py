@@ -196,6 +196,8 @@ def one_options(env_id, rs):
     full = rs.uniform() < 0.3
     N = int(rs.choice([1, 65, 400]))
     seeds = rs.randint(0, 2 ** 40, size=N).astype(np.uint64)
+    if os.environ.get("FUZZ_VERBOSE"):
+        print("      options %s N=%d view=%d ext=%d alt=%d objstate=%d full=%d" % (env_id, N, view, ext, alt, objstate, full), flush=True)
     env = mg.VecMiniGrid(env_id, num_envs=N, seeds=seeds, auto_reset=True, backend="torch", obs_mode="full" if full else "partial",
                          agent_view_size=view, extended_actions=ext, default_vis=not alt, object_state=objstate)
     obs = np_(env.reset())
