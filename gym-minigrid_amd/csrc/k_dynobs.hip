@@ -45,37 +45,49 @@ __global__ __launch_bounds__(256) void k_dynobs_init(const DynObsParams p)
     w.y = ob[4] | (ob[5] << 8) | (ob[6] << 16) | ((uint32_t)ob[7] << 24);
     reinterpret_cast<uint2 *>(p.obst0)[t] = w;
     reinterpret_cast<uint2 *>(p.obst)[t] = w;
-    p.pos0[t] = p.pos[t];
-    p.regen[t] = 0;
+    p.regen[t] = 0; // (k_dynobs_tape, next, turns the stream position k_levelgen left in `pos` into a rank and writes pos0)
 }
 
 // One wave per tile of 64 envs, lane per env, like k_step.  The walk is a chain of draw -> look at a cell -> maybe draw again,
-// every link depending on the one before and diverging between lanes.
+// every link depending on the one before and diverging between lanes; written as that loop it ran for the wave's unluckiest lane
+// with 25 of 64 lanes active and was bound by its chain of LDS round trips and branches (108 of the kernel's 143 us at 1 Mi 8x8 envs
+// went to it, measured by leaving it out).  Now:
 //   * every draw of the walk is `bounded(2)` (a 3-wide range: obstacles live in the interior, so the 3x3 box never clips):
 //     masked rejection on the low two bits of the tempered word.  The accepted draws are therefore simply the words whose
-//     two bits are not 3, in order: a window of 64 stream positions is three 64-bit masks (valid, bit 0, bit 1), and a draw
-//     is ffbl + clear-lowest-bit + two bit extracts: no loop, no memory access.
-//   * THE DRAW TAPE.  Each block has a tape: two bit planes (bit k of plane 0 / 1 = bit 0 / 1 of tempered word k) over 848
-//     stream positions -- the 624 words of the block and the first 224 of the NEXT one, which depend on the old block only
-//     (new[k] = twist(old[k], old[k+1], old[k+397]) for k < 227).  The whole wave builds it once per block (k_dynobs_tape at
-//     reset; the service loop of k_dynobs when a block is finished or restored: 14 rounds of 64 positions, two ballots
-//     each); a step reads its window as two unaligned 12-byte loads per lane, and again for every further 64 positions a
-//     long placement needs.  (Round 1 rebuilt every env's window every step with 64 coalesced loads + 192 ballots per wave --
-//     ~1,700 of its 4,400 VALU instructions and 256 B/env of reads for the ~11 words a step consumes -- and every env within 64
-//     words of its block's end, i.e. some lane of nearly every wave, fell through to one dependent global load per draw.)
-//   * positions 624..847 are consumed from the tape WITHOUT touching the block; the stored position then is >= 624 and the next
-//     step's service loop twists the whole block (in LDS, chunks of <= 227 independent words), rebuilds the tape and takes
-//     624 off the position.  Only a lane that runs off the tape altogether falls back to DynRng's word-by-word source, which
-//     first catches the block up in place (bit 30 of the stored position: words [0, pos - 624) already belong to the new block).
+//     two bits are not 3, in order.
+//   * THE DRAW TAPE is that sequence, per block: the ACCEPTED draws of 848 stream positions -- the 624 words of the block and the
+//     first 224 of the NEXT one, which depend on the old block only (new[k] = twist(old[k], old[k+1], old[k+397]) for k < 227) --
+//     as two bit planes indexed by RANK (bit j of plane 0 / 1 = bit 0 / 1 of the j-th accepted draw).  The whole wave builds it once
+//     per block (k_dynobs_tape at reset; the service loop of k_dynobs when a block is finished or restored): 14 rounds of 64
+//     positions, each lane with an accepted word drops its two bits at byte `rank` of an LDS strip (rank = accepted words before it:
+//     a running count + v_mbcnt of the round's ballot), then 14 rounds of two ballots over the strip.  An env's position is a rank,
+//     and the per-env position word carries the block's two constants beside it: R624 (accepted draws among the block's own 624
+//     words) and Rtot (among all 848).  A step reads 64 draws = 32 (dx, dy) samples as two unaligned 12-byte loads per lane.
+//   * A PLACEMENT IS STRAIGHT-LINE CODE.  A sample is the pair (draw 2k, draw 2k+1); an obstacle moves to the first sample whose cell
+//     is free.  For 16 samples at once: the even bits of the two planes say which dx each sample has (three masks), the odd bits which
+//     dy; with the nine cells of the 3x3 box read from the LDS image, hit = OR over dx of (Xdx & OR over the free dy of that column
+//     (Ydy)) is the mask of successful samples, and its lowest set bit the one the reference's loop stops at.  No loop, every lane
+//     busy, same cost for the first sample as for the sixteenth.  (The agent's cell is marked in the LDS image, which is private to
+//     this kernel, so "free" is one compare.)  A lane whose obstacle finds no free cell among its (at most 16) samples at hand, or
+//     sits in a box without a free cell, takes that obstacle and the rest of its walk through the reference's loop as written
+//     (`slow` below: draws one at a time, further windows of the tape, the hopeless-box skip, 101 samples at most).
+//   * ranks >= R624 are consumed from the tape WITHOUT touching the block; the next step's service loop then twists the whole block
+//     (in LDS, chunks of <= 227 independent words), rebuilds the tape and takes R624 off the position.  Only a lane that runs off the
+//     tape altogether falls back to DynRng's word-by-word source at stream position 848, which first catches the block up in place
+//     (bit 30 of the stored position: it then holds a STREAM position, and words [0, pos - 624) already belong to the new block).
 //   * the tile's cells are staged in LDS as k_step stages them; moved obstacles are written through to HBM.
 //   * history (1 Mi 8x8 envs, us per launch): lane-per-env straight from HBM 550-1,900; byte-wide windows in LDS 280; ballot-built
-//     register windows 254 (round 1); the tape 186; + look-ahead 224, further windows, the hopeless-box skip, one flat
-//     (obstacle, try) loop per lane: 143.
+//     register windows 254 (round 1); a tape of all 848 positions + validity mask 186; + look-ahead 224, further windows, the
+//     hopeless-box skip, one flat (obstacle, try) loop per lane: 143 (round 2); rank tape + straight-line placement: see DESIGN.md.
 typedef unsigned long long dyn_u64;
 #define MGX_DYN_PLANE_DW (MGX_DYN_TAPE_DW / 2)
 #define MGX_DYN_POSITIONS 848 /* 624 + 224: the head of the next block depends on the old block only for k < 227 */
-static_assert(MGX_DYN_POSITIONS <= 32 * MGX_DYN_PLANE_DW && (MGX_DYN_POSITIONS - 64) / 32 + 2 < MGX_DYN_PLANE_DW,
-              "the last window advance() may take starts at 848 - 64 and reads three dwords of each plane: they must lie inside the plane");
+#define MGX_DYN_STRIP 896     /* bytes of the LDS strip the accepted draws are compacted into (ranks < 848; the last byte takes the rejected words) */
+static_assert(MGX_DYN_POSITIONS <= 32 * MGX_DYN_PLANE_DW && MGX_DYN_STRIP == 32 * MGX_DYN_PLANE_DW && MGX_DYN_POSITIONS < 1024, "plane size / 10-bit ranks");
+// the per-env position word: rank | R624 << 10 | Rtot << 20, or (bit 30) a stream position; bit 31 = the block in memory is no
+// longer the episode-start block
+#define MGX_DYN_INPLACE 0x40000000u
+#define MGX_DYN_DIRTY 0x80000000u
 
 // low two bits of genrand's tempering of y (checked against the full tempering on 1e6 random words)
 __device__ __forceinline__ uint32_t temper2(uint32_t y)
@@ -84,52 +96,45 @@ __device__ __forceinline__ uint32_t temper2(uint32_t y)
     return (y1 ^ (y1 >> 18) ^ (y1 >> 11) ^ ((y1 >> 3) & 1u)) & 3u;
 }
 
+// The word-by-word source behind the tape (stream position p >= 848 when it takes over).
 struct DynRng {
-    dyn_u64 valid, lo, hi; // window: word pos+i is an accepted draw / its bit 0 / its bit 1
-    uint32_t *A;           // the env's block in HBM
-    uint32_t pos, c;       // window start, words of it consumed
-    uint32_t p;            // absolute position once the window is used up (0xFFFFFFFF while inside it)
-    bool inplace;          // words [0, p - 624) of the next block have been generated in place (else the block is untouched)
+    uint32_t *A;  // the env's block in HBM
+    uint32_t p;   // stream position (0xFFFFFFFF: not in use, the tape still supplies the draws)
+    bool inplace; // words [0, p - 624) of the next block have been generated in place (else the block is untouched)
+    __device__ __forceinline__ void take_over()
+    {
+        p = MGX_DYN_POSITIONS; // the tape supplied positions 624 .. 847 without touching the block: catch the block up first
+#pragma nounroll
+        for (uint32_t k = 0; k < MGX_DYN_POSITIONS - 624u; k++) A[k] = lg_twist_word(A[k], A[k + 1u], A[k + 397u]); // (k < 224 < 227)
+        inplace = true;
+    }
     __device__ __forceinline__ int draw3() // _rand_int(t, t + 3) - t
     {
-        if (p == 0xFFFFFFFFu) {
-            const dyn_u64 m = c < 64u ? valid >> c : 0ull;
-            if (m) {
-                const uint32_t idx = c + (uint32_t)__builtin_ctzll(m);
-                c = idx + 1u;
-                return (int)(((lo >> idx) & 1ull) | (((hi >> idx) & 1ull) << 1));
-            }
-            p = pos + 64u; // first word behind the window (a window always has 64 positions: the tape looks 224 words ahead)
-            if (p > 624u && !inplace) { // the tape supplied positions 624 .. p-1 without touching the block: catch the block up first
-#pragma nounroll
-                for (uint32_t k = 0; k < p - 624u; k++) A[k] = lg_twist_word(A[k], A[k + 1u], A[k + 397u]); // (k < 224 < 227)
-            }
-            if (p >= 624u) inplace = true;
-        }
         for (;;) {
-            uint32_t y;
-            if (p < 624u) y = A[p];
-            else {
-                inplace = true;
-                const uint32_t k = p % 624u, k1 = k + 1u == 624u ? 0u : k + 1u, km = k + 397u >= 624u ? k + 397u - 624u : k + 397u;
-                y = lg_twist_word(A[k], A[k1], A[km]);
-                A[k] = y;
-            }
+            const uint32_t k = p % 624u, k1 = k + 1u == 624u ? 0u : k + 1u, km = k + 397u >= 624u ? k + 397u - 624u : k + 397u;
+            const uint32_t y = lg_twist_word(A[k], A[k1], A[km]);
+            A[k] = y;
             p++;
             const uint32_t v = temper2(y);
             if (v != 3u) return (int)v;
         }
     }
-    __device__ __forceinline__ uint32_t end_pos() const { return p == 0xFFFFFFFFu ? pos + c : p; }
 };
 
-
-// The tape of a complete block `blk` (624 words in LDS) into `tp` (MGX_DYN_TAPE_DW dwords in LDS), by the whole wave:
-// MGX_DYN_PLANE_DW / 2 = 14 rounds of 64 stream positions, two ballots each.  Position k >= 624 is word k - 624 of the next block;
-// the plane's last 48 positions (848 .. 895) do not exist and are marked as rejected draws (both bits set), so a window that
-// reached them would skip them instead of reading zeros as draws (advance() stops at 848 anyway).
-__device__ __forceinline__ void dyn_build_tape(const uint32_t *blk, uint32_t *tp, int lane)
+// The tape of a complete block `blk` (624 words in LDS) into `tp` (MGX_DYN_TAPE_DW dwords in LDS: dword 2j = bit 0 of draws
+// 32j .. 32j+31, dword 2j+1 = their bit 1, so that a window is ONE run of 24 bytes), by the whole wave; `strip` is MGX_DYN_STRIP
+// bytes of LDS (16-byte aligned), `slot` one dword.  Returns the block's constants and, with WANT, the rank of stream position
+// `want` <= 848 (= accepted draws in front of it) to every lane.
+//   pass 1, 14 rounds of 64 positions: a lane with an accepted word drops its two bits at byte `rank` of the strip (rank = running
+//           count + v_mbcnt of the round's ballot; the others write to the strip's last byte, which no rank reaches);
+//   pass 2, lanes 0..27: 32 strip bytes -> one dword of each plane (bit k of four bytes at once: (w & 0x01010101) * 0x10204080 >> 28).
+//           (First version: 14 more rounds of two ballots over the strip and four v_writelane each; 120 instructions more per block.)
+template <bool WANT>
+__device__ __forceinline__ uint32_t dyn_build_tape(const uint32_t *blk, uint32_t *tp, uint8_t *strip, uint32_t *slot, int lane, uint32_t want,
+                                                   uint32_t &r624, uint32_t &rtot)
 {
+    uint32_t base = 0; // (wave-uniform)
+    r624 = 0;
 #pragma unroll
     for (int r = 0; r < MGX_DYN_PLANE_DW / 2; r++) {
         const int k = 64 * r + lane;
@@ -137,50 +142,89 @@ __device__ __forceinline__ void dyn_build_tape(const uint32_t *blk, uint32_t *tp
         if (k < 624) y = blk[k];
         else if (k < MGX_DYN_POSITIONS) { const int j = k - 624; y = lg_twist_word(blk[j], blk[j + 1], blk[j + 397]); } // (j < 224 < 227: old words only)
         const uint32_t v = k < MGX_DYN_POSITIONS ? temper2(y) : 3u;
-        const dyn_u64 ml = __ballot((v & 1u) != 0u), mh = __ballot((v & 2u) != 0u);
-        if (lane == 0) { tp[2 * r] = (uint32_t)ml; tp[2 * r + 1] = (uint32_t)(ml >> 32); }
-        if (lane == 1) { tp[MGX_DYN_PLANE_DW + 2 * r] = (uint32_t)mh; tp[MGX_DYN_PLANE_DW + 2 * r + 1] = (uint32_t)(mh >> 32); }
+        const dyn_u64 mv = __ballot(v != 3u);
+        const uint32_t rank = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mv >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mv, 0u));
+        strip[v != 3u ? rank : MGX_DYN_STRIP - 1u] = (uint8_t)v;
+        if (WANT && (uint32_t)k == want) *slot = rank;
+        if (r == 9) r624 = base + (uint32_t)__builtin_popcountll(mv & 0xFFFFFFFFFFFFull); // 624 = 64 * 9 + 48
+        base += (uint32_t)__builtin_popcountll(mv);
     }
+    rtot = base;
+    wave_sync();
+    if (lane < MGX_DYN_PLANE_DW) {
+        const uint4 q0 = reinterpret_cast<const uint4 *>(strip)[2 * lane], q1 = reinterpret_cast<const uint4 *>(strip)[2 * lane + 1];
+        const uint32_t w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        uint32_t p0 = 0, p1 = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            p0 |= (((w[i] & 0x01010101u) * 0x10204080u) >> 28) << (4 * i);
+            p1 |= ((((w[i] >> 1) & 0x01010101u) * 0x10204080u) >> 28) << (4 * i);
+        }
+        const uint32_t lo = 32u * (uint32_t)lane;
+        const uint32_t keep = base >= lo + 32u ? 0xFFFFFFFFu : base > lo ? (1u << (base - lo)) - 1u : 0u; // (draws that exist)
+        reinterpret_cast<uint2 *>(tp)[lane] = make_uint2(p0 & keep, p1 & keep);
+    }
+    wave_sync();
+    return WANT ? *slot : 0u;
 }
 
-// 64 positions of a tape starting at `pos` (< 624): unaligned 12-byte reads of the two planes -> (lo, hi)
-__device__ __forceinline__ void dyn_window(const uint32_t *tp, uint32_t pos, dyn_u64 &lo, dyn_u64 &hi)
+// 64 draws of a tape starting at rank `pos`: one unaligned 24-byte read -> (lo, hi).  Dwords past the tape's end are not read (a
+// window that starts in the last 64 ranks is shifted in from the dwords that exist).
+struct __attribute__((packed, aligned(4))) DynT6 { uint32_t a0, b0, a1, b1, a2, b2; };
+template <typename P>
+__device__ __forceinline__ void dyn_window(P tp, uint32_t pos, dyn_u64 &lo, dyn_u64 &hi)
 {
     const uint32_t d = pos >> 5, sh = pos & 31u;
-    const uint32_t a0 = tp[d], a1 = tp[d + 1], a2 = tp[d + 2];
-    const uint32_t b0 = tp[MGX_DYN_PLANE_DW + d], b1 = tp[MGX_DYN_PLANE_DW + d + 1], b2 = tp[MGX_DYN_PLANE_DW + d + 2];
-    lo = (dyn_u64)__builtin_amdgcn_alignbit(a1, a0, sh) | ((dyn_u64)__builtin_amdgcn_alignbit(a2, a1, sh) << 32);
-    hi = (dyn_u64)__builtin_amdgcn_alignbit(b1, b0, sh) | ((dyn_u64)__builtin_amdgcn_alignbit(b2, b1, sh) << 32);
+    DynT6 t;
+    if (d + 2u < MGX_DYN_PLANE_DW) t = *reinterpret_cast<const DynT6 *>(tp + 2u * d);
+    else {
+        t.a0 = tp[2u * d]; t.b0 = tp[2u * d + 1u];
+        t.a1 = d + 1u < MGX_DYN_PLANE_DW ? tp[2u * d + 2u] : 0u; t.b1 = d + 1u < MGX_DYN_PLANE_DW ? tp[2u * d + 3u] : 0u;
+        t.a2 = 0u; t.b2 = 0u;
+    }
+    lo = (dyn_u64)__builtin_amdgcn_alignbit(t.a1, t.a0, sh) | ((dyn_u64)__builtin_amdgcn_alignbit(t.a2, t.a1, sh) << 32);
+    hi = (dyn_u64)__builtin_amdgcn_alignbit(t.b1, t.b0, sh) | ((dyn_u64)__builtin_amdgcn_alignbit(t.b2, t.b1, sh) << 32);
 }
 
-// Reset time: tapes (and their episode-start copies) of the envs a reset really re-seeded; one wave per 64 envs.
+// Reset time: tapes (and their episode-start copies) of the envs a reset really re-seeded, and their position as a rank; one wave
+// per 64 envs.
 __global__ __launch_bounds__(256) void k_dynobs_tape(const DynObsParams p)
 {
-    __shared__ uint32_t s_blk[4][624 + MGX_DYN_TAPE_DW];
+    __shared__ __attribute__((aligned(16))) uint32_t s_blk[4][624 + MGX_DYN_TAPE_DW + MGX_DYN_STRIP / 4 + 4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t env0 = ((int64_t)blockIdx.x * 4 + wv) * 64;
     if (env0 >= p.n) return; // wave-uniform
     const int64_t env = env0 + lane;
     const bool mine = env < p.n && (!p.mask_reset || p.mask_reset[env]) && (!p.mask || p.mask[env]);
-    uint32_t *blk = s_blk[wv], *tp = blk + 624;
+    const uint32_t raw = mine ? p.pos[env] : 0u; // mt_idx as k_seed / k_levelgen left it: a stream position <= 624
+    uint32_t *blk = s_blk[wv], *tp = blk + 624, *slot = tp + MGX_DYN_TAPE_DW + MGX_DYN_STRIP / 4;
+    uint8_t *strip = reinterpret_cast<uint8_t *>(tp + MGX_DYN_TAPE_DW);
     for (dyn_u64 m = __ballot(mine); m; m &= m - 1) { // wave-uniform
-        const int64_t e = env0 + __builtin_ctzll(m);
+        const int el = __builtin_ctzll(m);
+        const int64_t e = env0 + el;
         const uint32_t *src = p.mt + e * 624;
         uint32_t v[10];
 #pragma unroll
-        for (int i = 0; i < 10; i++) { const int k = lane + 64 * i; v[i] = k < 624 ? src[k] : 0u; }
+        for (int i = 0; i < 10; i++) { const int k = lane + 64 * i; v[i] = src[k < 624 ? k : 623]; }
 #pragma unroll
         for (int i = 0; i < 10; i++) { const int k = lane + 64 * i; if (k < 624) blk[k] = v[i]; }
         wave_sync();
-        dyn_build_tape(blk, tp, lane);
-        wave_sync();
+        uint32_t r624, rtot;
+        const uint32_t want = (uint32_t)__shfl((int)raw, el);
+        const uint32_t rank = dyn_build_tape<true>(blk, tp, strip, slot, lane, want < 624u ? want : 624u, r624, rtot);
         if (lane < MGX_DYN_TAPE_DW) { p.tape[e * MGX_DYN_TAPE_DW + lane] = tp[lane]; p.tape0[e * MGX_DYN_TAPE_DW + lane] = tp[lane]; }
+        if (lane == el) { const uint32_t w = rank | (r624 << 10) | (rtot << 20); p.pos[e] = w; p.pos0[e] = w; }
         wave_sync();
     }
 }
 
+#if defined(MGX_EXP_DYN) && (MGX_EXP_DYN & 4)
+#define MGX_DYN_OCC __attribute__((amdgpu_waves_per_eu(8, 8)))
+#else
+#define MGX_DYN_OCC
+#endif
 template <int CW, int CH>
-__global__ __launch_bounds__(256) void k_dynobs(const DynObsParams p)
+__global__ __launch_bounds__(256) MGX_DYN_OCC void k_dynobs(const DynObsParams p)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -193,6 +237,8 @@ __global__ __launch_bounds__(256) void k_dynobs(const DynObsParams p)
     uint32_t *blk = reinterpret_cast<uint32_t *>(lds); // 624 words: a block being restored / finished (before the cells arrive)
     uint32_t *ps = reinterpret_cast<uint32_t *>(lds + cells_bytes);
     uint32_t *tp = ps + 64;                            // the tape of the block in `blk` (MGX_DYN_TAPE_DW dwords)
+    uint8_t *strip = reinterpret_cast<uint8_t *>(tp + MGX_DYN_TAPE_DW);
+    uint32_t *slot = tp + MGX_DYN_TAPE_DW + MGX_DYN_STRIP / 4;
     const int64_t env0 = (int64_t)tile * 64, env = env0 + lane;
     const bool valid = env < p.n;
 
@@ -201,10 +247,11 @@ __global__ __launch_bounds__(256) void k_dynobs(const DynObsParams p)
     const bool regen = valid && p.regen[env];
     uint32_t a = valid ? p.actions[env] : 0u;
     const uint32_t rec = p.agent[env].x;
-    bool dirty = (pos >> 31) != 0u;          // the block in memory is no longer the episode-start block
-    bool inplace = ((pos >> 30) & 1u) != 0u; // words [0, pos - 624) of the next block were generated in place (window overrun)
+    bool dirty = (pos & MGX_DYN_DIRTY) != 0u;     // the block in memory is no longer the episode-start block
+    bool inplace = (pos & MGX_DYN_INPLACE) != 0u; // `pos` is a stream position and words [0, pos - 624) of the next block were generated in place
     pos &= 0x3FFFFFFFu;
-    const bool need_restore = regen && dirty, need_finish = valid && !regen && pos >= 624u;
+    const bool need_restore = regen && dirty;
+    const bool need_finish = valid && !regen && (inplace || (pos & 1023u) >= ((pos >> 10) & 1023u));
     if (regen) { // the previous step ended the episode: cells/agent are already the episode start
         ow = reinterpret_cast<const uint2 *>(p.obst0)[env];
         pos = p.pos0[env];
@@ -212,92 +259,110 @@ __global__ __launch_bounds__(256) void k_dynobs(const DynObsParams p)
         inplace = false;
         p.regen[env] = 0;
     }
-    ps[lane] = pos | (inplace ? 0x40000000u : 0u);
+    ps[lane] = pos | (inplace ? MGX_DYN_INPLACE : 0u);
     wave_sync();
 
     dyn_u64 w_lo = 0, w_hi = 0;
+#if defined(MGX_EXP_DYN) && (MGX_EXP_DYN & 1) /* timing only (wrong results): no block service */
+    const dyn_u64 m_restore = 0, m_serviced = 0;
+#else
     const dyn_u64 m_restore = __ballot(need_restore);
     const dyn_u64 m_serviced = m_restore | __ballot(need_finish);
+#endif
     for (dyn_u64 m = m_serviced; m; m &= m - 1) { // wave-uniform: one env at a time, all 64 lanes on its block
         const int e = __builtin_ctzll(m);
         uint4 *dst4 = reinterpret_cast<uint4 *>(p.mt) + (env0 + e) * 156;
         uint4 *blk4 = reinterpret_cast<uint4 *>(blk);
         uint32_t *tape_e = p.tape + (env0 + e) * MGX_DYN_TAPE_DW;
-        uint32_t pe;
+        uint32_t pw; // env e's position word afterwards (flags aside)
         if ((m_restore >> e) & 1ull) {
             const uint4 *src4 = reinterpret_cast<const uint4 *>(p.mt0) + (env0 + e) * 156;
             { // (the three loads together, on clamped indices: a load / store pair per trip compiled to three dependent round trips)
-                uint4 v[3];
-#pragma unroll
-                for (int k = 0; k < 3; k++) { const int i = lane + 64 * k; v[k] = src4[i < 156 ? i : 155]; }
-#pragma unroll
-                for (int k = 0; k < 3; k++) { const int i = lane + 64 * k; if (i < 156) dst4[i] = v[k]; }
+                uint4 v0 = src4[lane], v1 = src4[lane + 64], v2 = src4[lane + 128 < 156 ? lane + 128 : 155];
+                dst4[lane] = v0; dst4[lane + 64] = v1;
+                if (lane + 128 < 156) dst4[lane + 128] = v2;
             }
             if (lane < MGX_DYN_TAPE_DW) { const uint32_t v = p.tape0[(env0 + e) * MGX_DYN_TAPE_DW + lane]; tape_e[lane] = v; tp[lane] = v; }
-            pe = ps[e] & 0x3FFFFFFFu;
+            pw = ps[e] & 0x3FFFFFFFu;
         } else {
             {
-                uint4 v[3];
-#pragma unroll
-                for (int k = 0; k < 3; k++) { const int i = lane + 64 * k; v[k] = dst4[i < 156 ? i : 155]; }
-#pragma unroll
-                for (int k = 0; k < 3; k++) { const int i = lane + 64 * k; if (i < 156) blk4[i] = v[k]; }
+                uint4 v0 = dst4[lane], v1 = dst4[lane + 64], v2 = dst4[lane + 128 < 156 ? lane + 128 : 155];
+                blk4[lane] = v0; blk4[lane + 64] = v1;
+                if (lane + 128 < 156) blk4[lane + 128] = v2;
             }
             wave_sync();
             const uint32_t pv = ps[e];
-            const uint32_t k0 = (pv & 0x40000000u) ? (pv & 0x3FFFFFFFu) % 624u : 0u; // words [0, k0) already belong to the new block
-            pe = (pv & 0x3FFFFFFFu) % 624u;
-            uint32_t c0 = k0;
-            while (c0 < 623u) { // chunks of <= 227 words: within one, nobody needs a word the chunk itself produces
-                const uint32_t c1 = c0 + 227u < 623u ? c0 + 227u : 623u;
-                uint32_t y[4];
+            const bool raw = (pv & MGX_DYN_INPLACE) != 0u;
+            const uint32_t k0 = raw ? (pv & 0x3FFFFFFFu) % 624u : 0u; // words [0, k0) already belong to the new block
+            uint32_t r624, rtot, rank = 0;
+            if (!raw) { // the whole block: three chunks of 192 words (three full rounds each; within a chunk nobody needs a word the
+                        // chunk itself produces: 192 < 227), then words 576 .. 622, then 623
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const uint32_t jj = c0 + (uint32_t)lane + 64u * r;
-                    y[r] = 0;
-                    if (jj < c1) y[r] = lg_twist_word(blk[jj], blk[jj + 1u], jj < 227u ? blk[jj + 397u] : blk[jj - 227u]);
-                }
-                wave_sync();
+                for (int c = 0; c < 3; c++) {
+                    uint32_t y[3];
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const uint32_t jj = c0 + (uint32_t)lane + 64u * r;
-                    if (jj < c1) blk[jj] = y[r];
+                    for (int r = 0; r < 3; r++) {
+                        const uint32_t jj = 192u * c + 64u * r + (uint32_t)lane;
+                        y[r] = lg_twist_word(blk[jj], blk[jj + 1u], jj < 227u ? blk[jj + 397u] : blk[jj - 227u]);
+                    }
+                    wave_sync();
+#pragma unroll
+                    for (int r = 0; r < 3; r++) blk[192u * c + 64u * r + (uint32_t)lane] = y[r];
+                    wave_sync();
                 }
+                const uint32_t jj = 576u + (uint32_t)lane;
+                uint32_t y = 0;
+                if (jj < 623u) y = lg_twist_word(blk[jj], blk[jj + 1u], blk[jj - 227u]);
                 wave_sync();
-                c0 = c1;
+                if (jj < 623u) blk[jj] = y;
+                wave_sync();
+            } else {
+                uint32_t c0 = k0;
+                while (c0 < 623u) { // chunks of <= 227 words: within one, nobody needs a word the chunk itself produces
+                    const uint32_t c1 = c0 + 227u < 623u ? c0 + 227u : 623u;
+                    uint32_t y[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const uint32_t jj = c0 + (uint32_t)lane + 64u * r;
+                        y[r] = 0;
+                        if (jj < c1) y[r] = lg_twist_word(blk[jj], blk[jj + 1u], jj < 227u ? blk[jj + 397u] : blk[jj - 227u]);
+                    }
+                    wave_sync();
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const uint32_t jj = c0 + (uint32_t)lane + 64u * r;
+                        if (jj < c1) blk[jj] = y[r];
+                    }
+                    wave_sync();
+                    c0 = c1;
+                }
             }
             if (lane == 0) blk[623] = lg_twist_word(blk[623], blk[0], blk[396]);
             wave_sync();
             for (int i = lane; i < 156; i += 64) dst4[i] = blk4[i];
-            dyn_build_tape(blk, tp, lane); // (reads blk only: the block is complete)
-            wave_sync();
+            // (the tape reads blk only: the block is complete)
+            if (raw) rank = dyn_build_tape<true>(blk, tp, strip, slot, lane, k0, r624, rtot);
+            else (void)dyn_build_tape<false>(blk, tp, strip, slot, lane, 0u, r624, rtot);
             if (lane < MGX_DYN_TAPE_DW) tape_e[lane] = tp[lane];
+            pw = (raw ? rank : (pv & 1023u) - ((pv >> 10) & 1023u)) | (r624 << 10) | (rtot << 20);
         }
         wave_sync();
-        if (lane == e) dyn_window(tp, pe, w_lo, w_hi); // (from LDS: the global tape was only just written)
+        if (lane == e) { pos = pw; dyn_window(tp, pw & 1023u, w_lo, w_hi); } // (from LDS: the global tape was only just written)
         wave_sync();
     }
-    if (need_finish) { pos %= 624u; dirty = true; inplace = false; }
-    if (valid && !((m_serviced >> lane) & 1ull)) { // this lane's window straight from its tape: two unaligned 12-byte reads
-        struct __attribute__((packed, aligned(4))) T3 { uint32_t a, b, c; };
-        const uint32_t *tpe = p.tape + env * MGX_DYN_TAPE_DW;
-        const uint32_t d = pos >> 5, sh = pos & 31u;
-        const T3 x = *reinterpret_cast<const T3 *>(tpe + d), y = *reinterpret_cast<const T3 *>(tpe + MGX_DYN_PLANE_DW + d);
-        w_lo = (dyn_u64)__builtin_amdgcn_alignbit(x.b, x.a, sh) | ((dyn_u64)__builtin_amdgcn_alignbit(x.c, x.b, sh) << 32);
-        w_hi = (dyn_u64)__builtin_amdgcn_alignbit(y.b, y.a, sh) | ((dyn_u64)__builtin_amdgcn_alignbit(y.c, y.b, sh) << 32);
+    if (need_finish) { dirty = true; inplace = false; }
+    if (valid && !((m_serviced >> lane) & 1ull)) { // this lane's window straight from its tape
+        dyn_window(p.tape + env * MGX_DYN_TAPE_DW, pos & 1023u, w_lo, w_hi); // (not serviced: rank < R624 <= 624, the plain 24-byte read)
     }
-    const dyn_u64 w_valid = ~(w_lo & w_hi); // masked rejection: the word is redrawn when its two bits are 3
-    if (m_serviced) { // blocks rewritten by the whole wave may be read word-wise by single lanes below (a window overrun): same
+    if (m_serviced) { // blocks rewritten by the whole wave may be read word-wise by single lanes below (off the tape): same
                       // CU, same L1, so the stores only have to be complete (an agent-scope fence would write back the XCD's L2)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
     stage_tile<CS>(p.cells, env0, S, LS, lds, lane);
     wave_sync();
-    if (!valid) return;
-
+    if (valid) {
     uint8_t *g = lds + lane * LS;
-    uint8_t *gg = p.cells + env * S;
     if (a >= 3u) a = 0u; // `if action >= self.action_space.n: action = 0`
     const int W = CW ? CW : p.W;
     const int ax = (int)(rec & 255u), ay = (int)((rec >> 8) & 255u), dir = (int)((rec >> 16) & 3u);
@@ -307,70 +372,111 @@ __global__ __launch_bounds__(256) void k_dynobs(const DynObsParams p)
         const uint32_t k = g[fx * H + fy] & 15u;
         not_clear = k != MGX_K_EMPTY && k != MGX_K_GOAL;
     }
-    DynRng r = {w_valid, w_lo, w_hi, p.mt + env * 624, pos, 0u, 0xFFFFFFFFu, inplace};
-    // The window as two 32-bit halves (fv/fl/fh: valid positions left / bit 0 / bit 1 of the current half): a draw is
-    // ffbl + clear-lowest-bit + two bit extracts, all 32-bit and branch-free but for the switch to the upper half.  The generic
-    // source `r` takes over behind the window (a step that needs more than its ~48 valid draws: rare).
-    uint32_t fv = (uint32_t)w_valid, fl = (uint32_t)w_lo, fh = (uint32_t)w_hi, fbase = 0u, flast = 0u;
-    uint32_t fv1 = (uint32_t)(w_valid >> 32), fl1 = (uint32_t)(w_lo >> 32), fh1 = (uint32_t)(w_hi >> 32);
-    uint32_t wstart = pos; // stream position of the window's first entry
+    // The window: wl / wh hold the next `navail` draws of the tape from bit 0 up; `rpos` is the rank of the next draw.
+    const uint32_t r624 = (pos >> 10) & 1023u, rtot = (pos >> 20) & 1023u;
+    uint32_t rpos = pos & 1023u;
+#if defined(MGX_EXP_DYN) && (MGX_EXP_DYN & 1)
+    if (r624 && rpos >= r624) rpos %= r624; // (timing only: with no service the position wraps instead)
+#endif
+    dyn_u64 wl = w_lo, wh = w_hi;
+    uint32_t navail = rtot - rpos < 64u ? rtot - rpos : 64u;
     const uint32_t *tape_l = p.tape + env * MGX_DYN_TAPE_DW;
-    // next half / next window; false once the tape of this block is used up (positions >= 624 + 64: the generic source goes on)
-    auto advance = [&]() -> bool {
-        if (fv1 != 0u) { fv = fv1; fl = fl1; fh = fh1; fv1 = 0u; fbase = 32u; return true; }
-        if (r.p != 0xFFFFFFFFu || wstart + 128u > MGX_DYN_POSITIONS) return false;
-        wstart += 64u; // a long placement (an obstacle with few free neighbours): the next 64 positions of the tape
-        struct __attribute__((packed, aligned(4))) T3 { uint32_t a, b, c; };
-        const uint32_t d = wstart >> 5, sh = wstart & 31u;
-        const T3 x = *reinterpret_cast<const T3 *>(tape_l + d), y = *reinterpret_cast<const T3 *>(tape_l + MGX_DYN_PLANE_DW + d);
-        fl = __builtin_amdgcn_alignbit(x.b, x.a, sh); fl1 = __builtin_amdgcn_alignbit(x.c, x.b, sh);
-        fh = __builtin_amdgcn_alignbit(y.b, y.a, sh); fh1 = __builtin_amdgcn_alignbit(y.c, y.b, sh);
-        fv = ~(fl & fh); fv1 = ~(fl1 & fh1);
-        fbase = 0u; flast = 0u;
-        r.pos = wstart; // (the generic source, should it take over, continues behind THIS window)
-        if (fv == 0u) { fv = fv1; fl = fl1; fh = fh1; fv1 = 0u; fbase = 32u; }
-        return fv != 0u;
-    };
-    auto draw3 = [&]() -> int {
-        if (fv == 0u && !advance()) { r.c = 64u; return r.draw3(); }
-        const uint32_t idx = (uint32_t)__builtin_ctz(fv);
-        fv &= fv - 1u;
-        flast = fbase + idx + 1u;
-        return (int)(((fl >> idx) & 1u) | (((fh >> idx) & 1u) << 1));
-    };
-    // n accepted draws whose values nobody looks at (a placement that cannot succeed still draws 2 x 101 times)
-    auto skip_draws = [&](int n) {
-        while (n > 0) {
-            if (fv == 0u && !advance()) { r.c = 64u; for (; n > 0; n--) (void)r.draw3(); return; }
-            const int have = __builtin_popcount(fv);
-            if (have <= n) { flast = fbase + 32u - (uint32_t)__builtin_clz(fv); fv = 0u; n -= have; } // the whole half
-            else { for (; n > 0; n--) { flast = fbase + (uint32_t)__builtin_ctz(fv) + 1u; fv &= fv - 1u; } }
+    DynRng r = {p.mt + env * 624, 0xFFFFFFFFu, false};
+#if defined(MGX_EXP_DYN) && (MGX_EXP_DYN & 2) /* timing only (wrong results): no placement */
+    const int n_obst = 0;
+#else
+    const int n_obst = p.n_obst;
+#endif
+    // ---- straight-line placements (all lanes together, obstacle by obstacle)
+    const uint8_t under_agent = g[ax * H + ay];
+    g[ax * H + ay] = 0xFFu; // the agent's cell is not free: marked in the LDS image for the length of the walk
+#if defined(MGX_EXP_DYN) && (MGX_EXP_DYN & 8) /* check aid: every placement through the loop */
+    int slow_from = 0;
+#else
+    int slow_from = n_obst; // first obstacle this lane takes through the loop below
+#endif
+    for (int i = 0; i < n_obst; i++) { // (wave-uniform trip count)
+        if (i == 4 && slow_from == n_obst && navail < 64u && rpos < rtot) { // a second window for obstacles 4..7 (16x16: eight of them)
+            dyn_window(tape_l, rpos, wl, wh);
+            navail = rtot - rpos < 64u ? rtot - rpos : 64u;
         }
-    };
-    // One loop over (obstacle, try) per lane, not a try loop per obstacle: with nested loops every lane waits, obstacle by
-    // obstacle, for the wave's unluckiest placement (an obstacle with one free neighbour needs ~9 samples, some lane's 30+),
-    // i.e. the sum over obstacles of the per-obstacle maxima; flattened, the wave runs for the lane with the most samples
-    // in total.  (SQ counters before: 21 of 64 lanes active on average.)
-    for (int i = 0, tries = 0; i < p.n_obst;) {
+        if (slow_from != n_obst) continue;
         const uint32_t o = (i < 4 ? ow.x >> (8 * i) : ow.y >> (8 * (i - 4))) & 255u; // x << 4 | y
         const int tx = (int)(o >> 4) - 1, ty = (int)(o & 15u) - 1; // top = old_pos + (-1, -1): interior, never clipped
+        const uint8_t *b = g + tx * H + ty;
+        const uint32_t c00 = b[0], c01 = b[1], c02 = b[2], c10 = b[H], c11 = b[H + 1], c12 = b[H + 2], c20 = b[2 * H], c21 = b[2 * H + 1], c22 = b[2 * H + 2];
+        const uint32_t E = 0x55555555u, l = (uint32_t)wl, h = (uint32_t)wh;
+        const uint32_t x1 = l & E, x2 = h & E, y1 = (l >> 1) & E, y2 = (h >> 1) & E;
+        const uint32_t x0 = E & ~(x1 | x2), y0 = E & ~(y1 | y2);
+        const uint32_t F = MGX_CODE_EMPTY;
+        const uint32_t s0 = (c00 == F ? y0 : 0u) | (c01 == F ? y1 : 0u) | (c02 == F ? y2 : 0u);
+        const uint32_t s1 = (c10 == F ? y0 : 0u) | (c11 == F ? y1 : 0u) | (c12 == F ? y2 : 0u);
+        const uint32_t s2 = (c20 == F ? y0 : 0u) | (c21 == F ? y1 : 0u) | (c22 == F ? y2 : 0u);
+        uint32_t hit = (x0 & s0) | (x1 & s1) | (x2 & s2);
+        const uint32_t np = navail >> 1; // whole samples at hand
+        if (np < 16u) hit &= (1u << (2u * np)) - 1u;
+        if (hit == 0u) { slow_from = i; continue; }
+        const uint32_t bp = (uint32_t)__builtin_ctz(hit); // even: the sample's dx draw
+        const int x = tx + (int)(((l >> bp) & 1u) | (((h >> bp) & 1u) << 1)), y = ty + (int)(((l >> (bp + 1u)) & 1u) | (((h >> (bp + 1u)) & 1u) << 1));
+        const uint32_t used = bp + 2u; // (<= 32)
+        wl >>= used; wh >>= used; navail -= used; rpos += used;
+        const int n8 = x * H + y, o8 = (tx + 1) * H + ty + 1;
+        g[n8] = (uint8_t)MGX_CODE_BALL_BLUE;
+        g[o8] = (uint8_t)MGX_CODE_EMPTY;
+        const uint32_t nb = ((uint32_t)x << 4) | (uint32_t)y;
+        if (i < 4) ow.x = (ow.x & ~(255u << (8 * i))) | (nb << (8 * i));
+        else ow.y = (ow.y & ~(255u << (8 * (i - 4)))) | (nb << (8 * (i - 4)));
+    }
+    // ---- the reference's loop, for the lanes the above left with work: draws one at a time
+    // next window of the tape; false once the tape is used up (the word-by-word source goes on behind stream position 848)
+    auto refill = [&]() -> bool {
+        if (r.p != 0xFFFFFFFFu) return false;
+        if (rpos >= rtot) { r.take_over(); return false; }
+        dyn_window(tape_l, rpos, wl, wh);
+        navail = rtot - rpos < 64u ? rtot - rpos : 64u;
+        return true;
+    };
+    auto draw3 = [&]() -> int {
+        if (navail == 0u && !refill()) return r.draw3();
+        const int v = (int)(((uint32_t)wl & 1u) | (((uint32_t)wh & 1u) << 1));
+        wl >>= 1; wh >>= 1; navail--; rpos++;
+        return v;
+    };
+    // n accepted draws whose values nobody looks at (a placement that cannot succeed still draws 2 x 101 times)
+    auto skip_draws = [&](uint32_t n) {
+        if (r.p == 0xFFFFFFFFu) {
+            const uint32_t take = rtot - rpos < n ? rtot - rpos : n;
+            rpos += take; n -= take; navail = 0u; // (the next draw loads the window at the new rank)
+            if (n == 0u) return;
+            r.take_over();
+        }
+        for (; n > 0u; n--) (void)r.draw3();
+    };
+    // One loop over (obstacle, try) per lane, not a try loop per obstacle: flattened, the wave runs for the lane with the most
+    // samples in total instead of the sum over obstacles of the per-obstacle maxima.
+#if defined(MGX_EXP_DYN) && (MGX_EXP_DYN & 16) /* timing only (wrong results): nobody takes the loop */
+    slow_from = n_obst;
+#endif
+    for (int i = slow_from, tries = 0; i < n_obst;) {
+        const uint32_t o = (i < 4 ? ow.x >> (8 * i) : ow.y >> (8 * (i - 4))) & 255u; // x << 4 | y
+        const int tx = (int)(o >> 4) - 1, ty = (int)(o & 15u) - 1;
         bool give_up = false;
-        if (tries == 8) { // eight misses: look at the 3x3 box once -- with no free cell in it the remaining 93 samples are
-                          // known to fail too, and all that is left of them is their 186 draws
+        if (tries == 0 || tries == 8) { // before the first sample and after eight misses: look at the 3x3 box -- with no free cell in it
+                                        // the remaining samples are known to fail too, and all that is left of them is their draws
             bool any = false;
 #pragma unroll
             for (int dxy = 0; dxy < 9; dxy++) {
                 const int x = tx + dxy / 3, y = ty + dxy % 3;
-                any = any || (g[x * H + y] == MGX_CODE_EMPTY && !(x == ax && y == ay));
+                any = any || g[x * H + y] == MGX_CODE_EMPTY;
             }
-            if (!any) { skip_draws(2 * (101 - tries)); give_up = true; }
+            if (!any) { skip_draws(2u * (uint32_t)(101 - tries)); give_up = true; }
         }
         if (!give_up) {
             const int x = tx + draw3(), y = ty + draw3();
-            if (g[x * H + y] == MGX_CODE_EMPTY && !(x == ax && y == ay)) {
+            if (g[x * H + y] == MGX_CODE_EMPTY) { // (the agent's cell carries the mark)
                 const int n8 = x * H + y, o8 = (tx + 1) * H + ty + 1;
-                g[n8] = (uint8_t)MGX_CODE_BALL_BLUE; gg[n8] = (uint8_t)MGX_CODE_BALL_BLUE;
-                g[o8] = (uint8_t)MGX_CODE_EMPTY; gg[o8] = (uint8_t)MGX_CODE_EMPTY;
+                g[n8] = (uint8_t)MGX_CODE_BALL_BLUE;
+                g[o8] = (uint8_t)MGX_CODE_EMPTY;
                 const uint32_t nb = ((uint32_t)x << 4) | (uint32_t)y;
                 if (i < 4) ow.x = (ow.x & ~(255u << (8 * i))) | (nb << (8 * i));
                 else ow.y = (ow.y & ~(255u << (8 * (i - 4)))) | (nb << (8 * (i - 4)));
@@ -382,11 +488,17 @@ __global__ __launch_bounds__(256) void k_dynobs(const DynObsParams p)
         }
         if (give_up) { i++; tries = 0; }
     }
-    if (r.p == 0xFFFFFFFFu) r.c = flast; // (else the generic source holds the position; r.pos = start of the last window)
     reinterpret_cast<uint2 *>(p.obst)[env] = ow;
-    const uint32_t pe = r.end_pos(); // (>= 624: the next step's service loop twists the block first)
-    p.pos[env] = pe | ((dirty || r.inplace) ? 0x80000000u : 0u) | (r.inplace ? 0x40000000u : 0u);
+    // (rank >= R624: the next step's service loop twists the block first)
+    p.pos[env] = r.p == 0xFFFFFFFFu ? (rpos | (r624 << 10) | (rtot << 20) | (dirty ? MGX_DYN_DIRTY : 0u)) : (r.p | MGX_DYN_INPLACE | MGX_DYN_DIRTY);
     p.act_out[env] = (uint8_t)(a | ((a == 2u && not_clear) ? 0x80u : 0u));
+    g[ax * H + ay] = under_agent;
+    }
+    // The moved obstacles go back as the whole tile, coalesced (64 x S bytes per wave).  Written through cell by cell -- two byte stores
+    // per moved obstacle and lane, each to a line of its own -- they were what the walk cost: 95 of k_dynobs' 113 us at 1 Mi 8x8 envs
+    // went to 8 Mi scattered byte stores (measured by leaving the walk out), not to the draws.
+    wave_sync();
+    unstage_tile<CS>(p.cells, env0, S, LS, lds, lane);
 }
 } // namespace
 
@@ -399,7 +511,7 @@ hipError_t mgx_launch_dynobs_init(const DynObsParams &p, hipStream_t st)
     return hipGetLastError();
 }
 
-int mgx_dynobs_wave_lds(int LS) { return (64 * LS > 2496 ? ((64 * LS + 15) & ~15) : 2496) + 64 * 4 + ((MGX_DYN_TAPE_DW * 4 + 15) & ~15); }
+int mgx_dynobs_wave_lds(int LS) { return (64 * LS > 2496 ? ((64 * LS + 15) & ~15) : 2496) + 64 * 4 + MGX_DYN_TAPE_DW * 4 + MGX_DYN_STRIP + 16; }
 
 hipError_t mgx_launch_dynobs(const DynObsParams &p, hipStream_t st)
 {

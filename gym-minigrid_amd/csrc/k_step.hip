@@ -1130,33 +1130,6 @@ struct RolloutParams {
     int grid_lds;           // bytes of the grid image per wave (the observation image follows)
 };
 
-template <int CS>
-__device__ __forceinline__ void unstage_tile(uint8_t *__restrict__ cells, int64_t env0, int S_rt, int LS, const uint8_t *lds, int lane)
-{ // inverse of stage_tile: the LDS image (LS bytes per env) back to the tile's 64*S contiguous bytes
-    const int S = CS ? CS : S_rt;
-    const int SD = S >> 2;
-    const int LSD = LS >> 2;
-    uint4 *dst = reinterpret_cast<uint4 *>(cells + env0 * S);
-    const uint32_t *l32 = reinterpret_cast<const uint32_t *>(lds);
-    const int n_chunks = 4 * S;
-    if constexpr (CS != 0 && ((CS >> 2) & 1) != 0) {
-        const uint4 *l128 = reinterpret_cast<const uint4 *>(lds);
-#pragma unroll 4
-        for (int c = lane; c < n_chunks; c += 64) dst[c] = l128[c];
-        return;
-    }
-#pragma unroll 4
-    for (int c = lane; c < n_chunks; c += 64) {
-        uint32_t w[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int dd = 4 * c + j, e = dd / SD;
-            w[j] = l32[e * LSD + (dd - e * SD)];
-        }
-        dst[c] = make_uint4(w[0], w[1], w[2], w[3]);
-    }
-}
-
 // CW = CH = 0: run-time grid size (any size whose tile image + observation image fit the LDS); V: agent_view_size (7 for the sized
 // instances, 3 / 5 / 9 / 11 on the run-time-size one: round 3 -- those handles took the captured graph before).
 template <int CW, int CH, int V>

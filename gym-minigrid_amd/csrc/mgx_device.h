@@ -98,6 +98,34 @@ __device__ __forceinline__ void stage_tile(const uint8_t *__restrict__ cells, in
     }
 }
 
+// LDS -> global: the inverse (k_rollout once per T steps; k_dynobs every step: the moved obstacles go back as whole tiles)
+template <int CS>
+__device__ __forceinline__ void unstage_tile(uint8_t *__restrict__ cells, int64_t env0, int S_rt, int LS, const uint8_t *lds, int lane)
+{ // inverse of stage_tile: the LDS image (LS bytes per env) back to the tile's 64*S contiguous bytes
+    const int S = CS ? CS : S_rt;
+    const int SD = S >> 2;
+    const int LSD = LS >> 2;
+    uint4 *dst = reinterpret_cast<uint4 *>(cells + env0 * S);
+    const uint32_t *l32 = reinterpret_cast<const uint32_t *>(lds);
+    const int n_chunks = 4 * S;
+    if constexpr (CS != 0 && ((CS >> 2) & 1) != 0) {
+        const uint4 *l128 = reinterpret_cast<const uint4 *>(lds);
+#pragma unroll 4
+        for (int c = lane; c < n_chunks; c += 64) dst[c] = l128[c];
+        return;
+    }
+#pragma unroll 4
+    for (int c = lane; c < n_chunks; c += 64) {
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int dd = 4 * c + j, e = dd / SD;
+            w[j] = l32[e * LSD + (dd - e * SD)];
+        }
+        dst[c] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 struct Lane {
     int ax, ay, dir;
