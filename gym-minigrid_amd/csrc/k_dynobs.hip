@@ -1,6 +1,7 @@
 // k_dynobs.hip -- Dynamic-Obstacles: the obstacle walk that precedes the base step (k_dynobs, k_dynobs_init).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "mgx_internal.h"
 #include "mgx_kernels.h"
@@ -80,6 +81,9 @@ __global__ __launch_bounds__(256) void k_dynobs_init(const DynObsParams p)
 //     register windows 254 (round 1); a tape of all 848 positions + validity mask 186; + look-ahead 224, further windows, the
 //     hopeless-box skip, one flat (obstacle, try) loop per lane: 143 (round 2); rank tape + straight-line placement: see DESIGN.md.
 typedef unsigned long long dyn_u64;
+#if defined(MGX_EXP_DYN) && (MGX_EXP_DYN & 32)
+__device__ unsigned long long g_dyn_count[4];
+#endif
 #define MGX_DYN_PLANE_DW (MGX_DYN_TAPE_DW / 2)
 #define MGX_DYN_POSITIONS 848 /* 624 + 224: the head of the next block depends on the old block only for k < 227 */
 #define MGX_DYN_STRIP 896     /* bytes of the LDS strip the accepted draws are compacted into (ranks < 848; the last byte takes the rejected words) */
@@ -395,39 +399,67 @@ __global__ __launch_bounds__(256) MGX_DYN_OCC void k_dynobs(const DynObsParams p
 #else
     int slow_from = n_obst; // first obstacle this lane takes through the loop below
 #endif
+    int slow_tries = 0;     // ... and the samples that obstacle has already missed
     for (int i = 0; i < n_obst; i++) { // (wave-uniform trip count)
-        if (i == 4 && slow_from == n_obst && navail < 64u && rpos < rtot) { // a second window for obstacles 4..7 (16x16: eight of them)
-            dyn_window(tape_l, rpos, wl, wh);
-            navail = rtot - rpos < 64u ? rtot - rpos : 64u;
-        }
-        if (slow_from != n_obst) continue;
+        const bool mine = slow_from == n_obst;
         const uint32_t o = (i < 4 ? ow.x >> (8 * i) : ow.y >> (8 * (i - 4))) & 255u; // x << 4 | y
         const int tx = (int)(o >> 4) - 1, ty = (int)(o & 15u) - 1; // top = old_pos + (-1, -1): interior, never clipped
         const uint8_t *b = g + tx * H + ty;
-        const uint32_t c00 = b[0], c01 = b[1], c02 = b[2], c10 = b[H], c11 = b[H + 1], c12 = b[H + 2], c20 = b[2 * H], c21 = b[2 * H + 1], c22 = b[2 * H + 2];
-        const uint32_t E = 0x55555555u, l = (uint32_t)wl, h = (uint32_t)wh;
-        const uint32_t x1 = l & E, x2 = h & E, y1 = (l >> 1) & E, y2 = (h >> 1) & E;
-        const uint32_t x0 = E & ~(x1 | x2), y0 = E & ~(y1 | y2);
+        uint32_t c00 = 0, c01 = 0, c02 = 0, c10 = 0, c11 = 0, c12 = 0, c20 = 0, c21 = 0, c22 = 0;
+        if (mine) { c00 = b[0]; c01 = b[1]; c02 = b[2]; c10 = b[H]; c11 = b[H + 1]; c12 = b[H + 2]; c20 = b[2 * H]; c21 = b[2 * H + 1]; c22 = b[2 * H + 2]; }
         const uint32_t F = MGX_CODE_EMPTY;
-        const uint32_t s0 = (c00 == F ? y0 : 0u) | (c01 == F ? y1 : 0u) | (c02 == F ? y2 : 0u);
-        const uint32_t s1 = (c10 == F ? y0 : 0u) | (c11 == F ? y1 : 0u) | (c12 == F ? y2 : 0u);
-        const uint32_t s2 = (c20 == F ? y0 : 0u) | (c21 == F ? y1 : 0u) | (c22 == F ? y2 : 0u);
-        uint32_t hit = (x0 & s0) | (x1 & s1) | (x2 & s2);
-        const uint32_t np = navail >> 1; // whole samples at hand
-        if (np < 16u) hit &= (1u << (2u * np)) - 1u;
-        if (hit == 0u) { slow_from = i; continue; }
-        const uint32_t bp = (uint32_t)__builtin_ctz(hit); // even: the sample's dx draw
-        const int x = tx + (int)(((l >> bp) & 1u) | (((h >> bp) & 1u) << 1)), y = ty + (int)(((l >> (bp + 1u)) & 1u) | (((h >> (bp + 1u)) & 1u) << 1));
-        const uint32_t used = bp + 2u; // (<= 32)
-        wl >>= used; wh >>= used; navail -= used; rpos += used;
-        const int n8 = x * H + y, o8 = (tx + 1) * H + ty + 1;
-        g[n8] = (uint8_t)MGX_CODE_BALL_BLUE;
-        g[o8] = (uint8_t)MGX_CODE_EMPTY;
-        const uint32_t nb = ((uint32_t)x << 4) | (uint32_t)y;
-        if (i < 4) ow.x = (ow.x & ~(255u << (8 * i))) | (nb << (8 * i));
-        else ow.y = (ow.y & ~(255u << (8 * (i - 4)))) | (nb << (8 * (i - 4)));
+        const bool f00 = c00 == F, f01 = c01 == F, f02 = c02 == F, f10 = c10 == F, f11 = c11 == F, f12 = c12 == F, f20 = c20 == F, f21 = c21 == F, f22 = c22 == F;
+        bool pending = mine;
+        int tries = 0;
+        if (pending && !(f00 || f01 || f02 || f10 || f11 || f12 || f20 || f21 || f22)) {
+            // no free cell in the box: all 101 samples fail, and all that is left of them is their 202 draws
+            if (rtot - rpos >= 202u) { rpos += 202u; navail = 0u; } // (the next sample loads the window at the new rank)
+            else { slow_from = i; slow_tries = 0; }                // (the tape ends first)
+            pending = false;
+        }
+        // rounds of up to 16 samples (one is the rule; a box with one or two free cells may take more)
+        while (__ballot(pending)) { // wave-uniform
+            if (pending) {
+                if (navail < 2u) { // the window is used up: the next 64 draws of the tape -- or, at the tape's end, the loop below
+                    if (rtot - rpos < 2u) { slow_from = i; slow_tries = tries; pending = false; }
+                    else { dyn_window(tape_l, rpos, wl, wh); navail = rtot - rpos < 64u ? rtot - rpos : 64u; }
+                }
+            }
+            if (pending) {
+                const uint32_t E = 0x55555555u, l = (uint32_t)wl, h = (uint32_t)wh;
+                const uint32_t x1 = l & E, x2 = h & E, y1 = (l >> 1) & E, y2 = (h >> 1) & E;
+                const uint32_t x0 = E & ~(x1 | x2), y0 = E & ~(y1 | y2);
+                const uint32_t s0 = (f00 ? y0 : 0u) | (f01 ? y1 : 0u) | (f02 ? y2 : 0u);
+                const uint32_t s1 = (f10 ? y0 : 0u) | (f11 ? y1 : 0u) | (f12 ? y2 : 0u);
+                const uint32_t s2 = (f20 ? y0 : 0u) | (f21 ? y1 : 0u) | (f22 ? y2 : 0u);
+                uint32_t hit = (x0 & s0) | (x1 & s1) | (x2 & s2);
+                uint32_t ns = navail >> 1; // whole samples at hand, 16 looked at, 101 at most for one obstacle
+                ns = ns < 16u ? ns : 16u;
+                ns = ns < (uint32_t)(101 - tries) ? ns : (uint32_t)(101 - tries);
+                if (ns < 16u) hit &= (1u << (2u * ns)) - 1u;
+                if (hit != 0u) {
+                    const uint32_t bp = (uint32_t)__builtin_ctz(hit); // even: the sample's dx draw
+                    const int x = tx + (int)(((l >> bp) & 1u) | (((h >> bp) & 1u) << 1)), y = ty + (int)(((l >> (bp + 1u)) & 1u) | (((h >> (bp + 1u)) & 1u) << 1));
+                    const uint32_t used = bp + 2u; // (<= 32)
+                    wl >>= used; wh >>= used; navail -= used; rpos += used;
+                    const int n8 = x * H + y, o8 = (tx + 1) * H + ty + 1;
+                    g[n8] = (uint8_t)MGX_CODE_BALL_BLUE;
+                    g[o8] = (uint8_t)MGX_CODE_EMPTY;
+                    const uint32_t nb = ((uint32_t)x << 4) | (uint32_t)y;
+                    if (i < 4) ow.x = (ow.x & ~(255u << (8 * i))) | (nb << (8 * i));
+                    else ow.y = (ow.y & ~(255u << (8 * (i - 4)))) | (nb << (8 * (i - 4)));
+                    pending = false;
+                } else { // ns samples missed
+                    const uint32_t used = 2u * ns;
+                    wl >>= used; wh >>= used; navail -= used; rpos += used;
+                    tries += (int)ns;
+                    if (tries >= 101) pending = false; // num_tries > max_tries raises (101 samples at most); the RecursionError is
+                                                       // swallowed by the bare except: the obstacle stays
+                }
+            }
+        }
     }
-    // ---- the reference's loop, for the lanes the above left with work: draws one at a time
+    // ---- the reference's loop, draw by draw, for a lane whose walk reaches the end of the tape within this step
     // next window of the tape; false once the tape is used up (the word-by-word source goes on behind stream position 848)
     auto refill = [&]() -> bool {
         if (r.p != 0xFFFFFFFFu) return false;
@@ -454,15 +486,22 @@ __global__ __launch_bounds__(256) MGX_DYN_OCC void k_dynobs(const DynObsParams p
     };
     // One loop over (obstacle, try) per lane, not a try loop per obstacle: flattened, the wave runs for the lane with the most
     // samples in total instead of the sum over obstacles of the per-obstacle maxima.
+#if defined(MGX_EXP_DYN) && (MGX_EXP_DYN & 32) /* count: lanes / waves that take the loop, lane-steps */
+    if (slow_from != n_obst) atomicAdd(&g_dyn_count[0], 1ull);
+    if (__ballot(slow_from != n_obst) && lane == __builtin_ctzll(__ballot(1))) atomicAdd(&g_dyn_count[1], 1ull);
+    atomicAdd(&g_dyn_count[2], 1ull);
+#endif
 #if defined(MGX_EXP_DYN) && (MGX_EXP_DYN & 16) /* timing only (wrong results): nobody takes the loop */
     slow_from = n_obst;
 #endif
-    for (int i = slow_from, tries = 0; i < n_obst;) {
+    bool look = true;
+    for (int i = slow_from, tries = slow_tries; i < n_obst;) {
         const uint32_t o = (i < 4 ? ow.x >> (8 * i) : ow.y >> (8 * (i - 4))) & 255u; // x << 4 | y
         const int tx = (int)(o >> 4) - 1, ty = (int)(o & 15u) - 1;
         bool give_up = false;
-        if (tries == 0 || tries == 8) { // before the first sample and after eight misses: look at the 3x3 box -- with no free cell in it
-                                        // the remaining samples are known to fail too, and all that is left of them is their draws
+        if (look) { // before an obstacle's first sample here: look at the 3x3 box -- with no free cell in it the remaining samples are
+                    // known to fail, and all that is left of them is their draws
+            look = false;
             bool any = false;
 #pragma unroll
             for (int dxy = 0; dxy < 9; dxy++) {
@@ -480,13 +519,12 @@ __global__ __launch_bounds__(256) MGX_DYN_OCC void k_dynobs(const DynObsParams p
                 const uint32_t nb = ((uint32_t)x << 4) | (uint32_t)y;
                 if (i < 4) ow.x = (ow.x & ~(255u << (8 * i))) | (nb << (8 * i));
                 else ow.y = (ow.y & ~(255u << (8 * (i - 4)))) | (nb << (8 * (i - 4)));
-                i++; tries = 0;
+                i++; tries = 0; look = true;
                 continue;
             }
-            give_up = ++tries > 100; // num_tries > max_tries raises (101 samples at most); the RecursionError is swallowed
-                                     // by the bare except: the obstacle stays
+            give_up = ++tries > 100; // (101 samples at most)
         }
-        if (give_up) { i++; tries = 0; }
+        if (give_up) { i++; tries = 0; look = true; }
     }
     reinterpret_cast<uint2 *>(p.obst)[env] = ow;
     // (rank >= R624: the next step's service loop twists the block first)
@@ -517,8 +555,12 @@ hipError_t mgx_launch_dynobs(const DynObsParams &p, hipStream_t st)
 {
     if (p.n_tiles == 0) return hipSuccess;
     if (p.wave_lds > 65536) return hipErrorInvalidValue;
-    int wpb = 65536 / p.wave_lds;
-    if (wpb > 4) wpb = 4;
+    // waves per block: four, or one where a wave's LDS is large (16x16: 18 KB per wave; 1 Mi envs, us per launch: three-wave blocks
+    // 255-281, two-wave 201, single-wave blocks 196 -- more of them fit a CU's 160 KB, and a block's LDS is free again as soon as its
+    // one wave is done)
+    int wpb = p.wave_lds > 8192 ? 1 : 4;
+    static const int wpb_env = getenv("MGX_DYN_WPB") ? atoi(getenv("MGX_DYN_WPB")) : 0; // (tuning runs)
+    if (wpb_env > 0 && wpb_env <= 4 && wpb_env * p.wave_lds <= 65536) wpb = wpb_env;
     const dim3 grid((unsigned)((p.n_tiles + wpb - 1) / wpb)), block(64 * wpb);
     const size_t shmem = (size_t)wpb * p.wave_lds;
 #define CASE(w, h) if (p.W == w && p.H == h) { hipLaunchKernelGGL((k_dynobs<w, h>), grid, block, shmem, st, p); return hipGetLastError(); }
@@ -527,6 +569,10 @@ hipError_t mgx_launch_dynobs(const DynObsParams &p, hipStream_t st)
     hipLaunchKernelGGL((k_dynobs<0, 0>), grid, block, shmem, st, p);
     return hipGetLastError();
 }
+
+#if defined(MGX_EXP_DYN) && (MGX_EXP_DYN & 32)
+extern "C" void mgx_debug_dyn_count(unsigned long long *out) { (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dyn_count), 32); }
+#endif
 
 hipError_t mgx_preload_dynobs_kernels()
 {
