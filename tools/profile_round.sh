@@ -53,6 +53,8 @@ if [ $PART = stats ] || [ $PART = all ]; then
   stats lavacrossing_1M --config lava4m --envs-per-gpu 1048576 --steps 512 --warmup 32
   stats lavacrossing_1M_newlevel --config lava4m --envs-per-gpu 1048576 --new-level-each-episode --steps 256
   stats dynobs8x8_1M --env MiniGrid-Dynamic-Obstacles-8x8-v0 --steps 512 --warmup 64
+  stats dynobs16x16_1M --env MiniGrid-Dynamic-Obstacles-16x16-v0 --steps 256 --warmup 32
+  stats multiroom_n6_256k_newlevel --env MiniGrid-MultiRoom-N6-v0 --envs-per-gpu 262144 --new-level-each-episode --steps 600 --warmup 30
   stats fourrooms_full_128k --env MiniGrid-FourRooms-v0 --envs-per-gpu 131072 --obs-mode full --steps 256
   stats fourrooms_full_512k --env MiniGrid-FourRooms-v0 --envs-per-gpu 524288 --obs-mode full --steps 256
   stats multiroom_n6_full_128k --env MiniGrid-MultiRoom-N6-v0 --envs-per-gpu 131072 --obs-mode full --steps 256
@@ -75,6 +77,7 @@ if [ $PART = pmc ] || [ $PART = all ]; then
     pmc multiroom_n6_256k $c --env MiniGrid-MultiRoom-N6-v0 --envs-per-gpu 262144     # the gather form k_step<0,0,3,7>
     pmc fourrooms_1M $c --env MiniGrid-FourRooms-v0 --envs-per-gpu 1048576
     pmc empty16x16_512k $c --env MiniGrid-Empty-16x16-v0 --envs-per-gpu 524288
+    pmc dynobs8x8_1M $c --env MiniGrid-Dynamic-Obstacles-8x8-v0
   done
 fi
 if [ $PART = sq ] || [ $PART = all ]; then
