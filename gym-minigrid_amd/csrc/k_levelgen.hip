@@ -27,34 +27,27 @@ struct WinRng {
     bool overflow;
 
     __device__ __forceinline__ bool alive() const { return !overflow; }
-    // word at stream position w (clamped into what exists): ONE load on a selected address, never a load inside a branch
-    __device__ __forceinline__ uint32_t word(int w) const
-    {
-        w = w < end ? w : end - 1;
-        const uint32_t *src = (mt2 && w >= 624) ? mt2 + (w - 624) : mt + w;
-        return *src;
-    }
+    // A window never straddles the two blocks (it is cut at stream position 624), so a refill is MGX_LGF_WIN loads off ONE pointer
+    // with immediate offsets -- all in flight together, one round trip -- and the words it reads past the block's end (the next
+    // env's, or the allocation's slack behind the last env: MGX_LGF_WIN words) are never handed out.  History: a rolled loop of single
+    // words (load, s_waitcnt vmcnt(0), ds_write, next) = 32 dependent round trips, the ISA had 173 inlined copies of it; then, with
+    // the second block, a pointer selected per word: 32 at once cost the kernel its registers (256 VGPRs + scratch), so 4 x 8.
+    __device__ __forceinline__ int stop_of(int from) const { return (from < 624 && end > 624) ? 624 : end; }
     __device__ __forceinline__ void fill(int from)
     {
-        // Eight loads at a time before their LDS writes (four round trips per refill).  As a rolled loop of single words -- load,
-        // s_waitcnt vmcnt(0), ds_write, next -- the refill was 32 dependent global round trips (the ISA had 173 inlined copies of that
-        // loop), paid every 32 draws by every draw-heavy generator: MultiRoom-N6 draws 287 words per level on average, KeyCorridorS3R3
-        // 158.  (All 32 at once cost the kernel its registers: 256 VGPRs + scratch, one wave per SIMD.)
-#pragma nounroll
-        for (int q = 0; q < MGX_LGF_WIN; q += 8) {
-            uint32_t t[8];
+        const uint32_t *src = (mt2 && from >= 624) ? mt2 + (from - 624) : mt + from;
+        uint32_t t[MGX_LGF_WIN];
 #pragma unroll
-            for (int k = 0; k < 8; k++) t[k] = word(from + q + k);
+        for (int k = 0; k < MGX_LGF_WIN; k++) t[k] = src[k];
 #pragma unroll
-            for (int k = 0; k < 8; k++) win[q + k] = t[k];
-        }
+        for (int k = 0; k < MGX_LGF_WIN; k++) win[k] = t[k];
     }
     __device__ __forceinline__ uint32_t next32()
     {
         if (idx >= limit) {
             if (!SLIDE || idx >= end) { overflow = true; return 0u; } // masked draws end on 0; place_obj-style loops test alive()
             base = idx;
-            limit = base + MGX_LGF_WIN < end ? base + MGX_LGF_WIN : end;
+            limit = base + MGX_LGF_WIN < stop_of(base) ? base + MGX_LGF_WIN : stop_of(base);
             fill(base);
         }
         return lg_temper(win[idx++ - base]);
@@ -243,7 +236,7 @@ __device__ __forceinline__ bool fast_level(const LevelGenParams &p, const FastLa
     WinRng<SLIDE> r;
     r.win = slice; r.mt = p.mt + env * 624; r.mt2 = p.mt2 ? p.mt2 + env * 624 : nullptr; r.end = end;
     r.base = idx0; r.idx = idx0; r.overflow = false;
-    r.limit = idx0 + MGX_LGF_WIN < end ? idx0 + MGX_LGF_WIN : end;
+    r.limit = idx0 + MGX_LGF_WIN < r.stop_of(idx0) ? idx0 + MGX_LGF_WIN : r.stop_of(idx0);
     r.fill(idx0);
     LgLevel L;
     L.cmds = reinterpret_cast<LgCmd *>(slice + MGX_LGF_WIN); L.ncmd = 0; L.max_cmds = fl.cmd_cap;

@@ -477,10 +477,10 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
         CREATE_TRY(hipMalloc((void **)&h->mt_init_d, sizeof init));
         CREATE_TRY(hipMemcpyAsync(h->mt_init_d, init, sizeof init, hipMemcpyHostToDevice, h->stream));
         CREATE_TRY(hipStreamSynchronize(h->stream)); // `init` is a stack array
-        CREATE_TRY(hipMalloc((void **)&h->mt_d, (size_t)h->n_pad * 624 * sizeof(uint32_t)));
+        CREATE_TRY(hipMalloc((void **)&h->mt_d, ((size_t)h->n_pad * 624 + 64) * sizeof(uint32_t))); // (+ slack: k_levelgen's window refills read whole windows)
         CREATE_TRY(hipMalloc((void **)&h->mt_idx_d, (size_t)h->n_pad * sizeof(uint32_t)));
         CREATE_TRY(hipMalloc((void **)&h->regen_d, (size_t)h->n_pad));
-        CREATE_TRY(hipMemsetAsync(h->mt_d, 0, (size_t)h->n_pad * 624 * sizeof(uint32_t), h->stream));
+        CREATE_TRY(hipMemsetAsync(h->mt_d, 0, ((size_t)h->n_pad * 624 + 64) * sizeof(uint32_t), h->stream));
         // new_level_each_episode handles of the draw-heavy families keep the NEXT block ready as well (LevelGenParams.mt2): a level may then
         // run across the end of its block on the lane-per-level path instead of being generated again by a whole wave (MultiRoom-N6 uses
         // 287 of a block's 624 words per level: every second level crossed).  The cheap families (tens of words per level) cross rarely
@@ -488,8 +488,8 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
         const bool cheap_draws = cfg->level_kind == MGX_LEVEL_EMPTY || cfg->level_kind == MGX_LEVEL_DOORKEY || cfg->level_kind == MGX_LEVEL_CROSSING ||
                                  cfg->level_kind == MGX_LEVEL_LAVAGAP || cfg->level_kind == MGX_LEVEL_DISTSHIFT;
         if (h->stream_mode && !(cfg->task_kind == MGX_TASK_DYNOBS) && !cheap_draws) {
-            CREATE_TRY(hipMalloc((void **)&h->mt2_d, (size_t)h->n_pad * 624 * sizeof(uint32_t)));
-            CREATE_TRY(hipMemsetAsync(h->mt2_d, 0, (size_t)h->n_pad * 624 * sizeof(uint32_t), h->stream));
+            CREATE_TRY(hipMalloc((void **)&h->mt2_d, ((size_t)h->n_pad * 624 + 64) * sizeof(uint32_t)));
+            CREATE_TRY(hipMemsetAsync(h->mt2_d, 0, ((size_t)h->n_pad * 624 + 64) * sizeof(uint32_t), h->stream));
         }
         CREATE_TRY(hipMemsetAsync(h->mt_idx_d, 0, (size_t)h->n_pad * sizeof(uint32_t), h->stream));
         CREATE_TRY(hipMemsetAsync(h->regen_d, 0, (size_t)h->n_pad, h->stream));
