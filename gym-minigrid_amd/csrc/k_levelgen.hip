@@ -224,7 +224,7 @@ static_assert(MGX_LG_LDS_PER_WAVE == MGX_LG_LDS_PER_WAVE_BYTES, "keep mgx_kernel
 // FAST PATH, one lane per level.  Returns false when the level has to go to the slow path.
 // Layout of a lane's LDS slice, sized per family by the launcher (fewer dwords per lane = more lanes generating per CU):
 // [0, 32) RNG window | 2*cmd_cap paint commands | 3*river_cap crossing lists | img_dw level image (rows <= 128 B) | 1 pad.
-struct FastLayout { int cmd_cap, river_cap, img_dw, slice_dw, n_fast_waves, span, lanes; }; // lanes: generating lanes per fast wave (64, or fewer for the long-tailed generators)
+struct FastLayout { int cmd_cap, river_cap, img_dw, slice_dw, n_fast_waves, span, lanes, queue_off; }; // lanes: generating lanes per fast wave (64, or fewer for the long-tailed generators)
 
 template <bool SLIDE>
 __device__ __forceinline__ bool fast_level(const LevelGenParams &p, const FastLayout &fl, int64_t env, uint32_t *slice, int W, int H, int cells, bool &crossed)
@@ -287,10 +287,16 @@ __device__ __forceinline__ bool fast_level(const LevelGenParams &p, const FastLa
     return true;
 }
 
-__global__ __launch_bounds__(256) void k_levelgen(const LevelGenParams p, const FastLayout fl)
+// (4 waves per SIMD = 128 VGPRs instead of 151, no spills: MultiRoom's four blocks per CU need them)
+#ifndef MGX_LG_WAVES
+#define MGX_LG_WAVES 4
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MGX_LG_WAVES, MGX_LG_WAVES))) void k_levelgen(const LevelGenParams p, const FastLayout fl)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_slices[]; // n_fast_waves x 64 lane slices; reused by the slow path (>= 4 workspaces)
-    __shared__ uint16_t s_queue[MGX_LGF_ENVS], s_slow[MGX_LGF_ENVS];
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_slices[]; // n_fast_waves x `lanes` slices; reused by the slow path (>= 4 workspaces)
+    // the two queues behind them, `span` entries each (as static arrays of the largest span they cost every block 8 KB: with
+    // MultiRoom's 37.6 KB of slices that was the difference between three and four blocks per CU)
+    uint16_t *s_queue = reinterpret_cast<uint16_t *>(reinterpret_cast<uint8_t *>(s_slices) + fl.queue_off), *s_slow = s_queue + fl.span;
     __shared__ int s_count, s_nslow, s_head;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t env_base = (int64_t)blockIdx.x * fl.span;
@@ -693,26 +699,28 @@ hipError_t mgx_launch_levelgen(const LevelGenParams &p, hipStream_t st)
     if (kind == MGX_LEVEL_KEYCORRIDOR && p.mt2) fl.lanes = 32; // (with the second block: 162 us per step against 178 for a wave per level)
     if (const char *e = getenv("MGX_LG_LANES")) { const int v = atoi(e); if (heavy && v >= 1 && v <= 64) fl.lanes = v; } // (tuning runs)
     const int slice_bytes = fl.lanes * fl.slice_dw * 4;
-    fl.n_fast_waves = 60 * 1024 / slice_bytes; // with the two queues (8 KB) a block stays under 64 KB of LDS
+    fl.n_fast_waves = 60 * 1024 / slice_bytes;
     if (fl.n_fast_waves > 4) fl.n_fast_waves = 4;
     if (fl.n_fast_waves < 1) fl.n_fast_waves = 1;
     if (kind == MGX_LEVEL_KEYCORRIDOR && !p.mt2) fl.n_fast_waves = 0; // a wave per level
     if (const char *e = getenv("MGX_LG_FAST_WAVES")) fl.n_fast_waves = atoi(e); // (tuning runs; 0 = every level takes the wave-per-level path)
+    fl.span = heavy ? 128 : 512;
+    while (fl.span < MGX_LGF_ENVS && (p.n + fl.span - 1) / fl.span > (heavy ? 8192 : 512)) fl.span *= 2;
+    if (const char *e = getenv("MGX_LG_SPAN")) { const int v = atoi(e); if (v >= 64 && v <= MGX_LGF_ENVS && (v & 63) == 0) fl.span = v; } // (tuning runs)
     size_t shmem = (size_t)(fl.n_fast_waves > 0 ? fl.n_fast_waves : 1) * slice_bytes;
     if (shmem < (size_t)slow_bytes) shmem = slow_bytes;
-    if (shmem > 56 * 1024) { // (only tuning runs get here: one block per CU with up to 148 KB of slices + the two queues' 8 KB)
+    fl.queue_off = (int)((shmem + 15) & ~(size_t)15);
+    shmem = (size_t)fl.queue_off + 4 * (size_t)fl.span; // the two queues: `span` 16-bit entries each
+    if (shmem > 60 * 1024) { // more dynamic LDS than a kernel gets unasked (up to 60 KB of slices + 8 KB of queues; tuning runs: up to 148 KB)
         static bool raised[64]; // per device (the attribute belongs to the function on the current device; racing callers set the same value)
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
         if (!raised[dev]) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_levelgen), hipFuncAttributeMaxDynamicSharedMemorySize, 148 * 1024);
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_levelgen), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
             if (e != hipSuccess) return e;
             raised[dev] = true;
         }
     }
-    fl.span = heavy ? 128 : 512;
-    while (fl.span < MGX_LGF_ENVS && (p.n + fl.span - 1) / fl.span > (heavy ? 8192 : 512)) fl.span *= 2;
-    if (const char *e = getenv("MGX_LG_SPAN")) { const int v = atoi(e); if (v >= 64 && v <= MGX_LGF_ENVS && (v & 63) == 0) fl.span = v; } // (tuning runs)
     hipLaunchKernelGGL(k_levelgen, dim3((unsigned)((p.n + fl.span - 1) / fl.span)), dim3(256), shmem, st, p, fl);
     return hipGetLastError();
 }
