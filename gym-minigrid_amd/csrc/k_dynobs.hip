@@ -530,6 +530,9 @@ __global__ __launch_bounds__(256) MGX_DYN_OCC void k_dynobs(const DynObsParams p
     // (rank >= R624: the next step's service loop twists the block first)
     p.pos[env] = r.p == 0xFFFFFFFFu ? (rpos | (r624 << 10) | (rtot << 20) | (dirty ? MGX_DYN_DIRTY : 0u)) : (r.p | MGX_DYN_INPLACE | MGX_DYN_DIRTY);
     p.act_out[env] = (uint8_t)(a | ((a == 2u && not_clear) ? 0x80u : 0u));
+    // the gather form of k_step (16x16) keeps the cell in front of the agent from its last observation pass; the walk has just made that
+    // stale, and this kernel has the image at hand (0 = unknown: outside the grid)
+    if (p.front) p.front[env] = (fx >= 0 && fx < W && fy >= 0 && fy < H) ? g[fx * H + fy] : (uint8_t)0;
     g[ax * H + ay] = under_agent;
     }
     // The moved obstacles go back as the whole tile, coalesced (64 x S bytes per wave).  Written through cell by cell -- two byte stores

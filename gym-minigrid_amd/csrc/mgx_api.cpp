@@ -206,7 +206,7 @@ StepParams base_params(mgx_handle h)
     p.task = h->cfg.task_kind;
     p.regen = h->dynobs ? h->restart_d : (h->stream_mode ? h->regen_d : nullptr);
     p.objaux = h->objaux_d; p.objcont = h->objcont_d; p.objaux0 = h->objaux0_d; p.objcont0 = h->objcont0_d; p.objcarry = h->objcarry_d;
-    p.front = h->dynobs ? nullptr : h->front_d; // (k_dynobs moves cells between two steps)
+    p.front = h->front_d; // (Dynamic-Obstacles: k_dynobs moves cells between two steps and rewrites the entry itself)
     return p;
 }
 
@@ -250,7 +250,7 @@ DynObsParams dynobs_params(mgx_handle h)
     memset(&d, 0, sizeof d);
     d.cells = h->cells_d; d.cells0 = h->cells0_d; d.agent = h->agent_d; d.act_out = h->act_d; d.regen = h->restart_d;
     d.obst = h->obst_d; d.obst0 = h->obst0_d; d.mt = h->mt_d; d.mt0 = h->mt0_d; d.pos = h->mt_idx_d; d.pos0 = h->pos0_d;
-    d.tape = h->tape_d; d.tape0 = h->tape0_d;
+    d.tape = h->tape_d; d.tape0 = h->tape0_d; d.front = h->front_d;
     d.n = h->n; d.W = h->W; d.H = h->H; d.S = h->S; d.n_obst = h->cfg.level_arg0;
     d.n_tiles = (int)(h->n_pad / 64); d.LS = h->LS; d.wave_lds = mgx_dynobs_wave_lds(h->LS);
     return d;

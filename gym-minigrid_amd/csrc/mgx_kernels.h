@@ -113,6 +113,7 @@ struct DynObsParams {
     uint32_t *mt, *mt0;     // u32[n_pad][624] MT19937 words (lazily regenerated in place past the first block) + snapshot
     uint32_t *pos, *pos0;   // u32[n_pad] words drawn since the block in `mt0` was generated (= mt_idx right after reset)
     uint32_t *tape, *tape0; // u32[n_pad][MGX_DYN_TAPE_DW] draw tape of the env's block (k_dynobs.hip) + its episode-start copy
+    uint8_t *front;         // StepParams.front of a gather-form handle (16x16; else null): k_dynobs leaves the cell in front of the agent AFTER the walk
     int64_t n;
     int W, H, S, n_obst;
     int n_tiles, LS, wave_lds; // k_dynobs: one wave per 64-env tile, cells + RNG windows staged in LDS
