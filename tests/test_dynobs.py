@@ -131,6 +131,38 @@ def test_long_episodes_cross_the_first_rng_block():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("base_id,size,n_obst", [("MiniGrid-Dynamic-Obstacles-5x5-v0", 5, 6), ("MiniGrid-Dynamic-Obstacles-5x5-v0", 5, 5),
+                                                  ("MiniGrid-Dynamic-Obstacles-6x6-v0", 6, 8)])
+def test_crowded_grids_run_off_the_draw_tape(base_id, size, n_obst, monkeypatch):
+    """More obstacles than any registered id has (the constructor's clamp set aside on both sides): in a 3x3 interior with six balls, the
+    goal and the agent nearly every 3x3 box is full, a walk draws 2 x 101 times per stuck obstacle -- several RNG blocks per step -- and
+    k_dynobs leaves its tape for the word-by-word source (stream positions, in-place twists, the service that converts back to ranks)
+    on almost every step; the registered ids get there a few times per million steps.  The 6x6 case is the crowded middle: rounds of
+    16 samples that miss, window refills, boxes with one free cell."""
+    import oracle.dynobs_oracle as dyn_oracle
+    monkeypatch.setattr(dyn_oracle, "n_obstacles_of", lambda size, n: int(n))
+    N, T = 96, 40
+    seeds = np.arange(N, dtype=np.uint64) * 7 + 3
+    cfg = mg.env_config(base_id)
+    cfg.level_arg0 = n_obst
+    orc = DynObsOracle(size, n_obst, False, seeds)
+    assert orc.n_obst == n_obst
+    env = mg.VecMiniGrid(config=cfg, num_envs=N, seeds=seeds, auto_reset=True, backend="numpy")
+    assert np.array_equal(env.reset(), orc.observe())
+    rs = np.random.RandomState(5)
+    for t in range(T):
+        a = rs.choice([0, 1, 0, 1, 2], size=N).astype(np.uint8)
+        obs, rew, done, _ = env.step(a)
+        oo, orew, odone = orc.step(a)
+        orc.reset_where(odone)
+        oo = np.where(odone.astype(bool)[:, None, None, None], orc.observe(), oo)
+        assert np.array_equal(done, odone) and np.array_equal(rew, orew.astype(np.float32)), t
+        assert np.array_equal(obs, oo), t
+        assert np.array_equal(env.get_state()["grid"], orc.base.grid), t
+    env.close()
+
+
+@pytest.mark.gpu
 def test_set_state_is_refused():
     env = mg.VecMiniGrid("MiniGrid-Dynamic-Obstacles-5x5-v0", num_envs=3, backend="numpy")
     env.reset()
