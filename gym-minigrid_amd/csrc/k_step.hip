@@ -1132,7 +1132,9 @@ struct RolloutParams {
 
 // CW = CH = 0: run-time grid size (any size whose tile image + observation image fit the LDS); V: agent_view_size (7 for the sized
 // instances, 3 / 5 / 9 / 11 on the run-time-size one: round 3 -- those handles took the captured graph before).
-template <int CW, int CH, int V>
+// FULL: the FullyObsWrapper observation (W x H x 3 per env and step, emit_full_obs on the resident tile: the agent's marker goes into the
+// LDS image for the length of the emission and comes out again) instead of the partial view.
+template <int CW, int CH, int V, bool FULL = false>
 __global__ __launch_bounds__(256) void k_rollout(const StepParams p, const RolloutParams q)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1195,9 +1197,20 @@ __global__ __launch_bounds__(256) void k_rollout(const StepParams p, const Rollo
         }
         if (q.obs) {
             StepParams po = p;
-            po.obs = q.obs + t * p.n * B;
-            emit_partial_obs<CW, CH, V, false>(po, L, img, g, env0, lane);
-            wave_sync(); // the image's readers are done before the next step's LDS writes (same wave: program order)
+            if constexpr (FULL) {
+                const int H = CH ? CH : p.H, W = CW ? CW : p.W;
+                po.obs = q.obs + t * p.n * (int64_t)(3 * W * H);
+                const int aidx = L.ax * H + L.ay;
+                const uint8_t under = g[aidx]; // (what the agent stands on: an empty cell, an open door, the goal)
+                emit_full_obs<CW, CH>(po, L, valid, lds, g, LS, env0, lane);
+                wave_sync();
+                if (valid) g[aidx] = under;
+                wave_sync();
+            } else {
+                po.obs = q.obs + t * p.n * B;
+                emit_partial_obs<CW, CH, V, false>(po, L, img, g, env0, lane);
+                wave_sync(); // the image's readers are done before the next step's LDS writes (same wave: program order)
+            }
         }
     }
     if (valid) p.agent[env] = pack_rec(L, p.task);
@@ -1253,7 +1266,7 @@ hipError_t mgx_preload_step_kernels()
 
 // Fused T-step rollout for partial-view handles with the default visibility: sized instances for the 7x7 view, the run-time-size one
 // for every other grid and for agent_view_size 3 / 5 / 9 / 11; returns hipErrorNotSupported when the two LDS images of a wave do not fit.
-hipError_t mgx_launch_rollout(const StepParams &p0, const uint8_t *actions, uint8_t *obs, float *reward, uint8_t *done, int64_t T, hipStream_t st)
+hipError_t mgx_launch_rollout(const StepParams &p0, const uint8_t *actions, uint8_t *obs, float *reward, uint8_t *done, int64_t T, int full, hipStream_t st)
 {
     StepParams p = p0;
     const int CS = (p.W * p.H + 3) & ~3, LS = CS + (((CS >> 2) & 1) ? 0 : 4);
@@ -1261,6 +1274,7 @@ hipError_t mgx_launch_rollout(const StepParams &p0, const uint8_t *actions, uint
     q.actions = actions; q.obs = obs; q.reward = reward; q.done = done; q.T = T;
     q.grid_lds = (64 * LS + 15) & ~15;
     p.wave_lds = (q.grid_lds + 32 * 3 * p.view * p.view + 15) & ~15; // + the half-tile observation image (4,704 B for the 7x7 view)
+    if (full) p.wave_lds = q.grid_lds + 3072 + 16;                  // + emit_full_obs' 3 KiB transpose scratch behind the grid image
     const int LDS_DEFAULT = 64 * 1024, LDS_MAX = 160 * 1024;
     int wpb = (LDS_DEFAULT - p.lds_guard) / p.wave_lds;
     if (wpb > 4) wpb = 4;
@@ -1277,6 +1291,12 @@ hipError_t mgx_launch_rollout(const StepParams &p0, const uint8_t *actions, uint
         hipLaunchKernelGGL(KERN, grid, block, shmem, st, p, q);                                                                            \
         return hipGetLastError();                                                                                                          \
     } while (0)
+    if (full) { // (the view size does not enter a full-grid observation: one instance per grid size)
+#define CASE(w, h) if (p.W == w && p.H == h) LAUNCH((k_rollout<w, h, 7, true>));
+        MGX_SIZED(CASE)
+#undef CASE
+        LAUNCH((k_rollout<0, 0, 7, true>));
+    }
     if (p.view == 7) {
 #define CASE(w, h) if (p.W == w && p.H == h) LAUNCH((k_rollout<w, h, 7>));
         MGX_SIZED(CASE)

@@ -845,7 +845,10 @@ extern "C" int mgx_rollout(mgx_handle h, int64_t T, const uint8_t *actions, uint
     // 13x13 and 16x16 -- and the graph beyond: measured at 262,144 envs, T = 64, the run-time-size k_rollout runs FourRooms 19x19 at
     // 20.7 us per step against 19.6 for the graph of gather steps and MultiRoom 25x25 at 27.5 against 21.8: a 23-40 KB tile image
     // leaves one or two waves per block)
-    const bool fused_ok = (h->kernel_mode == 0 || (h->kernel_mode == 3 && h->S <= 256)) && h->partial &&
+    // (FullyObs handles, round 3: the same kernel with emit_full_obs on the resident tile, grids up to 13x13 -- us per step at 1 Mi envs, graph of
+    // direct-form steps -> fused: DoorKey-8x8 54.6 -> 34.7, LavaCrossingS9N1 64.4 -> 50.0, S11N5 105 -> 82, RedBlueDoors-8x8 95 -> 65, MemoryS13
+    // 151 -> 138; at 16x16 the 19.7 KB of LDS per wave leave six waves per CU and the direct form wins, 44 against 51 at 262,144 envs)
+    const bool fused_ok = (h->partial ? (h->kernel_mode == 0 || (h->kernel_mode == 3 && h->S <= 256)) : h->S <= 192) &&
                           !h->cfg.alt_visibility && !h->objaux_d && !h->stream_mode &&
                           !h->dynobs && h->oh_nc < 0 && !h->flat && !(rf && !strcmp(rf, "graph"));
     if (fused_ok) {
@@ -853,7 +856,7 @@ extern "C" int mgx_rollout(mgx_handle h, int64_t T, const uint8_t *actions, uint
         p.do_step = 1;
         p.lds_guard = h->staged_guard; // (k_rollout stages the tile in LDS even where the single step gathers: sized grids up to 16x16)
         if (h->front_d) { int rc2 = forget_front(h); if (rc2) return rc2; } // k_rollout moves agents and cells without keeping the gather form's "cell in front"
-        const hipError_t e = mgx_launch_rollout(p, actions, obs, reward, done, T, h->stream);
+        const hipError_t e = mgx_launch_rollout(p, actions, obs, reward, done, T, h->partial ? 0 : 1, h->stream);
         if (e == hipSuccess) {
             h->steps_total += T * h->n;
             if (h->profiling) h->prof_launches += T;

@@ -131,7 +131,7 @@ struct StepLaunchCfg { int tail_blocks, stagger_units, stagger_min; };
 hipError_t mgx_step_launch_cfg(int device, StepLaunchCfg *out);
 hipError_t mgx_launch_step(const StepParams &p, int mode, int waves_per_block, const StepLaunchCfg &lc, hipStream_t st);
 const char *mgx_step_kernel_label(const StepParams &p, int mode); // the instantiation the selector picks, e.g. "k_step<8,8,0,7>"
-hipError_t mgx_launch_rollout(const StepParams &p, const uint8_t *actions, uint8_t *obs, float *reward, uint8_t *done, int64_t T, hipStream_t st);
+hipError_t mgx_launch_rollout(const StepParams &p, const uint8_t *actions, uint8_t *obs, float *reward, uint8_t *done, int64_t T, int full, hipStream_t st);
 hipError_t mgx_preload_step_kernels();
 // (every .hip file is a code object of its own; one lookup each loads it at mgx_create instead of inside the first reset / step)
 hipError_t mgx_preload_levelgen_kernels();

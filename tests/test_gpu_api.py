@@ -180,6 +180,46 @@ def test_rollout_fused_equals_stepping(env_id, N, T, auto, view, form, monkeypat
     a_env.close(); b_env.close()
 
 
+@pytest.mark.parametrize("form", ["fused", "graph"])
+@pytest.mark.parametrize("env_id,N,T,auto", [
+    ("MiniGrid-DoorKey-8x8-v0", 1008, 700, True),           # 8x8: 16-cell units (the transposed store path); time-outs at 640
+    ("MiniGrid-Empty-16x16-v0", 208, 40, True),             # configs[4]'s grid
+    ("MiniGrid-LavaCrossingS9N1-v0", 1552, 90, True),        # 9x9: 81 cells, the 12-byte-record path; resets every step
+    ("MiniGrid-Fetch-8x8-N3-v0", 784, 60, True),             # task rule, the terminal pickup undone under the agent's marker
+    ("MiniGrid-KeyCorridorS3R3-v0", 336, 80, False),         # 7x7, caller resets
+    ("MiniGrid-KeyCorridorS3R2-v0", 336, 300, True),         # 7x5: the run-time-size instance
+    ("MiniGrid-RedBlueDoors-6x6-v0", 336, 90, True),         # 12x6: the agent stands in open doors
+    ("MiniGrid-FourRooms-v0", 400, 60, True)])               # 19x19: past 16x16 the captured graph of direct-form steps either way
+def test_rollout_fully_observable_fused_equals_stepping(env_id, N, T, auto, form, monkeypatch):
+    """k_rollout with the FullyObsWrapper observation (emit_full_obs on the resident tile, the agent's marker put into the LDS image and
+    taken out again every step) against T mgx_step calls of the direct form: every output byte, then state and counters."""
+    if form == "graph":
+        monkeypatch.setenv("MGX_ROLLOUT", "graph")
+    seeds = np.arange(N, dtype=np.uint64) * 3 + 1
+    a_env = mg.VecMiniGrid(env_id, num_envs=N, seeds=seeds, backend="torch", auto_reset=auto, obs_mode="full")
+    b_env = mg.VecMiniGrid(env_id, num_envs=N, seeds=seeds, backend="torch", auto_reset=auto, obs_mode="full")
+    a_env.reset(); b_env.reset()
+    chunk = 64 if T > 200 else T
+    done_total = 0
+    for rep, t0 in enumerate(range(0, 2 * T, chunk)):
+        n = min(chunk, 2 * T - t0)
+        acts = a_env.fill_actions(22, t0, n)
+        obs, rew, done = a_env.rollout(acts)
+        for t in range(n):
+            o, r, d, _ = b_env.step(acts[t])
+            assert torch.equal(obs[t], o), (rep, t)
+            assert torch.equal(rew[t], r) and torch.equal(done[t], d), (rep, t)
+        done_total += int(done.sum())
+        if rep % 4 == 0:
+            sa, sb = a_env.get_state(), b_env.get_state()
+            for k in sa:
+                assert np.array_equal(sa[k], sb[k]), (k, rep)
+    if 2 * T >= a_env.max_steps or any(k in env_id for k in ("Lava", "Fetch")):
+        assert done_total > 0
+    assert a_env.stats() == b_env.stats()
+    a_env.close(); b_env.close()
+
+
 @pytest.mark.parametrize("N", [300, 1500])                 # (one partial 512-env span / whole spans + a partial one)
 @pytest.mark.parametrize("env_id", ["MiniGrid-DoorKey-8x8-v0", "MiniGrid-LavaCrossingS9N1-v0", "MiniGrid-Fetch-8x8-N3-v0"])
 def test_masked_reset_same_and_changed_seeds(env_id, N):
