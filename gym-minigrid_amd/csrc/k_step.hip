@@ -1118,9 +1118,10 @@ __global__ __launch_bounds__(256, (RAGGED && CW == 19) ? 8 : 1) void k_step_full
 // keeps its tile -- the 64 grids in LDS, the 64 agent records in registers -- across the whole loop: per env-step only the
 // action (1 B) comes in and the observation, reward and done flag (152 B) go out; cells and records are read once and written
 // back once per launch, and there is no launch boundary between steps (the per-step launches pay ~8 us each: DESIGN.md section 4).
-// The observation image gets LDS of its own behind the grid image (it overlays the grid in k_step).  Sized partial-view
-// handles only (7x7 view, default visibility, no hidden object state, no epilogue, no new_level_each_episode / Dynamic-Obstacles:
-// those interleave other kernels with the steps); everything else keeps the captured graph of per-step launches.
+// The observation image gets LDS of its own behind the grid image (it overlays the grid in k_step).  Default visibility, no hidden
+// object state, no epilogue, no new_level_each_episode / Dynamic-Obstacles (those interleave other kernels with the steps): partial
+// views of every size on grids up to 16x16, the FullyObs observation on grids up to 13x13; everything else keeps the captured graph
+// of per-step launches (mgx_rollout).
 struct RolloutParams {
     const uint8_t *actions; // u8[T][n]
     uint8_t *obs;           // u8[T][n][147] or null
