@@ -12,10 +12,14 @@
 // Dynamic-Obstacles (envs/dynamicobstacles.py:60-89).  The obstacle walk draws from the env's own MT19937 stream
 // inside step(), so it cannot live in the streaming step kernel: k_dynobs runs before it, one lane per env.
 //   RNG   : the per-env block `mt` is the one k_seed/k_levelgen left behind (words [pos, 624) not drawn yet); `tape` holds the
-//           low two bits of its tempered words and of the first 224 words of the next block (see "the draw tape" below).
+//           accepted two-bit draws of its tempered words and of the first 224 words of the next block (see "the draw tape" below).
 //   reset : the in-kernel auto-reset of the step kernels raises restart[env] (DynObsParams.regen); the walk then first restores
 //           the obstacle order and the RNG position of the episode start (ReseedWrapper: seed(s) + reset()), and block + tape
 //           only if the episode twisted or touched the block (bit 31 of the stored position).
+//   -DMGX_EXP_DYN=<bits> (tools/build_variant.sh; never in the product build) are measurement aids, most of them with WRONG results:
+//           1 no block service, 2 no walk, 4 ask for 8 waves per SIMD, 8 every placement through the draw-by-draw loop (a check aid:
+//           results stay right), 16 nobody takes that loop, 32 count the lanes that do (mgx_debug_dyn_count).  profiles/r03_dynobs_steps.txt
+//           holds what they measured.
 namespace {
 __global__ __launch_bounds__(256) void k_dynobs_init(const DynObsParams p)
 {
