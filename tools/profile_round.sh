@@ -1,6 +1,6 @@
 #!/bin/bash
 # Usage (GPU box, repo root): tools/profile_round.sh r02 [part]   -- regenerates the rocprofv3 evidence kept under profiles/
-#   part = stats | newlevel | pmc | sq | all (default).  Writes gpurun_out/profiles_<tag>/ ; copy what should be judged into profiles/.
+#   part = stats | dyn | newlevel | pmc | sq | all (default).  Writes gpurun_out/profiles_<tag>/ ; copy what should be judged into profiles/.
 # Every rocprofv3 command has `python3 bench.py ...` directly after `--` and runs from /tmp with TMPDIR=/tmp; counters are
 # collected in passes of their own (--pmc with --kernel-trace only).  Nothing is re-measured silently: a run whose slowest
 # launch of the top kernel took > 100x its fastest is KEPT and listed in <tag>_outliers.txt with that launch's duration.
@@ -64,6 +64,10 @@ if [ $PART = stats ] || [ $PART = all ]; then
   stats keycorridor_s6r3_512k --env MiniGrid-KeyCorridorS6R3-v0 --envs-per-gpu 524288 --steps 256
   stats obstructedmaze_2dlhb_256k --env MiniGrid-ObstructedMaze-2Dlhb-v0 --envs-per-gpu 262144 --steps 256
   stats empty8x8_1M_partial_onehot --obs-mode partial_onehot --steps 256
+fi
+if [ $PART = dyn ]; then   # only the Dynamic-Obstacles runs (re-taken after a change to k_dynobs or the k_step behind it)
+  stats dynobs8x8_1M --env MiniGrid-Dynamic-Obstacles-8x8-v0 --steps 512 --warmup 64
+  stats dynobs16x16_1M --env MiniGrid-Dynamic-Obstacles-16x16-v0 --steps 256 --warmup 32
 fi
 if [ $PART = newlevel ]; then   # only the runs in which k_levelgen works (re-taken after a change to it)
   stats lavacrossing_1M_newlevel --config lava4m --envs-per-gpu 1048576 --new-level-each-episode --steps 256
