@@ -591,10 +591,23 @@ LG_FN void lg_gen_keycorridor(const mgx_config &c, R &r, LgLevel &L)
         }
     if (!r.alive()) return;
     const int ax0 = T + S / 2, ay0 = (rows / 2) * T + S / 2; // RoomGrid parks the agent here while the objects are placed
+    // connect_all's "every room reachable from the agent's" (a breadth-first search over the doors before every random pick,
+    // roomgrid.py:306-331) is "one connected component": kept up to date as doors appear -- comp: 4 bits per room, the number of its
+    // component; n_comp components left.  (The search cost ~300 instructions per pick, 30 picks per level: 40 % of a level.)
+    uint64_t comp = 0;
+    const int n_rooms = 3 * rows;
+    for (int q = 0; q < n_rooms && q < 16; q++) comp |= (uint64_t)q << (4 * q);
+    int n_comp = n_rooms;
     auto mark = [&](int i, int j, int k) { // both sides of wall k of room (i, j) are now connected
         fl[3 * j + i] |= (int16_t)(1 << k);
         const int ni = i + (k == 0) - (k == 2), nj = j + (k == 1) - (k == 3);
         fl[3 * nj + ni] |= (int16_t)(1 << ((k + 2) & 3));
+        const uint32_t ca = (uint32_t)(comp >> (4 * (3 * j + i))) & 15u, cb = (uint32_t)(comp >> (4 * (3 * nj + ni))) & 15u;
+        if (ca != cb && n_rooms <= 16) {
+            for (int q = 0; q < n_rooms; q++)
+                if (((uint32_t)(comp >> (4 * q)) & 15u) == cb) comp = (comp & ~((uint64_t)15 << (4 * q))) | ((uint64_t)ca << (4 * q));
+            n_comp--;
+        }
     };
     auto door_xy = [&](int i, int j, int k, int *x, int *y) { // room.door_pos[k]
         if (k == 0) { *x = i * T + S - 1; *y = dr[3 * j + i]; }
@@ -640,20 +653,21 @@ LG_FN void lg_gen_keycorridor(const mgx_config &c, R &r, LgLevel &L)
         L.ax = ax; L.ay = ay; L.adir = d;
         if (fc == MGX_CODE_EMPTY || (fc & 15u) == MGX_K_WALL) break;
     }
-    const int n_rooms = 3 * rows;
     for (int it = 0; it <= 5000; it++) { // connect_all
-        uint32_t reach = 1u << (3 * aj + 1), frontier = reach; // rooms reachable from the agent's room
-        while (frontier) {
-            const int q = lg_ctz32(frontier);
-            frontier &= frontier - 1;
-            const int i = q % 3, j = q / 3;
-            for (int k = 0; k < 4; k++)
-                if (fl[q] & (1 << k)) {
-                    const int nq = 3 * (j + (k == 1) - (k == 3)) + i + (k == 0) - (k == 2);
-                    if (!(reach & (1u << nq))) { reach |= 1u << nq; frontier |= 1u << nq; }
-                }
+        if (n_rooms <= 16) { if (n_comp == 1) break; } // every room reachable from the agent's
+        else { // (more rooms than the packed component numbers hold -- no registered id: the search itself)
+            uint32_t reach = 1u << (3 * aj + 1), frontier = reach;
+            while (frontier) {
+                const int q = lg_ctz32(frontier);
+                frontier &= frontier - 1;
+                for (int k = 0; k < 4; k++)
+                    if (fl[q] & (1 << k)) {
+                        const int nq = 3 * (q / 3 + (k == 1) - (k == 3)) + q % 3 + (k == 0) - (k == 2);
+                        if (!(reach & (1u << nq))) { reach |= 1u << nq; frontier |= 1u << nq; }
+                    }
+            }
+            if (reach == (1u << n_rooms) - 1u) break;
         }
-        if (reach == (1u << n_rooms) - 1u) break;
         const int i = lg_randint(r, 0, 3), j = lg_randint(r, 0, rows), k = lg_randint(r, 0, 4);
         if (!r.alive()) return;
         const int ni = i + (k == 0) - (k == 2), nj = j + (k == 1) - (k == 3);
