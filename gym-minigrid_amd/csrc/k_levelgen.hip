@@ -332,7 +332,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MGX_LG_WAVE
     if (wv < fl.n_fast_waves && lane < fl.lanes) {
         uint32_t *slice = s_slices + ((size_t)wv * fl.lanes + lane) * fl.slice_dw;
         const int stride = fl.lanes * fl.n_fast_waves;
-        for (int i = wv * fl.lanes + lane; i < ((count + stride - 1) / stride) * stride; i += stride) {
+        // The queue goes round the waves level by level (entry lane * waves + wave of each chunk), not wave by wave: a steady flow of resets
+        // leaves a block a few dozen levels, and filled wave by wave they all sat in wave 0 -- one wave per block alone on its SIMD,
+        // running the union of 40 lanes' control flow with nothing to hide its latencies, three waves waiting at the barrier (PutNear,
+        // 262,144 envs: every launch 60-70 us for ~10 k cheap levels).
+        for (int i = lane * fl.n_fast_waves + wv; i < ((count + stride - 1) / stride) * stride; i += stride) {
             if (i >= count) continue;
             const int64_t env = env_base + s_queue[i];
             bool crossed;

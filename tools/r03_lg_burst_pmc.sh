@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counters of the ONE k_levelgen launch that makes a level for every env (the burst at step max_steps of a lock-step family):
-#   tools/r03_lg_burst_pmc.sh <env id> <envs> <steps>     (steps > max_steps; the launch with the most SQ_WAVES x work is picked by duration)
+#   tools/r03_lg_burst_pmc.sh <env id> <envs> <steps>     (steps > max_steps; the longest launch is picked; LG_PICK=median: the median one)
 env_id=$1; envs=$2; steps=$3
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 PY=$(readlink -f "$(command -v python3)")
@@ -22,8 +22,10 @@ by = collections.defaultdict(dict)
 for r in rows:
     by[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
     by[r["Dispatch_Id"]]["_dur"] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
-d = max(by.values(), key=lambda c: c["_dur"])
-print("burst launch: %.1f us under the counters" % (d["_dur"] / 1e3))
+import os
+v = sorted(by.values(), key=lambda c: c["_dur"])
+d = v[len(v) // 2] if os.environ.get("LG_PICK") == "median" else v[-1]   # LG_PICK=median: a steady-flow family's typical launch
+print("%s launch: %.1f us under the counters" % ("median" if os.environ.get("LG_PICK") == "median" else "burst", d["_dur"] / 1e3))
 for k in sorted(d):
     if k != "_dur": print("  %-28s %16.0f" % (k, d[k]))
 PY
