@@ -282,10 +282,10 @@ int mgx_get_object_state(mgx_handle h, uint8_t *contains, uint8_t *carry_aux, ui
 int mgx_observe(mgx_handle h, uint8_t *obs);
 /* T consecutive mgx_step calls in one host call (the reference caller's `for t: env.step(a[t])` loop, run_tests.py:41-68):
  * actions uint8 [T][N], obs [T][N][obs_bytes] (or NULL), reward float [T][N] (or NULL), done uint8 [T][N] (or NULL), all
- * DEVICE memory.  Sized partial-view handles (7x7 view, default visibility, no object_state, plain uint8 observations, no
- * new_level_each_episode / Dynamic-Obstacles) run all T steps in ONE kernel launch with the env state resident on chip
- * (k_rollout); every other handle captures its per-step launches into a hipGraph on first use and replays it while T and the
- * buffers stay the same.  Same results as T mgx_step calls either way.  Asynchronous on the handle's stream like mgx_step. */
+ * DEVICE memory.  Handles with the default visibility, no object_state, plain uint8 observations and no new_level_each_episode /
+ * Dynamic-Obstacles run all T steps in ONE kernel launch with the env state resident on chip (k_rollout): partial views of every
+ * size on grids up to 16x16, the FullyObs observation on grids up to 13x13; every other handle captures its per-step launches into
+ * a hipGraph on first use and replays it while T and the buffers stay the same.  Same results as T mgx_step calls either way.  Asynchronous on the handle's stream like mgx_step. */
 int mgx_rollout(mgx_handle h, int64_t T, const uint8_t *actions, uint8_t *obs, float *reward, uint8_t *done);
 
 /* obs['direction'] (minigrid.py:1375-1379): agent_dir of every env, uint8 [N]. */
