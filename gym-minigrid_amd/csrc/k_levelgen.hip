@@ -242,21 +242,18 @@ __device__ __forceinline__ bool fast_level(const LevelGenParams &p, const FastLa
     L.cmds = reinterpret_cast<LgCmd *>(slice + MGX_LGF_WIN); L.ncmd = 0; L.max_cmds = fl.cmd_cap;
     L.ws = reinterpret_cast<int16_t *>(slice + MGX_LGF_WIN + 2 * fl.cmd_cap); L.max_rivers = fl.river_cap;
     L.W = W; L.H = H; L.ax = L.ay = -1; L.adir = 0;
+    uint32_t *img32 = slice + MGX_LGF_WIN + 2 * fl.cmd_cap + 3 * fl.river_cap;
+    if (fl.img_dw) { // the level image in the slice, painted by lg_rect as the level grows (LgLevel.occ: the placement loops probe it)
+        uint8_t *img = reinterpret_cast<uint8_t *>(img32);
+        for (int k = 0; k < (p.S >> 2); k++) img32[k] = 4 * k + 3 < cells ? 0x01010101u * MGX_CODE_EMPTY : 0u;
+        for (int c = cells & ~3; c < cells; c++) img[c] = MGX_CODE_EMPTY;
+        L.occ = img;
+    }
     lg_generate(p.cfg, r, L);
     if (r.overflow || L.too_big) return false;
     uint32_t *dst = reinterpret_cast<uint32_t *>(p.cells0 + env * p.S);
     if (fl.img_dw) {
-        // paint command by command into the slice, then one pass of dword stores
-        uint32_t *img32 = slice + MGX_LGF_WIN + 2 * fl.cmd_cap + 3 * fl.river_cap;
-        uint8_t *img = reinterpret_cast<uint8_t *>(img32);
-        for (int k = 0; k < (p.S >> 2); k++) img32[k] = 4 * k + 3 < cells ? 0x01010101u * MGX_CODE_EMPTY : 0u;
-        for (int c = cells & ~3; c < cells; c++) img[c] = MGX_CODE_EMPTY;
-        for (int q = 0; q < L.ncmd; q++) {
-            const LgCmd c = L.cmds[q];
-            for (int x = c.x0; x <= c.x1; x++)
-                for (int y = c.y0; y <= c.y1; y++) img[x * H + y] = c.code;
-        }
-        for (int k = 0; k < (p.S >> 2); k++) dst[k] = img32[k];
+        for (int k = 0; k < (p.S >> 2); k++) dst[k] = img32[k]; // one pass of dword stores
     } else {
         // rows too long for the slice (13x13 and up): paint straight into the env's row in HBM (this lane's own stores,
         // in order)

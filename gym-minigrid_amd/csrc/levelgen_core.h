@@ -52,6 +52,9 @@ struct LgLevel {
     uint32_t task = 0; // per-env task word of the families with a task rule (Fetch: target code | mission template << 8)
     int max_cmds = MGX_LG_MAX_CMDS, max_rivers = MGX_LG_MAX_RIVERS; // capacities of cmds / ws (the GPU fast path has small ones)
     bool too_big = false; // a capacity was exceeded: the level is invalid and must be regenerated with full-size buffers
+    uint8_t *occ = nullptr; // (GPU lane-per-level path, small grids) the level painted as it grows: W*H cell codes, x*H + y, all EMPTY at the start.
+                            // The placement loops probe a cell per sample; against the command list that is a scan of every command so far
+                            // (KeyCorridor: ~40 per probe), against the image one byte.  Null: the scan (host, wave-per-level path, big grids).
 };
 
 LG_FN void lg_rect(LgLevel &L, int x0, int y0, int x1, int y1, uint32_t code)
@@ -61,6 +64,9 @@ LG_FN void lg_rect(LgLevel &L, int x0, int y0, int x1, int y1, uint32_t code)
     c.x0 = (uint8_t)x0; c.y0 = (uint8_t)y0; c.x1 = (uint8_t)x1; c.y1 = (uint8_t)y1; c.code = (uint8_t)code;
     c.cont = 0; c.pad[0] = c.pad[1] = 0;
     L.cmds[L.ncmd++] = c;
+    if (L.occ)
+        for (int x = x0; x <= x1; x++)
+            for (int y = y0; y <= y1; y++) L.occ[x * L.H + y] = (uint8_t)code;
 }
 LG_FN void lg_set(LgLevel &L, int x, int y, uint32_t code) { lg_rect(L, x, y, x, y, code); }
 // a Box with something inside (Box.contains, minigrid.py:332-364): handles created with object_state keep it in a plane of its own
@@ -80,7 +86,13 @@ LG_FN uint32_t lg_cell_code(const LgCmd *cmds, int n, int x, int y)
     }
     return code;
 }
-LG_FN bool lg_empty(const LgLevel &L, int x, int y) { return lg_cell_code(L.cmds, L.ncmd, x, y) == MGX_CODE_EMPTY; }
+// ... of the level so far
+LG_FN uint32_t lg_code_at(const LgLevel &L, int x, int y)
+{
+    if (L.occ) return ((unsigned)x < (unsigned)L.W && (unsigned)y < (unsigned)L.H) ? (uint32_t)L.occ[x * L.H + y] : (uint32_t)MGX_CODE_EMPTY;
+    return lg_cell_code(L.cmds, L.ncmd, x, y);
+}
+LG_FN bool lg_empty(const LgLevel &L, int x, int y) { return lg_code_at(L, x, y) == MGX_CODE_EMPTY; }
 // code of what the box in cell (x, y) contains (MGX_CODE_EMPTY: nothing, or no box there)
 LG_FN uint32_t lg_cell_cont(const LgCmd *cmds, int n, int x, int y)
 {
@@ -560,7 +572,7 @@ LG_FN void lg_gen_unlock(const mgx_config &c, R &r, LgLevel &L)
         if (!lg_empty(L, ax, ay)) continue;
         const int d = lg_randint(r, 0, 4);
         const int fx = ax + (d == 0) - (d == 2), fy = ay + (d == 1) - (d == 3);
-        const uint32_t fc = lg_cell_code(L.cmds, L.ncmd, fx, fy);
+        const uint32_t fc = lg_code_at(L, fx, fy);
         L.ax = ax; L.ay = ay; L.adir = d;
         if (fc == MGX_CODE_EMPTY || (fc & 15u) == MGX_K_WALL) break;
     }
@@ -649,7 +661,7 @@ LG_FN void lg_gen_keycorridor(const mgx_config &c, R &r, LgLevel &L)
         if (!r.alive()) return;
         if (!lg_empty(L, ax, ay)) continue;
         const int d = lg_randint(r, 0, 4);
-        const uint32_t fc = lg_cell_code(L.cmds, L.ncmd, ax + (d == 0) - (d == 2), ay + (d == 1) - (d == 3));
+        const uint32_t fc = lg_code_at(L, ax + (d == 0) - (d == 2), ay + (d == 1) - (d == 3));
         L.ax = ax; L.ay = ay; L.adir = d;
         if (fc == MGX_CODE_EMPTY || (fc & 15u) == MGX_K_WALL) break;
     }
@@ -771,7 +783,7 @@ LG_FN void lg_gen_obstructedmaze(const mgx_config &c, R &r, LgLevel &L)
         if (!r.alive()) return;
         if (!lg_empty(L, ax, ay)) continue;
         const int d = lg_randint(r, 0, 4);
-        const uint32_t fc = lg_cell_code(L.cmds, L.ncmd, ax + (d == 0) - (d == 2), ay + (d == 1) - (d == 3));
+        const uint32_t fc = lg_code_at(L, ax + (d == 0) - (d == 2), ay + (d == 1) - (d == 3));
         L.ax = ax; L.ay = ay; L.adir = d;
         if (fc == MGX_CODE_EMPTY || (fc & 15u) == MGX_K_WALL) break;
     }
