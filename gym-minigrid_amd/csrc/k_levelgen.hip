@@ -220,7 +220,13 @@ static_assert(MGX_LG_LDS_PER_WAVE == MGX_LG_LDS_PER_WAVE_BYTES, "keep mgx_kernel
    MultiRoom-N6 654 -> 199 us per step, KeyCorridorS3R3 338 -> 213 */
 #define MGX_LGF_CMDS 40
 #define MGX_LGF_RIVERS 8
-#define MGX_LGF_MAXS 128 /* largest grid row (bytes) painted in a lane slice */
+#ifndef MGX_LGF_MAXS
+#define MGX_LGF_MAXS 384 /* largest grid row (bytes) painted in a lane slice: up to 19x19 (128 until the placement loops probed the image; us per step with a
+                            new level per episode at 262,144 envs, 128 -> 384: ObstructedMaze-2Dlhb 55.8 -> 37.7, MemoryS13Random 43.9 -> 33.4, Playground 45.7 -> 40.7) */
+#endif
+#ifndef MGX_LGF_MAXS_CHEAP
+#define MGX_LGF_MAXS_CHEAP 128 /* ... for the cheap (non-sliding) form */
+#endif
 // FAST PATH, one lane per level.  Returns false when the level has to go to the slow path.
 // Layout of a lane's LDS slice, sized per family by the launcher (fewer dwords per lane = more lanes generating per CU):
 // [0, 32) RNG window | 2*cmd_cap paint commands | 3*river_cap crossing lists | img_dw level image (rows <= 128 B) | 1 pad.
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MGX_LG_WAVE
     // the cheap form for the families whose levels take a bounded, small number of draws on small grids (measured: the
     // sliding form costs the crossing generator 10-20 %); the sliding window and the direct paint for everything else
     const int kind = p.cfg.level_kind;
-    const bool cheap = p.S <= MGX_LGF_MAXS && (kind == MGX_LEVEL_EMPTY || kind == MGX_LEVEL_DOORKEY || kind == MGX_LEVEL_CROSSING ||
+    const bool cheap = p.S <= MGX_LGF_MAXS_CHEAP && (kind == MGX_LEVEL_EMPTY || kind == MGX_LEVEL_DOORKEY || kind == MGX_LEVEL_CROSSING ||
                                                kind == MGX_LEVEL_LAVAGAP || kind == MGX_LEVEL_DISTSHIFT);
     const bool slide = !cheap;
     if (fl.n_fast_waves == 0) { // every level by a whole wave (levelgen_one)
