@@ -704,7 +704,7 @@ hipError_t mgx_launch_levelgen(const LevelGenParams &p, hipStream_t st)
     fl.lanes = 64;
     if (kind == MGX_LEVEL_MULTIROOM) fl.lanes = 16;
     if (kind == MGX_LEVEL_KEYCORRIDOR && p.mt2) fl.lanes = 16; // (with the second block: 155 us per step -- 8 lanes 160, 12: 157, 20: 158, 24 / 32: 162 -- against 178 for a wave per level)
-    if (const char *e = getenv("MGX_LG_LANES")) { const int v = atoi(e); if (heavy && v >= 1 && v <= 64) fl.lanes = v; } // (tuning runs)
+    if (const char *e = getenv("MGX_LG_LANES")) { const int v = atoi(e); if (v >= 1 && v <= 64) fl.lanes = v; } // (tuning runs)
     const int slice_bytes = fl.lanes * fl.slice_dw * 4;
     fl.n_fast_waves = 60 * 1024 / slice_bytes;
     if (fl.n_fast_waves > 4) fl.n_fast_waves = 4;

@@ -1,0 +1,12 @@
+#!/bin/bash
+# steady-flow families: fewer generating lanes per wave (smaller slices, more blocks resident) with smaller spans (new_level_each_episode, us per step)
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O; cd $R
+b() { timeout -k 10 200 python bench.py --no-cpu-baseline --env $1 --envs-per-gpu ${2:-262144} --new-level-each-episode --steps 600 --warmup 32 2>/dev/null | grep "^{" | python -c "import sys,json,os; j=json.loads(sys.stdin.read()); print('%-34s n=%-8d lanes=%-4s span=%-5s %.3g steps/s %.1f us/step' % (j['config']['env_id'], j['config']['envs_per_gpu'], os.environ.get('MGX_LG_LANES','rule'), os.environ.get('MGX_LG_SPAN','rule'), j['value'], j['ms_per_step']*1e3))"; }
+for e in "MiniGrid-PutNear-8x8-N3-v0 262144" "MiniGrid-Fetch-8x8-N3-v0 262144" "MiniGrid-LavaCrossingS9N1-v0 1048576" "MiniGrid-KeyCorridorS3R3-v0 262144"; do
+  b $e
+  MGX_LG_LANES=16 MGX_LG_SPAN=128 b $e
+  MGX_LG_LANES=16 MGX_LG_SPAN=256 b $e
+  MGX_LG_LANES=32 MGX_LG_SPAN=256 b $e
+  MGX_LG_LANES=32 b $e
+  MGX_LG_LANES=16 b $e
+done 2>&1 | tee $O/stream16.txt
