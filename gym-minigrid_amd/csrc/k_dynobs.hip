@@ -370,178 +370,177 @@ __global__ __launch_bounds__(256) MGX_DYN_OCC void k_dynobs(const DynObsParams p
     stage_tile<CS>(p.cells, env0, S, LS, lds, lane);
     wave_sync();
     if (valid) {
-    uint8_t *g = lds + lane * LS;
-    if (a >= 3u) a = 0u; // `if action >= self.action_space.n: action = 0`
-    const int W = CW ? CW : p.W;
-    const int ax = (int)(rec & 255u), ay = (int)((rec >> 8) & 255u), dir = (int)((rec >> 16) & 3u);
-    const int fx = ax + (dir == 0) - (dir == 2), fy = ay + (dir == 1) - (dir == 3);
-    bool not_clear = false; // front_cell and front_cell.type != 'goal', BEFORE the obstacles move
-    if (fx >= 0 && fx < W && fy >= 0 && fy < H) {
-        const uint32_t k = g[fx * H + fy] & 15u;
-        not_clear = k != MGX_K_EMPTY && k != MGX_K_GOAL;
-    }
-    // The window: wl / wh hold the next `navail` draws of the tape from bit 0 up; `rpos` is the rank of the next draw.
-    const uint32_t r624 = (pos >> 10) & 1023u, rtot = (pos >> 20) & 1023u;
-    uint32_t rpos = pos & 1023u;
-#if defined(MGX_EXP_DYN) && (MGX_EXP_DYN & 1)
-    if (r624 && rpos >= r624) rpos %= r624; // (timing only: with no service the position wraps instead)
-#endif
-    dyn_u64 wl = w_lo, wh = w_hi;
-    uint32_t navail = rtot - rpos < 64u ? rtot - rpos : 64u;
-    const uint32_t *tape_l = p.tape + env * MGX_DYN_TAPE_DW;
-    DynRng r = {p.mt + env * 624, 0xFFFFFFFFu, false};
-#if defined(MGX_EXP_DYN) && (MGX_EXP_DYN & 2) /* timing only (wrong results): no placement */
-    const int n_obst = 0;
-#else
-    const int n_obst = p.n_obst;
-#endif
-    // ---- straight-line placements (all lanes together, obstacle by obstacle)
-    const uint8_t under_agent = g[ax * H + ay];
-    g[ax * H + ay] = 0xFFu; // the agent's cell is not free: marked in the LDS image for the length of the walk
-#if defined(MGX_EXP_DYN) && (MGX_EXP_DYN & 8) /* check aid: every placement through the loop */
-    int slow_from = 0;
-#else
-    int slow_from = n_obst; // first obstacle this lane takes through the loop below
-#endif
-    int slow_tries = 0;     // ... and the samples that obstacle has already missed
-    for (int i = 0; i < n_obst; i++) { // (wave-uniform trip count)
-        const bool mine = slow_from == n_obst;
-        const uint32_t o = (i < 4 ? ow.x >> (8 * i) : ow.y >> (8 * (i - 4))) & 255u; // x << 4 | y
-        const int tx = (int)(o >> 4) - 1, ty = (int)(o & 15u) - 1; // top = old_pos + (-1, -1): interior, never clipped
-        const uint8_t *b = g + tx * H + ty;
-        uint32_t c00 = 0, c01 = 0, c02 = 0, c10 = 0, c11 = 0, c12 = 0, c20 = 0, c21 = 0, c22 = 0;
-        if (mine) { c00 = b[0]; c01 = b[1]; c02 = b[2]; c10 = b[H]; c11 = b[H + 1]; c12 = b[H + 2]; c20 = b[2 * H]; c21 = b[2 * H + 1]; c22 = b[2 * H + 2]; }
-        const uint32_t F = MGX_CODE_EMPTY;
-        const bool f00 = c00 == F, f01 = c01 == F, f02 = c02 == F, f10 = c10 == F, f11 = c11 == F, f12 = c12 == F, f20 = c20 == F, f21 = c21 == F, f22 = c22 == F;
-        bool pending = mine;
-        int tries = 0;
-        if (pending && !(f00 || f01 || f02 || f10 || f11 || f12 || f20 || f21 || f22)) {
-            // no free cell in the box: all 101 samples fail, and all that is left of them is their 202 draws
-            if (rtot - rpos >= 202u) { rpos += 202u; navail = 0u; } // (the next sample loads the window at the new rank)
-            else { slow_from = i; slow_tries = 0; }                // (the tape ends first)
-            pending = false;
+        uint8_t *g = lds + lane * LS;
+        if (a >= 3u) a = 0u; // `if action >= self.action_space.n: action = 0`
+        const int W = CW ? CW : p.W;
+        const int ax = (int)(rec & 255u), ay = (int)((rec >> 8) & 255u), dir = (int)((rec >> 16) & 3u);
+        const int fx = ax + (dir == 0) - (dir == 2), fy = ay + (dir == 1) - (dir == 3);
+        bool not_clear = false; // front_cell and front_cell.type != 'goal', BEFORE the obstacles move
+        if (fx >= 0 && fx < W && fy >= 0 && fy < H) {
+            const uint32_t k = g[fx * H + fy] & 15u;
+            not_clear = k != MGX_K_EMPTY && k != MGX_K_GOAL;
         }
-        // rounds of up to 16 samples (one is the rule; a box with one or two free cells may take more)
-        while (__ballot(pending)) { // wave-uniform
-            if (pending) {
-                if (navail < 2u) { // the window is used up: the next 64 draws of the tape -- or, at the tape's end, the loop below
-                    if (rtot - rpos < 2u) { slow_from = i; slow_tries = tries; pending = false; }
-                    else { dyn_window(tape_l, rpos, wl, wh); navail = rtot - rpos < 64u ? rtot - rpos : 64u; }
+        // The window: wl / wh hold the next `navail` draws of the tape from bit 0 up; `rpos` is the rank of the next draw.
+        const uint32_t r624 = (pos >> 10) & 1023u, rtot = (pos >> 20) & 1023u;
+        uint32_t rpos = pos & 1023u;
+#if defined(MGX_EXP_DYN) && (MGX_EXP_DYN & 1)
+        if (r624 && rpos >= r624) rpos %= r624; // (timing only: with no service the position wraps instead)
+#endif
+        dyn_u64 wl = w_lo, wh = w_hi;
+        uint32_t navail = rtot - rpos < 64u ? rtot - rpos : 64u;
+        const uint32_t *tape_l = p.tape + env * MGX_DYN_TAPE_DW;
+        DynRng r = {p.mt + env * 624, 0xFFFFFFFFu, false};
+#if defined(MGX_EXP_DYN) && (MGX_EXP_DYN & 2) /* timing only (wrong results): no placement */
+        const int n_obst = 0;
+#else
+        const int n_obst = p.n_obst;
+#endif
+        // ---- straight-line placements (all lanes together, obstacle by obstacle)
+        const uint8_t under_agent = g[ax * H + ay];
+        g[ax * H + ay] = 0xFFu; // the agent's cell is not free: marked in the LDS image for the length of the walk
+#if defined(MGX_EXP_DYN) && (MGX_EXP_DYN & 8) /* check aid: every placement through the loop */
+        int slow_from = 0;
+#else
+        int slow_from = n_obst; // first obstacle this lane takes through the loop below
+#endif
+        int slow_tries = 0;     // ... and the samples that obstacle has already missed
+        for (int i = 0; i < n_obst; i++) { // (wave-uniform trip count)
+            const bool mine = slow_from == n_obst;
+            const uint32_t o = (i < 4 ? ow.x >> (8 * i) : ow.y >> (8 * (i - 4))) & 255u; // x << 4 | y
+            const int tx = (int)(o >> 4) - 1, ty = (int)(o & 15u) - 1; // top = old_pos + (-1, -1): interior, never clipped
+            const uint8_t *b = g + tx * H + ty;
+            uint32_t c00 = 0, c01 = 0, c02 = 0, c10 = 0, c11 = 0, c12 = 0, c20 = 0, c21 = 0, c22 = 0;
+            if (mine) { c00 = b[0]; c01 = b[1]; c02 = b[2]; c10 = b[H]; c11 = b[H + 1]; c12 = b[H + 2]; c20 = b[2 * H]; c21 = b[2 * H + 1]; c22 = b[2 * H + 2]; }
+            const uint32_t F = MGX_CODE_EMPTY;
+            const bool f00 = c00 == F, f01 = c01 == F, f02 = c02 == F, f10 = c10 == F, f11 = c11 == F, f12 = c12 == F, f20 = c20 == F, f21 = c21 == F, f22 = c22 == F;
+            bool pending = mine;
+            int tries = 0;
+            if (pending && !(f00 || f01 || f02 || f10 || f11 || f12 || f20 || f21 || f22)) {
+                // no free cell in the box: all 101 samples fail, and all that is left of them is their 202 draws
+                if (rtot - rpos >= 202u) { rpos += 202u; navail = 0u; } // (the next sample loads the window at the new rank)
+                else { slow_from = i; slow_tries = 0; }                // (the tape ends first)
+                pending = false;
+            }
+            // rounds of up to 16 samples (one is the rule; a box with one or two free cells may take more)
+            while (__ballot(pending)) { // wave-uniform
+                if (pending) {
+                    if (navail < 2u) { // the window is used up: the next 64 draws of the tape -- or, at the tape's end, the loop below
+                        if (rtot - rpos < 2u) { slow_from = i; slow_tries = tries; pending = false; }
+                        else { dyn_window(tape_l, rpos, wl, wh); navail = rtot - rpos < 64u ? rtot - rpos : 64u; }
+                    }
+                }
+                if (pending) {
+                    const uint32_t E = 0x55555555u, l = (uint32_t)wl, h = (uint32_t)wh;
+                    const uint32_t x1 = l & E, x2 = h & E, y1 = (l >> 1) & E, y2 = (h >> 1) & E;
+                    const uint32_t x0 = E & ~(x1 | x2), y0 = E & ~(y1 | y2);
+                    const uint32_t s0 = (f00 ? y0 : 0u) | (f01 ? y1 : 0u) | (f02 ? y2 : 0u);
+                    const uint32_t s1 = (f10 ? y0 : 0u) | (f11 ? y1 : 0u) | (f12 ? y2 : 0u);
+                    const uint32_t s2 = (f20 ? y0 : 0u) | (f21 ? y1 : 0u) | (f22 ? y2 : 0u);
+                    uint32_t hit = (x0 & s0) | (x1 & s1) | (x2 & s2);
+                    uint32_t ns = navail >> 1; // whole samples at hand, 16 looked at, 101 at most for one obstacle
+                    ns = ns < 16u ? ns : 16u;
+                    ns = ns < (uint32_t)(101 - tries) ? ns : (uint32_t)(101 - tries);
+                    if (ns < 16u) hit &= (1u << (2u * ns)) - 1u;
+                    if (hit != 0u) {
+                        const uint32_t bp = (uint32_t)__builtin_ctz(hit); // even: the sample's dx draw
+                        const int x = tx + (int)(((l >> bp) & 1u) | (((h >> bp) & 1u) << 1)), y = ty + (int)(((l >> (bp + 1u)) & 1u) | (((h >> (bp + 1u)) & 1u) << 1));
+                        const uint32_t used = bp + 2u; // (<= 32)
+                        wl >>= used; wh >>= used; navail -= used; rpos += used;
+                        const int n8 = x * H + y, o8 = (tx + 1) * H + ty + 1;
+                        g[n8] = (uint8_t)MGX_CODE_BALL_BLUE;
+                        g[o8] = (uint8_t)MGX_CODE_EMPTY;
+                        const uint32_t nb = ((uint32_t)x << 4) | (uint32_t)y;
+                        if (i < 4) ow.x = (ow.x & ~(255u << (8 * i))) | (nb << (8 * i));
+                        else ow.y = (ow.y & ~(255u << (8 * (i - 4)))) | (nb << (8 * (i - 4)));
+                        pending = false;
+                    } else { // ns samples missed
+                        const uint32_t used = 2u * ns;
+                        wl >>= used; wh >>= used; navail -= used; rpos += used;
+                        tries += (int)ns;
+                        if (tries >= 101) pending = false; // num_tries > max_tries raises (101 samples at most); the RecursionError is
+                                                           // swallowed by the bare except: the obstacle stays
+                    }
                 }
             }
-            if (pending) {
-                const uint32_t E = 0x55555555u, l = (uint32_t)wl, h = (uint32_t)wh;
-                const uint32_t x1 = l & E, x2 = h & E, y1 = (l >> 1) & E, y2 = (h >> 1) & E;
-                const uint32_t x0 = E & ~(x1 | x2), y0 = E & ~(y1 | y2);
-                const uint32_t s0 = (f00 ? y0 : 0u) | (f01 ? y1 : 0u) | (f02 ? y2 : 0u);
-                const uint32_t s1 = (f10 ? y0 : 0u) | (f11 ? y1 : 0u) | (f12 ? y2 : 0u);
-                const uint32_t s2 = (f20 ? y0 : 0u) | (f21 ? y1 : 0u) | (f22 ? y2 : 0u);
-                uint32_t hit = (x0 & s0) | (x1 & s1) | (x2 & s2);
-                uint32_t ns = navail >> 1; // whole samples at hand, 16 looked at, 101 at most for one obstacle
-                ns = ns < 16u ? ns : 16u;
-                ns = ns < (uint32_t)(101 - tries) ? ns : (uint32_t)(101 - tries);
-                if (ns < 16u) hit &= (1u << (2u * ns)) - 1u;
-                if (hit != 0u) {
-                    const uint32_t bp = (uint32_t)__builtin_ctz(hit); // even: the sample's dx draw
-                    const int x = tx + (int)(((l >> bp) & 1u) | (((h >> bp) & 1u) << 1)), y = ty + (int)(((l >> (bp + 1u)) & 1u) | (((h >> (bp + 1u)) & 1u) << 1));
-                    const uint32_t used = bp + 2u; // (<= 32)
-                    wl >>= used; wh >>= used; navail -= used; rpos += used;
+        }
+        // ---- the reference's loop, draw by draw, for a lane whose walk reaches the end of the tape within this step
+        // next window of the tape; false once the tape is used up (the word-by-word source goes on behind stream position 848)
+        auto refill = [&]() -> bool {
+            if (r.p != 0xFFFFFFFFu) return false;
+            if (rpos >= rtot) { r.take_over(); return false; }
+            dyn_window(tape_l, rpos, wl, wh);
+            navail = rtot - rpos < 64u ? rtot - rpos : 64u;
+            return true;
+        };
+        auto draw3 = [&]() -> int {
+            if (navail == 0u && !refill()) return r.draw3();
+            const int v = (int)(((uint32_t)wl & 1u) | (((uint32_t)wh & 1u) << 1));
+            wl >>= 1; wh >>= 1; navail--; rpos++;
+            return v;
+        };
+        // n accepted draws whose values nobody looks at (a placement that cannot succeed still draws 2 x 101 times)
+        auto skip_draws = [&](uint32_t n) {
+            if (r.p == 0xFFFFFFFFu) {
+                const uint32_t take = rtot - rpos < n ? rtot - rpos : n;
+                rpos += take; n -= take; navail = 0u; // (the next draw loads the window at the new rank)
+                if (n == 0u) return;
+                r.take_over();
+            }
+            for (; n > 0u; n--) (void)r.draw3();
+        };
+        // One loop over (obstacle, try) per lane, not a try loop per obstacle: flattened, the wave runs for the lane with the most
+        // samples in total instead of the sum over obstacles of the per-obstacle maxima.
+#if defined(MGX_EXP_DYN) && (MGX_EXP_DYN & 32) /* count: lanes / waves that take the loop, lane-steps */
+        if (slow_from != n_obst) atomicAdd(&g_dyn_count[0], 1ull);
+        if (__ballot(slow_from != n_obst) && lane == __builtin_ctzll(__ballot(1))) atomicAdd(&g_dyn_count[1], 1ull);
+        atomicAdd(&g_dyn_count[2], 1ull);
+#endif
+#if defined(MGX_EXP_DYN) && (MGX_EXP_DYN & 16) /* timing only (wrong results): nobody takes the loop */
+        slow_from = n_obst;
+#endif
+        bool look = true;
+        for (int i = slow_from, tries = slow_tries; i < n_obst;) {
+            const uint32_t o = (i < 4 ? ow.x >> (8 * i) : ow.y >> (8 * (i - 4))) & 255u; // x << 4 | y
+            const int tx = (int)(o >> 4) - 1, ty = (int)(o & 15u) - 1;
+            bool give_up = false;
+            if (look) { // before an obstacle's first sample here: look at the 3x3 box -- with no free cell in it the remaining samples are
+                        // known to fail, and all that is left of them is their draws
+                look = false;
+                bool any = false;
+#pragma unroll
+                for (int dxy = 0; dxy < 9; dxy++) {
+                    const int x = tx + dxy / 3, y = ty + dxy % 3;
+                    any = any || g[x * H + y] == MGX_CODE_EMPTY;
+                }
+                if (!any) { skip_draws(2u * (uint32_t)(101 - tries)); give_up = true; }
+            }
+            if (!give_up) {
+                const int x = tx + draw3(), y = ty + draw3();
+                if (g[x * H + y] == MGX_CODE_EMPTY) { // (the agent's cell carries the mark)
                     const int n8 = x * H + y, o8 = (tx + 1) * H + ty + 1;
                     g[n8] = (uint8_t)MGX_CODE_BALL_BLUE;
                     g[o8] = (uint8_t)MGX_CODE_EMPTY;
                     const uint32_t nb = ((uint32_t)x << 4) | (uint32_t)y;
                     if (i < 4) ow.x = (ow.x & ~(255u << (8 * i))) | (nb << (8 * i));
                     else ow.y = (ow.y & ~(255u << (8 * (i - 4)))) | (nb << (8 * (i - 4)));
-                    pending = false;
-                } else { // ns samples missed
-                    const uint32_t used = 2u * ns;
-                    wl >>= used; wh >>= used; navail -= used; rpos += used;
-                    tries += (int)ns;
-                    if (tries >= 101) pending = false; // num_tries > max_tries raises (101 samples at most); the RecursionError is
-                                                       // swallowed by the bare except: the obstacle stays
+                    i++; tries = 0; look = true;
+                    continue;
                 }
+                give_up = ++tries > 100; // (101 samples at most)
             }
+            if (give_up) { i++; tries = 0; look = true; }
         }
+        reinterpret_cast<uint2 *>(p.obst)[env] = ow;
+        // (rank >= R624: the next step's service loop twists the block first)
+        p.pos[env] = r.p == 0xFFFFFFFFu ? (rpos | (r624 << 10) | (rtot << 20) | (dirty ? MGX_DYN_DIRTY : 0u)) : (r.p | MGX_DYN_INPLACE | MGX_DYN_DIRTY);
+        p.act_out[env] = (uint8_t)(a | ((a == 2u && not_clear) ? 0x80u : 0u));
+        // the gather form of k_step (16x16) keeps the cell in front of the agent from its last observation pass; the walk has just made that
+        // stale, and this kernel has the image at hand (0 = unknown: outside the grid)
+        if (p.front) p.front[env] = (fx >= 0 && fx < W && fy >= 0 && fy < H) ? g[fx * H + fy] : (uint8_t)0;
+        g[ax * H + ay] = under_agent;
     }
-    // ---- the reference's loop, draw by draw, for a lane whose walk reaches the end of the tape within this step
-    // next window of the tape; false once the tape is used up (the word-by-word source goes on behind stream position 848)
-    auto refill = [&]() -> bool {
-        if (r.p != 0xFFFFFFFFu) return false;
-        if (rpos >= rtot) { r.take_over(); return false; }
-        dyn_window(tape_l, rpos, wl, wh);
-        navail = rtot - rpos < 64u ? rtot - rpos : 64u;
-        return true;
-    };
-    auto draw3 = [&]() -> int {
-        if (navail == 0u && !refill()) return r.draw3();
-        const int v = (int)(((uint32_t)wl & 1u) | (((uint32_t)wh & 1u) << 1));
-        wl >>= 1; wh >>= 1; navail--; rpos++;
-        return v;
-    };
-    // n accepted draws whose values nobody looks at (a placement that cannot succeed still draws 2 x 101 times)
-    auto skip_draws = [&](uint32_t n) {
-        if (r.p == 0xFFFFFFFFu) {
-            const uint32_t take = rtot - rpos < n ? rtot - rpos : n;
-            rpos += take; n -= take; navail = 0u; // (the next draw loads the window at the new rank)
-            if (n == 0u) return;
-            r.take_over();
-        }
-        for (; n > 0u; n--) (void)r.draw3();
-    };
-    // One loop over (obstacle, try) per lane, not a try loop per obstacle: flattened, the wave runs for the lane with the most
-    // samples in total instead of the sum over obstacles of the per-obstacle maxima.
-#if defined(MGX_EXP_DYN) && (MGX_EXP_DYN & 32) /* count: lanes / waves that take the loop, lane-steps */
-    if (slow_from != n_obst) atomicAdd(&g_dyn_count[0], 1ull);
-    if (__ballot(slow_from != n_obst) && lane == __builtin_ctzll(__ballot(1))) atomicAdd(&g_dyn_count[1], 1ull);
-    atomicAdd(&g_dyn_count[2], 1ull);
-#endif
-#if defined(MGX_EXP_DYN) && (MGX_EXP_DYN & 16) /* timing only (wrong results): nobody takes the loop */
-    slow_from = n_obst;
-#endif
-    bool look = true;
-    for (int i = slow_from, tries = slow_tries; i < n_obst;) {
-        const uint32_t o = (i < 4 ? ow.x >> (8 * i) : ow.y >> (8 * (i - 4))) & 255u; // x << 4 | y
-        const int tx = (int)(o >> 4) - 1, ty = (int)(o & 15u) - 1;
-        bool give_up = false;
-        if (look) { // before an obstacle's first sample here: look at the 3x3 box -- with no free cell in it the remaining samples are
-                    // known to fail, and all that is left of them is their draws
-            look = false;
-            bool any = false;
-#pragma unroll
-            for (int dxy = 0; dxy < 9; dxy++) {
-                const int x = tx + dxy / 3, y = ty + dxy % 3;
-                any = any || g[x * H + y] == MGX_CODE_EMPTY;
-            }
-            if (!any) { skip_draws(2u * (uint32_t)(101 - tries)); give_up = true; }
-        }
-        if (!give_up) {
-            const int x = tx + draw3(), y = ty + draw3();
-            if (g[x * H + y] == MGX_CODE_EMPTY) { // (the agent's cell carries the mark)
-                const int n8 = x * H + y, o8 = (tx + 1) * H + ty + 1;
-                g[n8] = (uint8_t)MGX_CODE_BALL_BLUE;
-                g[o8] = (uint8_t)MGX_CODE_EMPTY;
-                const uint32_t nb = ((uint32_t)x << 4) | (uint32_t)y;
-                if (i < 4) ow.x = (ow.x & ~(255u << (8 * i))) | (nb << (8 * i));
-                else ow.y = (ow.y & ~(255u << (8 * (i - 4)))) | (nb << (8 * (i - 4)));
-                i++; tries = 0; look = true;
-                continue;
-            }
-            give_up = ++tries > 100; // (101 samples at most)
-        }
-        if (give_up) { i++; tries = 0; look = true; }
-    }
-    reinterpret_cast<uint2 *>(p.obst)[env] = ow;
-    // (rank >= R624: the next step's service loop twists the block first)
-    p.pos[env] = r.p == 0xFFFFFFFFu ? (rpos | (r624 << 10) | (rtot << 20) | (dirty ? MGX_DYN_DIRTY : 0u)) : (r.p | MGX_DYN_INPLACE | MGX_DYN_DIRTY);
-    p.act_out[env] = (uint8_t)(a | ((a == 2u && not_clear) ? 0x80u : 0u));
-    // the gather form of k_step (16x16) keeps the cell in front of the agent from its last observation pass; the walk has just made that
-    // stale, and this kernel has the image at hand (0 = unknown: outside the grid)
-    if (p.front) p.front[env] = (fx >= 0 && fx < W && fy >= 0 && fy < H) ? g[fx * H + fy] : (uint8_t)0;
-    g[ax * H + ay] = under_agent;
-    }
-    // The moved obstacles go back as the whole tile, coalesced (64 x S bytes per wave).  Written through cell by cell -- two byte stores
-    // per moved obstacle and lane, each to a line of its own -- they were what the walk cost: 95 of k_dynobs' 113 us at 1 Mi 8x8 envs
-    // went to 8 Mi scattered byte stores (measured by leaving the walk out), not to the draws.
+    // The moved obstacles go back as the whole tile, coalesced (64 x S bytes per wave), not cell by cell (two byte stores per moved obstacle
+    // and lane, each to a line of its own: 111 -> 99 us per launch at 1 Mi 8x8 envs).
     wave_sync();
     unstage_tile<CS>(p.cells, env0, S, LS, lds, lane);
 }
