@@ -123,8 +123,7 @@ template <class R>
 LG_FN uint32_t lg_bounded(R &r, uint32_t max)
 {
     if (max == 0) return 0;
-    uint32_t mask = max;
-    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    const uint32_t mask = 0xFFFFFFFFu >> __builtin_clz(max); // smallest 2^k - 1 >= max (max != 0): the smear of max's top bit in two instructions
     uint32_t v;
     do { v = r.next32() & mask; } while (v > max);
     return v;
