@@ -42,6 +42,10 @@ struct WinRng {
 #pragma unroll
         for (int k = 0; k < MGX_LGF_WIN; k++) win[k] = t[k];
     }
+    // The word of the NEXT draw is read from the window right behind each draw (`ahead`): a draw is an LDS read, a tempering and a compare
+    // in a rejection loop, every one waiting for the one before; read one draw early, the ~100 cycles of the LDS round trip pass under
+    // the caller's work instead of in front of it.  (One word past the window's valid part is read and never used.)
+    uint32_t ahead;
     __device__ __forceinline__ uint32_t next32()
     {
         if (idx >= limit) {
@@ -49,8 +53,12 @@ struct WinRng {
             base = idx;
             limit = base + MGX_LGF_WIN < stop_of(base) ? base + MGX_LGF_WIN : stop_of(base);
             fill(base);
+            ahead = win[0];
         }
-        return lg_temper(win[idx++ - base]);
+        const uint32_t w = ahead;
+        idx++;
+        ahead = win[idx - base]; // (index <= MGX_LGF_WIN: the word behind the window is this lane's own slice)
+        return lg_temper(w);
     }
 };
 
@@ -244,6 +252,7 @@ __device__ __forceinline__ bool fast_level(const LevelGenParams &p, const FastLa
     r.base = idx0; r.idx = idx0; r.overflow = false;
     r.limit = idx0 + MGX_LGF_WIN < r.stop_of(idx0) ? idx0 + MGX_LGF_WIN : r.stop_of(idx0);
     r.fill(idx0);
+    r.ahead = slice[0];
     LgLevel L;
     L.cmds = reinterpret_cast<LgCmd *>(slice + MGX_LGF_WIN); L.ncmd = 0; L.max_cmds = fl.cmd_cap;
     L.ws = reinterpret_cast<int16_t *>(slice + MGX_LGF_WIN + 2 * fl.cmd_cap); L.max_rivers = fl.river_cap;
