@@ -276,69 +276,104 @@ LG_FN void lg_gen_distshift(const mgx_config &c, R &, LgLevel &L)
 // successful child, so it is a plain chain: place room 0, then up to 8 tries to attach the next room to the last one,
 // and so on; a chain that ends early is retried from scratch and the longest one wins (multiroom.py:46-66).
 // Rooms live in L.ws as 6 words each (topX, topY, sizeX, sizeY, entryX, entryY): two lists of up to 8 rooms.
+// The room search as a state machine, one ROOM TRY per call (the body of _placeRoom's loop): the host runs it in a plain loop, the GPU's
+// lane-per-level path runs 16 of them side by side and hands a lane its next level as soon as this one is done (k_levelgen.hip) -- as
+// one call per level the lanes of a wave waited for the longest search among them (0.35 lane efficiency).
+struct LgMultiRoom {
+    int numRooms, maxSz, nbest; // rooms wanted, largest room, length of the best chain so far (its rooms: L.ws[0..6*nbest))
+    int n, entryWall, ex, ey, tries; // the chain being built (its rooms: L.ws[48..)): rooms placed, the next room's entry door, exits tried from the parent
+    bool fresh;                      // the next call starts a new chain (draws its first entry door)
+};
+
 template <class R>
-LG_FN int lg_multiroom_chain(R &r, LgLevel &L, int16_t *rooms, int numRooms, int maxSz)
+LG_FN bool lg_multiroom_begin(const mgx_config &c, R &r, LgLevel &L, LgMultiRoom &m)
+{
+    const int minRooms = c.level_arg0 & 255, maxRooms = (c.level_arg0 >> 8) & 255;
+    L.ncmd = 0;
+    if (6 * L.max_rivers < 96 + 8 || maxRooms > 8) { L.too_big = true; return false; } // needs the full-size workspace
+    m.maxSz = c.level_arg1;
+    m.numRooms = lg_randint(r, minRooms, maxRooms + 1);
+    m.nbest = 0; m.n = 0; m.entryWall = 2; m.ex = m.ey = 0; m.tries = 0; m.fresh = true;
+    return true;
+}
+
+// one room try; true once a chain of numRooms rooms stands in L.ws[0..) (or the word source ran dry: test r.alive())
+template <class R>
+LG_FN bool lg_multiroom_step(R &r, LgLevel &L, LgMultiRoom &m)
 {
     const int W = L.W, H = L.H;
-    int n = 0;
-    int entryWall = 2;
-    int ex = lg_randint(r, 0, W - 2), ey = lg_randint(r, 0, W - 2);
-    int tries = 0;
-    for (;;) {
-        // _placeRoom: size, position relative to the entry door, bounds, overlap with all rooms but the parent
-        const int sx = lg_randint(r, 4, maxSz + 1), sy = lg_randint(r, 4, maxSz + 1);
-        int tx, ty;
-        if (n == 0) { tx = ex; ty = ey; }
-        else if (entryWall == 0) { tx = ex - sx + 1; ty = lg_randint(r, ey - sy + 2, ey); }
-        else if (entryWall == 1) { tx = lg_randint(r, ex - sx + 2, ex); ty = ey - sy + 1; }
-        else if (entryWall == 2) { tx = ex; ty = lg_randint(r, ey - sy + 2, ey); }
-        else { tx = lg_randint(r, ex - sx + 2, ex); ty = ey; }
-        bool ok = !(tx < 0 || ty < 0) && !(tx + sx > W || ty + sy >= H);
-        for (int k = 0; ok && k < n - 1; k++) {
-            const int16_t *q = rooms + 6 * k;
-            const bool nonOverlap = tx + sx < q[0] || q[0] + q[2] <= tx || ty + sy < q[1] || q[1] + q[3] <= ty;
-            if (!nonOverlap) ok = false;
-        }
-        if (!r.alive()) return n;
-        if (ok) {
-            int16_t *q = rooms + 6 * n;
-            q[0] = (int16_t)tx; q[1] = (int16_t)ty; q[2] = (int16_t)sx; q[3] = (int16_t)sy; q[4] = (int16_t)ex; q[5] = (int16_t)ey;
-            n++;
-            tries = 0;
-            if (n == numRooms) return n; // numLeft == 1
-        } else {
-            if (n == 0) return 0;        // the first room did not fit: the caller starts over
-            if (++tries == 8) return n;  // the parent gives up after 8 exit doors
-        }
-        // parent = last placed room: pick the exit wall (not its entry wall) and the exit door on it
-        const int16_t *pr = rooms + 6 * (n - 1);
-        const int pEntryWall = (n == 1) ? 2 : L.ws[96 + n - 1]; // entry wall of each placed room, kept behind the lists
-        int walls[3], nw = 0;
-        for (int w = 0; w < 4; w++) if (w != pEntryWall) walls[nw++] = w;
-        const int exitWall = walls[lg_randint(r, 0, 3)];
-        entryWall = (exitWall + 2) % 4;
-        if (exitWall == 0) { ex = pr[0] + pr[2] - 1; ey = pr[1] + lg_randint(r, 1, pr[3] - 1); }
-        else if (exitWall == 1) { ex = pr[0] + lg_randint(r, 1, pr[2] - 1); ey = pr[1] + pr[3] - 1; }
-        else if (exitWall == 2) { ex = pr[0]; ey = pr[1] + lg_randint(r, 1, pr[3] - 1); }
-        else { ex = pr[0] + lg_randint(r, 1, pr[2] - 1); ey = pr[1]; }
-        L.ws[96 + n] = (int16_t)entryWall; // becomes the entry wall of room n if it gets placed
+    int16_t *best = L.ws, *rooms = L.ws + 48;
+    if (m.fresh) { // a new chain: its first entry door
+        m.n = 0; m.entryWall = 2; m.tries = 0; m.fresh = false;
+        m.ex = lg_randint(r, 0, W - 2); m.ey = lg_randint(r, 0, W - 2);
     }
+    const int n = m.n, entryWall = m.entryWall, ex = m.ex, ey = m.ey;
+    // _placeRoom: size, position relative to the entry door, bounds, overlap with all rooms but the parent
+    const int sx = lg_randint(r, 4, m.maxSz + 1), sy = lg_randint(r, 4, m.maxSz + 1);
+    int tx, ty;
+    if (n == 0) { tx = ex; ty = ey; }
+    else if (entryWall == 0) { tx = ex - sx + 1; ty = lg_randint(r, ey - sy + 2, ey); }
+    else if (entryWall == 1) { tx = lg_randint(r, ex - sx + 2, ex); ty = ey - sy + 1; }
+    else if (entryWall == 2) { tx = ex; ty = lg_randint(r, ey - sy + 2, ey); }
+    else { tx = lg_randint(r, ex - sx + 2, ex); ty = ey; }
+    bool ok = !(tx < 0 || ty < 0) && !(tx + sx > W || ty + sy >= H);
+    for (int k = 0; ok && k < n - 1; k++) {
+        const int16_t *q = rooms + 6 * k;
+        const bool nonOverlap = tx + sx < q[0] || q[0] + q[2] <= tx || ty + sy < q[1] || q[1] + q[3] <= ty;
+        if (!nonOverlap) ok = false;
+    }
+    bool chain_over = false;
+    if (!r.alive()) chain_over = true;
+    else if (ok) {
+        int16_t *q = rooms + 6 * n;
+        q[0] = (int16_t)tx; q[1] = (int16_t)ty; q[2] = (int16_t)sx; q[3] = (int16_t)sy; q[4] = (int16_t)ex; q[5] = (int16_t)ey;
+        m.n = n + 1;
+        m.tries = 0;
+        if (m.n == m.numRooms) chain_over = true; // numLeft == 1
+    } else {
+        if (n == 0) chain_over = true;             // the first room did not fit: start over
+        else if (++m.tries == 8) chain_over = true; // the parent gives up after 8 exit doors
+    }
+    if (chain_over) { // the longest chain wins (multiroom.py:46-66)
+        if (!r.alive()) return true;
+        if (m.n > m.nbest) { for (int i = 0; i < 6 * m.n; i++) best[i] = rooms[i]; m.nbest = m.n; }
+        m.fresh = true;
+        return m.nbest >= m.numRooms;
+    }
+    // parent = last placed room: pick the exit wall (not its entry wall) and the exit door on it
+    const int np = m.n;
+    const int16_t *pr = rooms + 6 * (np - 1);
+    const int pEntryWall = (np == 1) ? 2 : L.ws[96 + np - 1]; // entry wall of each placed room, kept behind the lists
+    int walls[3], nw = 0;
+    for (int w = 0; w < 4; w++) if (w != pEntryWall) walls[nw++] = w;
+    const int exitWall = walls[lg_randint(r, 0, 3)];
+    m.entryWall = (exitWall + 2) % 4;
+    if (exitWall == 0) { m.ex = pr[0] + pr[2] - 1; m.ey = pr[1] + lg_randint(r, 1, pr[3] - 1); }
+    else if (exitWall == 1) { m.ex = pr[0] + lg_randint(r, 1, pr[2] - 1); m.ey = pr[1] + pr[3] - 1; }
+    else if (exitWall == 2) { m.ex = pr[0]; m.ey = pr[1] + lg_randint(r, 1, pr[3] - 1); }
+    else { m.ex = pr[0] + lg_randint(r, 1, pr[2] - 1); m.ey = pr[1]; }
+    L.ws[96 + np] = (int16_t)m.entryWall; // becomes the entry wall of room np if it gets placed
+    return false;
 }
+
+template <class R>
+LG_FN void lg_multiroom_finish(R &r, LgLevel &L, const LgMultiRoom &m);
 
 template <class R>
 LG_FN void lg_gen_multiroom(const mgx_config &c, R &r, LgLevel &L)
 {
-    const int minRooms = c.level_arg0 & 255, maxRooms = (c.level_arg0 >> 8) & 255, maxSz = c.level_arg1;
-    L.ncmd = 0;
-    if (6 * L.max_rivers < 96 + 8 || maxRooms > 8) { L.too_big = true; return; } // needs the full-size workspace
-    int16_t *best = L.ws, *cur = L.ws + 48;
-    const int numRooms = lg_randint(r, minRooms, maxRooms + 1);
-    int nbest = 0;
-    while (nbest < numRooms) {
-        const int n = lg_multiroom_chain(r, L, cur, numRooms, maxSz);
-        if (!r.alive()) return;
-        if (n > nbest) { for (int i = 0; i < 6 * n; i++) best[i] = cur[i]; nbest = n; }
-    }
+    LgMultiRoom m;
+    if (!lg_multiroom_begin(c, r, L, m)) return;
+    while (!lg_multiroom_step(r, L, m)) {}
+    if (!r.alive()) return;
+    lg_multiroom_finish(r, L, m);
+}
+
+template <class R>
+LG_FN void lg_multiroom_finish(R &r, LgLevel &L, const LgMultiRoom &m)
+{
+    const int16_t *best = L.ws;
+    const int nbest = m.nbest;
     // draw: walls of every room, then (from the second room on) its entry door in a colour other than the previous door's
     const int sortedColors[7] = {2, 1, 5, 3, 0, 6, 4}; // sorted(COLOR_NAMES): blue green grey purple red white yellow
     int prevColor = -1;
