@@ -240,20 +240,18 @@ static_assert(MGX_LG_LDS_PER_WAVE == MGX_LG_LDS_PER_WAVE_BYTES, "keep mgx_kernel
 // [0, 32) RNG window | 2*cmd_cap paint commands | 3*river_cap crossing lists | img_dw level image (rows <= 128 B) | 1 pad.
 struct FastLayout { int cmd_cap, river_cap, img_dw, slice_dw, n_fast_waves, span, lanes, queue_off; }; // lanes: generating lanes per fast wave (64, or fewer for the long-tailed generators)
 
+// the lane's word source and level buffers set up in its slice; false: this env's block is used up (slow path)
 template <bool SLIDE>
-__device__ __forceinline__ bool fast_level(const LevelGenParams &p, const FastLayout &fl, int64_t env, uint32_t *slice, int W, int H, int cells, bool &crossed)
+__device__ __forceinline__ bool fast_setup(const LevelGenParams &p, const FastLayout &fl, int64_t env, uint32_t *slice, int W, int H, int cells, WinRng<SLIDE> &r, LgLevel &L)
 {
-    crossed = false;
     const int idx0 = (int)p.mt_idx[env];
     const int end = p.mt2 ? 1248 : 624; // stream positions this env has ready: its block, and the next one where the handle keeps it
     if (idx0 >= 624 || (!SLIDE && (idx0 + MGX_LGF_WIN > end || fl.img_dw == 0))) return false;
-    WinRng<SLIDE> r;
     r.win = slice; r.mt = p.mt + env * 624; r.mt2 = p.mt2 ? p.mt2 + env * 624 : nullptr; r.end = end;
     r.base = idx0; r.idx = idx0; r.overflow = false;
     r.limit = idx0 + MGX_LGF_WIN < r.stop_of(idx0) ? idx0 + MGX_LGF_WIN : r.stop_of(idx0);
     r.fill(idx0);
     r.ahead = slice[0];
-    LgLevel L;
     L.cmds = reinterpret_cast<LgCmd *>(slice + MGX_LGF_WIN); L.ncmd = 0; L.max_cmds = fl.cmd_cap;
     L.ws = reinterpret_cast<int16_t *>(slice + MGX_LGF_WIN + 2 * fl.cmd_cap); L.max_rivers = fl.river_cap;
     L.W = W; L.H = H; L.ax = L.ay = -1; L.adir = 0;
@@ -264,13 +262,20 @@ __device__ __forceinline__ bool fast_level(const LevelGenParams &p, const FastLa
         for (int c = cells & ~3; c < cells; c++) img[c] = MGX_CODE_EMPTY;
         L.occ = img;
     }
-    lg_generate(p.cfg, r, L);
+    return true;
+}
+
+// the generated level into the env's next-level buffer; false: it has to be made again by the slow path
+template <bool SLIDE>
+__device__ __forceinline__ bool fast_store(const LevelGenParams &p, const FastLayout &fl, int64_t env, uint32_t *slice, int H, int cells, const WinRng<SLIDE> &r, const LgLevel &L, bool &crossed)
+{
     if (r.overflow || L.too_big) return false;
+    uint32_t *img32 = slice + MGX_LGF_WIN + 2 * fl.cmd_cap + 3 * fl.river_cap;
     uint32_t *dst = reinterpret_cast<uint32_t *>(p.cells0 + env * p.S);
     if (fl.img_dw) {
         for (int k = 0; k < (p.S >> 2); k++) dst[k] = img32[k]; // one pass of dword stores
     } else {
-        // rows too long for the slice (13x13 and up): paint straight into the env's row in HBM (this lane's own stores,
+        // rows too long for the slice (25x25 and up): paint straight into the env's row in HBM (this lane's own stores,
         // in order)
         uint8_t *dstb = reinterpret_cast<uint8_t *>(dst);
         for (int k = 0; k < (p.S >> 2); k++) dst[k] = 4 * k + 3 < cells ? 0x01010101u * MGX_CODE_EMPTY : 0u;
@@ -297,6 +302,17 @@ __device__ __forceinline__ bool fast_level(const LevelGenParams &p, const FastLa
     p.mt_idx[env] = (uint32_t)(crossed ? r.idx - 624 : r.idx);
     p.agent0[env] = make_uint2((uint32_t)((L.ax & 255) | ((L.ay & 255) << 8) | ((L.adir & 3) << 16)) | ((uint32_t)MGX_CODE_EMPTY << 24), L.task << 16);
     return true;
+}
+
+template <bool SLIDE>
+__device__ __forceinline__ bool fast_level(const LevelGenParams &p, const FastLayout &fl, int64_t env, uint32_t *slice, int W, int H, int cells, bool &crossed)
+{
+    crossed = false;
+    WinRng<SLIDE> r;
+    LgLevel L;
+    if (!fast_setup<SLIDE>(p, fl, env, slice, W, H, cells, r, L)) return false;
+    lg_generate(p.cfg, r, L);
+    return fast_store<SLIDE>(p, fl, env, slice, H, cells, r, L, crossed);
 }
 
 // (4 waves per SIMD = 128 VGPRs instead of 151, no spills: MultiRoom's four blocks per CU need them)
