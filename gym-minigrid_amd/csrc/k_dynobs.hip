@@ -23,12 +23,10 @@
 namespace {
 __global__ __launch_bounds__(256) void k_dynobs_init(const DynObsParams p)
 {
-    // snapshot of the RNG block (coalesced: 156 uint4 per env) of the envs this reset really re-seeded
+    // (the snapshot of the RNG block of the envs this reset really re-seeded is taken by k_dynobs_tape, which has the block in registers
+    // anyway: as 156 threads per env here -- 163 M threads at 1 Mi envs whatever the mask -- it made every caller-side reset(mask) of these
+    // handles a 100 us launch)
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < p.n * 156) {
-        const int64_t e = t / 156;
-        if ((!p.mask_reset || p.mask_reset[e]) && (!p.mask || p.mask[e])) reinterpret_cast<uint4 *>(p.mt0)[t] = reinterpret_cast<const uint4 *>(p.mt)[t];
-    }
     if (t >= p.n || (p.mask_reset && !p.mask_reset[t])) return;
     if (p.mask && !p.mask[t]) { // reset with the seed it already has: the next k_dynobs restores order, RNG position and block
         p.regen[t] = 1;
@@ -215,7 +213,7 @@ __global__ __launch_bounds__(256) void k_dynobs_tape(const DynObsParams p)
 #pragma unroll
         for (int i = 0; i < 10; i++) { const int k = lane + 64 * i; v[i] = src[k < 624 ? k : 623]; }
 #pragma unroll
-        for (int i = 0; i < 10; i++) { const int k = lane + 64 * i; if (k < 624) blk[k] = v[i]; }
+        for (int i = 0; i < 10; i++) { const int k = lane + 64 * i; if (k < 624) { blk[k] = v[i]; p.mt0[e * 624 + k] = v[i]; } } // (+ the episode-start snapshot)
         wave_sync();
         uint32_t r624, rtot;
         const uint32_t want = (uint32_t)__shfl((int)raw, el);
@@ -548,9 +546,8 @@ __global__ __launch_bounds__(256) MGX_DYN_OCC void k_dynobs(const DynObsParams p
 
 hipError_t mgx_launch_dynobs_init(const DynObsParams &p, hipStream_t st)
 {
-    const int64_t total = p.n * 156;
-    if (total == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_dynobs_init, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+    if (p.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_dynobs_init, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, st, p);
     hipLaunchKernelGGL(k_dynobs_tape, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, st, p); // tapes of the re-seeded envs' blocks
     return hipGetLastError();
 }
