@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void k_dynobs_tape(const DynObsParams p)
         const uint32_t want = (uint32_t)__shfl((int)raw, el);
         const uint32_t rank = dyn_build_tape<true>(blk, tp, strip, slot, lane, want < 624u ? want : 624u, r624, rtot);
         if (lane < MGX_DYN_TAPE_DW) { p.tape[e * MGX_DYN_TAPE_DW + lane] = tp[lane]; p.tape0[e * MGX_DYN_TAPE_DW + lane] = tp[lane]; }
-        if (lane == el) { const uint32_t w = rank | (r624 << 10) | (rtot << 20); p.pos[e] = w; p.pos0[e] = w; }
+        if (lane == el) { const uint32_t w = rank | (r624 << 10) | (rtot << 20); p.pos[e] = w; p.pos0[e] = w; p.sp0[e] = want; }
         wave_sync();
     }
 }
@@ -256,11 +256,19 @@ __global__ __launch_bounds__(256) MGX_DYN_OCC void k_dynobs(const DynObsParams p
     bool dirty = (pos & MGX_DYN_DIRTY) != 0u;     // the block in memory is no longer the episode-start block
     bool inplace = (pos & MGX_DYN_INPLACE) != 0u; // `pos` is a stream position and words [0, pos - 624) of the next block were generated in place
     pos &= 0x3FFFFFFFu;
-    const bool need_restore = regen && dirty;
-    const bool need_finish = valid && !regen && (inplace || (pos & 1023u) >= ((pos >> 10) & 1023u));
+    // (under a seed schedule the new episode runs on another seed than the last one: its block always comes from the snapshot)
+    const int bk = (p.bank && valid) ? (int)p.bank[env] : 0; // the list entry of the CURRENT episode (k_step / k_bank_advance moved it on)
+    const int64_t senv = env + (int64_t)bk * p.bank_envs;
+    const bool need_restore = regen && (dirty || p.bank != nullptr);
+    // A block is finished -- twisted on, the position re-based -- once the walk has drawn PAST its last accepted word (rank > R624; `>=` until
+    // round 4).  At rank == R624 the stream stands somewhere in the old block's tail of rejected words; the plain caller-side reset()
+    // (k_dynobs_handover) needs that position back exactly -- the level generator's next draw has another mask and may accept those words --
+    // and a re-based rank of 0 would have lost it.  The look-ahead the walk is guaranteed is the same (Rtot - R624 draws).  Without
+    // obstacles nothing is ever drawn and nothing needs finishing.
+    const bool need_finish = valid && !regen && p.n_obst > 0 && (inplace || (pos & 1023u) > ((pos >> 10) & 1023u));
     if (regen) { // the previous step ended the episode: cells/agent are already the episode start
-        ow = reinterpret_cast<const uint2 *>(p.obst0)[env];
-        pos = p.pos0[env];
+        ow = reinterpret_cast<const uint2 *>(p.obst0)[senv];
+        pos = p.pos0[senv];
         dirty = false;
         inplace = false;
         p.regen[env] = 0;
@@ -282,13 +290,14 @@ __global__ __launch_bounds__(256) MGX_DYN_OCC void k_dynobs(const DynObsParams p
         uint32_t *tape_e = p.tape + (env0 + e) * MGX_DYN_TAPE_DW;
         uint32_t pw; // env e's position word afterwards (flags aside)
         if ((m_restore >> e) & 1ull) {
-            const uint4 *src4 = reinterpret_cast<const uint4 *>(p.mt0) + (env0 + e) * 156;
+            const int64_t se = env0 + e + (int64_t)__shfl(bk, e) * p.bank_envs;
+            const uint4 *src4 = reinterpret_cast<const uint4 *>(p.mt0) + se * 156;
             { // (the three loads together, on clamped indices: a load / store pair per trip compiled to three dependent round trips)
                 uint4 v0 = src4[lane], v1 = src4[lane + 64], v2 = src4[lane + 128 < 156 ? lane + 128 : 155];
                 dst4[lane] = v0; dst4[lane + 64] = v1;
                 if (lane + 128 < 156) dst4[lane + 128] = v2;
             }
-            if (lane < MGX_DYN_TAPE_DW) { const uint32_t v = p.tape0[(env0 + e) * MGX_DYN_TAPE_DW + lane]; tape_e[lane] = v; tp[lane] = v; }
+            if (lane < MGX_DYN_TAPE_DW) { const uint32_t v = p.tape0[se * MGX_DYN_TAPE_DW + lane]; tape_e[lane] = v; tp[lane] = v; }
             pw = ps[e] & 0x3FFFFFFFu;
         } else {
             {
@@ -542,7 +551,120 @@ __global__ __launch_bounds__(256) MGX_DYN_OCC void k_dynobs(const DynObsParams p
     wave_sync();
     unstage_tile<CS>(p.cells, env0, S, LS, lds, lane);
 }
+
+// The plain caller-side reset() of a Dynamic-Obstacles env (minigrid.py:831-858 without a seed() in front: run_tests.py:64-66): the next level
+// is drawn from the stream where the obstacle walks left it.  The walk keeps that place as a RANK on the env's draw tape (or as a
+// half-regenerated block); k_levelgen wants a complete block in `mt` and a stream position in `mt_idx`.  One wave per 64 envs, one masked
+// env at a time, all 64 lanes on its block:
+//   restart pending (the in-kernel auto-reset ended the episode, the next k_dynobs would have restored it): block, position = the episode start's;
+//   stream position p (bit 30):   words [0, p % 624) of the block are the next block's already: finish it; position = p % 624;
+//   rank r, nothing drawn since the episode start: the start's stream position (sp0) -- r alone does not say where in a run of rejected
+//           words the stream stands, and the generator's next draw has another mask;
+//   rank r otherwise:  the walk's last draw was accepted word r - 1 of the tape's 848 positions, at stream index k: position k + 1; past
+//           624 the block is twisted on first.
+__global__ __launch_bounds__(256) void k_dynobs_handover(const DynObsParams p)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_blk[4][624 + 4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t env0 = ((int64_t)blockIdx.x * 4 + wv) * 64;
+    if (env0 >= p.n) return; // wave-uniform
+    const int64_t env = env0 + lane;
+    const bool mine = env < p.n && (!p.mask_reset || p.mask_reset[env]);
+    const uint32_t pw = mine ? p.pos[env] : 0u;
+    const bool restart = mine && p.regen[env];
+    const int bk = (mine && p.bank) ? (int)p.bank[env] : 0;
+    const int64_t senv = env + (int64_t)bk * p.bank_envs;
+    const uint32_t pw0 = mine ? p.pos0[senv] : 0u, sp0 = mine ? p.sp0[senv] : 0u;
+    uint32_t *blk = s_blk[wv], *slot = blk + 624;
+    for (dyn_u64 m = __ballot(mine); m; m &= m - 1) { // wave-uniform
+        const int el = __builtin_ctzll(m);
+        const int64_t e = env0 + el, se = env0 + el + (int64_t)__shfl(bk, el) * p.bank_envs;
+        const uint32_t w = (uint32_t)__shfl((int)pw, el), w0 = (uint32_t)__shfl((int)pw0, el), s0 = (uint32_t)__shfl((int)sp0, el);
+        const bool rs = __shfl((int)restart, el) != 0;
+        const bool dirty = (w & MGX_DYN_DIRTY) != 0u, raw = (w & MGX_DYN_INPLACE) != 0u;
+        const bool at_start = rs || (!dirty && !raw && (w & 0x3FFFFFFFu) == (w0 & 0x3FFFFFFFu));
+        uint32_t *dst = p.mt + e * 624;
+        if (at_start) { // (the live block is the episode start's unless the episode twisted or touched it -- or belongs to another seed)
+            if (rs && (dirty || p.bank)) {
+                const uint32_t *src = p.mt0 + se * 624;
+                uint32_t v[10];
+#pragma unroll
+                for (int i = 0; i < 10; i++) { const int k = lane + 64 * i; v[i] = src[k < 624 ? k : 623]; }
+#pragma unroll
+                for (int i = 0; i < 10; i++) { const int k = lane + 64 * i; if (k < 624) dst[k] = v[i]; }
+            }
+            if (lane == 0) p.mt_idx[e] = s0;
+            continue;
+        }
+        {
+            uint32_t v[10];
+#pragma unroll
+            for (int i = 0; i < 10; i++) { const int k = lane + 64 * i; v[i] = dst[k < 624 ? k : 623]; }
+#pragma unroll
+            for (int i = 0; i < 10; i++) { const int k = lane + 64 * i; if (k < 624) blk[k] = v[i]; }
+        }
+        wave_sync();
+        uint32_t k0 = 0, position = 0; // words [0, k0) already belong to the next block
+        bool twist = false;
+        if (raw) { k0 = (w & 0x3FFFFFFFu) % 624u; position = k0; twist = true; }
+        else {
+            const uint32_t r = w & 1023u; // (> 0: a rank of 0 is the episode start's, handled above; defensively treated as position 0)
+            uint32_t base = 0;
+            if (lane == 0) *slot = 0xFFFFFFFFu;
+            wave_sync();
+#pragma unroll 1
+            for (int rd = 0; rd < MGX_DYN_PLANE_DW / 2; rd++) {
+                const int k = 64 * rd + lane;
+                uint32_t y = 0;
+                if (k < 624) y = blk[k];
+                else if (k < MGX_DYN_POSITIONS) { const int j = k - 624; y = lg_twist_word(blk[j], blk[j + 1], blk[j + 397]); }
+                const bool acc = k < MGX_DYN_POSITIONS && temper2(y) != 3u;
+                const dyn_u64 mv = __ballot(acc);
+                const uint32_t rank = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mv >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mv, 0u));
+                if (acc && r > 0u && rank == r - 1u) *slot = (uint32_t)k;
+                base += (uint32_t)__builtin_popcountll(mv);
+            }
+            wave_sync();
+            const uint32_t k = *slot;
+            position = k == 0xFFFFFFFFu ? 0u : k + 1u;
+            if (position > 624u) { position -= 624u; twist = true; }
+        }
+        if (twist) { // the rest of the block, in chunks of <= 227 words (within one nobody needs a word the chunk itself produces), then word 623
+            uint32_t c0 = k0;
+            while (c0 < 623u) {
+                const uint32_t c1 = c0 + 227u < 623u ? c0 + 227u : 623u;
+                uint32_t y[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t jj = c0 + (uint32_t)lane + 64u * q;
+                    y[q] = 0;
+                    if (jj < c1) y[q] = lg_twist_word(blk[jj], blk[jj + 1u], jj < 227u ? blk[jj + 397u] : blk[jj - 227u]);
+                }
+                wave_sync();
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t jj = c0 + (uint32_t)lane + 64u * q;
+                    if (jj < c1) blk[jj] = y[q];
+                }
+                wave_sync();
+                c0 = c1;
+            }
+            if (lane == 0) blk[623] = lg_twist_word(blk[623], blk[0], blk[396]);
+            wave_sync();
+            for (int k = lane; k < 624; k += 64) dst[k] = blk[k];
+        }
+        if (lane == 0) p.mt_idx[e] = position;
+        wave_sync();
+    }
+}
 } // namespace
+
+hipError_t mgx_launch_dynobs_handover(const DynObsParams &p, hipStream_t st)
+{
+    if (p.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_dynobs_handover, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
 
 hipError_t mgx_launch_dynobs_init(const DynObsParams &p, hipStream_t st)
 {

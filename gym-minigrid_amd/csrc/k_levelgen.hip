@@ -400,22 +400,24 @@ __global__ __launch_bounds__(256) void k_consume(const ConsumeParams p)
     if (t < p.n * (int64_t)CPE) {
         const int64_t e = t / CPE;
         const int c = (int)(t - e * CPE);
-        const uint32_t *s = reinterpret_cast<const uint32_t *>(p.cells0 + e * p.S) + 4 * c;
+        const int64_t se = p.bank ? e + (int64_t)p.bank[e] * p.bank_envs : e; // seed schedule: the snapshot of the list entry this episode runs on
+        const uint32_t *s = reinterpret_cast<const uint32_t *>(p.cells0 + se * p.S) + 4 * c;
         uint32_t *d = reinterpret_cast<uint32_t *>(p.cells + e * p.S) + 4 * c;
         const int nd = (p.S >> 2) - 4 * c < 4 ? (p.S >> 2) - 4 * c : 4;
         for (int k = 0; k < nd; k++) d[k] = s[k];
         if (p.objaux) { // a generated level has no aux state; its boxes hold what the generator put into them (objcont0)
-            uint32_t *pl[3] = {reinterpret_cast<uint32_t *>(p.objaux + e * p.S) + 4 * c, reinterpret_cast<uint32_t *>(p.objaux0 + e * p.S) + 4 * c,
+            uint32_t *pl[3] = {reinterpret_cast<uint32_t *>(p.objaux + e * p.S) + 4 * c, reinterpret_cast<uint32_t *>(p.objaux0 + se * p.S) + 4 * c,
                                reinterpret_cast<uint32_t *>(p.objcont + e * p.S) + 4 * c};
-            const uint32_t *c0 = reinterpret_cast<const uint32_t *>(p.objcont0 + e * p.S) + 4 * c;
+            const uint32_t *c0 = reinterpret_cast<const uint32_t *>(p.objcont0 + se * p.S) + 4 * c;
             for (int k = 0; k < nd; k++) { pl[0][k] = 0u; pl[1][k] = 0u; pl[2][k] = c0[k]; }
         }
     }
     if (t < p.n) {
-        p.agent[t] = p.agent0[t];
+        p.agent[t] = p.agent0[p.bank ? t + (int64_t)p.bank[t] * p.bank_envs : t];
         if (p.regen) p.regen[t] = p.flag_regen ? 1 : 0;
         if (p.objaux) p.objcarry[t] = (uint16_t)(MGX_CODE_EMPTY << 8);
         if (p.front) p.front[t] = 0;
+        if (p.restart) p.restart[t] = 1;
     }
 }
 
@@ -427,24 +429,50 @@ __global__ __launch_bounds__(256) void k_consume_masked(const ConsumeParams p)
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool mine = t < p.n && p.mask[t];
+    const int bk = (mine && p.bank) ? (int)p.bank[t] : 0; // seed schedule: the list entry this episode runs on (k_bank_advance has moved it on)
     if (mine) {
-        p.agent[t] = p.agent0[t];
+        p.agent[t] = p.agent0[t + (int64_t)bk * p.bank_envs];
         if (p.regen) p.regen[t] = p.flag_regen ? 1 : 0;
         if (p.objaux) p.objcarry[t] = (uint16_t)(MGX_CODE_EMPTY << 8);
         if (p.front) p.front[t] = 0;
+        if (p.restart) p.restart[t] = 1;
     }
     const int SD = p.S >> 2;
     for (u64 m = __ballot(mine); m; m &= m - 1) {
-        const int64_t e = t - lane + __builtin_ctzll(m);
-        const uint32_t *s = reinterpret_cast<const uint32_t *>(p.cells0 + e * p.S);
+        const int el = __builtin_ctzll(m);
+        const int64_t e = t - lane + el;
+        const int64_t se = e + (int64_t)__shfl(bk, el) * p.bank_envs;
+        const uint32_t *s = reinterpret_cast<const uint32_t *>(p.cells0 + se * p.S);
         uint32_t *d = reinterpret_cast<uint32_t *>(p.cells + e * p.S);
         for (int i = lane; i < SD; i += 64) d[i] = s[i];
         if (p.objaux) {
-            uint32_t *a = reinterpret_cast<uint32_t *>(p.objaux + e * p.S), *a0 = reinterpret_cast<uint32_t *>(p.objaux0 + e * p.S);
-            uint32_t *c = reinterpret_cast<uint32_t *>(p.objcont + e * p.S), *c0 = reinterpret_cast<uint32_t *>(p.objcont0 + e * p.S);
+            uint32_t *a = reinterpret_cast<uint32_t *>(p.objaux + e * p.S), *a0 = reinterpret_cast<uint32_t *>(p.objaux0 + se * p.S);
+            uint32_t *c = reinterpret_cast<uint32_t *>(p.objcont + e * p.S), *c0 = reinterpret_cast<uint32_t *>(p.objcont0 + se * p.S);
             for (int i = lane; i < SD; i += 64) { a[i] = 0u; a0[i] = 0u; c[i] = c0[i]; }
         }
     }
+}
+
+// ---- small kernels of the seed schedule (mgx_set_seed_schedule) and of the plain caller-side reset()
+__global__ __launch_bounds__(256) void k_seed_column(const uint64_t *__restrict__ seeds, int K, int b, uint64_t *__restrict__ out, int64_t n)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = seeds[t * K + b];
+}
+__global__ __launch_bounds__(256) void k_bank_advance(uint8_t *bank, const uint8_t *__restrict__ mask, int K, int64_t n)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n || (mask && !mask[t])) return;
+    const int b = bank[t] + 1; // self.seed_idx = (self.seed_idx + 1) % len(self.seeds)   (wrappers.py:26)
+    bank[t] = (uint8_t)(b >= K ? 0 : b);
+}
+__global__ __launch_bounds__(256) void k_mark_plain_reset(const uint8_t *__restrict__ mask, uint8_t *regen, uint8_t *has_seed, uint8_t *reseeded, int64_t n)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n || (mask && !mask[t])) return;
+    regen[t] = 1;
+    has_seed[t] = 0;
+    reseeded[t] = 1;
 }
 
 
@@ -763,6 +791,24 @@ hipError_t mgx_launch_seed(const uint64_t *seeds, const uint8_t *mask, const uin
     const SeedBook book = {seed0, has_seed, reseeded, skip_same};
     if (mask) hipLaunchKernelGGL(k_seed_masked, dim3((unsigned)((n + MGX_SEEDM_SPAN - 1) / MGX_SEEDM_SPAN)), dim3(64), 0, st, seeds, mask, init, mt, mt2, mt_idx, regen, book, n);
     else hipLaunchKernelGGL(k_seed, dim3((unsigned)((n + MGX_SEED_SPAN - 1) / MGX_SEED_SPAN)), dim3(256), 0, st, seeds, mask, init, mt, mt2, mt_idx, regen, book, n);
+    return hipGetLastError();
+}
+
+hipError_t mgx_launch_seed_column(const uint64_t *seeds, int K, int b, uint64_t *out, int64_t n, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_seed_column, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, seeds, K, b, out, n);
+    return hipGetLastError();
+}
+
+hipError_t mgx_launch_bank_advance(uint8_t *bank, const uint8_t *mask, int K, int64_t n, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_bank_advance, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, bank, mask, K, n);
+    return hipGetLastError();
+}
+
+hipError_t mgx_launch_mark_plain_reset(const uint8_t *mask, uint8_t *regen, uint8_t *has_seed, uint8_t *reseeded, int64_t n, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_mark_plain_reset, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mask, regen, has_seed, reseeded, n);
     return hipGetLastError();
 }
 

@@ -251,11 +251,11 @@ __device__ __forceinline__ uint32_t transition_apply(const StepParams &p, Lane &
 // bit, set by every plane write of transition_apply, or a next level waiting in the snapshot); nothing carried.  TwoGoals' episodes end
 // on the `done` action, one env in seven per step under a random policy: copying 2 x S bytes per lane for each of them made its step
 // 208 us at 524,288 envs of 16x16.
-__device__ __forceinline__ void restore_objstate(const StepParams &p, int64_t env, bool planes)
+__device__ __forceinline__ void restore_objstate(const StepParams &p, int64_t env, int64_t senv, bool planes)
 {
     if (!p.objaux) return;
     if (planes) {
-        const uint32_t *a0 = reinterpret_cast<const uint32_t *>(p.objaux0 + env * p.S), *c0 = reinterpret_cast<const uint32_t *>(p.objcont0 + env * p.S);
+        const uint32_t *a0 = reinterpret_cast<const uint32_t *>(p.objaux0 + senv * p.S), *c0 = reinterpret_cast<const uint32_t *>(p.objcont0 + senv * p.S);
         uint32_t *a = reinterpret_cast<uint32_t *>(p.objaux + env * p.S), *c = reinterpret_cast<uint32_t *>(p.objcont + env * p.S);
         const int SD = p.S >> 2;
         for (int i0 = 0; i0 < SD; i0 += 4) { // (loads first, clamped; then the stores)
@@ -274,8 +274,9 @@ __device__ __forceinline__ void restore_objstate(const StepParams &p, int64_t en
 // S bytes with all loads issued back to back, so a wave pays ONE memory latency however many of its envs
 // finished (a wave-cooperative loop over done envs would pay one per env: measured 2x slower end to end on
 // LavaCrossing, where 40% of the waves see a reset every step).
+// (senv: the env's index in the snapshot arrays -- env itself, or env + bank * n_pad under a seed schedule)
 template <int CS>
-__device__ __forceinline__ void restore_own(const StepParams &p, int64_t env, uint8_t *g)
+__device__ __forceinline__ void restore_own(const StepParams &p, int64_t env, int64_t senv, uint8_t *g)
 {
     const int S = CS ? CS : p.S;
     uint32_t *l32 = reinterpret_cast<uint32_t *>(g);
@@ -283,7 +284,7 @@ __device__ __forceinline__ void restore_own(const StepParams &p, int64_t env, ui
         // (every load before the first store: written as one loop -- load, store, load, ... -- the stores may alias the next load as far
         // as the compiler knows, and the ISA was four dependent round trips: s_waitcnt vmcnt(0) behind each load.  Dynamic-Obstacles and
         // new_level_each_episode handles restore every finished env, i.e. some lane of nearly every wave on every step.)
-        const uint4 *s = reinterpret_cast<const uint4 *>(p.cells0 + env * S);
+        const uint4 *s = reinterpret_cast<const uint4 *>(p.cells0 + senv * S);
         uint4 *d = reinterpret_cast<uint4 *>(p.cells + env * S);
         uint4 v[CS / 16];
 #pragma unroll
@@ -294,7 +295,7 @@ __device__ __forceinline__ void restore_own(const StepParams &p, int64_t env, ui
             d[i] = v[i];
         }
     } else if constexpr (CS != 0 && (CS % 16) == 0) { // (16x16: 64 registers would not pay; four at a time)
-        const uint4 *s = reinterpret_cast<const uint4 *>(p.cells0 + env * S);
+        const uint4 *s = reinterpret_cast<const uint4 *>(p.cells0 + senv * S);
         uint4 *d = reinterpret_cast<uint4 *>(p.cells + env * S);
 #pragma unroll 1
         for (int i0 = 0; i0 < CS / 16; i0 += 4) {
@@ -308,7 +309,7 @@ __device__ __forceinline__ void restore_own(const StepParams &p, int64_t env, ui
             }
         }
     } else {
-        const uint32_t *s = reinterpret_cast<const uint32_t *>(p.cells0 + env * S);
+        const uint32_t *s = reinterpret_cast<const uint32_t *>(p.cells0 + senv * S);
         uint32_t *d = reinterpret_cast<uint32_t *>(p.cells + env * S);
         if constexpr (CS != 0) { // e.g. 9x9: 21 dword loads, all in flight before the first use
             uint32_t v[CS / 4];
@@ -756,18 +757,28 @@ __global__ __launch_bounds__(256, (MODE == 3 && V == 7 && !ALT && !OBJ) ? MGX_GA
         wave_stats(p, valid, done, reward, bad_act, oob, lane, tile);
         // the snapshot differs from the current cells only if a step changed one (dirty), if it holds the NEXT level (stream
         // mode) or if k_dynobs moved obstacles (both: p.regen)
-        const bool needs_copy = L.dirty != 0u || p.regen != nullptr;
+        // (... or, under a seed schedule, the level of the NEXT seed of the env's list: ReseedWrapper.reset, wrappers.py:24-28)
+        const bool needs_copy = L.dirty != 0u || p.regen != nullptr || p.bank != nullptr;
+        int nb = 0; // seed schedule: the list entry the new episode runs on
+        if (p.bank && p.auto_reset && valid && done) {
+            nb = (int)p.bank[env] + 1;
+            nb = nb >= p.n_banks ? 0 : nb;
+            p.bank[env] = (uint8_t)nb;
+        }
+        const int64_t senv = env + (int64_t)nb * p.bank_envs; // this env in the snapshot arrays
         if constexpr (GATHER) {
             // restore global -> global, by the whole wave one finished env at a time: these rows are long (> 256 B), a lane
             // copying its own row touches 64 different lines per instruction (MultiRoom's synchronised time-outs: +15 us
             // per step on average); the observation below reads the snapshot itself
             for (u64 m = __ballot(p.auto_reset && valid && done && needs_copy); m; m &= m - 1) {
-                const int64_t e = env0 + __builtin_ctzll(m);
-                const uint32_t *s = reinterpret_cast<const uint32_t *>(p.cells0 + e * S);
+                const int el = __builtin_ctzll(m);
+                const int64_t e = env0 + el;
+                const int64_t se = e + (int64_t)__shfl(nb, el) * p.bank_envs;
+                const uint32_t *s = reinterpret_cast<const uint32_t *>(p.cells0 + se * S);
                 uint32_t *d = reinterpret_cast<uint32_t *>(p.cells + e * S);
                 for (int i = lane; i < (S >> 2); i += 64) d[i] = s[i];
                 if (OBJ && p.objaux) { // the hidden planes ride along (a lane copying its own 2 x S bytes dword by dword: ObstructedMaze's lock-step time-outs)
-                    const uint32_t *a0 = reinterpret_cast<const uint32_t *>(p.objaux0 + e * S), *c0 = reinterpret_cast<const uint32_t *>(p.objcont0 + e * S);
+                    const uint32_t *a0 = reinterpret_cast<const uint32_t *>(p.objaux0 + se * S), *c0 = reinterpret_cast<const uint32_t *>(p.objcont0 + se * S);
                     uint32_t *a = reinterpret_cast<uint32_t *>(p.objaux + e * S), *c = reinterpret_cast<uint32_t *>(p.objcont + e * S);
                     for (int i = lane; i < (S >> 2); i += 64) { a[i] = a0[i]; c[i] = c0[i]; }
                 }
@@ -775,14 +786,14 @@ __global__ __launch_bounds__(256, (MODE == 3 && V == 7 && !ALT && !OBJ) ? MGX_GA
         }
         if (p.auto_reset && valid && done) {
             if constexpr (GATHER) {
-                row = p.cells0 + env * S;
+                row = p.cells0 + senv * S;
                 pidx = -1;
-            } else if (needs_copy) restore_own<CS>(p, env, g);
+            } else if (needs_copy) restore_own<CS>(p, env, senv, g);
             else if (nc != fc) g[fidx] = (uint8_t)fc; // a terminal step that changed a cell (Fetch's pickup): only the LDS image saw it
-            if (OBJ) restore_objstate(p, env, needs_copy && !GATHER); // (gather form: the planes were copied by the whole wave above)
+            if (OBJ) restore_objstate(p, env, senv, needs_copy && !GATHER); // (gather form: the planes were copied by the whole wave above)
             // (loaded here, by the waves that need it: fetching agent0 with the record up front takes a 3-6 us round trip under load
             // out of 40 % of LavaCrossing's waves and still measured +0.6 ... +1.5 us per launch -- 8 B per env of extra requests)
-            L = unpack_rec(p.agent0[env], p.task);
+            L = unpack_rec(p.agent0[senv], p.task);
             if (p.regen) p.regen[env] = 1; // the next-level buffer was consumed: k_levelgen refills it after this launch
         }
         if (valid) p.agent[env] = pack_rec(L, p.task);
@@ -880,7 +891,7 @@ template <int CW, int CH, bool RAGGED = false>
 // of six spilled dwords)
 __global__ __launch_bounds__(256, (RAGGED && CW == 19) ? 8 : 1) void k_step_fulldirect(const StepParams p)
 {
-    __shared__ uint32_t s_info[64]; // per env: agent idx | dir<<16 | reset<<18 | (1<<19 if a cell changed)
+    __shared__ uint32_t s_info[64]; // per env: agent idx | dir<<16 | reset<<18 | (1<<19 if a cell changed) | snapshot bank<<20 (seed schedule)
     __shared__ uint32_t s_wr[64];   // changed cell: idx | code<<16
     __shared__ uint32_t s_lut[256]; // cell code -> (type | color<<8 | state<<16)
     constexpr int CS = (CW * CH + 3) & ~3;
@@ -941,7 +952,7 @@ __global__ __launch_bounds__(256, (RAGGED && CW == 19) ? 8 : 1) void k_step_full
         if (p.task == MGX_TASK_MEMORY && act == 3u) act = 5u;
         float reward = 0.f;
         bool done = false, bad_act = false, oob = false, reset = false;
-        uint32_t wr = 0, changed = 0;
+        uint32_t wr = 0, changed = 0, nb = 0;
         if (p.do_step) {
             const int fidx = transition_begin<CW, CH>(p, L, act, valid, bad_act, oob);
             if (fidx >= 0) {
@@ -965,14 +976,20 @@ __global__ __launch_bounds__(256, (RAGGED && CW == 19) ? 8 : 1) void k_step_full
             if (p.done && valid) __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), &p.done[env]);
             wave_stats(p, valid, done, reward, bad_act, oob, lane, tile);
             if (p.auto_reset && valid && done) {
-                reset = L.dirty != 0u || p.regen != nullptr; // else the cells already equal the snapshot: nothing to copy back
-                L = unpack_rec(p.agent0[env], p.task);
-                if (CW == 0) restore_objstate(p, env, reset);
+                reset = L.dirty != 0u || p.regen != nullptr || p.bank != nullptr; // else the cells already equal the snapshot: nothing to copy back
+                if (p.bank) { // seed schedule: the level of the next seed of the env's list (ReseedWrapper.reset, wrappers.py:24-28)
+                    nb = (uint32_t)p.bank[env] + 1u;
+                    nb = nb >= (uint32_t)p.n_banks ? 0u : nb;
+                    p.bank[env] = (uint8_t)nb;
+                }
+                const int64_t senv = env + (int64_t)nb * p.bank_envs;
+                L = unpack_rec(p.agent0[senv], p.task);
+                if (CW == 0) restore_objstate(p, env, senv, reset);
                 if (p.regen) p.regen[env] = 1;
             }
             if (valid) p.agent[env] = pack_rec(L, p.task);
         }
-        s_info[lane] = (uint32_t)(L.ax * H + L.ay) | ((uint32_t)L.dir << 16) | ((uint32_t)reset << 18) | (changed << 19);
+        s_info[lane] = (uint32_t)(L.ax * H + L.ay) | ((uint32_t)L.dir << 16) | ((uint32_t)reset << 18) | (changed << 19) | (nb << 20);
         s_wr[lane] = wr;
         if constexpr (KPR != 0) s_first[lane] = first; // (a reset env's consumer reads the snapshot instead)
     }
@@ -984,7 +1001,7 @@ __global__ __launch_bounds__(256, (RAGGED && CW == 19) ? 8 : 1) void k_step_full
         const int nenv = nv >= 64 ? 64 : (int)nv;
         for (int e = 0; e < nenv; e++) { // restore the (few) envs that finished: block-uniform test, coalesced copy
             if (!((s_info[e] >> 18) & 1u)) continue;
-            const uint32_t *s0 = reinterpret_cast<const uint32_t *>(p.cells0 + (env0 + e) * S);
+            const uint32_t *s0 = reinterpret_cast<const uint32_t *>(p.cells0 + (env0 + e + (int64_t)(s_info[e] >> 20) * p.bank_envs) * S);
             uint32_t *d0 = reinterpret_cast<uint32_t *>(p.cells + (env0 + e) * S);
             for (int i = tid; i < UPE; i += 256) d0[i] = s0[i];
         }
@@ -1003,7 +1020,7 @@ __global__ __launch_bounds__(256, (RAGGED && CW == 19) ? 8 : 1) void k_step_full
                 uint32_t w = pr[k];
                 {
                     const uint32_t info = s_info[e];
-                    if ((info >> 18) & 1u) w = reinterpret_cast<const U4 *>(p.cells0 + (env0 + e) * S + c)->v; // env e was reset: its snapshot (rare)
+                    if ((info >> 18) & 1u) w = reinterpret_cast<const U4 *>(p.cells0 + (env0 + e + (int64_t)(info >> 20) * p.bank_envs) * S + c)->v; // env e was reset: its snapshot (rare)
                     if ((info >> 19) & 1u) {
                         const uint32_t x = s_wr[e], d = (x & 0xFFFFu) - (uint32_t)c;
                         if (d < 4u) w = (w & ~(0xFFu << (8u * d))) | ((x >> 16) << (8u * d));
@@ -1015,7 +1032,7 @@ __global__ __launch_bounds__(256, (RAGGED && CW == 19) ? 8 : 1) void k_step_full
                     uint32_t w2;
                     if (f0 + n_lo < n_flat) {
                         const uint32_t info = s_info[e + 1];
-                        w2 = ((info >> 18) & 1u) ? *reinterpret_cast<const uint32_t *>(p.cells0 + (env0 + e + 1) * S) : s_first[e + 1];
+                        w2 = ((info >> 18) & 1u) ? *reinterpret_cast<const uint32_t *>(p.cells0 + (env0 + e + 1 + (int64_t)(info >> 20) * p.bank_envs) * S) : s_first[e + 1];
                         if ((info >> 19) & 1u) {
                             const uint32_t x = s_wr[e + 1], d = x & 0xFFFFu;
                             if (d < 4u) w2 = (w2 & ~(0xFFu << (8u * d))) | ((x >> 16) << (8u * d));
@@ -1043,7 +1060,7 @@ __global__ __launch_bounds__(256, (RAGGED && CW == 19) ? 8 : 1) void k_step_full
             uint32_t tr[4];
             if (c + 3 < cells) { // the whole unit inside one env: one unaligned dword
                 const uint32_t info = s_info[e];
-                const uint8_t *rowp = (((info >> 18) & 1u) ? p.cells0 : p.cells) + (env0 + e) * S;
+                const uint8_t *rowp = ((info >> 18) & 1u) ? p.cells0 + (env0 + e + (int64_t)(info >> 20) * p.bank_envs) * S : p.cells + (env0 + e) * S;
                 uint32_t w = reinterpret_cast<const U4 *>(rowp + c)->v;
                 if ((info >> 19) & 1u) {
                     const uint32_t x = s_wr[e], d = (x & 0xFFFFu) - (uint32_t)c;
@@ -1060,7 +1077,7 @@ __global__ __launch_bounds__(256, (RAGGED && CW == 19) ? 8 : 1) void k_step_full
                     uint32_t code = MGX_CODE_EMPTY;
                     if (f0 + j < n_flat) {
                         const uint32_t info = s_info[e];
-                        code = ((((info >> 18) & 1u) ? p.cells0 : p.cells) + (env0 + e) * S)[c];
+                        code = (((info >> 18) & 1u) ? p.cells0 + (env0 + e + (int64_t)(info >> 20) * p.bank_envs) * S : p.cells + (env0 + e) * S)[c];
                         if (((info >> 19) & 1u) && (s_wr[e] & 0xFFFFu) == (uint32_t)c) code = s_wr[e] >> 16;
                         if ((info & 0xFFFFu) == (uint32_t)c) code = MGX_K_AGENT | (((info >> 16) & 3u) << 4);
                     }
@@ -1091,7 +1108,7 @@ __global__ __launch_bounds__(256, (RAGGED && CW == 19) ? 8 : 1) void k_step_full
         const bool rst = (info >> 18) & 1u;
         uint32_t w;
         if (KPF != 0 && !rst) w = pf[kk];
-        else w = reinterpret_cast<const uint32_t *>(rst ? p.cells0 + env0 * S : p.cells + env0 * S)[u];
+        else w = reinterpret_cast<const uint32_t *>(rst ? p.cells0 + (env0 + (int64_t)(info >> 20) * p.bank_envs) * S : p.cells + env0 * S)[u];
         if (rst) reinterpret_cast<uint32_t *>(p.cells + env0 * S)[u] = w; // restore, coalesced
         if (!dst) continue;
         if ((info >> 19) & 1u) { // the cell the transition changed (whether or not the load already saw it)

@@ -90,6 +90,13 @@ struct mgx_env_s {
     uint8_t *restart_d = nullptr; // u8[n_pad]: the in-kernel auto-reset restarted this env's episode; the next k_dynobs restores obstacle
                                   // order + RNG position first (NOT regen_d: those flags mean "k_levelgen, make this env a new level")
     uint32_t *mt0_d = nullptr, *pos0_d = nullptr, *tape_d = nullptr, *tape0_d = nullptr;
+    uint32_t *sp0_d = nullptr;    // DynObsParams.sp0
+    // seed schedule (mgx_set_seed_schedule): the snapshot arrays (cells0, agent0, objaux0, objcont0, obst0, mt0, pos0, tape0, sp0) hold
+    // snap_banks episode starts per env, bank-major; sched_K > 0 while a schedule is installed
+    int sched_K = 0, snap_banks = 1;
+    uint8_t *bank_d = nullptr;    // StepParams.bank
+    bool needs_full_reset = false; // a schedule was installed and the live episodes are invalid until mgx_reset(h, NULL, NULL, ...)
+    bool seeded = false;          // every env has been through mgx_reset(seeds) at least once: its RNG stream exists (plain reset())
     // object_state: hidden Goal/Box planes (+ episode-start snapshots) and the carried object's pair
     uint8_t *objaux_d = nullptr, *objaux0_d = nullptr, *objcont_d = nullptr, *objcont0_d = nullptr;
     uint16_t *objcarry_d = nullptr;
@@ -207,6 +214,7 @@ StepParams base_params(mgx_handle h)
     p.regen = h->dynobs ? h->restart_d : (h->stream_mode ? h->regen_d : nullptr);
     p.objaux = h->objaux_d; p.objcont = h->objcont_d; p.objaux0 = h->objaux0_d; p.objcont0 = h->objcont0_d; p.objcarry = h->objcarry_d;
     p.front = h->front_d; // (Dynamic-Obstacles: k_dynobs moves cells between two steps and rewrites the entry itself)
+    p.bank = h->sched_K ? h->bank_d : nullptr; p.n_banks = h->sched_K ? h->sched_K : 1; p.bank_envs = h->sched_K ? h->n_pad : 0;
     return p;
 }
 
@@ -250,7 +258,8 @@ DynObsParams dynobs_params(mgx_handle h)
     memset(&d, 0, sizeof d);
     d.cells = h->cells_d; d.cells0 = h->cells0_d; d.agent = h->agent_d; d.act_out = h->act_d; d.regen = h->restart_d;
     d.obst = h->obst_d; d.obst0 = h->obst0_d; d.mt = h->mt_d; d.mt0 = h->mt0_d; d.pos = h->mt_idx_d; d.pos0 = h->pos0_d;
-    d.tape = h->tape_d; d.tape0 = h->tape0_d; d.front = h->front_d;
+    d.tape = h->tape_d; d.tape0 = h->tape0_d; d.front = h->front_d; d.sp0 = h->sp0_d; d.mt_idx = h->mt_idx_d;
+    d.bank = h->sched_K ? h->bank_d : nullptr; d.bank_envs = h->sched_K ? h->n_pad : 0;
     d.n = h->n; d.W = h->W; d.H = h->H; d.S = h->S; d.n_obst = h->cfg.level_arg0;
     d.n_tiles = (int)(h->n_pad / 64); d.LS = h->LS; d.wave_lds = mgx_dynobs_wave_lds(h->LS);
     return d;
@@ -517,6 +526,8 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
         CREATE_TRY(hipMemsetAsync(h->obst0_d, 0, (size_t)h->n_pad * 8, h->stream));
         CREATE_TRY(hipMemsetAsync(h->mt0_d, 0, (size_t)h->n_pad * 624 * sizeof(uint32_t), h->stream));
         CREATE_TRY(hipMemsetAsync(h->pos0_d, 0, (size_t)h->n_pad * sizeof(uint32_t), h->stream));
+        CREATE_TRY(hipMalloc((void **)&h->sp0_d, (size_t)h->n_pad * sizeof(uint32_t)));
+        CREATE_TRY(hipMemsetAsync(h->sp0_d, 0, (size_t)h->n_pad * sizeof(uint32_t), h->stream));
     }
     CREATE_TRY(mgx_preload_step_kernels());
     {
@@ -558,6 +569,7 @@ extern "C" int mgx_destroy(mgx_handle h)
     if (h->roll_exec) (void)hipGraphExecDestroy(h->roll_exec);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     (void)hipFree(h->obst_d); (void)hipFree(h->obst0_d); (void)hipFree(h->act_d); (void)hipFree(h->restart_d); (void)hipFree(h->mt0_d); (void)hipFree(h->pos0_d); (void)hipFree(h->tape_d); (void)hipFree(h->tape0_d);
+    (void)hipFree(h->sp0_d); (void)hipFree(h->bank_d);
     for (auto &s : h->st_in) if (s.dev) (void)hipFree(s.dev);
     for (auto &s : h->st_out) if (s.dev) (void)hipFree(s.dev);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -670,6 +682,7 @@ static int set_state_impl(mgx_handle h, const uint8_t *grid, const uint8_t *aux,
     const void *d;
     int rc;
     h->snapshot_is_level = false;
+    h->sched_K = 0; h->needs_full_reset = false; // (the injected state is the episode start from now on: a seed schedule ends here)
     if ((rc = forget_front(h))) return rc;
     p.bcast = bcast ? 1 : 0;
     if ((rc = dev_in(h, 0, grid, n_src * cells * 3, &d))) return rc;
@@ -755,6 +768,8 @@ extern "C" int mgx_get_state(mgx_handle h, uint8_t *grid, uint8_t *aux, int32_t 
 // ------------------------------------------------------------------------------------------------ step / observe
 static int run_step(mgx_handle h, bool do_step, const uint8_t *actions, uint8_t *obs, float *reward, uint8_t *done, const uint8_t *obs_mask_dev = nullptr)
 {
+    if (h->needs_full_reset)
+        return mgx_fail(MGX_ERR_INVALID_STATE, "%s: a seed schedule was installed; start every env on it with mgx_reset(h, NULL, NULL, obs) first", do_step ? "mgx_step" : "mgx_observe");
     StepParams p = base_params(h);
     p.do_step = do_step ? 1 : 0;
     p.obs_mask = do_step ? nullptr : obs_mask_dev;
@@ -850,7 +865,7 @@ extern "C" int mgx_rollout(mgx_handle h, int64_t T, const uint8_t *actions, uint
     // 151 -> 138; at 16x16 the 19.7 KB of LDS per wave leave six waves per CU and the direct form wins, 44 against 51 at 262,144 envs)
     const bool fused_ok = (h->partial ? (h->kernel_mode == 0 || (h->kernel_mode == 3 && h->S <= 256)) : h->S <= 192) &&
                           !h->cfg.alt_visibility && !h->objaux_d && !h->stream_mode &&
-                          !h->dynobs && h->oh_nc < 0 && !h->flat && !(rf && !strcmp(rf, "graph"));
+                          !h->dynobs && h->oh_nc < 0 && !h->flat && !h->sched_K && !(rf && !strcmp(rf, "graph"));
     if (fused_ok) {
         StepParams p = base_params(h);
         p.do_step = 1;
@@ -1006,6 +1021,125 @@ extern "C" int mgx_get_pose(mgx_handle h, int32_t *pose)
     return finish_out(h, &o, 1);
 }
 
+namespace {
+
+ConsumeParams consume_params(mgx_handle h, const uint8_t *mask_dev)
+{
+    ConsumeParams c;
+    memset(&c, 0, sizeof c);
+    c.mask = mask_dev;
+    c.cells = h->cells_d; c.cells0 = h->cells0_d; c.agent = h->agent_d; c.agent0 = h->agent0_d; c.regen = h->regen_d;
+    c.objaux = h->objaux_d; c.objaux0 = h->objaux0_d; c.objcont = h->objcont_d; c.objcont0 = h->objcont0_d; c.objcarry = h->objcarry_d;
+    c.front = h->front_d; // (the reset envs' "cell in front" is unknown until their next observation pass)
+    c.n = h->n; c.S = h->S; c.flag_regen = 0;
+    return c;
+}
+
+// The snapshot arrays for K episode starts per env (bank-major).  Contents are lost: the caller regenerates every bank.
+int resize_snapshots(mgx_handle h, int K)
+{
+    if (K == h->snap_banks) return MGX_OK;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const size_t n = (size_t)h->n_pad * (size_t)K;
+    struct Arr { void **pp; size_t bytes; int fill; };
+    const Arr arrs[] = {{(void **)&h->cells0_d, n * h->S, 0}, {(void **)&h->agent0_d, n * sizeof(uint2), 0},
+                        {(void **)&h->objaux0_d, h->objaux_d ? n * h->S : 0, 0}, {(void **)&h->objcont0_d, h->objaux_d ? n * h->S : 0, MGX_CODE_EMPTY},
+                        {(void **)&h->obst0_d, h->dynobs ? n * 8 : 0, 0}, {(void **)&h->mt0_d, h->dynobs ? n * 624 * sizeof(uint32_t) : 0, 0},
+                        {(void **)&h->pos0_d, h->dynobs ? n * sizeof(uint32_t) : 0, 0}, {(void **)&h->tape0_d, h->dynobs ? n * MGX_DYN_TAPE_DW * sizeof(uint32_t) : 0, 0},
+                        {(void **)&h->sp0_d, h->dynobs ? n * sizeof(uint32_t) : 0, 0}};
+    // (new arrays first, the old ones go only when every allocation succeeded: a failed resize leaves the handle as it was)
+    void *fresh[sizeof arrs / sizeof arrs[0]] = {};
+    for (size_t i = 0; i < sizeof arrs / sizeof arrs[0]; i++) {
+        if (!arrs[i].bytes) continue;
+        const hipError_t e = hipMalloc(&fresh[i], arrs[i].bytes);
+        if (e != hipSuccess) {
+            for (size_t j = 0; j < i; j++) if (fresh[j]) (void)hipFree(fresh[j]);
+            (void)hipGetLastError();
+            return mgx_fail(MGX_ERR_HIP, "mgx_set_seed_schedule: %d episode-start snapshots per env need %zu more bytes: %s", K, arrs[i].bytes, hipGetErrorString(e));
+        }
+    }
+    for (size_t i = 0; i < sizeof arrs / sizeof arrs[0]; i++) {
+        if (!arrs[i].bytes) continue;
+        (void)hipFree(*arrs[i].pp);
+        *arrs[i].pp = fresh[i];
+        HIP_TRY(hipMemsetAsync(fresh[i], arrs[i].fill, arrs[i].bytes, h->stream));
+    }
+    h->snap_banks = K;
+    h->snapshot_is_level = false;
+    if (h->has_seed_d) HIP_TRY(hipMemsetAsync(h->has_seed_d, 0, (size_t)h->n_pad, h->stream));
+    if (h->roll_exec) { (void)hipGraphExecDestroy(h->roll_exec); h->roll_exec = nullptr; } // (a captured rollout holds the old pointers)
+    return MGX_OK;
+}
+
+} // namespace
+
+// ReseedWrapper(env_i, seeds = seeds[i][0..K-1], seed_idx = idx0) (wrappers.py:12-28): the K levels of every env generated once into K
+// resident episode-start snapshots; resets then copy from the bank the env's list index names.
+extern "C" int mgx_set_seed_schedule(mgx_handle h, const uint64_t *seeds, int32_t K, int32_t idx0)
+{
+    DeviceGuard dev_guard;
+    int rc = dev_guard.enter(h, "mgx_set_seed_schedule");
+    if (rc) return rc;
+    if (K == 0) { // remove the schedule: the current episode-start snapshot (bank 0 is NOT it in general) is undefined until the next seeded reset
+        if (h->sched_K) {
+            h->sched_K = 0; h->needs_full_reset = false;
+            if (h->has_seed_d) HIP_TRY(hipMemsetAsync(h->has_seed_d, 0, (size_t)h->n_pad, h->stream));
+            if (h->roll_exec) { (void)hipGraphExecDestroy(h->roll_exec); h->roll_exec = nullptr; }
+        }
+        return MGX_OK;
+    }
+    if (K < 1 || K > 255) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_set_seed_schedule: K = %d outside 0..255", K);
+    if (idx0 < 0 || idx0 >= K) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_set_seed_schedule: seed_idx %d outside 0..%d (the wrapper would raise IndexError)", idx0, K - 1);
+    if (!seeds) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_set_seed_schedule: seeds is required");
+    if (h->cfg.level_kind == MGX_LEVEL_NONE)
+        return mgx_fail(MGX_ERR_NO_LEVELGEN, "mgx_set_seed_schedule: this handle has no built-in level generator; use mgx_set_state");
+    if (h->cfg.new_level_each_episode)
+        return mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_set_seed_schedule: a new_level_each_episode handle is the env WITHOUT ReseedWrapper; create it with new_level_each_episode = 0");
+    if (h->one_level) return MGX_OK; // every seed gives the family's one level: mgx_reset(h, NULL, ...) is a restore with or without the wrapper
+    if (!h->device_levels)
+        return mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_set_seed_schedule: grids beyond 64x64 cells generate their levels on the host (mgx_reset with seeds)");
+    const size_t n = (size_t)h->n;
+    const void *ds = nullptr;
+    if ((rc = dev_in(h, 4, seeds, n * (size_t)K * sizeof(uint64_t), &ds, 8))) return rc;
+    if (!h->bank_d) {
+        HIP_TRY(hipMalloc((void **)&h->bank_d, (size_t)h->n_pad));
+    }
+    h->sched_K = 0;
+    if ((rc = resize_snapshots(h, K))) return rc;
+    if ((rc = forget_front(h))) return rc;
+    uint64_t *col = nullptr;
+    HIP_TRY(hipMalloc((void **)&col, n * sizeof(uint64_t)));
+    hipError_t e = hipSuccess;
+    for (int b = 0; b < K && e == hipSuccess && !rc; b++) {
+        const size_t off = (size_t)b * (size_t)h->n_pad;
+        e = mgx_launch_seed_column((const uint64_t *)ds, K, b, col, h->n, h->stream);
+        if (e == hipSuccess)
+            e = mgx_launch_seed(col, nullptr, h->mt_init_d, h->mt_d, h->mt2_d, h->mt_idx_d, h->regen_d, h->seed0_d, h->has_seed_d, h->reseeded_d, 0, h->n, h->stream);
+        if (e != hipSuccess) break;
+        LevelGenParams g = levelgen_params(h);
+        g.cells0 += off * h->S; g.agent0 += off;
+        if (g.objaux0) { g.objaux0 += off * h->S; g.objcont0 += off * h->S; }
+        e = mgx_launch_levelgen(g, h->stream);
+        if (e == hipSuccess && h->dynobs) { // obstacle order + the RNG state right behind this seed's reset(), into bank b
+            DynObsParams dp = dynobs_params(h);
+            dp.cells0 += off * h->S; dp.obst0 += off * 8; dp.mt0 += off * 624; dp.pos0 += off; dp.tape0 += off * MGX_DYN_TAPE_DW; dp.sp0 += off;
+            dp.bank = nullptr; dp.bank_envs = 0; // (the offsets above select the bank)
+            dp.mask = nullptr; dp.mask_reset = nullptr;
+            e = mgx_launch_dynobs_init(dp, h->stream);
+        }
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(col);
+    if (e != hipSuccess) return mgx_fail(MGX_ERR_HIP, "mgx_set_seed_schedule: %s", hipGetErrorString(e));
+    // the first reset takes entry idx0: the list index of the "current" episode is the one before it
+    HIP_TRY(hipMemsetAsync(h->bank_d, (idx0 + K - 1) % K, (size_t)h->n_pad, h->stream));
+    HIP_TRY(hipMemsetAsync(h->has_seed_d, 0, (size_t)h->n_pad, h->stream)); // (k_seed's bookkeeping describes the last bank only)
+    h->sched_K = K;
+    h->needs_full_reset = true;
+    h->seeded = true;
+    return MGX_OK;
+}
+
 extern "C" int mgx_reset(mgx_handle h, const uint64_t *seeds, const uint8_t *mask, uint8_t *obs)
 {
     DeviceGuard dev_guard;
@@ -1013,8 +1147,68 @@ extern "C" int mgx_reset(mgx_handle h, const uint64_t *seeds, const uint8_t *mas
     if (rc) return rc;
     if (h->cfg.level_kind == MGX_LEVEL_NONE)
         return mgx_fail(MGX_ERR_NO_LEVELGEN, "mgx_reset: this handle has no built-in level generator; use mgx_set_state");
-    if (!seeds) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_reset: seeds is required");
     const size_t n = (size_t)h->n, cells = (size_t)h->cells;
+    if (seeds && h->sched_K) { // explicit seeds define the episode start themselves: the schedule ends (include/mgx.h)
+        h->sched_K = 0; h->needs_full_reset = false;
+        if (h->has_seed_d) HIP_TRY(hipMemsetAsync(h->has_seed_d, 0, (size_t)h->n_pad, h->stream));
+        if (h->roll_exec) { (void)hipGraphExecDestroy(h->roll_exec); h->roll_exec = nullptr; }
+    }
+    if (!seeds && h->sched_K) {
+        // ReseedWrapper.reset() (wrappers.py:24-28): every masked env moves on to the next seed of its list; the level -- and for
+        // Dynamic-Obstacles the RNG state behind it -- is the resident snapshot of that list entry
+        if (h->needs_full_reset && mask)
+            return mgx_fail(MGX_ERR_INVALID_STATE, "mgx_reset: the first reset after mgx_set_seed_schedule must cover every env (mask = NULL)");
+        const void *dm = nullptr;
+        if ((rc = dev_in(h, 5, mask, n, &dm))) return rc;
+        HIP_TRY(mgx_launch_bank_advance(h->bank_d, (const uint8_t *)dm, h->sched_K, h->n, h->stream));
+        ConsumeParams c = consume_params(h, (const uint8_t *)dm);
+        c.regen = nullptr;
+        c.bank = h->bank_d; c.bank_envs = h->n_pad;
+        c.restart = h->dynobs ? h->restart_d : nullptr; // the next k_dynobs restores obstacle order, RNG position, block and tape from the bank
+        HIP_TRY(mgx_launch_consume(c, h->stream));
+        h->needs_full_reset = false;
+        if (obs) return run_step(h, false, nullptr, obs, nullptr, nullptr, (dm && is_device_ptr(obs)) ? (const uint8_t *)dm : nullptr);
+        return MGX_OK;
+    }
+    if (!seeds && !h->one_level) {
+        // The plain reset() (minigrid.py:831-858; the caller loop of run_tests.py:64-66): the env's RNG stream continues and the next
+        // level is drawn from it, on the GPU.
+        if (!h->device_levels)
+            return mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_reset: grids beyond 64x64 cells keep no RNG stream on the device; pass seeds");
+        if (!h->seeded)
+            return mgx_fail(MGX_ERR_INVALID_STATE, "mgx_reset: reset() without seeds continues the env's RNG stream, which starts with a seeded reset "
+                                                   "(MiniGridEnv.__init__ calls seed(1337), minigrid.py:824-826): call mgx_reset with seeds for every env first");
+        const void *dm = nullptr;
+        if ((rc = dev_in(h, 5, mask, n, &dm))) return rc;
+        ConsumeParams c = consume_params(h, (const uint8_t *)dm);
+        if (h->stream_mode) { // the next level is waiting in the buffer: make it current, refill behind it
+            c.flag_regen = 1;
+            HIP_TRY(mgx_launch_consume(c, h->stream));
+            if ((rc = launch_levelgen(h))) return rc;
+        } else {
+            if (h->dynobs) { // the obstacle walks' place in the stream back into (block, stream position)
+                DynObsParams dp = dynobs_params(h);
+                dp.mask_reset = (const uint8_t *)dm;
+                HIP_TRY(mgx_launch_dynobs_handover(dp, h->stream));
+            }
+            HIP_TRY(mgx_launch_mark_plain_reset((const uint8_t *)dm, h->regen_d, h->has_seed_d, h->reseeded_d, h->n, h->stream));
+            if ((rc = launch_levelgen(h))) return rc;
+            HIP_TRY(mgx_launch_consume(c, h->stream));
+            if (h->dynobs) {
+                DynObsParams dp = dynobs_params(h);
+                dp.mask = h->reseeded_d;
+                dp.mask_reset = (const uint8_t *)dm;
+                HIP_TRY(mgx_launch_dynobs_init(dp, h->stream));
+            }
+        }
+        if (obs) return run_step(h, false, nullptr, obs, nullptr, nullptr, (dm && is_device_ptr(obs)) ? (const uint8_t *)dm : nullptr);
+        return MGX_OK;
+    }
+    std::vector<uint64_t> zero_seeds;
+    if (!seeds && !(h->snapshot_is_level || !mask)) { // (a one-level family's first reset under a mask, without seeds: any seed gives its level)
+        zero_seeds.assign(n, 0);
+        seeds = zero_seeds.data();
+    }
     if (h->device_levels) {
         // Everything on the GPU: env.seed(s_i) (k_seed: SHA-512 key + MT19937 init_by_array per env), level 1 into the
         // next-level buffer (k_levelgen), make it current (k_consume); with new_level_each_episode level 2 is
@@ -1028,15 +1222,11 @@ extern "C" int mgx_reset(mgx_handle h, const uint64_t *seeds, const uint8_t *mas
         HIP_TRY(mgx_launch_seed((const uint64_t *)ds, (const uint8_t *)dm, h->mt_init_d, h->mt_d, h->mt2_d, h->mt_idx_d, h->regen_d, h->seed0_d, h->has_seed_d,
                                 h->reseeded_d, h->stream_mode ? 0 : 1, h->n, h->stream));
         if ((rc = launch_levelgen(h))) return rc;
-        ConsumeParams c;
-        memset(&c, 0, sizeof c);
-        c.mask = (const uint8_t *)dm;
-        c.cells = h->cells_d; c.cells0 = h->cells0_d; c.agent = h->agent_d; c.agent0 = h->agent0_d; c.regen = h->regen_d;
-        c.objaux = h->objaux_d; c.objaux0 = h->objaux0_d; c.objcont = h->objcont_d; c.objcont0 = h->objcont0_d; c.objcarry = h->objcarry_d;
-        c.front = h->front_d; // (the reset envs' "cell in front" is unknown until their next observation pass)
-        c.n = h->n; c.S = h->S; c.flag_regen = h->stream_mode ? 1 : 0;
+        ConsumeParams c = consume_params(h, (const uint8_t *)dm);
+        c.flag_regen = h->stream_mode ? 1 : 0;
         HIP_TRY(mgx_launch_consume(c, h->stream));
         if (h->stream_mode && (rc = launch_levelgen(h))) return rc;
+        if (!mask) h->seeded = true; // every env's RNG stream exists from here on: reset() without seeds may continue it
         if (h->dynobs) { // obstacle order out of the generator's markers + snapshot of the RNG right after reset()
             DynObsParams dp = dynobs_params(h);
             dp.mask = h->reseeded_d;
@@ -1068,19 +1258,15 @@ extern "C" int mgx_reset(mgx_handle h, const uint64_t *seeds, const uint8_t *mas
             h->snapshot_is_level = true;
         } else {
             if ((rc = dev_in(h, 5, mask, n, &dm))) return rc;
-            ConsumeParams c;
-            memset(&c, 0, sizeof c);
-            c.mask = (const uint8_t *)dm;
-            c.cells = h->cells_d; c.cells0 = h->cells0_d; c.agent = h->agent_d; c.agent0 = h->agent0_d; c.regen = nullptr;
-            c.objaux = h->objaux_d; c.objaux0 = h->objaux0_d; c.objcont = h->objcont_d; c.objcont0 = h->objcont0_d; c.objcarry = h->objcarry_d;
-            c.front = h->front_d; // (the reset envs' "cell in front" is unknown until their next observation pass)
-        c.n = h->n; c.S = h->S; c.flag_regen = 0;
+            ConsumeParams c = consume_params(h, (const uint8_t *)dm);
+            c.regen = nullptr;
             HIP_TRY(mgx_launch_consume(c, h->stream));
         }
         if (obs) return run_step(h, false, nullptr, obs, nullptr, nullptr, (dm && is_device_ptr(obs)) ? (const uint8_t *)dm : nullptr);
         return MGX_OK;
     }
     // per-seed levels generated on the host (grids beyond 64x64, or the first reset of a one-level family under a mask)
+    if (!seeds) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_reset: seeds is required here");
     std::vector<uint64_t> seeds_host;
     if (is_device_ptr(seeds)) { // the host generators read them
         seeds_host.resize(n);

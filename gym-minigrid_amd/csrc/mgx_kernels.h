@@ -61,6 +61,12 @@ struct StepParams {
     uint8_t *front;        // gather form only (else null): u8[n_pad], cell code in front of the agent as of the env's last observation pass;
                            // 0 = unknown (every entry point that changes cells or poses outside the step kernel clears it)
     const uint8_t *obs_mask; // observe after a masked reset: 64-env tiles without a masked env are skipped (else null)
+    // seed schedule (mgx_set_seed_schedule: ReseedWrapper with a list of K seeds, wrappers.py:12-28), else bank == null: every snapshot array
+    // (cells0, agent0, objaux0, objcont0) is [K][n_pad][...], bank k = the episode start under the k-th seed of the env's list.  An
+    // in-kernel reset of env e advances bank[e] (mod K) and restores from snapshot index e + bank[e] * bank_envs.
+    uint8_t *bank;         // u8[n_pad]: list index of the env's CURRENT episode
+    int n_banks;           // K
+    int64_t bank_envs;     // n_pad (0 without a schedule)
     int64_t n;
     int n_tiles;
     int W, H, S, LS, wave_lds, view;
@@ -97,6 +103,9 @@ struct ConsumeParams {
     uint8_t *objaux, *objaux0, *objcont, *objcont0; uint16_t *objcarry; // object_state handles (else null): aux planes to 0,
                                                                         // contains <- the generated level's (objcont0), nothing carried
     uint8_t *front;     // StepParams.front of gather-form handles (else null): cleared for every env consumed here
+    const uint8_t *bank; // seed schedule (StepParams.bank, already advanced for the envs being reset: k_bank_advance), else null
+    int64_t bank_envs;
+    uint8_t *restart;   // Dynamic-Obstacles handles under a seed schedule (else null): DynObsParams.regen, raised for every env consumed here
     int64_t n;
     int S, flag_regen;
 };
@@ -114,6 +123,11 @@ struct DynObsParams {
     uint32_t *pos, *pos0;   // u32[n_pad] words drawn since the block in `mt0` was generated (= mt_idx right after reset)
     uint32_t *tape, *tape0; // u32[n_pad][MGX_DYN_TAPE_DW] draw tape of the env's block (k_dynobs.hip) + its episode-start copy
     uint8_t *front;         // StepParams.front of a gather-form handle (16x16; else null): k_dynobs leaves the cell in front of the agent AFTER the walk
+    uint32_t *sp0;          // u32[n_pad] the stream position (mt_idx) the episode started at: what `pos0`'s rank was computed from; the plain
+                            // caller-side reset() of an env that has not drawn since needs it back exactly (k_dynobs_handover)
+    uint32_t *mt_idx;       // k_dynobs_handover: where the stream position goes (LevelGenParams.mt_idx; the same array as `pos`)
+    const uint8_t *bank;    // seed schedule (StepParams.bank), else null: obst0 / mt0 / pos0 / tape0 / sp0 are [K][n_pad][...]
+    int64_t bank_envs;
     int64_t n;
     int W, H, S, n_obst;
     int n_tiles, LS, wave_lds; // k_dynobs: one wave per 64-env tile, cells + RNG windows staged in LDS
@@ -122,10 +136,20 @@ struct DynObsParams {
 int mgx_dynobs_wave_lds(int LS);
 hipError_t mgx_launch_dynobs_init(const DynObsParams &p, hipStream_t st);
 hipError_t mgx_launch_dynobs(const DynObsParams &p, hipStream_t st);
+// plain caller-side reset() of Dynamic-Obstacles envs (mask null = all): the walk's position (a rank on the draw tape, or a half-regenerated
+// block) back into the form k_levelgen continues from -- a complete block in `mt` and a stream position in `mt_idx`
+hipError_t mgx_launch_dynobs_handover(const DynObsParams &p, hipStream_t st);
 hipError_t mgx_launch_levelgen(const LevelGenParams &p, hipStream_t st);
 hipError_t mgx_launch_seed(const uint64_t *seeds, const uint8_t *mask, const uint32_t *init, uint32_t *mt, uint32_t *mt2, uint32_t *mt_idx,
                            uint8_t *regen, uint64_t *seed0, uint8_t *has_seed, uint8_t *reseeded, int skip_same, int64_t n, hipStream_t st);
 hipError_t mgx_launch_consume(const ConsumeParams &p, hipStream_t st);
+// mgx_set_seed_schedule: out[i] = seeds[i][b] (the b-th seed of every env's list)
+hipError_t mgx_launch_seed_column(const uint64_t *seeds, int K, int b, uint64_t *out, int64_t n, hipStream_t st);
+// seed schedule, caller-side reset: bank[i] = (bank[i] + 1) % K for the masked envs (mask null = all)
+hipError_t mgx_launch_bank_advance(uint8_t *bank, const uint8_t *mask, int K, int64_t n, hipStream_t st);
+// plain caller-side reset(): the masked envs (null = all) are flagged for k_levelgen (regen = 1); their episode-start snapshots no longer
+// belong to a seed (has_seed = 0) and they count as re-seeded for k_dynobs_init (reseeded = 1)
+hipError_t mgx_launch_mark_plain_reset(const uint8_t *mask, uint8_t *regen, uint8_t *has_seed, uint8_t *reseeded, int64_t n, hipStream_t st);
 // launch shaping of one handle on its own device (k_step.hip: raised-priority tail blocks, first-round stagger)
 struct StepLaunchCfg { int tail_blocks, stagger_units, stagger_min; };
 hipError_t mgx_step_launch_cfg(int device, StepLaunchCfg *out);

@@ -14,7 +14,7 @@ ERR_NAMES = {-1: "INVALID_ARG", -2: "INVALID_STATE", -3: "INVALID_ACTION", -4: "
 OBS_PARTIAL, OBS_FULL, OBS_PARTIAL_ONEHOT, OBS_FULL_ONEHOT, OBS_FULL_ONEHOT_NOCOLOR, OBS_PARTIAL_FLAT, OBS_FULL_FLAT = 0, 1, 2, 3, 4, 5, 6
 # mgx_task_kind (include/mgx.h)
 (TASK_NONE, TASK_FETCH, TASK_GOTODOOR, TASK_DYNOBS, TASK_GOTOOBJECT, TASK_REDBLUEDOORS, TASK_MEMORY, TASK_UNLOCK, TASK_PICKUPBOX, TASK_NOTE,
- TASK_PUTNEAR) = range(11)
+ TASK_PUTNEAR, TASK_TWOGOALS) = range(12)
 TASKS_WITH_EPISODE_MISSION = (TASK_FETCH, TASK_GOTOOBJECT, TASK_PICKUPBOX, TASK_NOTE, TASK_PUTNEAR)  # the mission names per-episode objects
 
 
@@ -70,6 +70,7 @@ SIGNATURES = {
     "mgx_get_task": (_int, [_vp, _vp]),
     "mgx_generate_level_stream": (_int, [ctypes.POINTER(Config), ctypes.c_uint64, _i64, _vp, _vp]),
     "mgx_reset": (_int, [_vp, _vp, _vp, _vp]),
+    "mgx_set_seed_schedule": (_int, [_vp, _vp, ctypes.c_int32, ctypes.c_int32]),
     "mgx_set_state": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "mgx_get_state": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "mgx_set_object_state": (_int, [_vp, _vp, _vp, _vp]),

@@ -35,21 +35,26 @@ class SingleEnv:
         self.reward_range = self._vec.reward_range
         self.max_steps = self._vec.max_steps
         self.width, self.height = self._vec.width, self._vec.height
-        self._seed = 1337  # MiniGridEnv.__init__(seed=1337)
+        # MiniGridEnv.__init__ ends with `self.seed(seed=1337); self.reset()` (minigrid.py:824-829)
+        self._seed_pending = True
         self.reset()
 
     def seed(self, seed=1337):
-        self._seed = int(seed)
-        self._vec.seed(np.array([self._seed], np.uint64))
+        """np_random is replaced (minigrid.py:860-863); the next reset() draws its level from the new stream."""
+        self._vec.seed(np.array([int(seed) % (1 << 64)], np.uint64))
+        self._seed_pending = True
         return [seed]
 
     def _obs(self, image):
         return {"image": image[0].copy(), "direction": int(self._vec.direction()[0]), "mission": self._vec.missions()[0]}
 
     def reset(self):
-        """A reset WITHOUT a preceding seed() continues the env's RNG stream in the reference; here it replays the level of
-        the last seed (ReseedWrapper semantics) -- call seed() first for a specific level, as the reference's tests do."""
-        return self._obs(self._vec.reset())
+        """minigrid.py:831-858.  After seed(s) the level is the first one of that stream; a reset() WITHOUT a preceding seed() continues
+        the env's RNG stream and draws the next level, as in the reference (the `if done: env.reset()` loop of run_tests.py:64-66 sees a
+        new level per episode; gym.make(id) followed by reset() gives the SECOND level of seed 1337)."""
+        obs = self._vec.reset(reseed=self._seed_pending)
+        self._seed_pending = False
+        return self._obs(obs)
 
     def step(self, action):
         obs, reward, done, info = self._vec.step(np.array([int(action)], np.uint8))
@@ -87,6 +92,28 @@ class SingleEnv:
 
     def close(self):
         self._vec.close()
+
+
+class ReseedWrapper:
+    """The reference's ReseedWrapper for a SingleEnv (wrappers.py:12-32): every reset() seeds the env with the next entry of `seeds`,
+    cyclically, then resets it.  (Batched and on the GPU this is VecMiniGrid.set_seed_schedule.)"""
+
+    def __init__(self, env, seeds=(0,), seed_idx=0):
+        self.env = env
+        self.seeds = [int(s) for s in seeds]
+        self.seed_idx = int(seed_idx)
+
+    def reset(self):
+        seed = self.seeds[self.seed_idx]
+        self.seed_idx = (self.seed_idx + 1) % len(self.seeds)
+        self.env.seed(seed)
+        return self.env.reset()
+
+    def step(self, action):
+        return self.env.step(action)
+
+    def __getattr__(self, name):  # gym.core.Wrapper forwards everything else to the wrapped env
+        return getattr(self.env, name)
 
 
 def make(env_id, **kwargs):

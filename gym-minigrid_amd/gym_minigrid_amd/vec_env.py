@@ -2,7 +2,9 @@
 
 Mirrors, for N lockstep env instances, the methods and attributes callers use on
 `gym_minigrid.minigrid.MiniGridEnv` (/root/reference/gym_minigrid/minigrid.py):
-    reset() -> obs                      :831-858   (+ ReseedWrapper: seed(s_i) then reset(), wrappers.py:24-28)
+    reset() -> obs                      :831-858   (reseed=True: ReseedWrapper(seeds=[s_i]) -- seed(s_i) then reset(), wrappers.py:24-28;
+                                                    reseed=False: the plain reset(), the env's RNG stream continues;
+                                                    set_seed_schedule(): ReseedWrapper with a list of seeds per env, wrappers.py:12-28)
     seed(seed)                          :860-863
     step(actions) -> obs, reward, done, info   :1227-1325
     action_space = Discrete(7)          :792
@@ -176,15 +178,33 @@ class VecMiniGrid:
         self._seeds_dev = None  # device copy (torch backend), made on first use
         return [seed]
 
-    def reset(self, mask=None):
-        """seed(seed_i); reset() for every env (or those with mask[i] != 0).  Returns the obs buffer of ALL envs (the one
-        step() returns: with a mask only the tiles holding a reset env are rewritten, the rest still hold the last step)."""
-        seeds = self.seeds
+    def set_seed_schedule(self, seeds, seed_idx=0):
+        """ReseedWrapper(env_i, seeds=seeds[i], seed_idx=seed_idx) for every env (wrappers.py:12-28): seeds (N, K) uint64.  From now on every
+        reset of env i -- the in-kernel one of auto_reset=True and reset(reseed=False) -- re-seeds it with the next entry of its list,
+        cyclically.  Like the wrapper's constructor this does not reset: call reset(reseed=False) next (step() refuses until then).
+        seeds=None removes the schedule."""
         if self._torch is not None:
             self._bind_stream()
-            if self._seeds_dev is None:  # keep the seeds on the GPU: a masked reset per step must not upload 8 B per env
+        if seeds is None:
+            _lib.check(_lib.lib().mgx_set_seed_schedule(self._h, None, 0, 0))
+            return
+        s = np.ascontiguousarray(seeds, dtype=np.uint64)
+        if s.ndim != 2 or s.shape[0] != self.num_envs:
+            raise ValueError("seeds must have shape (%d, K)" % self.num_envs)
+        _lib.check(_lib.lib().mgx_set_seed_schedule(self._h, _ptr(s), int(s.shape[1]), int(seed_idx)))
+
+    def reset(self, mask=None, reseed=True):
+        """reseed=True: seed(seed_i); reset() for every env (or those with mask[i] != 0) -- ReseedWrapper(seeds=[seed_i]) semantics.
+        reseed=False: the reference's plain reset() (minigrid.py:831-858; `if done: env.reset()`, run_tests.py:64-66): the env's own RNG
+        stream continues and a NEW level is drawn from it -- or, after set_seed_schedule(), ReseedWrapper.reset(): the next seed of the
+        env's list.  Returns the obs buffer of ALL envs (the one step() returns: with a mask only the tiles holding a reset env are
+        rewritten, the rest still hold the last step)."""
+        seeds = self.seeds if reseed else None
+        if self._torch is not None:
+            self._bind_stream()
+            if reseed and self._seeds_dev is None:  # keep the seeds on the GPU: a masked reset per step must not upload 8 B per env
                 self._seeds_dev = self._torch.from_numpy(self.seeds.view(np.int64)).to(self._dev)
-            seeds = self._seeds_dev
+            seeds = self._seeds_dev if reseed else None
         if mask is None or isinstance(mask, np.ndarray) or self._torch is None or not isinstance(mask, self._torch.Tensor):
             m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)
         else:                            # e.g. the `done` tensor step() returned: used in place

@@ -9,7 +9,8 @@
  *   mgx_create / mgx_destroy   MiniGridEnv.__init__ kwargs        minigrid.py:767-829
  *   mgx_env_config             per-id constructor arguments       envs/empty.py:10-28, envs/doorkey.py:9-13,
  *                                                                 envs/crossing.py:12-22, envs/lavagap.py:10-19
- *   mgx_reset                  seed(s); reset()                   minigrid.py:831-863, wrappers.py:24-28
+ *   mgx_reset                  seed(s); reset()  |  reset()       minigrid.py:831-863 (caller loop: run_tests.py:64-66), wrappers.py:24-28
+ *   mgx_set_seed_schedule      ReseedWrapper(env, seeds, seed_idx) wrappers.py:12-28
  *   mgx_set_state/get_state    env.grid / agent_pos / agent_dir / carrying / step_count attributes
  *                                                                 minigrid.py:816-823,851-854, Grid.encode :571-594
  *   mgx_observe                gen_obs()                          minigrid.py:1359-1381
@@ -179,9 +180,10 @@ typedef struct {
     int32_t see_through_walls;  /* 1 = skip process_vis (minigrid.py:1344-1347) */
     int32_t lava_v1;            /* 1 = class name contains 'v1': lava gives reward -1, no done (minigrid.py:1262-1268) */
     int32_t obs_mode;           /* mgx_obs_mode */
-    int32_t auto_reset;         /* 0 = reference semantics (caller resets, run_tests.py:64-66).
+    int32_t auto_reset;         /* 0 = reference semantics (caller resets, run_tests.py:64-66: mgx_reset in one of its three forms).
                                    1 = on done the env is restored to its episode-start state (the state last given
-                                       by mgx_reset / mgx_set_state: ReseedWrapper(seeds=[s]) semantics) inside the same
+                                       by mgx_reset / mgx_set_state: ReseedWrapper(seeds=[s]) semantics; with
+                                       mgx_set_seed_schedule: the level of the NEXT seed of the env's list) inside the same
                                        step, and obs is the first observation of the new episode (VecEnv convention);
                                        reward/done still describe the terminal transition. */
     int32_t level_kind;         /* mgx_level_kind */
@@ -247,17 +249,42 @@ int mgx_generate_level_stream_ex(const mgx_config *cfg, uint64_t seed, int64_t K
 int mgx_generate_level_stream_full(const mgx_config *cfg, uint64_t seed, int64_t K, uint8_t *grid, int32_t *agent, uint32_t *task,
                                    uint8_t *contains);
 
-/* env.seed(seeds[i]); env.reset() for every env with mask[i] != 0 (mask NULL = all).
+/* The reference's reset() of every env with mask[i] != 0 (mask NULL = all), in its three forms:
+ *
+ *   seeds != NULL             env.seed(seeds[i]); env.reset()                     minigrid.py:831-863 (ReseedWrapper(seeds=[s]), wrappers.py:24-28)
+ *   seeds == NULL, no schedule  env.reset()  -- the plain caller-side reset of `if done: env.reset()` (run_tests.py:64-66): the env's own
+ *                             RNG stream CONTINUES from where the last reset (and, for Dynamic-Obstacles, the obstacle walks since)
+ *                             left it, and the next level is drawn from it (minigrid.py:836-839).  The env must have been seeded by an
+ *                             earlier mgx_reset(seeds) (MiniGridEnv.__init__ does `self.seed(1337); self.reset()`, minigrid.py:824-829:
+ *                             a binding that mirrors gym.make() issues that first call itself), else MGX_ERR_INVALID_STATE.
+ *   seeds == NULL, schedule   ReseedWrapper(seeds=[s0..sK-1]).reset(): env i is re-seeded with the next entry of ITS seed list
+ *                             (mgx_set_seed_schedule below), cyclically                wrappers.py:19-28
+ *
  * For the families that draw random numbers the whole reset runs on the GPU (k_seed: SHA-512 key + MT19937
  * init_by_array per env, then k_levelgen); an env whose seed is the one it already has is restored from its
  * episode-start snapshot instead (same result: the level and the RNG state are functions of the seed).
  * Families whose level does not depend on the seed (Empty with a fixed start, DistShift, fixed TwoGoals) generate it
- * once on the host at the first full reset; every later reset is a restore on the device.  Grids beyond 64x64 cells
- * with a random family are generated per env on the host (seeds may still be a device pointer).
+ * once on the host at the first full reset; every later reset, of any form, is a restore on the device.  Grids beyond 64x64 cells
+ * with a random family are generated per env on the host (seeds may still be a device pointer; the seeds == NULL forms are
+ * MGX_ERR_UNSUPPORTED there: their RNG stream lives on the host only for the length of a call).
+ * With auto_reset = 1 the state a reset leaves behind is also the new episode-start snapshot (plain form: the level just drawn).
  * obs (optional) receives the current observation of all envs; with a mask and a DEVICE obs buffer only the 64-env
  * tiles that contain a reset env are rewritten (pass the buffer the last mgx_step wrote, as the reference's
  * `if done: obs = env.reset()` loop does, and the other entries are already right). */
 int mgx_reset(mgx_handle h, const uint64_t *seeds, const uint8_t *mask, uint8_t *obs);
+
+/* ReseedWrapper(env_i, seeds = seeds[i][0 .. K-1], seed_idx = idx0) for every env (wrappers.py:12-28): from now on every reset of
+ * env i -- the in-kernel one of auto_reset = 1 handles and mgx_reset(h, NULL, mask, obs) -- is `env.seed(seeds[i][j]); env.reset()`
+ * with j = idx0, idx0 + 1, ... mod K, counted per env.  seeds: uint64 [N][K] (host or device pointer), 1 <= K <= 255, 0 <= idx0 < K.
+ * The K levels of every env are functions of its K seeds: they are generated here, once, on the GPU (K x (k_seed + k_levelgen)) into
+ * K episode-start snapshots per env that stay resident in HBM (K x (W*H + 8) bytes per env; Dynamic-Obstacles: + 2.7 KB of RNG
+ * state each), so a reset at run time -- in the step kernel or in mgx_reset -- is a copy, whatever K is.
+ * The wrapper's constructor does not reset, and neither does this call: the live episodes are INVALID afterwards (their RNG state was
+ * used to generate the snapshots) and mgx_step / mgx_observe return MGX_ERR_INVALID_STATE until mgx_reset(h, NULL, NULL, obs) has
+ * started every env on seeds[i][idx0].  K = 0 (seeds may be NULL) removes the schedule; so do mgx_reset with seeds != NULL and
+ * mgx_set_state, which define the episode start themselves.  Not for new_level_each_episode handles (the two settings are the two
+ * alternatives of the reference: with or without the wrapper) and not for grids beyond 64x64 cells: MGX_ERR_UNSUPPORTED. */
+int mgx_set_seed_schedule(mgx_handle h, const uint64_t *seeds, int32_t K, int32_t idx0);
 
 /* Inject / read back the full simulator state.  set_state also records the state as the
  * episode start used by auto_reset.  aux, carry, steps may be NULL (zeros / nothing / 0).

@@ -42,8 +42,12 @@ def n_obstacles_of(size, n_obstacles):
 
 
 class DynObsOracle:
-    def __init__(self, size, n_obstacles, random_start, seeds, view=7):
+    def __init__(self, size, n_obstacles, random_start, seeds, view=7, seed_lists=None, seed_idx=0):
         self.size, self.n_obst, self.random_start = int(size), n_obstacles_of(size, n_obstacles), bool(random_start)
+        if seed_lists is not None:  # ReseedWrapper(env, seeds=seed_lists[e], seed_idx): `seeds` is ignored
+            self.seed_lists = [[int(v) for v in sl] for sl in seed_lists]
+            self.seed_idx = [int(seed_idx)] * len(self.seed_lists)
+            seeds = [0] * len(self.seed_lists)
         self.seeds = [int(s) for s in seeds]
         self.n = len(self.seeds)
         self.max_steps = 4 * size * size
@@ -73,11 +77,18 @@ class DynObsOracle:
                 continue
             return x, y
 
-    def reset_where(self, mask):
-        """env.seed(s); env.reset() for the masked envs (ReseedWrapper semantics, wrappers.py:24-28)."""
+    def reset_where(self, mask, reseed=True):
+        """env.seed(s); env.reset() for the masked envs (ReseedWrapper semantics, wrappers.py:24-28).  reseed=False: the plain reset()
+        (minigrid.py:831-858) -- the env's RandomState goes on from where the obstacle walks left it.  With `seed_lists` set (one list
+        per env) and reseed=True: ReseedWrapper(seeds=list) -- the next entry of the env's list, cyclically (wrappers.py:19-28)."""
         S = self.size
         for e in np.flatnonzero(np.asarray(mask, bool)):
-            self.rng[e] = np_random(self.seeds[e])
+            if reseed:
+                lists = getattr(self, "seed_lists", None)
+                if lists is not None:
+                    self.seeds[e] = int(lists[e][self.seed_idx[e]])
+                    self.seed_idx[e] = (self.seed_idx[e] + 1) % len(lists[e])
+                self.rng[e] = np_random(self.seeds[e])
             g = self.base.grid[e]
             g[:] = (EMPTY, 0, 0)
             g[0, :] = g[S - 1, :] = g[:, 0] = g[:, S - 1] = (WALL, GREY, 0)

@@ -51,7 +51,7 @@ import numpy as np  # noqa: E402
 import gym  # noqa: E402
 import gym_minigrid  # noqa: E402,F401
 from gym_minigrid import minigrid as M  # noqa: E402
-from gym_minigrid.wrappers import FullyObsWrapper, ViewSizeWrapper  # noqa: E402
+from gym_minigrid.wrappers import FullyObsWrapper, ReseedWrapper, ViewSizeWrapper  # noqa: E402
 
 OUT = os.path.join(REPO, "tests", "golden")
 
@@ -307,14 +307,20 @@ def doorkey_script(env):
 
 
 # --------------------------------------------------------------------------- recorder
-def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False, reseed=True, n_actions=7, objstate=False, gym_id=None):
+def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False, reseed=True, n_actions=7, objstate=False, gym_id=None,
+                seed_lists=None, seed_idx0=0):
+    """seed_lists (round 4): trace k runs under the reference's own ReseedWrapper(env, seeds=seed_lists[k], seed_idx=seed_idx0)
+    (wrappers.py:12-28): every reset() -- the first one included -- seeds with the next entry of the list, cyclically.  `seeds` is
+    then ignored; z['seed'][k] is the seed of the first episode and z['seed_list'] (K, L) the lists."""
+    if seed_lists is not None:
+        seeds = [sl[seed_idx0] for sl in seed_lists]
     K = len(seeds)
     env0 = make_env()
     W, H = env0.width, env0.height
     V = int(env0.agent_view_size)
     meta = dict(env_id=name, W=W, H=H, max_steps=int(env0.max_steps), view=V,
                 see_through=bool(env0.see_through_walls), lava_v1=bool(v1), full_obs=bool(full_obs),
-                reseed=bool(reseed), extended=bool(n_actions > 7), alt_vis=not bool(env0.default_vis),
+                reseed=("list" if seed_lists is not None else bool(reseed)), seed_idx0=int(seed_idx0), extended=bool(n_actions > 7), alt_vis=not bool(env0.default_vis),
                 task=11 if type(env0).__name__.startswith("TwoGoals") else 10 if type(env0).__name__.startswith("PutNear") else 9 if type(env0).__name__ == "LockedRoom" else 7 if type(env0).__name__ == "Unlock" else 8 if type(env0).__name__ in ("UnlockPickup", "BlockedUnlockPickup") or type(env0).__name__.startswith(("KeyCorridor", "ObstructedMaze")) else 6 if type(env0).__name__.startswith("Memory") else 5 if type(env0).__name__.startswith("RedBlueDoor") else 4 if type(env0).__name__.startswith(("GoToObject", "GotoEnv")) else (1 if hasattr(env0, "targetType") else (2 if hasattr(env0, "target_pos") else 0)),
                 objstate=bool(objstate), dynobs=int(getattr(env0, "n_obstacles", 0)), gym_id=gym_id or "")
     z = dict(
@@ -335,10 +341,17 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
         z["carry_aux"] = np.zeros((K, T), np.uint8)
         z["carry_contains"] = np.zeros((K, T, 3), np.uint8)
     rk, rt, rg, ra, rag, ro, rtask, rcont, rfull = [], [], [], [], [], [], [], [], []
+    if seed_lists is not None:
+        z["seed_list"] = np.asarray(seed_lists, np.int64)
     for k, s in enumerate(seeds):
         env = make_env()
-        env.seed(int(s))
-        o = env.reset()
+        wrapped = None
+        if seed_lists is not None:
+            wrapped = ReseedWrapper(env, seeds=[int(v) for v in seed_lists[k]], seed_idx=int(seed_idx0))
+            o = wrapped.reset()
+        else:
+            env.seed(int(s))
+            o = env.reset()
         z["seed"][k] = s
         z["init_grid"][k] = env.grid.encode()
         z["init_aux"][k] = aux_plane(env)
@@ -386,9 +399,12 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
             if full_obs:
                 z["full"][k, t] = full_image(env)
             if d:
-                if reseed:
-                    env.seed(int(s))
-                o2 = env.reset()  # reseed=False: the env's own RNG stream continues -> a new level
+                if wrapped is not None:
+                    o2 = wrapped.reset()  # ReseedWrapper: seed(next of the list); reset()
+                else:
+                    if reseed:
+                        env.seed(int(s))
+                    o2 = env.reset()  # reseed=False: the env's own RNG stream continues -> a new level
                 rk.append(k)
                 rt.append(t)
                 rg.append(env.grid.encode())
@@ -985,6 +1001,22 @@ def main():
     record_case("DoorKey-5x5-stream", mk("MiniGrid-DoorKey-5x5-v0"), [0, 1, 2], 800, reseed=False)
     record_case("LavaGapS6-stream", mk("MiniGrid-LavaGapS6-v0"), [0, 1, 2, 3], 400, reseed=False)
     record_case("Empty-Random-6x6-stream", mk("MiniGrid-Empty-Random-6x6-v0"), [0, 1], 450, reseed=False)
+    # round 4: the two episode boundaries the C ABI lacked.  (1) plain caller-side reset() without seed() on the BASELINE families and on
+    # Dynamic-Obstacles, whose step() itself draws from the stream the next level continues (minigrid.py:836-839, run_tests.py:64-66);
+    record_case("DoorKey-8x8-stream", mk("MiniGrid-DoorKey-8x8-v0"), list(range(6)), 1400, scripts=[doorkey_script] * 3 + [None] * 3, reseed=False)
+    record_case("DynObs-8x8-stream", mk("MiniGrid-Dynamic-Obstacles-8x8-v0"), list(range(10)), 400, reseed=False, n_actions=4, gym_id="MiniGrid-Dynamic-Obstacles-8x8-v0")
+    record_case("DynObs-Random-6x6-stream", mk("MiniGrid-Dynamic-Obstacles-Random-6x6-v0"), list(range(8)), 300, reseed=False, n_actions=4, gym_id="MiniGrid-Dynamic-Obstacles-Random-6x6-v0")
+    record_case("DynObs-16x16-stream", mk("MiniGrid-Dynamic-Obstacles-16x16-v0"), list(range(3)), 400, reseed=False, n_actions=4, gym_id="MiniGrid-Dynamic-Obstacles-16x16-v0")
+    # (2) the reference's ReseedWrapper with a list of K > 1 seeds (wrappers.py:12-28), recorded through the wrapper class itself
+    sl = lambda K, L, base: [[base + 10 * k + j for j in range(L)] for k in range(K)]  # noqa: E731
+    record_case("Empty-Random-6x6-seedlist", mk("MiniGrid-Empty-Random-6x6-v0"), None, 450, seed_lists=sl(4, 3, 100), gym_id="MiniGrid-Empty-Random-6x6-v0")
+    record_case("DoorKey-8x8-seedlist", mk("MiniGrid-DoorKey-8x8-v0"), None, 1400, scripts=[doorkey_script] * 3 + [None] * 3, seed_lists=sl(6, 3, 200), gym_id="MiniGrid-DoorKey-8x8-v0")
+    record_case("LavaCrossingS9N1-seedlist", mk("MiniGrid-LavaCrossingS9N1-v0"), None, 500, seed_lists=sl(6, 4, 300), seed_idx0=2, gym_id="MiniGrid-LavaCrossingS9N1-v0")
+    record_case("Fetch-8x8-N3-seedlist", mk("MiniGrid-Fetch-8x8-N3-v0"), None, 500, scripts=[fetch_script(0), fetch_script(1)] * 2 + [None] * 2, seed_lists=sl(6, 3, 400), gym_id="MiniGrid-Fetch-8x8-N3-v0")
+    record_case("ObstructedMaze-1Dlhb-seedlist", mk("MiniGrid-ObstructedMaze-1Dlhb-v0"), None, 700, scripts=[obstructed_script] * 4 + [None] * 2, seed_lists=sl(6, 2, 500),
+                objstate=True, gym_id="MiniGrid-ObstructedMaze-1Dlhb-v0")
+    record_case("DynObs-8x8-seedlist", mk("MiniGrid-Dynamic-Obstacles-8x8-v0"), None, 400, seed_lists=sl(10, 3, 600), seed_idx0=1, n_actions=4, gym_id="MiniGrid-Dynamic-Obstacles-8x8-v0")
+    record_case("DynObs-16x16-seedlist", mk("MiniGrid-Dynamic-Obstacles-16x16-v0"), None, 300, seed_lists=sl(3, 2, 700), n_actions=4, gym_id="MiniGrid-Dynamic-Obstacles-16x16-v0")
     if only:
         return
     record_levels()

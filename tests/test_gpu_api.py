@@ -290,7 +290,7 @@ def test_single_env_adapter_replays_reference_loop(case, mission):
     recorded trace -- obs dict, float reward, bool done, the attributes callers read."""
     from conftest import load_case
     meta, z = load_case(case)
-    assert meta["reseed"]
+    assert meta["reseed"] is True
     env = mg.make("MiniGrid-%s-v0" % case)
     assert env.actions.forward == 2 and env.action_space.n == 7
     for k in range(2):

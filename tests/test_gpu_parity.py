@@ -102,8 +102,9 @@ def test_golden_trace_autoreset(name):
     """auto_reset=True: terminal reward/done are reported, obs is the first observation of the next episode
     (the reference's recorded `reset()` observation), state is the episode start."""
     meta, z = load_case(name)
-    if not meta.get("reseed", True):
-        pytest.skip("recorded without re-seeding (a new level per episode): tests/test_gpu_stream.py::test_reference_stream_traces replays it")
+    if meta.get("reseed", True) is not True:
+        pytest.skip("recorded without re-seeding (a new level per episode: tests/test_gpu_stream.py::test_reference_stream_traces replays it) or under "
+                    "ReseedWrapper with a seed list (tests/test_gpu_episode_boundary.py)")
     K, T = z["actions"].shape
     N = 64 + K
     sel = np.arange(N) % K

@@ -17,7 +17,7 @@ def stream_cases():
     out = []
     for name in golden_cases():
         meta, _ = load_case(name)
-        if not meta.get("reseed", True) and meta["W"] * meta["H"] <= 4096:
+        if meta.get("reseed", True) is False and meta["W"] * meta["H"] <= 4096:
             out.append(name)
     return out
 

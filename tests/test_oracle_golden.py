@@ -53,7 +53,7 @@ def test_oracle_replays_reference_trace(name):
         # caller-side reset on done, same seed -> the recorded reset state is the episode start
         assert sorted(k for k, _ in resets.get(t, [])) == sorted(np.flatnonzero(done).tolist())
         for k, r in resets.get(t, []):
-            if meta.get("reseed", True):  # same seed -> the recorded reset state is the episode start
+            if meta.get("reseed", True) is True:  # same seed -> the recorded reset state is the episode start
                 assert np.array_equal(z["reset_grid"][r], z["init_grid"][k])
                 assert np.array_equal(z["reset_aux"][r], z["init_aux"][k])
                 assert np.array_equal(z["reset_agent"][r], z["init_agent"][k])
@@ -63,7 +63,8 @@ def test_oracle_replays_reference_trace(name):
                     assert np.array_equal(z["reset_full"][r], z["init_full"][k])
                 if objstate:
                     assert np.array_equal(z["reset_contains"][r], z["init_contains"][k])
-            else:                         # the RNG stream continued: a new level, injected from the recording
+            else:                         # the RNG stream continued / ReseedWrapper moved on to the next seed of its list
+                                          # (tests/test_episode_boundary.py pins those levels): injected from the recording
                 env.grid0[k], env.aux0[k], env.agent0[k] = z["reset_grid"][r], z["reset_aux"][r], z["reset_agent"][r]
                 if meta.get("task", 0):
                     env.task[k] = z["reset_task"][r]
