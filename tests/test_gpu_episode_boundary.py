@@ -125,8 +125,8 @@ def level_tables(env_id, lists):
     ("MiniGrid-DoorKey-5x5-v0", "partial", 64 * 5 + 3, 3, 520), ("MiniGrid-LavaCrossingS9N1-v0", "partial", 64 * 9 + 17, 4, 200),
     ("MiniGrid-LavaCrossingS9N1-v0", "full", 64 * 3 + 1, 2, 150),            # FullyObs, LDS form
     ("MiniGrid-Empty-Random-6x6-v0", "full", 64 * 4 + 5, 5, 330),            # FullyObs, direct form
-    ("MiniGrid-FourRooms-v0", "partial", 64 * 2 + 9, 3, 230),                # gather form, 19x19
-    ("MiniGrid-FourRooms-v0", "full", 64 * 2 + 9, 2, 210),                   # FullyObs, ragged direct form
+    ("MiniGrid-LockedRoom-v0", "partial", 64 * 2 + 9, 3, 400),               # gather form, 19x19
+    ("MiniGrid-LockedRoom-v0", "full", 64 * 2 + 9, 2, 390),                  # FullyObs, ragged direct form
     ("MiniGrid-LavaCrossingS11N5-v0", "full", 64 + 3, 3, 150),
     ("MiniGrid-Fetch-8x8-N3-v0", "partial", 64 * 3 + 2, 3, 200), ("MiniGrid-GoToObject-6x6-N2-v0", "partial", 64 * 3, 7, 120),
     ("MiniGrid-TwoGoals-Random-16x16-v0", "partial", 64 * 2 + 2, 2, 150),    # gather form with object state
