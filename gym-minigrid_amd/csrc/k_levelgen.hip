@@ -129,6 +129,25 @@ __device__ __forceinline__ void advance_env(const LevelGenParams &p, int64_t env
     wave_sync();
 }
 
+__device__ __forceinline__ uint32_t ib_step2(uint32_t prev, uint32_t tab, uint32_t kj);
+__device__ __forceinline__ uint32_t ib_step3(uint32_t prev, uint32_t old, uint32_t i);
+// init_by_array(key of `seed`) by ONE lane into 624 words of LDS (untwisted state, as numpy's RandomState.seed leaves it)
+__device__ __noinline__ void seed_block_one_lane(uint64_t seed, const uint32_t *__restrict__ init, uint32_t *m)
+{
+    uint32_t key[2];
+    const int klen = lg_seed_key(seed, key);
+    const uint32_t kj0 = key[0], kj1 = klen == 2 ? key[1] + 1u : key[0]; // key[j] + j for j = (i - 1) % klen
+    uint32_t prev = init[0];
+#pragma nounroll
+    for (int i = 1; i < 624; i++) { prev = ib_step2(prev, init[i], (i & 1) ? kj0 : kj1); m[i] = prev; }
+    prev = ib_step2(prev, m[1], kj1); // the 624th step of the first loop wraps to i = 1 (623 % klen picks key[1] + 1, or key[0] again for a one-word key)
+    m[1] = prev;
+#pragma nounroll
+    for (int i = 2; i < 624; i++) { prev = ib_step3(prev, m[i], (uint32_t)i); m[i] = prev; }
+    m[1] = ib_step3(prev, m[1], 1u);
+    m[0] = 0x80000000u;
+}
+
 // One level, generated by one wave into its LDS workspace and written back coalesced.
 __device__ __forceinline__ void levelgen_one(const LevelGenParams &p, int64_t env, uint8_t *base, int lane)
 {
@@ -137,7 +156,15 @@ __device__ __forceinline__ void levelgen_one(const LevelGenParams &p, int64_t en
     int16_t *ws = reinterpret_cast<int16_t *>(res + 4);
     LgCmd *cmds = reinterpret_cast<LgCmd *>(ws + MGX_LG_WS_WORDS);
     uint32_t *mt = p.mt + env * 624;
-    block_load(mt, cur, lane);
+    // A virtual state (seed + first words only) that a level outgrew: the env's full first block is re-derived from its seed -- ONE lane
+    // runs init_by_array into LDS (the recurrences are sequential per env; rare: tools/draw_stats.cpp), the wave twists it -- and written
+    // to `mt` below; from then on the env's state is materialized.
+    const bool was_virtual = p.virt && p.virt[env];
+    if (was_virtual) {
+        if (lane == 0) seed_block_one_lane(p.seed0[env], p.mt_init, nxt);
+        wave_sync();
+        twist_to(nxt, cur, lane);
+    } else block_load(mt, cur, lane);
     const int idx0 = (int)p.mt_idx[env];
     wave_sync();
     // The block after this one: kept in HBM by new_level_each_episode handles (p.mt2); otherwise, if the read index is within 64 words
@@ -186,6 +213,8 @@ __device__ __forceinline__ void levelgen_one(const LevelGenParams &p, int64_t en
             }
         }
     }
+    if (was_virtual && !res[2]) block_store(mt, cur, lane);
+    if (was_virtual && lane == 0) p.virt[env] = 0;
     if (res[2]) { // moved into a later block: it becomes the env's state (and the one after it is made ready, where the handle keeps one)
         uint32_t *blk = res[2] == 1 ? cur : nxt, *other = res[2] == 1 ? nxt : cur;
         block_store(mt, blk, lane);
@@ -245,9 +274,11 @@ template <bool SLIDE>
 __device__ __forceinline__ bool fast_setup(const LevelGenParams &p, const FastLayout &fl, int64_t env, uint32_t *slice, int W, int H, int cells, WinRng<SLIDE> &r, LgLevel &L)
 {
     const int idx0 = (int)p.mt_idx[env];
-    const int end = p.mt2 ? 1248 : 624; // stream positions this env has ready: its block, and the next one where the handle keeps it
-    if (idx0 >= 624 || (!SLIDE && (idx0 + MGX_LGF_WIN > end || fl.img_dw == 0))) return false;
-    r.win = slice; r.mt = p.mt + env * 624; r.mt2 = p.mt2 ? p.mt2 + env * 624 : nullptr; r.end = end;
+    const bool v = p.virt && p.virt[env]; // virtual state: only the first MGX_SEED_WIN words of the first block exist (LevelGenParams.win)
+    const int blk = v ? MGX_SEED_WIN : 624;
+    const int end = v ? MGX_SEED_WIN : (p.mt2 ? 1248 : 624); // stream positions this env has ready: its block, and the next one where the handle keeps it
+    if (idx0 >= blk || (!SLIDE && (idx0 + MGX_LGF_WIN > end || fl.img_dw == 0))) return false;
+    r.win = slice; r.mt = v ? p.win + env * MGX_SEED_WIN : p.mt + env * 624; r.mt2 = (!v && p.mt2) ? p.mt2 + env * 624 : nullptr; r.end = end;
     r.base = idx0; r.idx = idx0; r.overflow = false;
     r.limit = idx0 + MGX_LGF_WIN < r.stop_of(idx0) ? idx0 + MGX_LGF_WIN : r.stop_of(idx0);
     r.fill(idx0);
@@ -352,7 +383,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MGX_LG_WAVE
     const int kind = p.cfg.level_kind;
     const bool cheap = p.S <= MGX_LGF_MAXS_CHEAP && (kind == MGX_LEVEL_EMPTY || kind == MGX_LEVEL_DOORKEY || kind == MGX_LEVEL_CROSSING ||
                                                kind == MGX_LEVEL_LAVAGAP || kind == MGX_LEVEL_DISTSHIFT);
-    const bool slide = !cheap;
+    const bool slide = !cheap || p.virt != nullptr; // (a virtual state is 64 words long: the cheap form's all-or-nothing window of 32 would send 1 % of DoorKey-8x8's levels to the slow path)
     if (fl.n_fast_waves == 0) { // every level by a whole wave (levelgen_one)
         for (int i = tid; i < count; i += 256) s_slow[i] = s_queue[i];
         if (tid == 0) s_nslow = count;
@@ -619,6 +650,101 @@ __device__ __forceinline__ void twist_rounds(uint32_t *s, int lane)
     wave_sync();
 }
 
+// The first MGX_SEED_WIN words of the first twisted block, without the block: new[k] = old[k + 397] ^ g(old[k], old[k + 1]) for k < 227, so
+// of init_by_array's 624 words only old[0 .. WIN] and old[397 .. 397 + WIN) are ever looked at -- but every one of them stands at the end of
+// the two sequential passes, so the chains run in full (pass 2 once for its last word, then again in lockstep with pass 3, as in
+// seed_passes) and simply keep nothing else: g(old[k], old[k + 1]) goes into a register as soon as old[k + 1] is known (k = 2 .. WIN - 1; old[1] is
+// the chain's LAST word), and is folded with old[k + 397] when that one comes by.  No LDS, no HBM traffic but the 256-byte result.
+__device__ __forceinline__ uint32_t tw_g(uint32_t a, uint32_t b)
+{
+    const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+    return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+__device__ __forceinline__ void seed_window(uint64_t seed, const uint32_t *__restrict__ init, uint32_t *win)
+{
+    constexpr int WIN = MGX_SEED_WIN;
+    static_assert(WIN % 16 == 0 && WIN <= 96, "chunks of 16; old[0 .. WIN] must be complete before old[397] comes by");
+    uint32_t key[2];
+    const int klen = lg_seed_key(seed, key);
+    const uint32_t kj0 = key[0], kj1 = klen == 2 ? key[1] + 1u : key[0];
+    uint32_t prev = init[0], v1 = 0;
+#pragma unroll 1
+    for (int i0 = 0; i0 < 624; i0 += 16) {
+        uint32_t tab[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) tab[k] = init[i0 + k];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if (i0 + k == 0) continue;
+            prev = ib_step2(prev, tab[k], (k & 1) ? kj0 : kj1);
+            if (i0 + k == 1) v1 = prev;
+        }
+    }
+    const uint32_t m1 = ib_step2(prev, v1, kj1);
+    uint32_t px = init[0], py = m1;
+    uint32_t t[WIN];          // t[k] = g(old[k], old[k + 1]), then new[k]
+    uint32_t y2 = 0, ylast = 0, y397 = 0, y398 = 0;
+    // one chunk of 16 steps; EARLY: i0 <= WIN (old[2 .. WIN] come by), LATE: the chunks that hold old[397 .. 397 + WIN)
+#define MGX_SW_CHUNK(I0, EARLY, LATE)                                                                       \
+    {                                                                                                        \
+        uint32_t tab[16];                                                                                    \
+        _Pragma("unroll") for (int k = 0; k < 16; k++) tab[k] = init[(I0) + k];                             \
+        _Pragma("unroll") for (int k = 0; k < 16; k++) {                                                    \
+            const int i = (I0) + k;                                                                          \
+            if (i == 0) continue;                                                                            \
+            px = ib_step2(px, tab[k], (k & 1) ? kj0 : kj1);                                                  \
+            if (i == 1) continue;                                                                            \
+            py = ib_step3(py, px, (uint32_t)i);                                                              \
+            if (EARLY) {                                                                                     \
+                if (i == 2) y2 = py;                                                                         \
+                if (i >= 3 && i <= WIN) { uint32_t gv = tw_g(ylast, py); asm volatile("" : "+v"(gv)); t[(i - 1) < WIN ? (i - 1) : 0] = gv; } \
+                ylast = py;                                                                                  \
+            }                                                                                                \
+            if (LATE) {                                                                                      \
+                if (i == 397) y397 = py;                                                                     \
+                if (i == 398) y398 = py;                                                                     \
+                if (i >= 399 && i < 397 + WIN) { uint32_t nv = t[(i - 397) < WIN ? (i - 397) : 0] ^ py; asm volatile("" : "+v"(nv)); t[(i - 397) < WIN ? (i - 397) : 0] = nv; } \
+            }                                                                                                \
+        }                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0); /* (unrolled chunks: keeps the scheduler from running the x chain 80 steps ahead of the y chain -- 200+ VGPRs) */ \
+    }
+    // (the index clamps above only keep the compiler from seeing an out-of-range constant in dead arms; the empty asm statements pin each
+    // folded word where it is computed -- left alone the compiler sinks all 64 folds to the end of the kernel and keeps the raw chain words,
+    // split into three masked pieces each, alive until then: 249 VGPRs)
+#pragma unroll
+    for (int c = 0; c <= WIN / 16; c++) MGX_SW_CHUNK(16 * c, true, false)
+#pragma unroll 1
+    for (int i0 = WIN + 16; i0 < 384; i0 += 16) MGX_SW_CHUNK(i0, false, false)
+#pragma unroll
+    for (int c = 0; c < (397 + WIN - 384 + 15) / 16; c++) MGX_SW_CHUNK(384 + 16 * c, false, true)
+#pragma unroll 1
+    for (int i0 = 384 + 16 * ((397 + WIN - 384 + 15) / 16); i0 < 624; i0 += 16) MGX_SW_CHUNK(i0, false, false)
+#undef MGX_SW_CHUNK
+    const uint32_t y1 = ib_step3(py, m1, 1u); // old[1]; old[0] = 0x80000000
+    t[0] = y397 ^ tw_g(0x80000000u, y1);
+    t[1] = y398 ^ tw_g(y1, y2);
+    uint4 *w4 = reinterpret_cast<uint4 *>(win);
+#pragma unroll
+    for (int q = 0; q < WIN / 4; q++) w4[q] = make_uint4(t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]);
+}
+
+// up to 64 queued envs of a span by one wave, virtual form: every lane its env's window
+__device__ __forceinline__ void seed_queue_wave_window(const uint64_t *__restrict__ seeds, const uint32_t *__restrict__ init, uint32_t *win, uint8_t *virt,
+                                                       uint32_t *mt_idx, uint8_t *regen, const SeedBook &book, int64_t base, const uint16_t *s_queue,
+                                                       int q0, int count, int lane)
+{
+    const int q = q0 + lane;
+    if (q >= count) return;
+    const int64_t env = base + s_queue[q];
+    const uint64_t sd = seeds[env];
+    seed_window(sd, init, win + env * MGX_SEED_WIN);
+    mt_idx[env] = 0;
+    regen[env] = 1;
+    virt[env] = 1;
+    book.seed0[env] = sd;
+    book.has_seed[env] = 1;
+}
+
 // up to 64 queued envs of a span by one wave: the two passes lane-per-env, then the block twists together
 __device__ __forceinline__ void seed_queue_wave(const uint64_t *__restrict__ seeds, const uint32_t *__restrict__ init, uint32_t *mt, uint32_t *mt2, uint32_t *mt_idx,
                                                 uint8_t *regen, const SeedBook &book, int64_t base, const uint16_t *s_queue, int q0, int count,
@@ -647,13 +773,41 @@ __device__ __forceinline__ void seed_queue_wave(const uint64_t *__restrict__ see
     }
 }
 
-__global__ __launch_bounds__(256) void k_seed(const uint64_t *__restrict__ seeds, const uint8_t *__restrict__ mask,
+// (MATERIALIZE) as seed_queue_wave, for envs whose seed is on record: block into `mt`, virt cleared, nothing else touched
+__device__ __forceinline__ void seed_queue_wave_materialize(const uint64_t *__restrict__ seed0, const uint32_t *__restrict__ init, uint32_t *mt, uint8_t *virt,
+                                                            int64_t base, const uint16_t *s_queue, int q0, int count, uint32_t *s_blk, int lane)
+{
+    const int q = q0 + lane;
+    const bool have = q < count;
+    const int64_t env = have ? base + s_queue[q] : 0;
+    if (have) seed_passes(seed0[env], init, mt + env * 624);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const int nq = count - q0 < 64 ? count - q0 : 64;
+    uint32_t r[10];
+    twist_load(mt + (base + s_queue[q0]) * 624, r, lane);
+    for (int l = 0; l < nq; l++) {
+        twist_to_lds(s_blk, r, lane);
+        if (l + 1 < nq) twist_load(mt + (base + s_queue[q0 + l + 1]) * 624, r, lane);
+        twist_block_wave(mt + (base + s_queue[q0 + l]) * 624, nullptr, s_blk, lane);
+    }
+    if (have) virt[env] = 0;
+}
+
+// FORM 0: the full state (block in `mt`, first twist done).  FORM 1: the virtual state (`mt` = LevelGenParams.win, `mt2` = LevelGenParams.virt as
+// bytes): no LDS block, twice the waves per SIMD.
+#ifndef MGX_SEEDW_WAVES
+#define MGX_SEEDW_WAVES 4 /* waves per SIMD the window form is held to (its 64 pending words live in registers) */
+#endif
+template <int FORM>
+__device__ __forceinline__ void seed_body(const uint64_t *__restrict__ seeds, const uint8_t *__restrict__ mask,
                                               const uint32_t *__restrict__ init, uint32_t *mt, uint32_t *mt2, uint32_t *mt_idx,
                                               uint8_t *regen, SeedBook book, int64_t n)
 {
     __shared__ uint16_t s_queue[MGX_SEED_SPAN];
     __shared__ int s_count;
-    __shared__ uint32_t s_blk[4][624];
+    __shared__ uint32_t s_blk[FORM == 0 ? 4 : 1][FORM == 0 ? 624 : 1];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t base = (int64_t)blockIdx.x * MGX_SEED_SPAN;
     if (tid == 0) s_count = 0;
@@ -668,7 +822,11 @@ __global__ __launch_bounds__(256) void k_seed(const uint64_t *__restrict__ seeds
     }
     __syncthreads();
     const int count = s_count;
-    for (int q0 = wv * 64; q0 < count; q0 += 256) seed_queue_wave(seeds, init, mt, mt2, mt_idx, regen, book, base, s_queue, q0, count, s_blk[wv], lane); // wave-uniform trip count
+    if constexpr (FORM == 1) {
+        for (int q0 = wv * 64; q0 < count; q0 += 256) seed_queue_wave_window(seeds, init, mt, reinterpret_cast<uint8_t *>(mt2), mt_idx, regen, book, base, s_queue, q0, count, lane);
+    } else {
+        for (int q0 = wv * 64; q0 < count; q0 += 256) seed_queue_wave(seeds, init, mt, mt2, mt_idx, regen, book, base, s_queue, q0, count, s_blk[wv], lane); // wave-uniform trip count
+    }
 }
 
 // Masked form (caller-side `reset(mask = done)`: ~1 % of the envs): one wave per 512-env span compacts the masked envs
@@ -678,11 +836,22 @@ __global__ __launch_bounds__(256) void k_seed(const uint64_t *__restrict__ seeds
 // them with; staging the table in LDS changed nothing.  A dense mask is still correct here, only slower than k_seed's
 // four waves per span.)
 #define MGX_SEEDM_SPAN 512
-__global__ __launch_bounds__(64) void k_seed_masked(const uint64_t *__restrict__ seeds, const uint8_t *__restrict__ mask,
+// FORM 0 / 1 as k_seed.  FORM 2, MATERIALIZE (the plain reset() of envs that still hold a virtual state): the masked envs (mask null = all)
+// with virt[env] set get their full first block from seed0 (= `seeds`) into `mt`; flags, seed book and mt_idx stay as they are.
+#define MGX_SEED_ARGS const uint64_t *__restrict__ seeds, const uint8_t *__restrict__ mask, const uint32_t *__restrict__ init, uint32_t *mt, uint32_t *mt2, \
+                      uint32_t *mt_idx, uint8_t *regen, SeedBook book, int64_t n
+__global__ __launch_bounds__(256) void k_seed(MGX_SEED_ARGS) { seed_body<0>(seeds, mask, init, mt, mt2, mt_idx, regen, book, n); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MGX_SEEDW_WAVES, MGX_SEEDW_WAVES))) void k_seed_window(MGX_SEED_ARGS)
+{
+    seed_body<1>(seeds, mask, init, mt, mt2, mt_idx, regen, book, n);
+}
+
+template <int FORM>
+__device__ __forceinline__ void seed_masked_body(const uint64_t *__restrict__ seeds, const uint8_t *__restrict__ mask,
                                                     const uint32_t *__restrict__ init, uint32_t *mt, uint32_t *mt2, uint32_t *mt_idx,
                                                     uint8_t *regen, SeedBook book, int64_t n)
 {
-    __shared__ uint32_t s_blk[624];
+    __shared__ uint32_t s_blk[FORM == 1 ? 1 : 624];
     __shared__ uint16_t s_queue[MGX_SEEDM_SPAN], s_masked[MGX_SEEDM_SPAN];
     __shared__ int s_count;
     const int lane = threadIdx.x;
@@ -691,6 +860,16 @@ __global__ __launch_bounds__(64) void k_seed_masked(const uint64_t *__restrict__
     wave_sync();
     // masked envs of the span first (LDS only), then the seed comparison for all of them at once: a lane that loaded its
     // operands inside the scan paid one round trip per mask byte position that any lane of the wave had set
+    uint8_t *virt = reinterpret_cast<uint8_t *>(mt2); // (FORM 1 / 2)
+    if constexpr (FORM == 2) {
+        for (int k = lane; k < MGX_SEEDM_SPAN; k += 64)
+            if (base + k < n && (!mask || mask[base + k]) && virt[base + k]) s_queue[atomicAdd(&s_count, 1)] = (uint16_t)k;
+        wave_sync();
+        const int cnt = s_count;
+        // (the full-state body with its own seeds: mt_idx / regen / book writes of seed_queue_wave are redirected to scratch-free no-ops below)
+        for (int q0 = 0; q0 < cnt; q0 += 64) seed_queue_wave_materialize(seeds, init, mt, virt, base, s_queue, q0, cnt, s_blk, lane);
+        return;
+    } else
     if (base + MGX_SEEDM_SPAN <= n && ((uintptr_t)(mask + base) & 7u) == 0) {
         // the span's 512 mask bytes in ONE round trip, 8 per lane (a byte per lane and round was 8 dependent round trips)
         static_assert(MGX_SEEDM_SPAN == 512, "8 mask bytes per lane");
@@ -719,8 +898,19 @@ __global__ __launch_bounds__(64) void k_seed_masked(const uint64_t *__restrict__
     wave_sync();
     const int count = s_count;
     if (count == 0) return;
-    for (int q0 = 0; q0 < count; q0 += 64) seed_queue_wave(seeds, init, mt, mt2, mt_idx, regen, book, base, s_queue, q0, count, s_blk, lane);
+    if constexpr (FORM == 1) {
+        for (int q0 = 0; q0 < count; q0 += 64) seed_queue_wave_window(seeds, init, mt, virt, mt_idx, regen, book, base, s_queue, q0, count, lane);
+    } else {
+        for (int q0 = 0; q0 < count; q0 += 64) seed_queue_wave(seeds, init, mt, mt2, mt_idx, regen, book, base, s_queue, q0, count, s_blk, lane);
+    }
 }
+
+__global__ __launch_bounds__(64) void k_seed_masked(MGX_SEED_ARGS) { seed_masked_body<0>(seeds, mask, init, mt, mt2, mt_idx, regen, book, n); }
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MGX_SEEDW_WAVES, MGX_SEEDW_WAVES))) void k_seed_masked_window(MGX_SEED_ARGS)
+{
+    seed_masked_body<1>(seeds, mask, init, mt, mt2, mt_idx, regen, book, n);
+}
+__global__ __launch_bounds__(64) void k_seed_materialize(MGX_SEED_ARGS) { seed_masked_body<2>(seeds, mask, init, mt, mt2, mt_idx, regen, book, n); }
 
 } // namespace
 
@@ -791,6 +981,24 @@ hipError_t mgx_launch_seed(const uint64_t *seeds, const uint8_t *mask, const uin
     const SeedBook book = {seed0, has_seed, reseeded, skip_same};
     if (mask) hipLaunchKernelGGL(k_seed_masked, dim3((unsigned)((n + MGX_SEEDM_SPAN - 1) / MGX_SEEDM_SPAN)), dim3(64), 0, st, seeds, mask, init, mt, mt2, mt_idx, regen, book, n);
     else hipLaunchKernelGGL(k_seed, dim3((unsigned)((n + MGX_SEED_SPAN - 1) / MGX_SEED_SPAN)), dim3(256), 0, st, seeds, mask, init, mt, mt2, mt_idx, regen, book, n);
+    return hipGetLastError();
+}
+
+hipError_t mgx_launch_seed_window(const uint64_t *seeds, const uint8_t *mask, const uint32_t *init, uint32_t *win, uint8_t *virt, uint32_t *mt_idx,
+                                  uint8_t *regen, uint64_t *seed0, uint8_t *has_seed, uint8_t *reseeded, int skip_same, int64_t n, hipStream_t st)
+{
+    const SeedBook book = {seed0, has_seed, reseeded, skip_same};
+    uint32_t *virt32 = reinterpret_cast<uint32_t *>(virt); // (rides in the kernels' `mt2` slot)
+    if (mask) hipLaunchKernelGGL(k_seed_masked_window, dim3((unsigned)((n + MGX_SEEDM_SPAN - 1) / MGX_SEEDM_SPAN)), dim3(64), 0, st, seeds, mask, init, win, virt32, mt_idx, regen, book, n);
+    else hipLaunchKernelGGL(k_seed_window, dim3((unsigned)((n + MGX_SEED_SPAN - 1) / MGX_SEED_SPAN)), dim3(256), 0, st, seeds, mask, init, win, virt32, mt_idx, regen, book, n);
+    return hipGetLastError();
+}
+
+hipError_t mgx_launch_seed_materialize(const uint8_t *mask, const uint32_t *init, uint32_t *mt, uint8_t *virt, const uint64_t *seed0, int64_t n, hipStream_t st)
+{
+    const SeedBook book = {nullptr, nullptr, nullptr, 0};
+    hipLaunchKernelGGL(k_seed_materialize, dim3((unsigned)((n + MGX_SEEDM_SPAN - 1) / MGX_SEEDM_SPAN)), dim3(64), 0, st, seed0, mask, init, mt,
+                       reinterpret_cast<uint32_t *>(virt), (uint32_t *)nullptr, (uint8_t *)nullptr, book, n);
     return hipGetLastError();
 }
 

@@ -1121,7 +1121,7 @@ LG_FN uint64_t lg_rotr64(uint64_t x, int n) { return (x >> n) | (x << (64 - n));
 
 LG_FN uint64_t lg_sha512_h0(const uint8_t *msg, int len) // len < 112: one block
 {
-    const uint64_t K[80] = {
+    static const uint64_t K[80] = {
         0x428a2f98d728ae22ULL, 0x7137449123ef65cdULL, 0xb5c0fbcfec4d3b2fULL, 0xe9b5dba58189dbbcULL, 0x3956c25bf348b538ULL,
         0x59f111f1b605d019ULL, 0x923f82a4af194f9bULL, 0xab1c5ed5da6d8118ULL, 0xd807aa98a3030242ULL, 0x12835b0145706fbeULL,
         0x243185be4ee4b28cULL, 0x550c7dc3d5ffb4e2ULL, 0x72be5d74f27b896fULL, 0x80deb1fe3b1696b1ULL, 0x9bdc06a725c71235ULL,
@@ -1153,24 +1153,28 @@ LG_FN uint64_t lg_sha512_h0(const uint8_t *msg, int len) // len < 112: one block
     w[15] = (uint64_t)len * 8; // message length in bits (len < 112, so the length field is the last word alone)
     uint64_t a = 0x6a09e667f3bcc908ULL, b = 0xbb67ae8584caa73bULL, c = 0x3c6ef372fe94f82bULL, d = 0xa54ff53a5f1d36f1ULL,
              e = 0x510e527fade682d1ULL, f = 0x9b05688c2b3e6c1fULL, g = 0x1f83d9abfb41bd6bULL, h = 0x5be0cd19137e2179ULL;
+    // 5 groups of 16 rounds, the group loop ROLLED and the round constants read from the table: fully unrolled (round 3) the 80 constants
+    // became 160 literal-holding VGPRs that the compiler hoisted out of the seed kernels' env loop -- k_seed ran at 186 VGPRs, two waves per
+    // SIMD -- and 5,000 instructions of straight-line code.  (The schedule indices stay compile-time: the round loop inside is unrolled.)
+#pragma unroll 1
+    for (int grp = 0; grp < 5; grp++) {
 #pragma unroll
-    for (int t = 0; t < 80; t++) {
-        uint64_t wt;
-        if (t < 16) wt = w[t];
-        else {
-            const uint64_t w15 = w[(t - 15) & 15], w2 = w[(t - 2) & 15];
-            const uint64_t s0 = lg_rotr64(w15, 1) ^ lg_rotr64(w15, 8) ^ (w15 >> 7);
-            const uint64_t s1 = lg_rotr64(w2, 19) ^ lg_rotr64(w2, 61) ^ (w2 >> 6);
-            wt = w[t & 15] + s0 + w[(t - 7) & 15] + s1;
-            w[t & 15] = wt;
+        for (int r = 0; r < 16; r++) {
+            if (grp > 0) {
+                const uint64_t w15 = w[(r + 1) & 15], w2 = w[(r + 14) & 15];
+                const uint64_t s0 = lg_rotr64(w15, 1) ^ lg_rotr64(w15, 8) ^ (w15 >> 7);
+                const uint64_t s1 = lg_rotr64(w2, 19) ^ lg_rotr64(w2, 61) ^ (w2 >> 6);
+                w[r] = w[r] + s0 + w[(r + 9) & 15] + s1;
+            }
+            const uint64_t wt = w[r];
+            const uint64_t S1 = lg_rotr64(e, 14) ^ lg_rotr64(e, 18) ^ lg_rotr64(e, 41);
+            const uint64_t ch = (e & f) ^ (~e & g);
+            const uint64_t t1 = h + S1 + ch + K[16 * grp + r] + wt;
+            const uint64_t S0 = lg_rotr64(a, 28) ^ lg_rotr64(a, 34) ^ lg_rotr64(a, 39);
+            const uint64_t mj = (a & b) ^ (a & c) ^ (b & c);
+            const uint64_t t2 = S0 + mj;
+            h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
         }
-        const uint64_t S1 = lg_rotr64(e, 14) ^ lg_rotr64(e, 18) ^ lg_rotr64(e, 41);
-        const uint64_t ch = (e & f) ^ (~e & g);
-        const uint64_t t1 = h + S1 + ch + K[t] + wt;
-        const uint64_t S0 = lg_rotr64(a, 28) ^ lg_rotr64(a, 34) ^ lg_rotr64(a, 39);
-        const uint64_t mj = (a & b) ^ (a & c) ^ (b & c);
-        const uint64_t t2 = S0 + mj;
-        h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
     }
     return 0x6a09e667f3bcc908ULL + a;
 }

@@ -97,6 +97,11 @@ struct mgx_env_s {
     uint8_t *bank_d = nullptr;    // StepParams.bank
     bool needs_full_reset = false; // a schedule was installed and the live episodes are invalid until mgx_reset(h, NULL, NULL, ...)
     bool seeded = false;          // every env has been through mgx_reset(seeds) at least once: its RNG stream exists (plain reset())
+    // virtual RNG states (LevelGenParams.win / virt): seed() leaves the seed + the first MGX_SEED_WIN words of the stream, not the 2.5 KB block
+    bool virt_mode = false;
+    uint32_t *win_d = nullptr;
+    uint8_t *virt_d = nullptr;
+    bool maybe_virtual = false;   // some env may still hold a virtual state (a plain reset() materializes the masked ones first)
     // object_state: hidden Goal/Box planes (+ episode-start snapshots) and the carried object's pair
     uint8_t *objaux_d = nullptr, *objaux0_d = nullptr, *objcont_d = nullptr, *objcont0_d = nullptr;
     uint16_t *objcarry_d = nullptr;
@@ -249,6 +254,7 @@ LevelGenParams levelgen_params(mgx_handle h)
     g.objaux0 = h->objaux0_d; g.objcont0 = h->objcont0_d;
     g.ctr = h->ctr_d;
     g.n = h->n; g.n_tiles = (int)(h->n_pad / 64); g.S = h->S;
+    g.win = h->win_d; g.virt = h->virt_d; g.seed0 = h->seed0_d; g.mt_init = h->mt_init_d;
     return g;
 }
 
@@ -263,6 +269,18 @@ DynObsParams dynobs_params(mgx_handle h)
     d.n = h->n; d.W = h->W; d.H = h->H; d.S = h->S; d.n_obst = h->cfg.level_arg0;
     d.n_tiles = (int)(h->n_pad / 64); d.LS = h->LS; d.wave_lds = mgx_dynobs_wave_lds(h->LS);
     return d;
+}
+
+// env.seed(seeds[i]) of the masked envs on the device, in the handle's form (full block / virtual state)
+hipError_t launch_seed(mgx_handle h, const uint64_t *seeds_dev, const uint8_t *mask_dev, int skip_same)
+{
+    if (h->virt_mode) {
+        h->maybe_virtual = true;
+        return mgx_launch_seed_window(seeds_dev, mask_dev, h->mt_init_d, h->win_d, h->virt_d, h->mt_idx_d, h->regen_d, h->seed0_d, h->has_seed_d, h->reseeded_d,
+                                      skip_same, h->n, h->stream);
+    }
+    return mgx_launch_seed(seeds_dev, mask_dev, h->mt_init_d, h->mt_d, h->mt2_d, h->mt_idx_d, h->regen_d, h->seed0_d, h->has_seed_d, h->reseeded_d, skip_same,
+                           h->n, h->stream);
 }
 
 int launch_levelgen(mgx_handle h)
@@ -507,6 +525,23 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
         CREATE_TRY(hipMalloc((void **)&h->reseeded_d, (size_t)h->n_pad));
         CREATE_TRY(hipMemsetAsync(h->has_seed_d, 0, (size_t)h->n_pad, h->stream));
         CREATE_TRY(hipMemsetAsync(h->reseeded_d, 0, (size_t)h->n_pad, h->stream));
+        // Virtual RNG states: handles that re-seed at every episode boundary (no stream mode; Dynamic-Obstacles draws inside step()) of the
+        // families whose levels take a few dozen draws (tools/draw_stats.cpp: the share of levels past 64 words is 0 for most of them, 2 %
+        // for DoorKey-5x5, 6 % for Fetch-5x5; KeyCorridor, Playground, MultiRoom and the 16x16 ObstructedMaze ids draw 50 ... 300 and keep
+        // the full block).  MGX_SEED_FORM=full / window overrides the rule (tests, tuning).
+        const int k = cfg->level_kind;
+        const bool short_draws = k == MGX_LEVEL_EMPTY || k == MGX_LEVEL_DOORKEY || k == MGX_LEVEL_CROSSING || k == MGX_LEVEL_LAVAGAP || k == MGX_LEVEL_FETCH ||
+                                 k == MGX_LEVEL_GOTODOOR || k == MGX_LEVEL_FOURROOMS || k == MGX_LEVEL_GOTOOBJECT || k == MGX_LEVEL_REDBLUEDOORS ||
+                                 k == MGX_LEVEL_MEMORY || k == MGX_LEVEL_UNLOCK || k == MGX_LEVEL_LOCKEDROOM || k == MGX_LEVEL_PUTNEAR || k == MGX_LEVEL_TWOGOALS ||
+                                 (k == MGX_LEVEL_OBSTRUCTEDMAZE && cfg->level_arg1 == 0);
+        const char *sf = getenv("MGX_SEED_FORM");
+        h->virt_mode = !h->stream_mode && cfg->task_kind != MGX_TASK_DYNOBS && (sf ? !strcmp(sf, "window") : short_draws);
+        if (h->virt_mode) {
+            CREATE_TRY(hipMalloc((void **)&h->win_d, ((size_t)h->n_pad * MGX_SEED_WIN + 64) * sizeof(uint32_t))); // (+ slack: see mt_d)
+            CREATE_TRY(hipMalloc((void **)&h->virt_d, (size_t)h->n_pad));
+            CREATE_TRY(hipMemsetAsync(h->win_d, 0, ((size_t)h->n_pad * MGX_SEED_WIN + 64) * sizeof(uint32_t), h->stream));
+            CREATE_TRY(hipMemsetAsync(h->virt_d, 0, (size_t)h->n_pad, h->stream));
+        }
     }
     if (cfg->task_kind == MGX_TASK_DYNOBS) {
         if (!h->device_levels) { int rc = mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_create: Dynamic-Obstacles needs the on-device level generator"); mgx_destroy(h); return rc; }
@@ -569,7 +604,7 @@ extern "C" int mgx_destroy(mgx_handle h)
     if (h->roll_exec) (void)hipGraphExecDestroy(h->roll_exec);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     (void)hipFree(h->obst_d); (void)hipFree(h->obst0_d); (void)hipFree(h->act_d); (void)hipFree(h->restart_d); (void)hipFree(h->mt0_d); (void)hipFree(h->pos0_d); (void)hipFree(h->tape_d); (void)hipFree(h->tape0_d);
-    (void)hipFree(h->sp0_d); (void)hipFree(h->bank_d);
+    (void)hipFree(h->sp0_d); (void)hipFree(h->bank_d); (void)hipFree(h->win_d); (void)hipFree(h->virt_d);
     for (auto &s : h->st_in) if (s.dev) (void)hipFree(s.dev);
     for (auto &s : h->st_out) if (s.dev) (void)hipFree(s.dev);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1113,8 +1148,7 @@ extern "C" int mgx_set_seed_schedule(mgx_handle h, const uint64_t *seeds, int32_
     for (int b = 0; b < K && e == hipSuccess && !rc; b++) {
         const size_t off = (size_t)b * (size_t)h->n_pad;
         e = mgx_launch_seed_column((const uint64_t *)ds, K, b, col, h->n, h->stream);
-        if (e == hipSuccess)
-            e = mgx_launch_seed(col, nullptr, h->mt_init_d, h->mt_d, h->mt2_d, h->mt_idx_d, h->regen_d, h->seed0_d, h->has_seed_d, h->reseeded_d, 0, h->n, h->stream);
+        if (e == hipSuccess) e = launch_seed(h, col, nullptr, 0);
         if (e != hipSuccess) break;
         LevelGenParams g = levelgen_params(h);
         g.cells0 += off * h->S; g.agent0 += off;
@@ -1191,6 +1225,10 @@ extern "C" int mgx_reset(mgx_handle h, const uint64_t *seeds, const uint8_t *mas
                 dp.mask_reset = (const uint8_t *)dm;
                 HIP_TRY(mgx_launch_dynobs_handover(dp, h->stream));
             }
+            if (h->maybe_virtual) { // the stream goes on past the first level: the masked envs that still hold seed + first words get their block
+                HIP_TRY(mgx_launch_seed_materialize((const uint8_t *)dm, h->mt_init_d, h->mt_d, h->virt_d, h->seed0_d, h->n, h->stream));
+                if (!mask) h->maybe_virtual = false;
+            }
             HIP_TRY(mgx_launch_mark_plain_reset((const uint8_t *)dm, h->regen_d, h->has_seed_d, h->reseeded_d, h->n, h->stream));
             if ((rc = launch_levelgen(h))) return rc;
             HIP_TRY(mgx_launch_consume(c, h->stream));
@@ -1219,8 +1257,7 @@ extern "C" int mgx_reset(mgx_handle h, const uint64_t *seeds, const uint8_t *mas
         // (k_seed clears the regeneration flags of the envs being reset before it raises those of the envs it really seeds)
         // (an env that keeps its seed keeps its level: with the snapshot still holding it -- not in stream mode, where the
         // buffer holds the NEXT level -- seeding and generation are skipped for it and k_consume alone restores it)
-        HIP_TRY(mgx_launch_seed((const uint64_t *)ds, (const uint8_t *)dm, h->mt_init_d, h->mt_d, h->mt2_d, h->mt_idx_d, h->regen_d, h->seed0_d, h->has_seed_d,
-                                h->reseeded_d, h->stream_mode ? 0 : 1, h->n, h->stream));
+        HIP_TRY(launch_seed(h, (const uint64_t *)ds, (const uint8_t *)dm, h->stream_mode ? 0 : 1));
         if ((rc = launch_levelgen(h))) return rc;
         ConsumeParams c = consume_params(h, (const uint8_t *)dm);
         c.flag_regen = h->stream_mode ? 1 : 0;

@@ -33,6 +33,15 @@ struct LevelGenParams {
     uint32_t *mt2;     // new_level_each_episode handles (else null): u32[n_pad][624], always twist(mt) = the block AFTER `mt`, kept ready by
                        // whoever advances an env's block, so that a level may run across the end of `mt` on the lane-per-level path
     uint32_t *mt_idx;  // u32[n_pad]       next unread word of the block (624 = exhausted / freshly seeded)
+    // Handles whose RNG state is rarely needed beyond the first level (every episode re-seeded: ReseedWrapper semantics, no stream mode,
+    // no Dynamic-Obstacles; families whose levels take a few dozen draws) keep a VIRTUAL state per env after seed(): the seed itself
+    // (seed0) plus the first MGX_SEED_WIN words of the first block (`win`), which is all a level reads -- 256 B per env instead of a
+    // 2.5 KB block written, read back for the twist and written again.  virt[env] = 1 while that holds; whoever needs more (a level that
+    // runs past the window: levelgen_one; the plain reset(): k_seed_masked<MATERIALIZE>) re-derives the block from seed0 into `mt` first.
+    uint32_t *win;     // u32[n_pad][MGX_SEED_WIN] (+ slack) or null
+    uint8_t *virt;     // u8[n_pad] or null
+    const uint64_t *seed0;   // u64[n_pad] the seed behind a virtual state
+    const uint32_t *mt_init; // init_genrand(19650218)'s 624 words
     uint8_t *regen;    // u8[n_pad]        work flags, cleared here
     uint8_t *cells0;   // next-level buffer (codes) and its agent record
     uint2 *agent0;
@@ -132,6 +141,7 @@ struct DynObsParams {
     int W, H, S, n_obst;
     int n_tiles, LS, wave_lds; // k_dynobs: one wave per 64-env tile, cells + RNG windows staged in LDS
 };
+#define MGX_SEED_WIN 64 /* words of the first MT19937 block a virtual RNG state keeps (tools/draw_stats.cpp: what the families' levels draw) */
 #define MGX_DYN_TAPE_DW 56 /* two bit planes of 848 stream positions (624 of the block + 224 of the next), 28 dwords each */
 int mgx_dynobs_wave_lds(int LS);
 hipError_t mgx_launch_dynobs_init(const DynObsParams &p, hipStream_t st);
@@ -142,6 +152,11 @@ hipError_t mgx_launch_dynobs_handover(const DynObsParams &p, hipStream_t st);
 hipError_t mgx_launch_levelgen(const LevelGenParams &p, hipStream_t st);
 hipError_t mgx_launch_seed(const uint64_t *seeds, const uint8_t *mask, const uint32_t *init, uint32_t *mt, uint32_t *mt2, uint32_t *mt_idx,
                            uint8_t *regen, uint64_t *seed0, uint8_t *has_seed, uint8_t *reseeded, int skip_same, int64_t n, hipStream_t st);
+// env.seed() of virtual-state handles (LevelGenParams.win / virt): the first MGX_SEED_WIN words only
+hipError_t mgx_launch_seed_window(const uint64_t *seeds, const uint8_t *mask, const uint32_t *init, uint32_t *win, uint8_t *virt, uint32_t *mt_idx,
+                                  uint8_t *regen, uint64_t *seed0, uint8_t *has_seed, uint8_t *reseeded, int skip_same, int64_t n, hipStream_t st);
+// the masked envs (null = all) that still hold a virtual state get their full first block (from seed0) into `mt`; mt_idx is kept
+hipError_t mgx_launch_seed_materialize(const uint8_t *mask, const uint32_t *init, uint32_t *mt, uint8_t *virt, const uint64_t *seed0, int64_t n, hipStream_t st);
 hipError_t mgx_launch_consume(const ConsumeParams &p, hipStream_t st);
 // mgx_set_seed_schedule: out[i] = seeds[i][b] (the b-th seed of every env's list)
 hipError_t mgx_launch_seed_column(const uint64_t *seeds, int K, int b, uint64_t *out, int64_t n, hipStream_t st);
