@@ -684,6 +684,7 @@ __device__ __forceinline__ void seed_window(uint64_t seed, const uint32_t *__res
     uint32_t px = init[0], py = m1;
     uint32_t t[WIN];          // t[k] = g(old[k], old[k + 1]), then new[k]
     uint32_t y2 = 0, ylast = 0, y397 = 0, y398 = 0;
+#define MGX_SW_BARRIER __builtin_amdgcn_sched_barrier(0); /* (unrolled chunks: keeps the scheduler from running the x chain far ahead of the y chain) */
     // one chunk of 16 steps; EARLY: i0 <= WIN (old[2 .. WIN] come by), LATE: the chunks that hold old[397 .. 397 + WIN)
 #define MGX_SW_CHUNK(I0, EARLY, LATE)                                                                       \
     {                                                                                                        \
@@ -706,7 +707,7 @@ __device__ __forceinline__ void seed_window(uint64_t seed, const uint32_t *__res
                 if (i >= 399 && i < 397 + WIN) { uint32_t nv = t[(i - 397) < WIN ? (i - 397) : 0] ^ py; asm volatile("" : "+v"(nv)); t[(i - 397) < WIN ? (i - 397) : 0] = nv; } \
             }                                                                                                \
         }                                                                                                    \
-        __builtin_amdgcn_sched_barrier(0); /* (unrolled chunks: keeps the scheduler from running the x chain 80 steps ahead of the y chain -- 200+ VGPRs) */ \
+        MGX_SW_BARRIER \
     }
     // (the index clamps above only keep the compiler from seeing an out-of-range constant in dead arms; the empty asm statements pin each
     // folded word where it is computed -- left alone the compiler sinks all 64 folds to the end of the kernel and keeps the raw chain words,

@@ -2,7 +2,8 @@ import sys, time
 sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/gym-minigrid_amd')
 import torch, numpy as np, gym_minigrid_amd as mg, ctypes
 from gym_minigrid_amd import _lib
-for env_id in ("MiniGrid-LavaCrossingS9N1-v0", "MiniGrid-DoorKey-8x8-v0", "MiniGrid-Empty-8x8-v0", "MiniGrid-Dynamic-Obstacles-8x8-v0", "MiniGrid-Fetch-8x8-N3-v0", "MiniGrid-MultiRoom-N4-S5-v0"):
+IDS = sys.argv[1:] or ("MiniGrid-LavaCrossingS9N1-v0", "MiniGrid-DoorKey-8x8-v0", "MiniGrid-Empty-8x8-v0", "MiniGrid-Dynamic-Obstacles-8x8-v0", "MiniGrid-Fetch-8x8-N3-v0", "MiniGrid-MultiRoom-N4-S5-v0")
+for env_id in IDS:
     N = 1 << 20
     env = mg.VecMiniGrid(env_id, num_envs=N, seeds=0, backend="torch", auto_reset=False)
     torch.cuda.synchronize(); t0=time.perf_counter(); env.reset(); torch.cuda.synchronize(); print(env_id, "full reset %.2f ms" % ((time.perf_counter()-t0)*1e3))
