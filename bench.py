@@ -189,7 +189,7 @@ def parse_args(argv=None):
                     help="N > 1 logging exchange every --log-every steps: all-gather of per-env done/reward on a side stream "
                          "(default), all-reduce of (episodes, reward_sum), or none")
     ap.add_argument("--log-every", type=int, default=None,
-                    help="steps between two logging exchanges (default min(256, --steps): never fewer than one inside the timed region)")
+                    help="steps between two logging exchanges (default min(256, --steps // 2 + 1): a short run exchanges once, half-way through its timed region)")
     ap.add_argument("--new-level-each-episode", action="store_true",
                     help="plain reference episode boundary: every reset draws a new level on the GPU (k_levelgen)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -321,9 +321,11 @@ def main():
         dist.all_gather_object(idents, ident)
         keys = [i["host"] + "|" + i["key"] for i in idents]
         distinct = len(set(keys)) == world
+        if not all(i.get("verifiable", True) for i in idents):
+            distinct = None   # a runtime that reports neither UUID nor PCI address: device indices under per-rank visibility masks prove nothing either way
         rccl = {"backend": dist.get_backend(), "world": world, "distinct_devices": distinct,
                 "devices": [{k: v for k, v in i.items() if k in ("rank", "local_rank", "index", "name", "uuid", "pci", "host")} for i in idents]}
-        if not distinct and not (args.rehearse_on_one_gpu or dry):
+        if distinct is False and not (args.rehearse_on_one_gpu or dry):
             raise SystemExit("bench.py: %d ranks but only %d distinct GPUs (%s); one rank per GPU, or --rehearse-on-one-gpu" % (world, len(set(keys)), sorted(set(keys))))
 
     n_local = args.envs_per_gpu

@@ -684,7 +684,7 @@ hipError_t mgx_launch_dynobs(const DynObsParams &p, hipStream_t st)
     // 255-281, two-wave 201, single-wave blocks 196 -- more of them fit a CU's 160 KB, and a block's LDS is free again as soon as its
     // one wave is done)
     int wpb = p.wave_lds > 8192 ? 1 : 4;
-    static const int wpb_env = getenv("MGX_DYN_WPB") ? atoi(getenv("MGX_DYN_WPB")) : 0; // (tuning runs)
+    static const int wpb_env = MGX_TUNE_ENV("MGX_DYN_WPB") ? atoi(MGX_TUNE_ENV("MGX_DYN_WPB")) : 0; // (tuning builds)
     if (wpb_env > 0 && wpb_env <= 4 && wpb_env * p.wave_lds <= 65536) wpb = wpb_env;
     const dim3 grid((unsigned)((p.n_tiles + wpb - 1) / wpb)), block(64 * wpb);
     const size_t shmem = (size_t)wpb * p.wave_lds;

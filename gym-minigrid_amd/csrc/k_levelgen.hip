@@ -948,16 +948,25 @@ hipError_t mgx_launch_levelgen(const LevelGenParams &p, hipStream_t st)
     fl.lanes = 64;
     if (kind == MGX_LEVEL_MULTIROOM) fl.lanes = 16;
     if (kind == MGX_LEVEL_KEYCORRIDOR && p.mt2) fl.lanes = 16; // (with the second block: 155 us per step -- 8 lanes 160, 12: 157, 20: 158, 24 / 32: 162 -- against 178 for a wave per level)
-    if (const char *e = getenv("MGX_LG_LANES")) { const int v = atoi(e); if (v >= 1 && v <= 64) fl.lanes = v; } // (tuning runs)
+    // (tuning builds only, read once per process and clamped: a negative MGX_LG_FAST_WAVES used to leave every flagged level ungenerated)
+    struct LgTune { int lanes, fast_waves, span; };
+    static const LgTune tune = [] {
+        LgTune t = {0, -1, 0};
+        if (const char *e = MGX_TUNE_ENV("MGX_LG_LANES")) { const int v = atoi(e); if (v >= 1 && v <= 64) t.lanes = v; }
+        if (const char *e = MGX_TUNE_ENV("MGX_LG_FAST_WAVES")) { const int v = atoi(e); if (v >= 0 && v <= 4) t.fast_waves = v; }
+        if (const char *e = MGX_TUNE_ENV("MGX_LG_SPAN")) { const int v = atoi(e); if (v >= 64 && v <= MGX_LGF_ENVS && (v & 63) == 0) t.span = v; }
+        return t;
+    }();
+    if (tune.lanes) fl.lanes = tune.lanes;
     const int slice_bytes = fl.lanes * fl.slice_dw * 4;
     fl.n_fast_waves = 60 * 1024 / slice_bytes;
     if (fl.n_fast_waves > 4) fl.n_fast_waves = 4;
     if (fl.n_fast_waves < 1) fl.n_fast_waves = 1;
     if (kind == MGX_LEVEL_KEYCORRIDOR && !p.mt2) fl.n_fast_waves = 0; // a wave per level
-    if (const char *e = getenv("MGX_LG_FAST_WAVES")) fl.n_fast_waves = atoi(e); // (tuning runs; 0 = every level takes the wave-per-level path)
+    if (tune.fast_waves >= 0) fl.n_fast_waves = tune.fast_waves; // (0 = every level takes the wave-per-level path)
     fl.span = heavy ? 128 : 512;
     while (fl.span < MGX_LGF_ENVS && (p.n + fl.span - 1) / fl.span > (heavy ? 8192 : 512)) fl.span *= 2;
-    if (const char *e = getenv("MGX_LG_SPAN")) { const int v = atoi(e); if (v >= 64 && v <= MGX_LGF_ENVS && (v & 63) == 0) fl.span = v; } // (tuning runs)
+    if (tune.span) fl.span = tune.span;
     size_t shmem = (size_t)(fl.n_fast_waves > 0 ? fl.n_fast_waves : 1) * slice_bytes;
     if (shmem < (size_t)slow_bytes) shmem = slow_bytes;
     fl.queue_off = (int)((shmem + 15) & ~(size_t)15);

@@ -386,7 +386,9 @@ __device__ __forceinline__ void emit_partial_obs(const StepParams &p, const Lane
             const bool inb = vf[V - 1 - vy] && vl[vx];
             // (LDS forms: a cell outside the grid is read where its index points -- a neighbouring env's row or the guard band,
             // StepParams.lds_guard -- and replaced by the wall below; only the global-memory form has to clamp the index)
-            const int idx = (GATHER && !inb) ? base : rowbase + (vx - V / 2) * sr;
+            // (... and the window form: its V x RS excerpt is this lane's own small LDS slot, an index outside the grid would point below the
+            // wave's allocation or into a neighbour's slot)
+            const int idx = ((GATHER || WIN != 0) && !inb) ? base : rowbase + (vx - V / 2) * sr;
 #ifdef MGX_EXP_FIXED_GATHER /* timing / counter experiment only (wrong observations): every lane reads the same offset of its own row, which is
                                conflict-free under the odd dword stride -- what the view gather would cost without LDS bank conflicts */
             uint32_t c = g[(vx * V + vy) & 63];
@@ -1401,7 +1403,7 @@ hipError_t mgx_step_launch_cfg(int device, StepLaunchCfg *out)
     int cus = 256;
     hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
     if (e != hipSuccess) return e;
-    const char *t = getenv("MGX_TAIL_BLOCKS"), *s = getenv("MGX_STAGGER"), *m = getenv("MGX_STAGGER_MIN");
+    const char *t = MGX_TUNE_ENV("MGX_TAIL_BLOCKS"), *s = MGX_TUNE_ENV("MGX_STAGGER"), *m = MGX_TUNE_ENV("MGX_STAGGER_MIN");
     out->tail_blocks = t ? atoi(t) : 2 * cus;
     out->stagger_units = s ? atoi(s) : 5;
     out->stagger_min = m ? atoi(m) : -1; // (tuning runs: the smallest grid that staggers; default: one round of resident blocks)

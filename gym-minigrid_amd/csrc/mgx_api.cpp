@@ -31,7 +31,11 @@ int mgx_fail(int status, const char *fmt, ...)
 }
 
 extern "C" const char *mgx_last_error(void) { return g_err; }
-extern "C" const char *mgx_version(void) { return "mgx 0.2 (gfx950)"; }
+#ifdef MGX_TUNING
+extern "C" const char *mgx_version(void) { return "mgx 0.3 (gfx950, tuning build)"; }
+#else
+extern "C" const char *mgx_version(void) { return "mgx 0.3 (gfx950)"; }
+#endif
 
 #define HIP_TRY(expr)                                                                                         \
     do {                                                                                                      \
@@ -419,7 +423,7 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     }
     h->wpb = (LDS_DEFAULT - 2 * h->lds_guard) / h->wave_lds;
     if (h->wpb > 4) h->wpb = 4;
-    if (const char *e = getenv("MGX_WPB")) { const int w = atoi(e); if (w >= 1 && w < h->wpb) h->wpb = w; } // (tuning runs: waves per block of k_step)
+    if (const char *e = MGX_TUNE_ENV("MGX_WPB")) { const int w = atoi(e); if (w >= 1 && w < h->wpb) h->wpb = w; } // (tuning runs: waves per block of k_step)
     const bool raise_lds = h->wpb < 1; // (done below, once the buffers that select the kernel instantiation exist)
     if (raise_lds) h->wpb = 1;
 #define CREATE_TRY(expr)                                                                     \
@@ -515,8 +519,10 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
         const bool cheap_draws = cfg->level_kind == MGX_LEVEL_EMPTY || cfg->level_kind == MGX_LEVEL_DOORKEY || cfg->level_kind == MGX_LEVEL_CROSSING ||
                                  cfg->level_kind == MGX_LEVEL_LAVAGAP || cfg->level_kind == MGX_LEVEL_DISTSHIFT;
         if (h->stream_mode && !(cfg->task_kind == MGX_TASK_DYNOBS) && !cheap_draws) {
-            CREATE_TRY(hipMalloc((void **)&h->mt2_d, ((size_t)h->n_pad * 624 + 64) * sizeof(uint32_t)));
-            CREATE_TRY(hipMemsetAsync(h->mt2_d, 0, ((size_t)h->n_pad * 624 + 64) * sizeof(uint32_t), h->stream));
+            // (2.5 KB per env on top of the first block's 2.5 KB -- include/mgx.h, new_level_each_episode.  An optimisation only: a handle that
+            // cannot get it keeps the single-block rule, where a level that runs past its block is generated again by a whole wave.)
+            if (hipMalloc((void **)&h->mt2_d, ((size_t)h->n_pad * 624 + 64) * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); h->mt2_d = nullptr; }
+            else CREATE_TRY(hipMemsetAsync(h->mt2_d, 0, ((size_t)h->n_pad * 624 + 64) * sizeof(uint32_t), h->stream));
         }
         CREATE_TRY(hipMemsetAsync(h->mt_idx_d, 0, (size_t)h->n_pad * sizeof(uint32_t), h->stream));
         CREATE_TRY(hipMemsetAsync(h->regen_d, 0, (size_t)h->n_pad, h->stream));

@@ -28,6 +28,15 @@ void mgx_mt_init_table(uint32_t out[624]);
 #define MGX_K_DOOR_CLOSED 11
 #define MGX_K_DOOR_LOCKED 12
 #define MGX_CODE_EMPTY 0x01
+// Environment knobs (DESIGN.md has the table).  Form selection -- MGX_PARTIAL_KERNEL, MGX_FULL_KERNEL, MGX_ROLLOUT, MGX_SEED_FORM: which of two
+// equivalent kernel forms a handle takes; the tests run both sides of every size rule with them -- is read with getenv in every build.  The
+// TUNING knobs (launch shaping, waves per block, level-generator lanes / spans) exist only in builds with -DMGX_TUNING (tools/build_variant.sh):
+// the default library does not look at them.
+#ifdef MGX_TUNING
+#define MGX_TUNE_ENV(name) getenv(name)
+#else
+#define MGX_TUNE_ENV(name) ((const char *)nullptr)
+#endif
 #define MGX_CODE_WALL_GREY 0x52 /* Wall() default colour grey=5: what Grid.slice pads with (minigrid.py:469) */
 
 #endif

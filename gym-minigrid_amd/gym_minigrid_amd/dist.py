@@ -54,6 +54,10 @@ def device_identity(index):
         ident["pci"] = "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, getattr(p, "pci_device_id", 0))
     # (both: a runtime that reports one constant UUID for every GPU must not make distinct GPUs look like one)
     ident["key"] = "%s|%s" % (ident.get("uuid", "-"), ident.get("pci", "index-%d" % index))
+    # Neither a UUID nor a PCI address: the device index is all there is, and under per-rank HIP_VISIBLE_DEVICES every rank sees index 0
+    # (while a shared mask makes distinct indices look trustworthy without proof).  Such an identity is marked unverifiable and bench.py
+    # then reports distinct_devices = null instead of aborting a legitimate N-GPU run.
+    ident["verifiable"] = "uuid" in ident or "pci" in ident
     return ident
 
 

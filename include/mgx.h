@@ -75,7 +75,9 @@ extern "C" {
 typedef enum {
     MGX_OK = 0,
     MGX_ERR_INVALID_ARG = -1,
-    MGX_ERR_INVALID_STATE = -2,  /* set_state: a cell / agent / carry value the reference cannot produce */
+    MGX_ERR_INVALID_STATE = -2,  /* set_state: a cell / agent / carry value the reference cannot produce; reset / step: a call the handle's
+                                    state does not allow yet (reset() without seeds before any seeded reset; step before the reset that starts
+                                    a seed schedule) */
     MGX_ERR_INVALID_ACTION = -3, /* an action >= 7 was stepped (reference: AssertionError, minigrid.py:1318) */
     MGX_ERR_OUT_OF_BOUNDS = -4,  /* agent neighbour outside the grid (reference: Grid.get assert, :417-418), or strafe_right
                                     onto a goal while the left cell is not a goal (reference: AttributeError, :1310) */
@@ -192,7 +194,10 @@ typedef struct {
                                    (ReseedWrapper(seeds=[s]), wrappers.py:12-32); 1 = plain reference behaviour: the
                                    env's own RNG stream (seeded by mgx_reset) continues and every reset() draws a NEW
                                    level (minigrid.py:836-839), generated on the GPU from a per-env MT19937 state kept
-                                   in HBM.  Needs a level_kind with a generator and W*H <= 4096. */
+                                   in HBM.  Needs a level_kind with a generator and W*H <= 4096.  Device memory per env: the
+                                   MT19937 block, 2.5 KB; the draw-heavy families (everything but Empty / DoorKey / Crossing /
+                                   LavaGap / DistShift) keep the following block ready as well, 5 KB in all -- dropped silently
+                                   (same results, slower level bursts) when that second allocation fails. */
     int32_t agent_view_size;    /* 0 = 7 (minigrid.py:776).  ViewSizeWrapper (wrappers.py:579-608): 3, 5, 7, 9 or 11;
                                    obs is then uint8 [N][V][V][3].  Ignored by MGX_OBS_FULL. */
     int32_t extended_actions;   /* 1 = ExtendedActions (minigrid.py:747-764): 7 = strafe_left, 8 = strafe_right */

@@ -2,7 +2,7 @@
 the first round's waves by SIMD slot, guard bands around the LDS tile images) change WHEN waves run, never what they compute.
 Pinned twice against the CPU oracle: at the size where the rules switch on by themselves (more than one round of blocks), and
 in a child process that forces them onto a small batch through the tuning overrides (MGX_STAGGER_MIN / MGX_STAGGER / MGX_TAIL_BLOCKS /
-MGX_WPB are read once per process)."""
+MGX_WPB are read once per process; they exist in -DMGX_TUNING builds only, so the second half runs under MGX_LIB=<such a build>)."""
 import os
 import subprocess
 import sys
@@ -52,6 +52,9 @@ def test_rules_switch_on_above_one_round_of_blocks():
     {"MGX_STAGGER": "0", "MGX_TAIL_BLOCKS": "0"},
 ])
 def test_forced_rules_on_a_small_batch(overrides):
+    from gym_minigrid_amd import _lib
+    if b"tuning" not in _lib.lib().mgx_version():
+        pytest.skip("the default library is built without the tuning knobs (-DMGX_TUNING: tools/build_variant.sh tuning -DMGX_TUNING; MGX_LIB=ab/tuning.so)")
     env = dict(os.environ, **overrides)
     r = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
