@@ -33,6 +33,7 @@
 #include "mgx_internal.h"
 #include "mgx_kernels.h"
 #include "mgx_device.h"
+#include "dynobs_device.h"
 
 namespace {
 
@@ -667,8 +668,11 @@ __device__ __forceinline__ void emit_full_obs(const StepParams &p, const Lane &L
 #else
 #define MGX_GATHER_WAVES(CW) 1
 #endif
-template <int CW, int CH, int MODE, int V, bool ALT = false, bool OBJ = (CW == 0)>
-__global__ __launch_bounds__(256, (MODE == 3 && V == 7 && !ALT && !OBJ) ? MGX_GATHER_WAVES(CW) : 1) void k_step(const StepParams p)
+// DYN (Dynamic-Obstacles, staged partial form): the obstacle walk of envs/dynamicobstacles.py:60-80 runs in front of the transition on the
+// SAME staged tile (dynobs_device.h) -- one launch instead of k_dynobs + k_step, the cells read once and written back once per step, no
+// folded-action buffer in between.
+template <int CW, int CH, int MODE, int V, bool ALT, bool OBJ, bool DYN>
+__device__ __forceinline__ void step_body(const StepParams &p, const DynObsParams *dp)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -701,9 +705,10 @@ __global__ __launch_bounds__(256, (MODE == 3 && V == 7 && !ALT && !OBJ) ? MGX_GA
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 0, 4)" : "=s"(slot));
         for (uint32_t i = (slot < 7u ? slot : 7u) * (uint32_t)p.stagger; i; i--) __builtin_amdgcn_s_sleep(4);
     }
-    const uint2 rec = p.agent[env]; // agent/cells arrays are padded to whole tiles
     uint32_t act = 6;
-    if (p.do_step && valid) act = __builtin_nontemporal_load(&p.actions[env]);
+    if constexpr (DYN) act = dynobs_walk<CW, CH, true>(*dp, lds, lane, tile); // (stages the tile; the walk never moves the agent)
+    else if (p.do_step && valid) act = __builtin_nontemporal_load(&p.actions[env]);
+    const uint2 rec = p.agent[env]; // agent/cells arrays are padded to whole tiles
     const bool crash = p.task == MGX_TASK_DYNOBS && (act & 0x80u); // k_dynobs' verdict rides on the folded action
     if (p.task == MGX_TASK_DYNOBS) act &= 0x7Fu;
     if (p.task == MGX_TASK_MEMORY && act == 3u) act = 5u; // `if action == pickup: action = toggle` (envs/memory.py:89-90)
@@ -715,7 +720,7 @@ __global__ __launch_bounds__(256, (MODE == 3 && V == 7 && !ALT && !OBJ) ? MGX_GA
     // MODE 3 (large grids): no tile image in LDS -- at 25x25 it would be 40 KB per wave and leave 4 waves per CU; each
     // lane gathers its forward cell and its VxV view straight from its row in HBM/L2 instead (50 byte loads).
     constexpr bool GATHER = MODE == 3;
-    if constexpr (!GATHER) {
+    if constexpr (!GATHER && !DYN) {
         stage_tile<CS>(p.cells, env0, S, LS, lds, lane);
         wave_sync();
     }
@@ -800,6 +805,10 @@ __global__ __launch_bounds__(256, (MODE == 3 && V == 7 && !ALT && !OBJ) ? MGX_GA
         }
         if (valid) p.agent[env] = pack_rec(L, p.task);
     }
+    if constexpr (DYN) { // the moved obstacles (and the restored rows of finished envs) go home as the whole tile, coalesced
+        wave_sync();
+        unstage_tile<CS>(p.cells, env0, S, LS, lds, lane);
+    }
     if constexpr (GATHER) { if (!p.obs && p.front && p.do_step && valid) p.front[env] = 0; } // (no observation pass: nothing to remember)
     if (p.obs) {
         if constexpr (GATHER) {
@@ -866,6 +875,18 @@ __global__ __launch_bounds__(256, (MODE == 3 && V == 7 && !ALT && !OBJ) ? MGX_GA
 #endif
         else emit_full_obs<CW, CH>(p, L, valid, lds, g, LS, env0, lane);
     }
+}
+
+template <int CW, int CH, int MODE, int V, bool ALT = false, bool OBJ = (CW == 0)>
+__global__ __launch_bounds__(256, (MODE == 3 && V == 7 && !ALT && !OBJ) ? MGX_GATHER_WAVES(CW) : 1) void k_step(const StepParams p)
+{
+    step_body<CW, CH, MODE, V, ALT, OBJ, false>(p, nullptr);
+}
+
+template <int CW, int CH>
+__global__ __launch_bounds__(256) void k_step_dyn(const StepParams p, const DynObsParams d)
+{
+    step_body<CW, CH, 0, 7, false, false, true>(p, &d);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1438,6 +1459,26 @@ hipError_t mgx_launch_step(const StepParams &p0, int mode, int waves_per_block, 
     }
 #endif
     hipLaunchKernelGGL(c.fn, sh.grid, sh.block, sh.shmem, st, p);
+    return hipGetLastError();
+}
+
+// Dynamic-Obstacles, staged partial form (7x7 view, default visibility): walk + step in one launch.  p.wave_lds is the step's; the walk's
+// extra LDS (position words, tape, strip) lies behind the tile image and is dead by the time the observation image overlays it.
+hipError_t mgx_launch_step_dyn(const StepParams &p0, const DynObsParams &d, const StepLaunchCfg &lc, hipStream_t st)
+{
+    StepParams p = p0;
+    if (d.wave_lds > p.wave_lds) p.wave_lds = (d.wave_lds + 15) & ~15;
+    int wpb = (64 * 1024 - 2 * p.lds_guard) / p.wave_lds;
+    if (wpb > 4) wpb = 4;
+    if (wpb < 1) return hipErrorNotSupported;
+    const int blocks = (p.n_tiles + wpb - 1) / wpb, tb = lc.tail_blocks * 4 / wpb;
+    p.tail_block0 = (tb > 0 && blocks > tb) ? blocks - tb : 0x7fffffff;
+    p.stagger = 0; // (the walk's own loads come first and spread the waves by themselves)
+    const size_t shmem = (size_t)wpb * p.wave_lds + 2 * (size_t)p.lds_guard;
+#define CASE(w, h) if (p.W == w && p.H == h) { hipLaunchKernelGGL((k_step_dyn<w, h>), dim3(blocks), dim3(64 * wpb), shmem, st, p, d); return hipGetLastError(); }
+    CASE(5, 5) CASE(6, 6) CASE(8, 8) // the registered Dynamic-Obstacles sizes that stage their tile (16x16 gathers)
+#undef CASE
+    hipLaunchKernelGGL((k_step_dyn<0, 0>), dim3(blocks), dim3(64 * wpb), shmem, st, p, d);
     return hipGetLastError();
 }
 

@@ -90,6 +90,7 @@ struct mgx_env_s {
     bool assume_device = false; // inside the capture: arguments were classified up front
     // Dynamic-Obstacles: obstacle order (+ episode-start copy), RNG block snapshot, folded actions
     bool dynobs = false;
+    bool dyn_fused = false; // ... and its walk runs inside the step kernel (k_step_dyn: staged partial form, 7x7 view, default visibility)
     uint8_t *obst_d = nullptr, *obst0_d = nullptr, *act_d = nullptr;
     uint8_t *restart_d = nullptr; // u8[n_pad]: the in-kernel auto-reset restarted this env's episode; the next k_dynobs restores obstacle
                                   // order + RNG position first (NOT regen_d: those flags mean "k_levelgen, make this env a new level")
@@ -552,6 +553,10 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     if (cfg->task_kind == MGX_TASK_DYNOBS) {
         if (!h->device_levels) { int rc = mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_create: Dynamic-Obstacles needs the on-device level generator"); mgx_destroy(h); return rc; }
         h->dynobs = true;
+        // (form selection, read in every build: MGX_DYNOBS=split keeps the walk a kernel of its own -- tests run both)
+        const char *df = getenv("MGX_DYNOBS");
+        h->dyn_fused = h->kernel_mode == 0 && view == 7 && !cfg->alt_visibility && !(df && !strcmp(df, "split")) &&
+                       mgx_dynobs_wave_lds(h->LS) + 2 * h->lds_guard <= 64 * 1024;
         CREATE_TRY(hipMalloc((void **)&h->obst_d, (size_t)h->n_pad * 8));
         CREATE_TRY(hipMalloc((void **)&h->obst0_d, (size_t)h->n_pad * 8));
         CREATE_TRY(hipMalloc((void **)&h->act_d, (size_t)h->n_pad));
@@ -820,7 +825,7 @@ static int run_step(mgx_handle h, bool do_step, const uint8_t *actions, uint8_t 
         if (!actions) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_step: actions is required");
         if ((rc = dev_in(h, 0, actions, (size_t)h->n, &d))) return rc;
         p.actions = (const uint8_t *)d;
-        if (h->dynobs) { // the obstacle walk precedes the base step and folds the actions (envs/dynamicobstacles.py:60-80)
+        if (h->dynobs && !h->dyn_fused) { // the obstacle walk precedes the base step and folds the actions (envs/dynamicobstacles.py:60-80)
             DynObsParams dp = dynobs_params(h);
             dp.actions = p.actions;
             HIP_TRY(mgx_launch_dynobs(dp, h->stream));
@@ -844,7 +849,11 @@ static int run_step(mgx_handle h, bool do_step, const uint8_t *actions, uint8_t 
         }
         HIP_TRY(hipEventRecord(h->prof_ev[2 * h->prof_samples], h->stream));
     }
-    HIP_TRY(mgx_launch_step(p, h->kernel_mode, h->wpb, h->launch_cfg, h->stream));
+    if (do_step && h->dyn_fused) { // Dynamic-Obstacles, staged partial form: walk + step in ONE launch on the staged tile
+        DynObsParams dp = dynobs_params(h);
+        dp.actions = p.actions;
+        HIP_TRY(mgx_launch_step_dyn(p, dp, h->launch_cfg, h->stream));
+    } else HIP_TRY(mgx_launch_step(p, h->kernel_mode, h->wpb, h->launch_cfg, h->stream));
     if (sample) {
         HIP_TRY(hipEventRecord(h->prof_ev[2 * h->prof_samples + 1], h->stream));
         h->prof_samples++;

@@ -51,6 +51,7 @@ struct LevelGenParams {
     int64_t n;
     int n_tiles, S;
 };
+struct DynObsParams;
 struct StepParams {
     uint8_t *cells;        // u8[n_pad][S]   internal cell codes, x-major
     uint2 *agent;          // [n_pad]        x | y<<8 | dir<<16 | carry<<24 ; step_count
@@ -169,6 +170,7 @@ hipError_t mgx_launch_mark_plain_reset(const uint8_t *mask, uint8_t *regen, uint
 struct StepLaunchCfg { int tail_blocks, stagger_units, stagger_min; };
 hipError_t mgx_step_launch_cfg(int device, StepLaunchCfg *out);
 hipError_t mgx_launch_step(const StepParams &p, int mode, int waves_per_block, const StepLaunchCfg &lc, hipStream_t st);
+hipError_t mgx_launch_step_dyn(const StepParams &p, const DynObsParams &d, const StepLaunchCfg &lc, hipStream_t st); // (declared below: DynObsParams)
 const char *mgx_step_kernel_label(const StepParams &p, int mode); // the instantiation the selector picks, e.g. "k_step<8,8,0,7>"
 hipError_t mgx_launch_rollout(const StepParams &p, const uint8_t *actions, uint8_t *obs, float *reward, uint8_t *done, int64_t T, int full, hipStream_t st);
 hipError_t mgx_preload_step_kernels();

@@ -47,8 +47,13 @@ def test_registry_matches_constructor_clamp():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,size,n_obst,rnd", CASES)
-@pytest.mark.parametrize("mode", ["partial", "full"])
-def test_gpu_matches_reference_trace(name, size, n_obst, rnd, mode):
+@pytest.mark.parametrize("mode", ["partial", "full", "partial-split"])
+def test_gpu_matches_reference_trace(name, size, n_obst, rnd, mode, monkeypatch):
+    """partial: the walk fused into the staged step kernel (k_step_dyn; 16x16 gathers and keeps the walk a kernel of its own);
+    partial-split: k_dynobs + k_step on every size (MGX_DYNOBS=split); full: k_dynobs + the FullyObs kernels."""
+    if mode == "partial-split":
+        monkeypatch.setenv("MGX_DYNOBS", "split")
+        mode = "partial"
     meta, z = load_case(name)
     K, T = z["actions"].shape
     N = 64 + K                                              # more than one tile; env i replays trace i % K
