@@ -291,8 +291,10 @@ __device__ __forceinline__ uint32_t dynobs_walk(const DynObsParams &p, uint8_t *
     }
     if (need_finish) { dirty = true; inplace = false; }
     if (valid && !((m_serviced >> lane) & 1ull)) { // this lane's window straight from its tape
-        dyn_window(p.tape + env * MGX_DYN_TAPE_DW, pos & 1023u, w_lo, w_hi); // (not serviced: rank < R624 <= 624, the plain 24-byte read)
+        dyn_window(p.tape + env * MGX_DYN_TAPE_DW, pos & 1023u, w_lo, w_hi); // (not serviced: rank <= R624 <= 624)
     }
+    // (round 4: asking for the tile's cells -- into registers -- and for these windows BEFORE the service loop, so that the wave's dependent
+    // round trips overlap, measured slower: k_dynobs<8,8> 84 -> 89.6 us, the fused k_step_dyn<8,8> 118.9 -> 126.4 at 104 instead of 87 VGPRs)
     if (m_serviced) { // blocks rewritten by the whole wave may be read word-wise by single lanes below (off the tape): same
                       // CU, same L1, so the stores only have to be complete (an agent-scope fence would write back the XCD's L2)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
