@@ -1471,12 +1471,13 @@ hipError_t mgx_launch_step_dyn(const StepParams &p0, const DynObsParams &d, cons
     int wpb = (64 * 1024 - 2 * p.lds_guard) / p.wave_lds;
     if (wpb > 4) wpb = 4;
     if (wpb < 1) return hipErrorNotSupported;
+    if (p.wave_lds > 8192) wpb = 1; // (as k_dynobs: more one-wave blocks fit a CU's 160 KB, and a block's LDS is free as soon as its wave is done)
     const int blocks = (p.n_tiles + wpb - 1) / wpb, tb = lc.tail_blocks * 4 / wpb;
     p.tail_block0 = (tb > 0 && blocks > tb) ? blocks - tb : 0x7fffffff;
     p.stagger = 0; // (the walk's own loads come first and spread the waves by themselves)
     const size_t shmem = (size_t)wpb * p.wave_lds + 2 * (size_t)p.lds_guard;
 #define CASE(w, h) if (p.W == w && p.H == h) { hipLaunchKernelGGL((k_step_dyn<w, h>), dim3(blocks), dim3(64 * wpb), shmem, st, p, d); return hipGetLastError(); }
-    CASE(5, 5) CASE(6, 6) CASE(8, 8) // the registered Dynamic-Obstacles sizes that stage their tile (16x16 gathers)
+    CASE(5, 5) CASE(6, 6) CASE(8, 8) CASE(16, 16) // the registered Dynamic-Obstacles sizes
 #undef CASE
     hipLaunchKernelGGL((k_step_dyn<0, 0>), dim3(blocks), dim3(64 * wpb), shmem, st, p, d);
     return hipGetLastError();

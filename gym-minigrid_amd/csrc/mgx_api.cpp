@@ -555,8 +555,9 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
         h->dynobs = true;
         // (form selection, read in every build: MGX_DYNOBS=split keeps the walk a kernel of its own -- tests run both)
         const char *df = getenv("MGX_DYNOBS");
-        h->dyn_fused = h->kernel_mode == 0 && view == 7 && !cfg->alt_visibility && !(df && !strcmp(df, "split")) &&
-                       mgx_dynobs_wave_lds(h->LS) + 2 * h->lds_guard <= 64 * 1024;
+        // (16x16: the single step gathers, mode 3; the fused kernel stages the tile -- the walk needs it in LDS anyway)
+        h->dyn_fused = (h->kernel_mode == 0 || (h->kernel_mode == 3 && h->partial)) && view == 7 && !cfg->alt_visibility && !(df && !strcmp(df, "split")) &&
+                       mgx_dynobs_wave_lds(h->LS) + 2 * h->staged_guard <= 64 * 1024;
         CREATE_TRY(hipMalloc((void **)&h->obst_d, (size_t)h->n_pad * 8));
         CREATE_TRY(hipMalloc((void **)&h->obst0_d, (size_t)h->n_pad * 8));
         CREATE_TRY(hipMalloc((void **)&h->act_d, (size_t)h->n_pad));
@@ -852,7 +853,11 @@ static int run_step(mgx_handle h, bool do_step, const uint8_t *actions, uint8_t 
     if (do_step && h->dyn_fused) { // Dynamic-Obstacles, staged partial form: walk + step in ONE launch on the staged tile
         DynObsParams dp = dynobs_params(h);
         dp.actions = p.actions;
-        HIP_TRY(mgx_launch_step_dyn(p, dp, h->launch_cfg, h->stream));
+        dp.front = nullptr;
+        StepParams pf = p;
+        pf.lds_guard = h->staged_guard; // (a handle whose single step gathers: this kernel stages)
+        if (h->kernel_mode == 3) { const int img = 32 * h->view * h->view * 3; pf.wave_lds = ((64 * h->LS > img ? 64 * h->LS : img) + 15) & ~15; pf.front = nullptr; }
+        HIP_TRY(mgx_launch_step_dyn(pf, dp, h->launch_cfg, h->stream));
     } else HIP_TRY(mgx_launch_step(p, h->kernel_mode, h->wpb, h->launch_cfg, h->stream));
     if (sample) {
         HIP_TRY(hipEventRecord(h->prof_ev[2 * h->prof_samples + 1], h->stream));
