@@ -489,6 +489,104 @@ __device__ __forceinline__ void emit_partial_obs(const StepParams &p, const Lane
     // the agent's own cell shows what it carries, after occlusion; always visible (minigrid.py:1349-1356)
     code[V / 2][V - 1] = L.carry;
 
+    if (p.onehot) {
+        // OneHotPartialObsWrapper fused (wrappers.py:226-243: out[vx][vy][type] = out[.., 11 + color] = out[.., 18 + state] = 1, 21 channels): the
+        // V*V*21 bytes per env leave straight from here -- no triples written to HBM and read back by a second kernel (2 x 147 B per env-step).
+        // An env's 1,029 bytes are not 16-byte aligned, 16 envs' are: the tile goes out in four quarters.  Per quarter: the wave zeroes a
+        // 16 x 1,029-byte LDS image, every lane drops the three ones of 12-13 cells into it (byte writes at type / 11 + color / 18 + state;
+        // the cell codes of all 64 envs were parked in LDS first, so all 64 lanes work on every quarter), and the image leaves as 16-B/lane
+        // non-temporal stores.  ~90 LDS instructions and ~200 VALU per quarter against 16 KB stored.
+#ifndef MGX_OH_UNIT
+#define MGX_OH_UNIT 16 /* envs per LDS image: 16 (16-byte stores) or 8 (8-byte stores, half the LDS) */
+#endif
+        constexpr int QE = MGX_OH_UNIT, SB = QE == 16 ? 16 : 8; // envs per image, bytes per lane and store
+        constexpr int NC = V * V, CSTR = (NC + 3) & ~3, NB = 21, QB = QE * NC * NB;
+        static_assert(QB % SB == 0, "an image is a whole number of stores");
+        wave_sync(); // every lane has gathered its view: the grid image (or the window excerpts) may be overwritten
+        uint32_t *cw = reinterpret_cast<uint32_t *>(lds) + lane * (CSTR / 4);
+#pragma unroll
+        for (int q = 0; q < CSTR / 4; q++) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int idx = 4 * q + j;
+                if (idx < NC) w |= (code[idx / V][idx % V] & 255u) << (8 * j);
+            }
+            cw[q] = w;
+        }
+        uint8_t *img = lds + 64 * CSTR;
+        const int64_t nvv = p.n - env0;
+        const int n_env = nvv >= 64 ? 64 : (int)nvv;
+        uint8_t *dst = p.obs + env0 * (int64_t)(NC * NB);
+        constexpr int NCH = QB / SB, NZ = (QB + 15) / 16; // stores / 16-byte zero chunks per image
+        for (int qt = 0; qt < 64 / QE && QE * qt < n_env; qt++) { // wave-uniform
+            wave_sync(); // (the codes are parked / the previous quarter's image has been read)
+            // (every loop below has a compile-time trip count: rolled, with run-time bounds, the store loop was one ds_read -> s_waitcnt -> store
+            // per trip with a page of tail-handling branches around it)
+#pragma unroll
+            for (int i = 0; i < (NZ + 63) / 64; i++) {
+                const int c = lane + 64 * i;
+                if (64 * i + 63 < NZ || c < NZ) reinterpret_cast<uint4 *>(img)[c] = make_uint4(0u, 0u, 0u, 0u);
+            }
+            wave_sync();
+            {
+                constexpr int NI = (QE * NC + 63) / 64;
+                uint32_t cc[NI];
+#pragma unroll
+                for (int i = 0; i < NI; i++) { // the cell codes first, all in flight
+                    const int ci = lane + 64 * i, cj = ci < QE * NC ? ci : 0;
+                    const int e = cj / NC, cell = cj - e * NC; // (compile-time divisor)
+                    cc[i] = lds[(QE * qt + e) * CSTR + cell];
+                }
+#pragma unroll
+                for (int i = 0; i < NI; i++) {
+                    const int ci = lane + 64 * i;
+                    if (64 * i + 63 < QE * NC || ci < QE * NC) {
+                        const uint32_t c = cc[i], k = c & 15u, col = (c >> 4) & 7u;
+                        const bool shut = k > MGX_K_AGENT; // closed / locked door: type 4, state 1 / 2
+                        uint8_t *o = img + ci * NB;
+                        o[shut ? 4u : k] = 1;
+                        o[11u + col] = 1;
+                        o[18u + (shut ? k - 10u : 0u)] = 1;
+                    }
+                }
+            }
+            wave_sync();
+            const int q_env = n_env - QE * qt >= QE ? QE : n_env - QE * qt;
+            uint8_t *d = dst + (size_t)qt * QB;
+            if (q_env == QE) { // a whole image: groups of six reads, then their six stores
+                constexpr int NS = (NCH + 63) / 64, G = 6;
+#pragma unroll
+                for (int i0 = 0; i0 < NS; i0 += G) {
+                    uint4 v4[G];
+                    unsigned long long v8[G];
+#pragma unroll
+                    for (int g = 0; g < G; g++) {
+                        const int c = lane + 64 * (i0 + g), cr = c < NCH ? c : NCH - 1;
+                        if (i0 + g < NS) { if constexpr (SB == 16) v4[g] = reinterpret_cast<const uint4 *>(img)[cr]; else v8[g] = reinterpret_cast<const unsigned long long *>(img)[cr]; }
+                    }
+#pragma unroll
+                    for (int g = 0; g < G; g++) {
+                        const int c = lane + 64 * (i0 + g);
+                        if (i0 + g < NS && (64 * (i0 + g) + 63 < NCH || c < NCH)) {
+                            if constexpr (SB == 16) nt_store16(reinterpret_cast<uint4 *>(d) + c, v4[g]);
+                            else __builtin_nontemporal_store(v8[g], reinterpret_cast<unsigned long long *>(d) + c);
+                        }
+                    }
+                }
+            } else { // the short last image of a tail tile
+                const int lim = q_env * NC * NB;
+                for (int c = lane; c < NCH; c += 64) {
+                    if (SB * c + SB <= lim) {
+                        if constexpr (SB == 16) reinterpret_cast<uint4 *>(d)[c] = reinterpret_cast<const uint4 *>(img)[c];
+                        else reinterpret_cast<unsigned long long *>(d)[c] = reinterpret_cast<const unsigned long long *>(img)[c];
+                    } else
+                        for (int bb = SB * c; bb < lim; bb++) d[bb] = img[bb];
+                }
+            }
+        }
+        return;
+    }
     // 49 codes -> 49 (type, color, state) triples (image[vx][vy][c], vx-major) in 37 dwords, FOUR CELLS PER INSTRUCTION: the codes
     // of 4 consecutive cells are packed into one dword and decoded byte-parallel with the instructions that issue at full rate
     // on this chip (and / or / xor / add / sub / lshr: tools/ubench/issue_rate.hip; v_perm, v_cndmask, v_cmp, v_bfe, v_lshl*, SDWA run

@@ -60,6 +60,7 @@ struct mgx_env_s {
     StepLaunchCfg launch_cfg = {0, 0, -1}; // raised-priority tail / stagger of THIS handle's device (mgx_step_launch_cfg, at create)
     bool partial = true;   // the simulator emits the VxV view (else the full grid)
     int oh_nc = -1, oh_ns = 0; // one-hot epilogue channels (oh_nc < 0: none)
+    bool oh_fused = false;     // ... expanded inside the step kernel (partial views up to 7x7: StepParams.onehot), no k_onehot pass
     uint8_t *tri_d = nullptr;  // triples scratch feeding the one-hot / flat epilogue
     bool flat = false;         // FlatObsWrapper epilogue (obs is float)
     float *mission_d = nullptr;   // [missions][96*27] one-hot mission blocks for k_flat
@@ -224,6 +225,7 @@ StepParams base_params(mgx_handle h)
     p.regen = h->dynobs ? h->restart_d : (h->stream_mode ? h->regen_d : nullptr);
     p.objaux = h->objaux_d; p.objcont = h->objcont_d; p.objaux0 = h->objaux0_d; p.objcont0 = h->objcont0_d; p.objcarry = h->objcarry_d;
     p.front = h->front_d; // (Dynamic-Obstacles: k_dynobs moves cells between two steps and rewrites the entry itself)
+    p.onehot = h->oh_fused ? 1 : 0;
     p.bank = h->sched_K ? h->bank_d : nullptr; p.n_banks = h->sched_K ? h->sched_K : 1; p.bank_envs = h->sched_K ? h->n_pad : 0;
     return p;
 }
@@ -404,6 +406,20 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
         const int rs = view <= 3 ? 4 : (view <= 7 ? 8 : 12), slot = ((view * rs / 4) | 1) * 4;
         if (64 * slot > need) need = 64 * slot;
     }
+    // OneHotPartialObsWrapper inside the step kernel (views up to 7x7): the wave parks its 64 x V*V cell codes and builds the image a quarter
+    // tile (16 envs x V*V*21 bytes) at a time.  Built and pinned (tests run both forms), and it moves 1,115 instead of 1,409 bytes per env-step --
+    // but it is the SLOWER form (256 us against 39 + 208 for k_step + k_onehot at 1 Mi Empty-8x8 envs: its 19.4 KB of LDS per wave leave two
+    // waves per SIMD, and eight waves queue on one LDS pipe for 3,500 cycles of image traffic per tile; profiles/r04_onehot_fused.txt), so
+    // the default stays the two-kernel form and MGX_ONEHOT=fused selects this one.
+    const char *ohf = getenv("MGX_ONEHOT");
+    h->oh_fused = cfg->obs_mode == MGX_OBS_PARTIAL_ONEHOT && view <= 7 && ohf && !strcmp(ohf, "fused");
+    if (h->oh_fused) {
+#ifndef MGX_OH_UNIT
+#define MGX_OH_UNIT 16
+#endif
+        const int oh_need = 64 * ((view * view + 3) & ~3) + ((MGX_OH_UNIT * view * view * 21 + 15) & ~15);
+        if (oh_need > need) need = oh_need;
+    }
     h->lds_guard = h->kernel_mode == 0 ? guard : 0;
     h->staged_guard = guard;
     h->wave_lds = (need + 15) & ~15;
@@ -424,6 +440,7 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     }
     h->wpb = (LDS_DEFAULT - 2 * h->lds_guard) / h->wave_lds;
     if (h->wpb > 4) h->wpb = 4;
+    if (h->oh_fused && h->wpb > 1 && MGX_OH_UNIT == 16) h->wpb = 1; // (19.4 KB per wave at the 7x7 view: eight one-wave blocks fit a CU's LDS, two three-wave blocks would)
     if (const char *e = MGX_TUNE_ENV("MGX_WPB")) { const int w = atoi(e); if (w >= 1 && w < h->wpb) h->wpb = w; } // (tuning runs: waves per block of k_step)
     const bool raise_lds = h->wpb < 1; // (done below, once the buffers that select the kernel instantiation exist)
     if (raise_lds) h->wpb = 1;
@@ -455,7 +472,7 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     CREATE_TRY(hipMalloc((void **)&h->agent_d, ab));
     CREATE_TRY(hipMalloc((void **)&h->agent0_d, ab));
     CREATE_TRY(hipMalloc((void **)&h->ctr_d, sizeof(MgxCounters)));
-    if (h->oh_nc >= 0 || h->flat) CREATE_TRY(hipMalloc((void **)&h->tri_d, (size_t)h->n * h->tri_bytes + 16));
+    if ((h->oh_nc >= 0 && !h->oh_fused) || h->flat) CREATE_TRY(hipMalloc((void **)&h->tri_d, (size_t)h->n * h->tri_bytes + 16));
     if (h->flat) { // the family's mission strings as character codes (wrappers.py:563-571)
         const int family = mission_family(cfg), rows = mgx_mission_rows(family);
         std::vector<float> tab((size_t)rows * MGX_FLAT_MISSION, 0.f);
@@ -838,7 +855,7 @@ static int run_step(mgx_handle h, bool do_step, const uint8_t *actions, uint8_t 
     if ((rc = dev_out(h, 1, reward, (size_t)h->n * sizeof(float), &o[1], 4))) return rc;
     if ((rc = dev_out(h, 2, done, (size_t)h->n, &o[2]))) return rc;
     p.obs = (uint8_t *)o[0].dev; p.reward = (float *)o[1].dev; p.done = (uint8_t *)o[2].dev;
-    if ((h->oh_nc >= 0 || h->flat) && p.obs) p.obs = h->tri_d; // the simulator writes triples; the epilogue below expands them
+    if (((h->oh_nc >= 0 && !h->oh_fused) || h->flat) && p.obs) p.obs = h->tri_d; // the simulator writes triples; the epilogue below expands them
     // profiling: this launch alone between its own two events (not while a graph is being captured)
     const bool sample = do_step && h->profiling && !h->assume_device && h->prof_samples < MGX_PROF_MAX_SAMPLES &&
                         (h->prof_launches % h->prof_stride) == 0;
@@ -863,7 +880,7 @@ static int run_step(mgx_handle h, bool do_step, const uint8_t *actions, uint8_t 
         HIP_TRY(hipEventRecord(h->prof_ev[2 * h->prof_samples + 1], h->stream));
         h->prof_samples++;
     }
-    if (h->oh_nc >= 0 && o[0].dev)
+    if (h->oh_nc >= 0 && !h->oh_fused && o[0].dev)
         HIP_TRY(mgx_launch_onehot(h->tri_d, (uint8_t *)o[0].dev, h->n * (h->tri_bytes / 3), h->oh_nc, h->oh_ns, h->stream));
     if (h->flat && o[0].dev)
         HIP_TRY(mgx_launch_flat(h->tri_d, h->agent_d, h->mission_d, (float *)o[0].dev, h->n, (int)h->tri_bytes, mission_family(&h->cfg), h->stream));

@@ -71,6 +71,8 @@ struct StepParams {
     uint8_t *front;        // gather form only (else null): u8[n_pad], cell code in front of the agent as of the env's last observation pass;
                            // 0 = unknown (every entry point that changes cells or poses outside the step kernel clears it)
     const uint8_t *obs_mask; // observe after a masked reset: 64-env tiles without a masked env are skipped (else null)
+    int onehot;            // partial view only: 1 = `obs` receives the OneHotPartialObsWrapper image (V*V*21 bytes per env) straight from the
+                           // step kernel; wave_lds then holds the parked cell codes + a 16-env quarter of that image (mgx_create)
     // seed schedule (mgx_set_seed_schedule: ReseedWrapper with a list of K seeds, wrappers.py:12-28), else bank == null: every snapshot array
     // (cells0, agent0, objaux0, objcont0) is [K][n_pad][...], bank k = the episode start under the k-th seed of the env's list.  An
     // in-kernel reset of env e advances bank[e] (mod K) and restores from snapshot index e + bank[e] * bank_envs.

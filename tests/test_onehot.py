@@ -19,9 +19,16 @@ def test_numpy_restatement_matches_reference_wrapper():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode,nc,ns", [("partial_onehot", 7, 3), ("full_onehot", 7, 4), ("full_onehot_nocolor", 0, 4)])
-@pytest.mark.parametrize("W,H,view,N", [(8, 8, 7, 64 * 5 + 7), (9, 9, 5, 131), (16, 16, 7, 200), (7, 11, 3, 65), (5, 5, 7, 1)])
-def test_onehot_epilogue(mode, nc, ns, W, H, view, N):
+@pytest.mark.parametrize("mode,nc,ns", [("partial_onehot", 7, 3), ("partial_onehot-fused", 7, 3), ("full_onehot", 7, 4), ("full_onehot_nocolor", 0, 4)])
+@pytest.mark.parametrize("W,H,view,N", [(8, 8, 7, 64 * 5 + 7), (9, 9, 5, 131), (16, 16, 7, 200), (7, 11, 3, 65), (5, 5, 7, 1), (19, 19, 7, 64 + 17), (8, 8, 9, 70),
+                                        (6, 6, 7, 64 * 2 + 33), (8, 8, 7, 64 * 3 + 48)])
+def test_onehot_epilogue(mode, nc, ns, W, H, view, N, monkeypatch):
+    """partial_onehot: plain triples + the k_onehot pass (the default, and the only form for the 9x9 view); -fused: expanded inside the step
+    kernel (StepParams.onehot, MGX_ONEHOT=fused: staged and gather forms, tail tiles that end inside a 16-env quarter).  full_*: k_onehot
+    behind the FullyObs kernels."""
+    if mode.endswith("-fused"):
+        monkeypatch.setenv("MGX_ONEHOT", "fused")
+        mode = mode[:-6]
     T, max_steps = 24, 11
     grid, aux, agent, carry, steps = random_states(N, W, H, seed=W + view, density=0.4)
     orc = make_oracle(W, H, max_steps, False, False, grid, aux, agent, carry, steps)
