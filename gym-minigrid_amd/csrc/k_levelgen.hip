@@ -448,6 +448,7 @@ __global__ __launch_bounds__(256) void k_consume(const ConsumeParams p)
         if (p.regen) p.regen[t] = p.flag_regen ? 1 : 0;
         if (p.objaux) p.objcarry[t] = (uint16_t)(MGX_CODE_EMPTY << 8);
         if (p.front) p.front[t] = 0;
+        if (p.wcache) reinterpret_cast<uint32_t *>(p.wcache + t * 64)[15] = 0u;
         if (p.restart) p.restart[t] = 1;
     }
 }
@@ -466,6 +467,7 @@ __global__ __launch_bounds__(256) void k_consume_masked(const ConsumeParams p)
         if (p.regen) p.regen[t] = p.flag_regen ? 1 : 0;
         if (p.objaux) p.objcarry[t] = (uint16_t)(MGX_CODE_EMPTY << 8);
         if (p.front) p.front[t] = 0;
+        if (p.wcache) reinterpret_cast<uint32_t *>(p.wcache + t * 64)[15] = 0u;
         if (p.restart) p.restart[t] = 1;
     }
     const int SD = p.S >> 2;

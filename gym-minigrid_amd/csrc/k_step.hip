@@ -815,6 +815,18 @@ __device__ __forceinline__ void step_body(const StepParams &p, const DynObsParam
     // own traffic and fetched again for the view (FETCH_SIZE: 428 B per env-step at 1 Mi FourRooms envs, 633 at MultiRoom-N6)
     uint32_t front0 = 0;
     if constexpr (MODE == 3) { if (p.front && p.do_step) front0 = p.front[env]; }
+    // (gather form, 7x7 view) the window excerpt of the env's last observation pass + the pose it was loaded for (StepParams.wcache): 64
+    // bytes per lane, 4 KB contiguous per wave
+    constexpr bool WC = MODE == 3 && V == 7 && !ALT;
+    uint4 wc[WC ? 4 : 1];
+    if constexpr (WC) {
+        if (p.wcache) {
+            const uint4 *r4 = reinterpret_cast<const uint4 *>(p.wcache + env * 64);
+#pragma unroll
+            for (int i = 0; i < 4; i++) wc[i] = r4[i];
+        }
+    }
+    bool was_reset = false;
     // MODE 3 (large grids): no tile image in LDS -- at 25x25 it would be 40 KB per wave and leave 4 waves per CU; each
     // lane gathers its forward cell and its VxV view straight from its row in HBM/L2 instead (50 byte loads).
     constexpr bool GATHER = MODE == 3;
@@ -890,6 +902,7 @@ __device__ __forceinline__ void step_body(const StepParams &p, const DynObsParam
             }
         }
         if (p.auto_reset && valid && done) {
+            was_reset = true;
             if constexpr (GATHER) {
                 row = p.cells0 + senv * S;
                 pidx = -1;
@@ -908,6 +921,7 @@ __device__ __forceinline__ void step_body(const StepParams &p, const DynObsParam
         unstage_tile<CS>(p.cells, env0, S, LS, lds, lane);
     }
     if constexpr (GATHER) { if (!p.obs && p.front && p.do_step && valid) p.front[env] = 0; } // (no observation pass: nothing to remember)
+    if constexpr (WC) { if (!p.obs && p.wcache && p.do_step && valid) reinterpret_cast<uint32_t *>(p.wcache + env * 64)[15] = 0u; }
     if (p.obs) {
         if constexpr (GATHER) {
             // The VxV view always lies inside a world-aligned VxV window whose columns (fixed world x) are V contiguous bytes: V unaligned
@@ -929,10 +943,25 @@ __device__ __forceinline__ void step_body(const StepParams &p, const DynObsParam
                 // outside the grid hold a copy of the border column, rows outside it are not there at all -- and the observation's own
                 // in-grid tests (on the real W x H) turn exactly those cells into the grey wall Grid.slice pads with.
                 UR raw[V];
+                // The cached excerpt belongs to a pose: a step that turned, moved or restarted the episode reloads it (7 loads in ONE branch,
+                // issued together), every other step -- 4 of 7 random actions, and every blocked forward -- observes from the record.
+                const uint32_t tag = (uint32_t)L.ax | ((uint32_t)L.ay << 8) | ((uint32_t)L.dir << 16) | (1u << 24);
+                bool hit = false;
+                if constexpr (WC) hit = p.wcache != nullptr && !was_reset && wc[3].w == tag;
+                if (!hit) {
 #pragma unroll
-                for (int k = 0; k < V; k++) {
-                    const int x = x0 + k, xc = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);
-                    raw[k] = *reinterpret_cast<const UR *>(row + xc * H + yc); // (yc + RS <= H: inside the row for every column)
+                    for (int k = 0; k < V; k++) {
+                        const int x = x0 + k, xc = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);
+                        raw[k] = *reinterpret_cast<const UR *>(row + xc * H + yc); // (yc + RS <= H: inside the row for every column)
+                    }
+                }
+                if constexpr (WC) {
+                    if (hit) {
+                        const uint32_t cw[16] = {wc[0].x, wc[0].y, wc[0].z, wc[0].w, wc[1].x, wc[1].y, wc[1].z, wc[1].w,
+                                                 wc[2].x, wc[2].y, wc[2].z, wc[2].w, wc[3].x, wc[3].y, wc[3].z, wc[3].w};
+#pragma unroll
+                        for (int k = 0; k < V; k++) { raw[k].w[0] = cw[2 * k]; raw[k].w[1] = cw[2 * k + 1]; }
+                    }
                 }
                 uint32_t *win32 = reinterpret_cast<uint32_t *>(lds) + lane * SLOT; // odd dword stride per lane
 #pragma unroll
@@ -942,6 +971,18 @@ __device__ __forceinline__ void step_body(const StepParams &p, const DynObsParam
                 uint8_t *win = reinterpret_cast<uint8_t *>(win32);
                 const int fdx = (L.dir == 0) - (L.dir == 2), fdy = (L.dir == 1) - (L.dir == 3);
                 if (pidx >= 0) win[(L.ax + fdx - x0) * RS + L.ay + fdy - yc] = (uint8_t)pcode; // the front cell this step changed (the agent did not move then)
+                if constexpr (WC) {
+                    // the record follows: rewritten when it was reloaded or when this step changed a cell of it (4 x 16 B per lane, contiguous over the wave)
+                    if (p.wcache && valid && (!hit || pidx >= 0)) {
+                        uint32_t o[16];
+#pragma unroll
+                        for (int q = 0; q < 14; q++) o[q] = win32[q];
+                        o[14] = 0u; o[15] = tag;
+                        uint4 *w4 = reinterpret_cast<uint4 *>(p.wcache + env * 64);
+#pragma unroll
+                        for (int i = 0; i < 4; i++) w4[i] = make_uint4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+                    }
+                }
                 // the cell in front of the (new) pose lies inside the excerpt whenever it lies inside the grid: remembered for the next step
                 if (p.front && valid) {
                     const int fx = L.ax + fdx, fy = L.ay + fdy;
@@ -950,6 +991,7 @@ __device__ __forceinline__ void step_body(const StepParams &p, const DynObsParam
                 emit_partial_obs<CW, CH, V, ALT, false, RS>(p, L, lds, win, env0, lane, -1, 0, nullptr, x0, yc);
             } else { // (a grid lower than the excerpt: V*V byte loads)
                 if (p.front && valid) p.front[env] = 0;
+                if constexpr (WC) { if (p.wcache && valid) reinterpret_cast<uint32_t *>(p.wcache + env * 64)[15] = 0u; }
                 emit_partial_obs<CW, CH, V, ALT, true>(p, L, lds, row, env0, lane, pidx, pcode);
             }
         }

@@ -71,6 +71,7 @@ struct mgx_env_s {
     hipStream_t own_stream = nullptr, stream = nullptr;
     uint8_t *cells_d = nullptr, *cells0_d = nullptr;
     uint8_t *front_d = nullptr; // StepParams.front (gather form: kernel_mode 3)
+    uint8_t *wcache_d = nullptr; // StepParams.wcache (gather form, 7x7 view, default visibility, no Dynamic-Obstacles)
     uint2 *agent_d = nullptr, *agent0_d = nullptr;
     MgxCounters *ctr_d = nullptr;
     // new level each episode: per-env MT19937 block + read index, regeneration flags
@@ -225,6 +226,7 @@ StepParams base_params(mgx_handle h)
     p.regen = h->dynobs ? h->restart_d : (h->stream_mode ? h->regen_d : nullptr);
     p.objaux = h->objaux_d; p.objcont = h->objcont_d; p.objaux0 = h->objaux0_d; p.objcont0 = h->objcont0_d; p.objcarry = h->objcarry_d;
     p.front = h->front_d; // (Dynamic-Obstacles: k_dynobs moves cells between two steps and rewrites the entry itself)
+    p.wcache = h->wcache_d;
     p.onehot = h->oh_fused ? 1 : 0;
     p.bank = h->sched_K ? h->bank_d : nullptr; p.n_banks = h->sched_K ? h->sched_K : 1; p.bank_envs = h->sched_K ? h->n_pad : 0;
     return p;
@@ -235,6 +237,7 @@ StepParams base_params(mgx_handle h)
 int forget_front(mgx_handle h)
 {
     if (h->front_d) HIP_TRY(hipMemsetAsync(h->front_d, 0, (size_t)h->n_pad, h->stream));
+    if (h->wcache_d) HIP_TRY(hipMemsetAsync(h->wcache_d, 0, (size_t)h->n_pad * 64, h->stream)); // (every pose tag: no record belongs to a pose any more)
     return MGX_OK;
 }
 
@@ -519,6 +522,12 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     if (h->kernel_mode == 3) {
         CREATE_TRY(hipMalloc((void **)&h->front_d, (size_t)h->n_pad));
         CREATE_TRY(hipMemsetAsync(h->front_d, 0, (size_t)h->n_pad, h->stream));
+        // (MGX_GATHER_CACHE=off: the gather form without its per-env window records -- tests and A/B runs)
+        const char *gc = getenv("MGX_GATHER_CACHE");
+        if (view == 7 && !cfg->alt_visibility && cfg->task_kind != MGX_TASK_DYNOBS && !(gc && !strcmp(gc, "off"))) {
+            CREATE_TRY(hipMalloc((void **)&h->wcache_d, (size_t)h->n_pad * 64));
+            CREATE_TRY(hipMemsetAsync(h->wcache_d, 0, (size_t)h->n_pad * 64, h->stream));
+        }
     }
     if (h->device_levels) {
         uint32_t init[624];
@@ -626,7 +635,7 @@ extern "C" int mgx_destroy(mgx_handle h)
     (void)dev_guard.enter_device(h->device, "mgx_destroy");
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->cells_d); (void)hipFree(h->cells0_d); (void)hipFree(h->agent_d); (void)hipFree(h->agent0_d);
-    (void)hipFree(h->ctr_d); (void)hipFree(h->tri_d); (void)hipFree(h->mission_d); (void)hipFree(h->front_d);
+    (void)hipFree(h->ctr_d); (void)hipFree(h->tri_d); (void)hipFree(h->mission_d); (void)hipFree(h->front_d); (void)hipFree(h->wcache_d);
     (void)hipFree(h->objaux_d); (void)hipFree(h->objaux0_d); (void)hipFree(h->objcont_d); (void)hipFree(h->objcont0_d); (void)hipFree(h->objcarry_d);
     (void)hipFree(h->mt_d); (void)hipFree(h->mt2_d); (void)hipFree(h->mt_idx_d); (void)hipFree(h->regen_d); (void)hipFree(h->mt_init_d);
     (void)hipFree(h->seed0_d); (void)hipFree(h->has_seed_d); (void)hipFree(h->reseeded_d);
@@ -1103,6 +1112,7 @@ ConsumeParams consume_params(mgx_handle h, const uint8_t *mask_dev)
     c.cells = h->cells_d; c.cells0 = h->cells0_d; c.agent = h->agent_d; c.agent0 = h->agent0_d; c.regen = h->regen_d;
     c.objaux = h->objaux_d; c.objaux0 = h->objaux0_d; c.objcont = h->objcont_d; c.objcont0 = h->objcont0_d; c.objcarry = h->objcarry_d;
     c.front = h->front_d; // (the reset envs' "cell in front" is unknown until their next observation pass)
+    c.wcache = h->wcache_d;
     c.n = h->n; c.S = h->S; c.flag_regen = 0;
     return c;
 }

@@ -70,6 +70,11 @@ struct StepParams {
                            // handle's own `restart` flags for k_dynobs (else null)
     uint8_t *front;        // gather form only (else null): u8[n_pad], cell code in front of the agent as of the env's last observation pass;
                            // 0 = unknown (every entry point that changes cells or poses outside the step kernel clears it)
+    uint8_t *wcache;       // gather form, 7x7 view, default visibility (else null): u8[n_pad][64], the view's window excerpt as the env's last
+                           // observation pass loaded it -- 7 columns x 8 rows -- and, in the last dword, the pose it belongs to (x | y << 8 |
+                           // dir << 16 | 1 << 24; 0 = none).  A step that leaves the pose as it is (turn-free, move-free: 4 of 7 random actions, and
+                           // every blocked forward) observes from this ONE coalesced 64-byte read instead of seven unaligned loads that cost two
+                           // 128-byte lines.  Cleared wherever `front` is.
     const uint8_t *obs_mask; // observe after a masked reset: 64-env tiles without a masked env are skipped (else null)
     int onehot;            // partial view only: 1 = `obs` receives the OneHotPartialObsWrapper image (V*V*21 bytes per env) straight from the
                            // step kernel; wave_lds then holds the parked cell codes + a 16-env quarter of that image (mgx_create)
@@ -115,6 +120,7 @@ struct ConsumeParams {
     uint8_t *objaux, *objaux0, *objcont, *objcont0; uint16_t *objcarry; // object_state handles (else null): aux planes to 0,
                                                                         // contains <- the generated level's (objcont0), nothing carried
     uint8_t *front;     // StepParams.front of gather-form handles (else null): cleared for every env consumed here
+    uint8_t *wcache;    // StepParams.wcache (else null): the pose tag of every env consumed here is cleared
     const uint8_t *bank; // seed schedule (StepParams.bank, already advanced for the envs being reset: k_bank_advance), else null
     int64_t bank_envs;
     uint8_t *restart;   // Dynamic-Obstacles handles under a seed schedule (else null): DynObsParams.regen, raised for every env consumed here
