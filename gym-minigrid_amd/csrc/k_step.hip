@@ -354,7 +354,9 @@ __device__ __forceinline__ void wave_stats(const StepParams &p, bool valid, bool
 // B = 3*V*V bytes per env is always 3 mod 4 for odd V, so the byte-phase logic below is the same for every V.
 // WIN != 0 (the gather form's window): `g` is not the env's grid but a raw V-column x WIN-row excerpt of it (column stride WIN bytes) whose
 // cell (0, 0) is world cell (wx0, wy0); indices are taken relative to that origin while the in-grid tests still use the real W x H.
-template <int CW, int CH, int V, bool ALT, bool GATHER = false, int WIN = 0>
+// OH: the OneHotPartialObsWrapper image instead of the triples (a template parameter, not a run-time branch: with the expansion compiled
+// into every instance the step kernels went from 66-70 to 176 VGPRs).
+template <int CW, int CH, int V, bool ALT, bool GATHER = false, int WIN = 0, bool OH = false>
 __device__ __forceinline__ void emit_partial_obs(const StepParams &p, const Lane &L, uint8_t *lds, const uint8_t *g,
                                                  int64_t env0, int lane, int pidx = -1, uint32_t pcode = 0, unsigned long long *tlv = nullptr,
                                                  int wx0 = 0, int wy0 = 0)
@@ -489,7 +491,7 @@ __device__ __forceinline__ void emit_partial_obs(const StepParams &p, const Lane
     // the agent's own cell shows what it carries, after occlusion; always visible (minigrid.py:1349-1356)
     code[V / 2][V - 1] = L.carry;
 
-    if (p.onehot) {
+    if constexpr (OH) {
         // OneHotPartialObsWrapper fused (wrappers.py:226-243: out[vx][vy][type] = out[.., 11 + color] = out[.., 18 + state] = 1, 21 channels): the
         // V*V*21 bytes per env leave straight from here -- no triples written to HBM and read back by a second kernel (2 x 147 B per env-step).
         // An env's 1,029 bytes are not 16-byte aligned, 16 envs' are: the tile goes out in four quarters.  Per quarter: the wave zeroes a
@@ -769,7 +771,7 @@ __device__ __forceinline__ void emit_full_obs(const StepParams &p, const Lane &L
 // DYN (Dynamic-Obstacles, staged partial form): the obstacle walk of envs/dynamicobstacles.py:60-80 runs in front of the transition on the
 // SAME staged tile (dynobs_device.h) -- one launch instead of k_dynobs + k_step, the cells read once and written back once per step, no
 // folded-action buffer in between.
-template <int CW, int CH, int MODE, int V, bool ALT, bool OBJ, bool DYN>
+template <int CW, int CH, int MODE, int V, bool ALT, bool OBJ, bool DYN, bool OH = false>
 __device__ __forceinline__ void step_body(const StepParams &p, const DynObsParams *dp)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -988,11 +990,11 @@ __device__ __forceinline__ void step_body(const StepParams &p, const DynObsParam
                     const int fx = L.ax + fdx, fy = L.ay + fdy;
                     p.front[env] = ((unsigned)fx < (unsigned)W && (unsigned)fy < (unsigned)H) ? win[(fx - x0) * RS + fy - yc] : (uint8_t)0;
                 }
-                emit_partial_obs<CW, CH, V, ALT, false, RS>(p, L, lds, win, env0, lane, -1, 0, nullptr, x0, yc);
+                emit_partial_obs<CW, CH, V, ALT, false, RS, OH>(p, L, lds, win, env0, lane, -1, 0, nullptr, x0, yc);
             } else { // (a grid lower than the excerpt: V*V byte loads)
                 if (p.front && valid) p.front[env] = 0;
                 if constexpr (WC) { if (p.wcache && valid) reinterpret_cast<uint32_t *>(p.wcache + env * 64)[15] = 0u; }
-                emit_partial_obs<CW, CH, V, ALT, true>(p, L, lds, row, env0, lane, pidx, pcode);
+                emit_partial_obs<CW, CH, V, ALT, true, 0, OH>(p, L, lds, row, env0, lane, pidx, pcode);
             }
         }
 #ifdef MGX_TIMELINE
@@ -1011,7 +1013,7 @@ __device__ __forceinline__ void step_body(const StepParams &p, const DynObsParam
             }
         }
 #else
-        else if (MODE == 0) emit_partial_obs<CW, CH, V, ALT>(p, L, lds, g, env0, lane);
+        else if (MODE == 0) emit_partial_obs<CW, CH, V, ALT, false, 0, OH>(p, L, lds, g, env0, lane);
 #endif
         else emit_full_obs<CW, CH>(p, L, valid, lds, g, LS, env0, lane);
     }
@@ -1021,6 +1023,13 @@ template <int CW, int CH, int MODE, int V, bool ALT = false, bool OBJ = (CW == 0
 __global__ __launch_bounds__(256, (MODE == 3 && V == 7 && !ALT && !OBJ) ? MGX_GATHER_WAVES(CW) : 1) void k_step(const StepParams p)
 {
     step_body<CW, CH, MODE, V, ALT, OBJ, false>(p, nullptr);
+}
+
+// OneHotPartialObsWrapper expanded in the step kernel (StepParams.onehot; run-time grid size, views 3 / 5 / 7, staged or gather form)
+template <int MODE, int V>
+__global__ __launch_bounds__(256) void k_step_onehot(const StepParams p)
+{
+    step_body<0, 0, MODE, V, false, true, false, true>(p, nullptr);
 }
 
 template <int CW, int CH>
@@ -1494,6 +1503,13 @@ hipError_t mgx_launch_rollout(const StepParams &p0, const uint8_t *actions, uint
 static StepChoice choose_step_kernel(const StepParams &p, int mode)
 {
     const StepChoice none = {nullptr, false, "none"};
+    if (p.onehot) { // (mgx_create sets it for partial views up to 7x7 with the default visibility only)
+        if (p.alt_vis || (mode != 0 && mode != 3)) return none;
+#define OCASE(v) if (p.view == v) return mode == 0 ? StepChoice{k_step_onehot<0, v>, false, "k_step_onehot<0," MGX_STR(v) ">"} : StepChoice{k_step_onehot<3, v>, false, "k_step_onehot<3," MGX_STR(v) ">"};
+        OCASE(3) OCASE(5) OCASE(7)
+#undef OCASE
+        return none;
+    }
     if (mode == 3) { // large grids: gather form (the default view and visibility by the size rule, anything else when the tile image cannot fit the LDS)
         if (p.view == 7 && !p.alt_vis && !p.objaux) { // the default view: 13x13 Memory, every 16x16 id, 17x17 Memory, FourRooms / LockedRoom / Playground 19x19, MultiRoom 25x25, any other size
 #define GCASE(w, h) if (p.W == w && p.H == h) return {k_step<w, h, 3, 7, false, false>, false, "k_step<" #w "," #h ",3,7>"};

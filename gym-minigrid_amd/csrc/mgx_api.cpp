@@ -415,7 +415,7 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     // waves per SIMD, and eight waves queue on one LDS pipe for 3,500 cycles of image traffic per tile; profiles/r04_onehot_fused.txt), so
     // the default stays the two-kernel form and MGX_ONEHOT=fused selects this one.
     const char *ohf = getenv("MGX_ONEHOT");
-    h->oh_fused = cfg->obs_mode == MGX_OBS_PARTIAL_ONEHOT && view <= 7 && ohf && !strcmp(ohf, "fused");
+    h->oh_fused = cfg->obs_mode == MGX_OBS_PARTIAL_ONEHOT && view <= 7 && !cfg->alt_visibility && cfg->task_kind != MGX_TASK_DYNOBS && ohf && !strcmp(ohf, "fused");
     if (h->oh_fused) {
 #ifndef MGX_OH_UNIT
 #define MGX_OH_UNIT 16
