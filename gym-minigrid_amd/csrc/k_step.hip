@@ -949,7 +949,11 @@ __device__ __forceinline__ void step_body(const StepParams &p, const DynObsParam
                 // issued together), every other step -- 4 of 7 random actions, and every blocked forward -- observes from the record.
                 const uint32_t tag = (uint32_t)L.ax | ((uint32_t)L.ay << 8) | ((uint32_t)L.dir << 16) | (1u << 24);
                 bool hit = false;
-                if constexpr (WC) hit = p.wcache != nullptr && !was_reset && wc[3].w == tag;
+                uint32_t streak = 0; // consecutive misses of this env (bits 27:26 of the record's last dword, saturating at 3)
+                if constexpr (WC) {
+                    hit = p.wcache != nullptr && !was_reset && (wc[3].w & 0x0103FFFFu) == tag;
+                    streak = p.wcache ? (wc[3].w >> 26) & 3u : 0u;
+                }
                 if (!hit) {
 #pragma unroll
                     for (int k = 0; k < V; k++) {
@@ -974,15 +978,27 @@ __device__ __forceinline__ void step_body(const StepParams &p, const DynObsParam
                 const int fdx = (L.dir == 0) - (L.dir == 2), fdy = (L.dir == 1) - (L.dir == 3);
                 if (pidx >= 0) win[(L.ax + fdx - x0) * RS + L.ay + fdy - yc] = (uint8_t)pcode; // the front cell this step changed (the agent did not move then)
                 if constexpr (WC) {
-                    // the record follows: rewritten when it was reloaded or when this step changed a cell of it (4 x 16 B per lane, contiguous over the wave)
-                    if (p.wcache && valid && (!hit || pidx >= 0)) {
-                        uint32_t o[16];
+                    // The record follows (4 x 16 B per lane, contiguous over the wave): rewritten when this step changed a cell of it, and when it
+                    // was reloaded -- unless the env keeps missing.  An agent that walks misses on every step, and a record rewritten behind
+                    // each of them would be 64 bytes per step for nothing: after two misses in a row only the last dword is kept up to date
+                    // (no pose, the miss count), until a step that leaves the pose alone reloads the window -- that one writes the record
+                    // again, whatever the count.
+                    if (p.wcache && valid) {
+                        const bool stayed = !was_reset && ((uint32_t)L.ax | ((uint32_t)L.ay << 8) | ((uint32_t)L.dir << 16)) == (rec.x & 0x3FFFFu);
+                        const uint32_t streak1 = hit ? 0u : (stayed ? 0u : (streak < 3u ? streak + 1u : 3u));
+                        uint32_t *w32 = reinterpret_cast<uint32_t *>(p.wcache + env * 64);
+                        if ((hit && pidx >= 0) || (!hit && (streak <= 1u || stayed))) {
+                            uint32_t o[16];
 #pragma unroll
-                        for (int q = 0; q < 14; q++) o[q] = win32[q];
-                        o[14] = 0u; o[15] = tag;
-                        uint4 *w4 = reinterpret_cast<uint4 *>(p.wcache + env * 64);
+                            for (int q = 0; q < 14; q++) o[q] = win32[q];
+                            o[14] = 0u; o[15] = tag | (streak1 << 26);
+                            uint4 *w4 = reinterpret_cast<uint4 *>(w32);
 #pragma unroll
-                        for (int i = 0; i < 4; i++) w4[i] = make_uint4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+                            for (int i = 0; i < 4; i++) w4[i] = make_uint4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+                        } else {
+                            const uint32_t last = hit ? (tag | (streak1 << 26)) : (streak1 << 26); // (a miss that does not rewrite: the record belongs to no pose)
+                            if (last != wc[3].w) w32[15] = last;
+                        }
                     }
                 }
                 // the cell in front of the (new) pose lies inside the excerpt whenever it lies inside the grid: remembered for the next step
