@@ -260,6 +260,96 @@ def one_rollout(env_id, rs):
     return N * T * 3, dict(N=N, T=T, mode=mode, stream=stream, rollout=True)
 
 
+def one_boundary(env_id, rs):
+    """The other two episode boundaries of the reference (round 4): the plain caller-side reset() -- the env's RNG stream continues, level k of env i
+    is host generate_level_stream(seed_i)[k] -- and ReseedWrapper with a list of K seeds per env (mgx_set_seed_schedule), in-kernel or caller-side."""
+    cfg = mg.env_config(env_id)
+    dyn = cfg.task_kind == _lib.TASK_DYNOBS
+    kind = str(rs.choice(["plain", "schedule-auto", "schedule-caller"]))
+    full = bool(rs.randint(2))
+    N = int(rs.choice([1, 63, 65, 200])) if not dyn else int(rs.choice([1, 65, 130]))
+    T, L = 100, 50
+    seeds = rs.randint(0, 2 ** 63, size=N, dtype=np.int64).astype(np.uint64) if rs.uniform() < 0.5 else rs.randint(0, 30, size=N).astype(np.uint64)
+    K = int(rs.randint(1, 6))
+    idx0 = int(rs.randint(K))
+    lists = rs.randint(0, 40, size=(N, K)).astype(np.uint64) if rs.uniform() < 0.5 else rs.randint(0, 2 ** 62, size=(N, K), dtype=np.int64).astype(np.uint64)
+    sched = kind != "plain"
+    try:
+        env = mg.VecMiniGrid(env_id, num_envs=N, seeds=seeds, auto_reset=kind == "schedule-auto", backend="torch", obs_mode="full" if full else "partial")
+        if sched:
+            env.set_seed_schedule(lists, seed_idx=idx0)
+            obs = np_(env.reset(reseed=False))
+        else:
+            obs = np_(env.reset())
+    except mg.MgxError as e:
+        assert cfg.width * cfg.height > 4096, (env_id, e)     # host-generated grids keep no RNG stream on the device
+        return 0, None
+    idx = np.arange(N)
+    ep = np.full(N, idx0 if sched else 0, np.int64)
+    if dyn:
+        orc = DynObsOracle(cfg.width, cfg.level_arg0, "Random" in env_id, seeds, seed_lists=lists if sched else None, seed_idx=idx0)
+        observe = lambda: orc.base.observe(True)[int(full)]  # noqa: E731
+    else:
+        if sched:
+            g, a, tk, ct = mg.generate_levels(env_id, lists.reshape(-1), with_task=True, with_contains=True)
+            G, A, TK, C = g.reshape((N, K) + g.shape[1:]), a.reshape(N, K, 3), tk.reshape(N, K), ct.reshape((N, K) + ct.shape[1:])
+        else:
+            levels = [mg.generate_level_stream(env_id, int(sd), L, with_task=True, with_contains=True) for sd in seeds]
+            G, A, TK, C = (np.stack([lv[j] for lv in levels]) for j in range(4))
+        orc = OracleEnvs(cfg.width, cfg.height, cfg.max_steps, cfg.see_through_walls, cfg.lava_v1, task=cfg.task_kind)
+        orc.set_state(G[idx, ep], A[idx, ep])
+        orc.task = TK[idx, ep].copy()
+        if cfg.object_state:
+            orc.set_contains(C[idx, ep])
+        observe = lambda: orc.observe(True)[int(full)]  # noqa: E731
+    assert np.array_equal(obs, observe()), (env_id, kind, "start")
+    nact = 3 if dyn else 7
+    for t in range(T):
+        a = rs.randint(0, nact, size=N).astype(np.uint8)
+        if rs.uniform() < 0.5:
+            a[rs.uniform(size=N) < 0.5] = 2
+        obs, rew, done, _ = env.step(torch.from_numpy(a).cuda())
+        if dyn:
+            oo, orew, odone = orc.step(a)
+            if full:
+                oo = observe()
+        else:
+            o1, o2, orew, odone = orc.step(a, True)
+            oo = (o2 if full else o1).copy()
+        d = odone.astype(bool)
+        assert np.array_equal(np_(done), odone), (env_id, kind, t)
+        assert np.array_equal(np_(rew), orew.astype(np.float32)), (env_id, kind, t)
+        if kind != "schedule-auto":
+            assert np.array_equal(np_(obs), oo), (env_id, kind, t)       # the terminal observation, as the reference returns it
+        if d.any():
+            ep[d] = (ep[d] + 1) % K if sched else ep[d] + 1
+            if not sched and ep.max() >= L:
+                break
+            if dyn:
+                orc.reset_where(odone, reseed=sched)
+            else:
+                orc.grid0[d], orc.agent0[d] = G[d, ep[d]], A[d, ep[d]]
+                if cfg.object_state:
+                    orc.contains0[d] = C[d, ep[d]]
+                orc.reset_where(odone)
+                if cfg.task_kind and cfg.task_kind != _lib.TASK_TWOGOALS:
+                    orc.task[d] = TK[d, ep[d]]
+            if kind == "schedule-auto":
+                oo = oo.copy()
+                oo[d] = observe()[d]
+            else:
+                robs = np_(env.reset(mask=done, reseed=False))
+                assert np.array_equal(robs[d], observe()[d]), (env_id, kind, t, "reset")
+        if kind == "schedule-auto":
+            assert np.array_equal(np_(obs), oo), (env_id, kind, t)
+    st = env.get_state()
+    base = orc.base if dyn else orc
+    assert np.array_equal(st["grid"], base.grid) and np.array_equal(st["agent"], base.agent), (env_id, kind)
+    env.clear_faults()
+    env.close()
+    return N * T, dict(N=N, boundary=kind, K=K if sched else 0, full=full)
+
+
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -282,6 +372,10 @@ def main():
             total += n
             print("round %d %-46s ok  %s  (%.0f s)" % (r, env_id, desc, time.perf_counter() - t0), flush=True)
             n, desc = one_options(env_id, rs)
+            total += n
+            if desc:
+                print("round %d %-46s ok  %s  (%.0f s)" % (r, env_id, desc, time.perf_counter() - t0), flush=True)
+            n, desc = one_boundary(env_id, rs)
             total += n
             if desc:
                 print("round %d %-46s ok  %s  (%.0f s)" % (r, env_id, desc, time.perf_counter() - t0), flush=True)
