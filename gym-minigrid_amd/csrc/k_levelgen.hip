@@ -843,7 +843,11 @@ __device__ __forceinline__ void seed_body(const uint64_t *__restrict__ seeds, co
 // with virt[env] set get their full first block from seed0 (= `seeds`) into `mt`; flags, seed book and mt_idx stay as they are.
 #define MGX_SEED_ARGS const uint64_t *__restrict__ seeds, const uint8_t *__restrict__ mask, const uint32_t *__restrict__ init, uint32_t *mt, uint32_t *mt2, \
                       uint32_t *mt_idx, uint8_t *regen, SeedBook book, int64_t n
-__global__ __launch_bounds__(256) void k_seed(MGX_SEED_ARGS) { seed_body<0>(seeds, mask, init, mt, mt2, mt_idx, regen, book, n); }
+#ifndef MGX_SEED_WAVES
+#define MGX_SEED_WAVES 3 /* waves per SIMD of the full form: it is bound by its 7.5 KB of row traffic per env, and more waves only deepen the queue
+                            (1 Mi envs, us per launch: 2 waves 1,993 | 3: 1,975 | 4: 2,179 | the 5 its 94 VGPRs allow: 2,111) */
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MGX_SEED_WAVES, MGX_SEED_WAVES))) void k_seed(MGX_SEED_ARGS) { seed_body<0>(seeds, mask, init, mt, mt2, mt_idx, regen, book, n); }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MGX_SEEDW_WAVES, MGX_SEEDW_WAVES))) void k_seed_window(MGX_SEED_ARGS)
 {
     seed_body<1>(seeds, mask, init, mt, mt2, mt_idx, regen, book, n);
