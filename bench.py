@@ -113,6 +113,12 @@ def step_kernel_bytes_per_step(W, H, obs_mode, view=7, kernel=""):
     cells = (W * H + 3) // 4 * 4
     if re.match(r"k_step<\d+,\d+,3,", kernel):
         cells = view * (4 if view <= 3 else 8 if view <= 7 else 12) + 1   # V columns of 4 / 8 / 12 bytes + the forward cell
+    if kernel.startswith("k_step_dyn<"):
+        # Dynamic-Obstacles, walk fused into the step: the tile read AND written back (the obstacles moved), obstacle order 8 + 8, RNG position
+        # 4 + 4, the 24-byte window of the draw tape -- plus what every step moves
+        return 2 * cells + 8 + 8 + 8 + 8 + 4 + 4 + 24 + 1 + obs_cells(W, H, obs_mode, view) * 3 + 4 + 1
+    if kernel.startswith("k_step_onehot<"):
+        return cells + 8 + 8 + 1 + obs_cells(W, H, obs_mode, view) * 21 + 4 + 1   # the one-hot image leaves from the step kernel itself
     return cells + 8 + 8 + 1 + obs_cells(W, H, obs_mode, view) * 3 + 4 + 1
 
 

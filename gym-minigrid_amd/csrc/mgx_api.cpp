@@ -1394,7 +1394,13 @@ extern "C" uint32_t mgx_action_at(uint64_t seed, int64_t env, int64_t t) { retur
 extern "C" int mgx_step_kernel_name(mgx_handle h, char *out, int cap)
 {
     if (!h || !out || cap < 1) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_step_kernel_name: null argument");
+    char dyn_name[32];
     const char *name = mgx_step_kernel_label(base_params(h), h->kernel_mode); // (host-side table lookup: no device call)
+    if (h->dyn_fused) { // walk + step in one launch (mgx_launch_step_dyn: sized instances for the registered Dynamic-Obstacles grids)
+        const bool sized = (h->W == h->H) && (h->W == 5 || h->W == 6 || h->W == 8 || h->W == 16);
+        snprintf(dyn_name, sizeof dyn_name, "k_step_dyn<%d,%d>", sized ? h->W : 0, sized ? h->H : 0);
+        name = dyn_name;
+    }
     const int len = (int)strlen(name);
     if (len + 1 > cap) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_step_kernel_name: need %d bytes", len + 1);
     memcpy(out, name, (size_t)len + 1);

@@ -5,7 +5,7 @@
 # collected in passes of their own (--pmc with --kernel-trace only).  Nothing is re-measured silently: a run whose slowest
 # launch of the top kernel took > 100x its fastest is KEPT and listed in <tag>_outliers.txt with that launch's duration.
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 PART=${2:-all}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
@@ -52,6 +52,8 @@ if [ $PART = stats ] || [ $PART = all ]; then
   stats lavacrossing_4M --config lava4m --envs-per-gpu 4194304 --steps 256 --warmup 16
   stats lavacrossing_1M --config lava4m --envs-per-gpu 1048576 --steps 512 --warmup 32
   stats lavacrossing_1M_newlevel --config lava4m --envs-per-gpu 1048576 --new-level-each-episode --steps 256
+  stats doorkey8x8_1M_newlevel --config doorkey8 --new-level-each-episode --steps 1400 --warmup 64   # (episodes time out at 640 steps: two boundaries inside)
+  stats keycorridor_s3r3_256k_newlevel --env MiniGrid-KeyCorridorS3R3-v0 --envs-per-gpu 262144 --new-level-each-episode --steps 600 --warmup 30
   stats dynobs8x8_1M --env MiniGrid-Dynamic-Obstacles-8x8-v0 --steps 512 --warmup 64
   stats dynobs16x16_1M --env MiniGrid-Dynamic-Obstacles-16x16-v0 --steps 256 --warmup 32
   stats multiroom_n6_256k_newlevel --env MiniGrid-MultiRoom-N6-v0 --envs-per-gpu 262144 --new-level-each-episode --steps 600 --warmup 30
