@@ -819,6 +819,11 @@ __device__ __forceinline__ void step_body(const StepParams &p, const DynObsParam
     if constexpr (MODE == 3) { if (p.front && p.do_step) front0 = p.front[env]; }
     // (gather form, 7x7 view) the window excerpt of the env's last observation pass + the pose it was loaded for (StepParams.wcache): 64
     // bytes per lane, 4 KB contiguous per wave
+#ifdef MGX_WC_STRICT /* (A/B builds) a miss rewrites the record only when the step left the pose alone */
+#define MGX_WC_WRITE_ON_MISS(streak) false
+#else
+#define MGX_WC_WRITE_ON_MISS(streak) ((streak) <= 1u) /* ... or while the env has missed at most once in a row */
+#endif
     constexpr bool WC = MODE == 3 && V == 7 && !ALT;
     uint4 wc[WC ? 4 : 1];
     if constexpr (WC) {
@@ -987,7 +992,7 @@ __device__ __forceinline__ void step_body(const StepParams &p, const DynObsParam
                         const bool stayed = !was_reset && ((uint32_t)L.ax | ((uint32_t)L.ay << 8) | ((uint32_t)L.dir << 16)) == (rec.x & 0x3FFFFu);
                         const uint32_t streak1 = hit ? 0u : (stayed ? 0u : (streak < 3u ? streak + 1u : 3u));
                         uint32_t *w32 = reinterpret_cast<uint32_t *>(p.wcache + env * 64);
-                        if ((hit && pidx >= 0) || (!hit && (streak <= 1u || stayed))) {
+                        if ((hit && pidx >= 0) || (!hit && (MGX_WC_WRITE_ON_MISS(streak) || stayed))) {
                             uint32_t o[16];
 #pragma unroll
                             for (int q = 0; q < 14; q++) o[q] = win32[q];

@@ -524,7 +524,10 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
         CREATE_TRY(hipMemsetAsync(h->front_d, 0, (size_t)h->n_pad, h->stream));
         // (MGX_GATHER_CACHE=off: the gather form without its per-env window records -- tests and A/B runs)
         const char *gc = getenv("MGX_GATHER_CACHE");
-        if (view == 7 && !cfg->alt_visibility && cfg->task_kind != MGX_TASK_DYNOBS && !(gc && !strcmp(gc, "off"))) {
+        // (not for TwoGoals: its episodes end on the `done` action, one env in seven per step under a random policy, and a record per pose that is
+        // thrown away that often measured 11 % slower -- profiles/r04_gather_window_cache.txt; MGX_GATHER_CACHE=on forces it)
+        const bool wc_rule = cfg->task_kind != MGX_TASK_TWOGOALS;
+        if (view == 7 && !cfg->alt_visibility && cfg->task_kind != MGX_TASK_DYNOBS && (gc ? !strcmp(gc, "on") : wc_rule)) {
             CREATE_TRY(hipMalloc((void **)&h->wcache_d, (size_t)h->n_pad * 64));
             CREATE_TRY(hipMemsetAsync(h->wcache_d, 0, (size_t)h->n_pad * 64, h->stream));
         }
