@@ -26,6 +26,8 @@ WORKLOADS = {  # name -> (traffic.json key, layout bytes per env-step, envs)
     "multiroom_n6_256k": ("MiniGrid-MultiRoom-N6-v0/partial/262144", 226, 262144),
     "fourrooms_1M": ("MiniGrid-FourRooms-v0/partial/1048576", 226, 1048576),
     "empty16x16_512k": ("MiniGrid-Empty-16x16-v0/partial/524288", 226, 524288),
+    # Dynamic-Obstacles, walk fused into the step (k_step_dyn): tile read + written back, obstacle order, RNG position, tape window: 345 B
+    "dynobs8x8_1M": ("MiniGrid-Dynamic-Obstacles-8x8-v0/partial/1048576", 345, 1048576),
 }
 
 
