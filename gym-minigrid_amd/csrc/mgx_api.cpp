@@ -930,6 +930,8 @@ extern "C" int mgx_rollout(mgx_handle h, int64_t T, const uint8_t *actions, uint
     int rc = dev_guard.enter(h, "mgx_rollout");
     if (rc) return rc;
     if (T <= 0 || !actions) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_rollout: T > 0 and actions are required");
+    if (h->needs_full_reset)
+        return mgx_fail(MGX_ERR_INVALID_STATE, "mgx_rollout: a seed schedule was installed; start every env on it with mgx_reset(h, NULL, NULL, obs) first");
     const void *args[4] = {actions, obs, reward, done};
     for (const void *a : args)
         if (a && !is_device_ptr(a)) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_rollout: buffers must be device memory (host buffers: call mgx_step per step)");
