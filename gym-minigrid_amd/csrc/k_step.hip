@@ -501,9 +501,10 @@ __device__ __forceinline__ void emit_partial_obs(const StepParams &p, const Lane
 #ifndef MGX_OH_UNIT
 #define MGX_OH_UNIT 16 /* envs per LDS image: 16 (16-byte stores) or 8 (8-byte stores, half the LDS) */
 #endif
-        constexpr int QE = MGX_OH_UNIT, SB = QE == 16 ? 16 : 8; // envs per image, bytes per lane and store
+        constexpr int QE = MGX_OH_UNIT, SB = QE == 8 ? 8 : 16; // envs per image, bytes per lane and store
         constexpr int NC = V * V, CSTR = (NC + 3) & ~3, NB = 21, QB = QE * NC * NB;
-        static_assert(QB % SB == 0, "an image is a whole number of stores");
+        // (QE = 4: an image of 4,116 bytes is 257 16-byte stores at a 4-BYTE-aligned address -- global_store_dwordx4 only needs that -- and one dword)
+        static_assert(QB % 4 == 0, "an image is a whole number of dwords");
         wave_sync(); // every lane has gathered its view: the grid image (or the window excerpts) may be overwritten
         uint32_t *cw = reinterpret_cast<uint32_t *>(lds) + lane * (CSTR / 4);
 #pragma unroll
@@ -520,7 +521,7 @@ __device__ __forceinline__ void emit_partial_obs(const StepParams &p, const Lane
         const int64_t nvv = p.n - env0;
         const int n_env = nvv >= 64 ? 64 : (int)nvv;
         uint8_t *dst = p.obs + env0 * (int64_t)(NC * NB);
-        constexpr int NCH = QB / SB, NZ = (QB + 15) / 16; // stores / 16-byte zero chunks per image
+        constexpr int NCH = QB / SB, NZ = (QB + 15) / 16, REMW = (QB - NCH * SB) / 4; // stores / 16-byte zero chunks per image / dwords behind the last store
         for (int qt = 0; qt < 64 / QE && QE * qt < n_env; qt++) { // wave-uniform
             wave_sync(); // (the codes are parked / the previous quarter's image has been read)
             // (every loop below has a compile-time trip count: rolled, with run-time bounds, the store loop was one ds_read -> s_waitcnt -> store
@@ -576,9 +577,10 @@ __device__ __forceinline__ void emit_partial_obs(const StepParams &p, const Lane
                         }
                     }
                 }
+                if constexpr (REMW != 0) { if (lane < REMW) reinterpret_cast<uint32_t *>(d)[NCH * (SB / 4) + lane] = reinterpret_cast<const uint32_t *>(img)[NCH * (SB / 4) + lane]; }
             } else { // the short last image of a tail tile
                 const int lim = q_env * NC * NB;
-                for (int c = lane; c < NCH; c += 64) {
+                for (int c = lane; c < NCH + (REMW ? 1 : 0); c += 64) {
                     if (SB * c + SB <= lim) {
                         if constexpr (SB == 16) reinterpret_cast<uint4 *>(d)[c] = reinterpret_cast<const uint4 *>(img)[c];
                         else reinterpret_cast<unsigned long long *>(d)[c] = reinterpret_cast<const unsigned long long *>(img)[c];
