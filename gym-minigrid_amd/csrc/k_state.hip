@@ -37,10 +37,14 @@ __global__ __launch_bounds__(256) void k_pack_state(const PackParams p)
                 else if (st != 0) bad = true;
                 if (ty == 1 && (co != 0 || ax != 0)) bad = true; // None encodes as exactly (1,0,0)
                 code = (k & 15u) | ((co & 7u) << 4) | ((ax & 1u) << 7);
-                if (p.objaux) { p.objaux[t] = (uint8_t)(ax & 0xFEu); p.objaux0[t] = (uint8_t)(ax & 0xFEu); p.objcont[t] = MGX_CODE_EMPTY; p.objcont0[t] = MGX_CODE_EMPTY; }
-            } else if (p.objaux) { p.objaux[t] = 0; p.objaux0[t] = 0; p.objcont[t] = MGX_CODE_EMPTY; p.objcont0[t] = MGX_CODE_EMPTY; }
+                if (p.objaux) { p.objaux[t] = (uint8_t)(ax & 0xFEu); p.objcont[t] = MGX_CODE_EMPTY; }
+                if (p.objaux && p.cells0) { p.objaux0[t] = (uint8_t)(ax & 0xFEu); p.objcont0[t] = MGX_CODE_EMPTY; }
+            } else if (p.objaux) {
+                p.objaux[t] = 0; p.objcont[t] = MGX_CODE_EMPTY;
+                if (p.cells0) { p.objaux0[t] = 0; p.objcont0[t] = MGX_CODE_EMPTY; }
+            }
             p.cells[t] = (uint8_t)code;
-            p.cells0[t] = (uint8_t)code;
+            if (p.cells0) p.cells0[t] = (uint8_t)code; // (null: the snapshot arrays hold the NEXT level of a new_level_each_episode handle)
         }
     }
     if (t < p.n && (!p.mask || p.mask[t])) {
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(256) void k_pack_state(const PackParams p)
         p.rec[t] = rec;
         if (p.objaux) p.objcarry[t] = (uint16_t)(MGX_CODE_EMPTY << 8);
         // the episode start always has nothing carried and step_count 0 (reset(), minigrid.py:851-854)
-        p.rec0[t] = make_uint2((rec.x & 0x00FFFFFFu) | ((uint32_t)MGX_CODE_EMPTY << 24), p.has_task ? (w1 & 0xFFFF0000u) : 0u);
+        if (p.cells0) p.rec0[t] = make_uint2((rec.x & 0x00FFFFFFu) | ((uint32_t)MGX_CODE_EMPTY << 24), p.has_task ? (w1 & 0xFFFF0000u) : 0u);
     }
     if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicAdd(&p.ctr->invalid_state, 1ull);
 }
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(256) void k_task(uint2 *rec, uint2 *rec0, const uin
     if (i >= n) return;
     if (set && (!mask || mask[i])) {
         rec[i].y = (rec[i].y & 0xFFFFu) | (set[i] << 16);
-        rec0[i].y = (rec0[i].y & 0xFFFFu) | (set[i] << 16);
+        if (rec0) rec0[i].y = (rec0[i].y & 0xFFFFu) | (set[i] << 16);
     }
     if (get) get[i] = rec[i].y >> 16;
 }
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(256) void k_objstate(const ObjStateParams p)
             if (bad) atomicAdd(&p.ctr->invalid_state, 1ull);
             const uint8_t code = (uint8_t)((k & 15u) | ((co & 7u) << 4));
             p.objcont[e * p.S + c] = code;
-            p.objcont0[e * p.S + c] = code;
+            if (p.objcont0) p.objcont0[e * p.S + c] = code;
         }
         if (p.contains_out) {
             const uint32_t tr = decode_triple(p.objcont[e * p.S + c]);

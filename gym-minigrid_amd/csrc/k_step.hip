@@ -887,9 +887,12 @@ __device__ __forceinline__ void step_body(const StepParams &p, const DynObsParam
         const bool needs_copy = L.dirty != 0u || p.regen != nullptr || p.bank != nullptr;
         int nb = 0; // seed schedule: the list entry the new episode runs on
         if (p.bank && p.auto_reset && valid && done) {
-            nb = (int)p.bank[env] + 1;
-            nb = nb >= p.n_banks ? 0 : nb;
-            p.bank[env] = (uint8_t)nb;
+            if (p.ring) { nb = (int)p.bank[env]; p.bank[env] = (uint8_t)((nb + 1) & (p.ring - 1)); } // (ring of next-level buffers: this one is consumed)
+            else {
+                nb = (int)p.bank[env] + 1;
+                nb = nb >= p.n_banks ? 0 : nb;
+                p.bank[env] = (uint8_t)nb;
+            }
         }
         const int64_t senv = env + (int64_t)nb * p.bank_envs; // this env in the snapshot arrays
         if constexpr (GATHER) {
@@ -921,7 +924,7 @@ __device__ __forceinline__ void step_body(const StepParams &p, const DynObsParam
             // (loaded here, by the waves that need it: fetching agent0 with the record up front takes a 3-6 us round trip under load
             // out of 40 % of LavaCrossing's waves and still measured +0.6 ... +1.5 us per launch -- 8 B per env of extra requests)
             L = unpack_rec(p.agent0[senv], p.task);
-            if (p.regen) p.regen[env] = 1; // the next-level buffer was consumed: k_levelgen refills it after this launch
+            if (p.regen) p.regen[env] = (uint8_t)(p.ring ? nb + 1 : 1); // the next-level buffer was consumed: k_levelgen refills it (ring: THAT buffer)
         }
         if (valid) p.agent[env] = pack_rec(L, p.task);
     }

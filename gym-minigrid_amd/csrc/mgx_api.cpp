@@ -109,6 +109,17 @@ struct mgx_env_s {
     uint32_t *win_d = nullptr;
     uint8_t *virt_d = nullptr;
     bool maybe_virtual = false;   // some env may still hold a virtual state (a plain reset() materializes the masked ones first)
+    // new_level_each_episode with the generator running BESIDE the steps (cheap families on the staged kernels): a ring of R next-level buffers
+    // per env (snapshot banks; bank_d = the one the env's next reset consumes), the flags of step s in lg_flags[s % R], and every R/2 steps
+    // k_levelgen for the flags of those steps -- in step order, the order of the env's RNG stream -- on a stream of its own: forked behind the
+    // last of them, joined R/2 steps later, before the first of its buffers can be needed again (an env finishes at most one episode per step)
+    int lg_ring = 0;                               // R buffers (a power of two, 0: one buffer, the generator behind every step)
+    uint8_t *lg_flags[MGX_LG_RING_MAX] = {};       // ([0] = regen_d)
+    int lg_s = 0;                                  // the flag array the NEXT step raises
+    bool lg_dirty[MGX_LG_RING_MAX] = {};           // raised by a step, not handed to a generator yet
+    bool lg_unjoined[2] = {};                      // the generator launches for the first / second half of the arrays: not waited for by the caller's stream yet
+    hipStream_t lg_stream = nullptr;
+    hipEvent_t lg_fork = nullptr, lg_join[2] = {};
     // object_state: hidden Goal/Box planes (+ episode-start snapshots) and the carried object's pair
     uint8_t *objaux_d = nullptr, *objaux0_d = nullptr, *objcont_d = nullptr, *objcont0_d = nullptr;
     uint16_t *objcarry_d = nullptr;
@@ -229,6 +240,7 @@ StepParams base_params(mgx_handle h)
     p.wcache = h->wcache_d;
     p.onehot = h->oh_fused ? 1 : 0;
     p.bank = h->sched_K ? h->bank_d : nullptr; p.n_banks = h->sched_K ? h->sched_K : 1; p.bank_envs = h->sched_K ? h->n_pad : 0;
+    if (h->lg_ring) { p.bank = h->bank_d; p.n_banks = h->lg_ring; p.bank_envs = h->n_pad; p.ring = h->lg_ring; }
     return p;
 }
 
@@ -265,6 +277,7 @@ LevelGenParams levelgen_params(mgx_handle h)
     g.ctr = h->ctr_d;
     g.n = h->n; g.n_tiles = (int)(h->n_pad / 64); g.S = h->S;
     g.win = h->win_d; g.virt = h->virt_d; g.seed0 = h->seed0_d; g.mt_init = h->mt_init_d;
+    g.bank_envs = h->lg_ring ? h->n_pad : 0;
     return g;
 }
 
@@ -296,6 +309,42 @@ hipError_t launch_seed(mgx_handle h, const uint64_t *seeds_dev, const uint8_t *m
 int launch_levelgen(mgx_handle h)
 {
     HIP_TRY(mgx_launch_levelgen(levelgen_params(h), h->stream));
+    return MGX_OK;
+}
+
+// new_level_each_episode handles, once every env has been seeded: the snapshot arrays hold the NEXT level of each env, already drawn from its RNG
+// stream.  State injected from outside (set_state, set_task, set_object_state: attribute assignments in the reference, which draw nothing) then
+// changes the current episode only and leaves that level where it is.
+bool next_level_waiting(mgx_handle h) { return h->stream_mode && h->seeded && h->device_levels; }
+
+// Ring handles: generators may still be running beside the caller's stream, and the last step's flags may not have been handed to one yet.
+// Every entry point that reads or rewrites next-level buffers, RNG state or flags from the host side first brings all of that onto the caller's stream.
+int lg_drain(mgx_handle h)
+{
+    if (!h->lg_ring) return MGX_OK;
+    for (int pr = 0; pr < 2; pr++)
+        if (h->lg_unjoined[pr]) { HIP_TRY(hipStreamWaitEvent(h->stream, h->lg_join[pr], 0)); h->lg_unjoined[pr] = false; }
+    for (int k = 0; k < h->lg_ring; k++) { // (the steps of a half whose generators have not been launched)
+        const int a = (h->lg_s + k) & (h->lg_ring - 1); // oldest first
+        if (!h->lg_dirty[a]) continue;
+        LevelGenParams g = levelgen_params(h);
+        g.regen = h->lg_flags[a];
+        HIP_TRY(mgx_launch_levelgen(g, h->stream));
+        h->lg_dirty[a] = false;
+    }
+    h->lg_s = 0;
+    return MGX_OK;
+}
+
+// ... and after a host-side reset of the single-buffer kind (buffer 0 = the masked envs' next level) the ring is completed behind it
+int lg_ring_init(mgx_handle h, const uint8_t *mask_dev)
+{
+    if (!h->lg_ring) return MGX_OK;
+    for (int b = 1; b < h->lg_ring; b++) {
+        HIP_TRY(mgx_launch_ring_init(h->bank_d, h->regen_d, mask_dev, h->n, b + 1, h->stream));
+        const int rc = launch_levelgen(h);
+        if (rc) return rc;
+    }
     return MGX_OK;
 }
 
@@ -426,6 +475,7 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
     h->lds_guard = h->kernel_mode == 0 ? guard : 0;
     h->staged_guard = guard;
     h->wave_lds = (need + 15) & ~15;
+    if (const char *e = MGX_TUNE_ENV("MGX_EXTRA_LDS")) h->wave_lds += atoi(e) & ~15; // (tuning builds: what the step costs with fewer resident blocks)
     // a family that draws no random numbers (Empty with a fixed start) has only one level: nothing to generate
     const bool uses_rng = cfg->level_kind != MGX_LEVEL_NONE && cfg->level_kind != MGX_LEVEL_DISTSHIFT &&
                           !((cfg->level_kind == MGX_LEVEL_EMPTY || cfg->level_kind == MGX_LEVEL_TWOGOALS) && cfg->level_arg0 == 0);
@@ -605,6 +655,44 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
         CREATE_TRY(hipMalloc((void **)&h->sp0_d, (size_t)h->n_pad * sizeof(uint32_t)));
         CREATE_TRY(hipMemsetAsync(h->sp0_d, 0, (size_t)h->n_pad * sizeof(uint32_t), h->stream));
     }
+    {   // The generator beside the steps: new_level_each_episode handles of the families whose levels take a few dozen draws, on the staged
+        // kernels.  k_levelgen behind every step is compute (MT19937 draws, rejection loops: 17 us for the ~50 k levels a step of 1 Mi LavaCrossing
+        // envs ends) in front of a memory-bound step; beside the steps it fills the step's stalls.  Two things decide the form, both measured
+        // (profiles/README.md, round 4): a kernel with both kinds of block runs every step wave at the generator's 128 VGPRs (74 us against 62
+        // for the two launches), and an event pair between two streams costs 10-20 us on this stack, so the coupling is loose: a fork every
+        // R/2 steps, its join due R/2 steps later.  us per step at 1 Mi / 512 Ki / 64 Ki LavaCrossingS9N1 envs: one buffer 59.0 / 39.5 / 21.2,
+        // R = 4: 58.7 / 38.5 / 19.1, R = 8: 53.8 / 33.4 / 16.5, R = 16: 53.8 / 32.0 / 15.1 (replay 44.0 / 24 / 9); families whose episodes
+        // end rarely (DoorKey, Empty-Random, SimpleCrossing) are within 1 us either way.  (R * (S + 8) B per env: 1.7 KB at 9x9.)
+        // MGX_LG_RING=off | 2 | 4 | 8 | 16: one buffer and k_levelgen behind every step on the caller's stream (tests, A/B), or another depth.
+        const char *lf = getenv("MGX_LG_RING");
+        const int k = cfg->level_kind;
+        const bool cheap = k == MGX_LEVEL_EMPTY || k == MGX_LEVEL_DOORKEY || k == MGX_LEVEL_CROSSING || k == MGX_LEVEL_LAVAGAP;
+        const int R = lf ? atoi(lf) : 16; // ("off" -> 0)
+        if (h->stream_mode && cheap && h->kernel_mode == 0 && !cfg->object_state && cfg->obs_mode == MGX_OBS_PARTIAL && !h->mt2_d &&
+            (R == 2 || R == 4 || R == 8 || R == 16)) h->lg_ring = R;
+        if (h->lg_ring) {
+            int prio_lo = 0, prio_hi = 0;
+            CREATE_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+            CREATE_TRY(hipStreamCreateWithPriority(&h->lg_stream, hipStreamNonBlocking, prio_hi));
+            CREATE_TRY(hipEventCreateWithFlags(&h->lg_fork, hipEventDisableTiming));
+            for (int a = 0; a < 2; a++) CREATE_TRY(hipEventCreateWithFlags(&h->lg_join[a], hipEventDisableTiming));
+            const size_t cb = (size_t)R * h->n_pad * h->S, ab = (size_t)R * h->n_pad * sizeof(uint2);
+            (void)hipFree(h->cells0_d); (void)hipFree(h->agent0_d);
+            h->cells0_d = nullptr; h->agent0_d = nullptr;
+            CREATE_TRY(hipMalloc((void **)&h->cells0_d, cb));
+            CREATE_TRY(hipMalloc((void **)&h->agent0_d, ab));
+            CREATE_TRY(hipMemsetAsync(h->cells0_d, 0, cb, h->stream));
+            CREATE_TRY(hipMemsetAsync(h->agent0_d, 0, ab, h->stream));
+            h->snap_banks = R;
+            CREATE_TRY(hipMalloc((void **)&h->bank_d, (size_t)h->n_pad));
+            CREATE_TRY(hipMemsetAsync(h->bank_d, 0, (size_t)h->n_pad, h->stream));
+            h->lg_flags[0] = h->regen_d;
+            for (int a = 1; a < R; a++) {
+                CREATE_TRY(hipMalloc((void **)&h->lg_flags[a], (size_t)h->n_pad));
+                CREATE_TRY(hipMemsetAsync(h->lg_flags[a], 0, (size_t)h->n_pad, h->stream));
+            }
+        }
+    }
     CREATE_TRY(mgx_preload_step_kernels());
     {
         const StepParams sp = base_params(h);
@@ -637,6 +725,7 @@ extern "C" int mgx_destroy(mgx_handle h)
     DeviceGuard dev_guard;
     (void)dev_guard.enter_device(h->device, "mgx_destroy");
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->lg_stream) (void)hipStreamSynchronize(h->lg_stream);
     (void)hipFree(h->cells_d); (void)hipFree(h->cells0_d); (void)hipFree(h->agent_d); (void)hipFree(h->agent0_d);
     (void)hipFree(h->ctr_d); (void)hipFree(h->tri_d); (void)hipFree(h->mission_d); (void)hipFree(h->front_d); (void)hipFree(h->wcache_d);
     (void)hipFree(h->objaux_d); (void)hipFree(h->objaux0_d); (void)hipFree(h->objcont_d); (void)hipFree(h->objcont0_d); (void)hipFree(h->objcarry_d);
@@ -644,6 +733,10 @@ extern "C" int mgx_destroy(mgx_handle h)
     (void)hipFree(h->seed0_d); (void)hipFree(h->has_seed_d); (void)hipFree(h->reseeded_d);
     if (h->roll_exec) (void)hipGraphExecDestroy(h->roll_exec);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    if (h->lg_stream) (void)hipStreamDestroy(h->lg_stream);
+    if (h->lg_fork) (void)hipEventDestroy(h->lg_fork);
+    for (int a = 0; a < 2; a++) if (h->lg_join[a]) (void)hipEventDestroy(h->lg_join[a]);
+    for (int a = 1; a < MGX_LG_RING_MAX; a++) (void)hipFree(h->lg_flags[a]);
     (void)hipFree(h->obst_d); (void)hipFree(h->obst0_d); (void)hipFree(h->act_d); (void)hipFree(h->restart_d); (void)hipFree(h->mt0_d); (void)hipFree(h->pos0_d); (void)hipFree(h->tape_d); (void)hipFree(h->tape0_d);
     (void)hipFree(h->sp0_d); (void)hipFree(h->bank_d); (void)hipFree(h->win_d); (void)hipFree(h->virt_d);
     for (auto &s : h->st_in) if (s.dev) (void)hipFree(s.dev);
@@ -661,6 +754,7 @@ extern "C" int mgx_set_stream(mgx_handle h, void *hip_stream)
     DeviceGuard dev_guard;
     int rc = dev_guard.enter(h, "mgx_set_stream");
     if (rc) return rc;
+    if ((rc = lg_drain(h))) return rc; // (generators beside the steps join the old stream first)
     HIP_TRY(hipStreamSynchronize(h->stream)); // hand-over point: everything enqueued so far is complete
     h->stream = (hipStream_t)hip_stream; // NULL is a real stream: the device's default (null) stream
     return MGX_OK;
@@ -671,6 +765,7 @@ extern "C" int mgx_use_own_stream(mgx_handle h)
     DeviceGuard dev_guard;
     int rc = dev_guard.enter(h, "mgx_use_own_stream");
     if (rc) return rc;
+    if ((rc = lg_drain(h))) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->stream = h->own_stream;
     return MGX_OK;
@@ -689,6 +784,7 @@ extern "C" int mgx_sync(mgx_handle h)
     int rc = dev_guard.enter(h, "mgx_sync");
     if (rc) return rc;
     MgxCounters c;
+    if ((rc = lg_drain(h))) return rc; // ("everything enqueued is complete" includes the generators running beside the caller's stream)
     rc = read_counters(h, &c);
     if (rc) return rc;
     if (c.invalid_actions > h->base_bad_act)
@@ -757,6 +853,7 @@ static int set_state_impl(mgx_handle h, const uint8_t *grid, const uint8_t *aux,
     memset(&p, 0, sizeof p);
     const void *d;
     int rc;
+    if ((rc = lg_drain(h))) return rc;
     h->snapshot_is_level = false;
     h->sched_K = 0; h->needs_full_reset = false; // (the injected state is the episode start from now on: a seed schedule ends here)
     if ((rc = forget_front(h))) return rc;
@@ -773,7 +870,7 @@ static int set_state_impl(mgx_handle h, const uint8_t *grid, const uint8_t *aux,
     p.steps = (const int32_t *)d;
     if ((rc = dev_in(h, 5, mask_host, n, &d))) return rc;
     p.mask = (const uint8_t *)d;
-    p.cells = h->cells_d; p.cells0 = h->cells0_d; p.rec = h->agent_d; p.rec0 = h->agent0_d;
+    p.cells = h->cells_d; p.cells0 = next_level_waiting(h) ? nullptr : h->cells0_d; p.rec = h->agent_d; p.rec0 = h->agent0_d;
     p.objaux = h->objaux_d; p.objaux0 = h->objaux0_d; p.objcont = h->objcont_d; p.objcont0 = h->objcont0_d; p.objcarry = h->objcarry_d;
     p.ctr = h->ctr_d;
     p.n = h->n; p.W = h->W; p.H = h->H; p.S = h->S; p.has_task = h->cfg.task_kind != MGX_TASK_NONE;
@@ -782,10 +879,15 @@ static int set_state_impl(mgx_handle h, const uint8_t *grid, const uint8_t *aux,
     HIP_TRY(mgx_launch_pack(p, h->stream));
     if (h->has_seed_d) HIP_TRY(hipMemsetAsync(h->has_seed_d, 0, (size_t)h->n_pad, h->stream)); // the snapshots no longer belong to seeds
     if ((rc = read_counters(h, &after))) return rc;
-    if (h->stream_mode) { // the injected state is the CURRENT episode; the next one comes from the env's RNG stream
-        if (mask_host) HIP_TRY(hipMemcpyAsync(h->regen_d, p.mask, n, hipMemcpyDeviceToDevice, h->stream));
+    // new_level_each_episode: the injected state is the CURRENT episode (the reference's env.grid / agent_pos assignments draw nothing); the next
+    // level is the one already waiting in the buffer, drawn from the env's stream where its last reset left it.  Only a handle whose envs were
+    // never all seeded has no such level yet: it is drawn here.
+    if (h->stream_mode && !next_level_waiting(h)) {
+        if (h->lg_ring) HIP_TRY(mgx_launch_ring_init(h->bank_d, h->regen_d, mask_host ? p.mask : nullptr, h->n, 1, h->stream));
+        else if (mask_host) HIP_TRY(hipMemcpyAsync(h->regen_d, p.mask, n, hipMemcpyDeviceToDevice, h->stream));
         else HIP_TRY(hipMemsetAsync(h->regen_d, 1, n, h->stream));
         if ((rc = launch_levelgen(h))) return rc;
+        if ((rc = lg_ring_init(h, mask_host ? p.mask : nullptr))) return rc;
     }
     if (after.invalid_state != before.invalid_state)
         return mgx_fail(MGX_ERR_INVALID_STATE, "mgx_set_state: input holds a cell/agent/carry value the reference cannot produce "
@@ -879,7 +981,28 @@ static int run_step(mgx_handle h, bool do_step, const uint8_t *actions, uint8_t 
         }
         HIP_TRY(hipEventRecord(h->prof_ev[2 * h->prof_samples], h->stream));
     }
-    if (do_step && h->dyn_fused) { // Dynamic-Obstacles, staged partial form: walk + step in ONE launch on the staged tile
+    if (do_step && h->lg_ring) {
+        const int a = h->lg_s, half = h->lg_ring / 2, grp = a / half;
+        // (first step of a half: the generators forked a half ago refilled the buffers consumed a whole turn of the ring ago -- the first of which
+        // this step may need again -- and cleared this half's flag arrays)
+        if (a == grp * half && h->lg_unjoined[grp]) { HIP_TRY(hipStreamWaitEvent(h->stream, h->lg_join[grp], 0)); h->lg_unjoined[grp] = false; }
+        p.regen = h->lg_flags[a];
+        HIP_TRY(mgx_launch_step(p, h->kernel_mode, h->wpb, h->launch_cfg, h->stream));
+        h->lg_dirty[a] = true;
+        if (a == grp * half + half - 1) { // last step of a half: its flags, in step order (the env's RNG stream), beside the steps of the other half
+            HIP_TRY(hipEventRecord(h->lg_fork, h->stream));
+            HIP_TRY(hipStreamWaitEvent(h->lg_stream, h->lg_fork, 0));
+            LevelGenParams g = levelgen_params(h);
+            for (int b = grp * half; b <= a; b++) {
+                g.regen = h->lg_flags[b];
+                HIP_TRY(mgx_launch_levelgen(g, h->lg_stream));
+                h->lg_dirty[b] = false;
+            }
+            HIP_TRY(hipEventRecord(h->lg_join[grp], h->lg_stream));
+            h->lg_unjoined[grp] = true;
+        }
+        h->lg_s = (a + 1) & (h->lg_ring - 1);
+    } else if (do_step && h->dyn_fused) { // Dynamic-Obstacles, staged partial form: walk + step in ONE launch on the staged tile
         DynObsParams dp = dynobs_params(h);
         dp.actions = p.actions;
         dp.front = nullptr;
@@ -899,7 +1022,7 @@ static int run_step(mgx_handle h, bool do_step, const uint8_t *actions, uint8_t 
     if (do_step) {
         h->steps_total += h->n;
         if (h->profiling) h->prof_launches++;
-        if (h->stream_mode && (rc = launch_levelgen(h))) return rc; // refill the next-level buffers this step consumed
+        if (h->stream_mode && !h->lg_ring && (rc = launch_levelgen(h))) return rc; // refill the next-level buffers this step consumed
     }
     return finish_out(h, o, 3);
 }
@@ -966,6 +1089,7 @@ extern "C" int mgx_rollout(mgx_handle h, int64_t T, const uint8_t *actions, uint
         if (e != hipErrorNotSupported) return mgx_fail(MGX_ERR_HIP, "mgx_rollout: k_rollout launch failed: %s", hipGetErrorString(e));
         (void)hipGetLastError();
     }
+    if ((rc = lg_drain(h))) return rc; // (the captured steps start from "no flags waiting", and end there: the graph drains behind its last step)
     const bool cached = h->roll_exec && h->roll_T == T && !memcmp(h->roll_args, args, sizeof args);
     if (!cached) {
         if (h->roll_exec) { (void)hipGraphExecDestroy(h->roll_exec); h->roll_exec = nullptr; }
@@ -978,6 +1102,7 @@ extern "C" int mgx_rollout(mgx_handle h, int64_t T, const uint8_t *actions, uint
         for (int64_t t = 0; t < T && !rc; t++)
             rc = run_step(h, true, actions + t * h->n, obs ? obs + t * h->n * h->obs_bytes : nullptr,
                           reward ? reward + t * h->n : nullptr, done ? done + t * h->n : nullptr);
+        if (!rc) rc = lg_drain(h);
         h->assume_device = false;
         h->stream = user_stream;
         hipGraph_t graph = nullptr;
@@ -1018,7 +1143,7 @@ static int objstate_io(mgx_handle h, const char *fn, const uint8_t *ci, const ui
     if ((rc = dev_out(h, 1, ao, n, &o[1]))) return rc;
     if ((rc = dev_out(h, 2, cco, n * 3, &o[2]))) return rc;
     p.contains_out = (uint8_t *)o[0].dev; p.carry_aux_out = (uint8_t *)o[1].dev; p.carry_contains_out = (uint8_t *)o[2].dev;
-    p.objcont = h->objcont_d; p.objcont0 = h->objcont0_d; p.objcarry = h->objcarry_d; p.ctr = h->ctr_d;
+    p.objcont = h->objcont_d; p.objcont0 = next_level_waiting(h) ? nullptr : h->objcont0_d; p.objcarry = h->objcarry_d; p.ctr = h->ctr_d;
     p.n = h->n; p.W = h->W; p.H = h->H; p.S = h->S;
     MgxCounters before, after;
     if ((rc = read_counters(h, &before))) return rc;
@@ -1053,7 +1178,7 @@ static int set_task_impl(mgx_handle h, const uint32_t *task, const uint8_t *mask
     const void *d, *dm;
     if ((rc = dev_in(h, 4, task, (size_t)h->n * sizeof(uint32_t), &d, 4))) return rc;
     if ((rc = dev_in(h, 5, mask, (size_t)h->n, &dm))) return rc;
-    HIP_TRY(mgx_launch_task(h->agent_d, h->agent0_d, (const uint32_t *)d, nullptr, (const uint8_t *)dm, h->n, h->stream));
+    HIP_TRY(mgx_launch_task(h->agent_d, next_level_waiting(h) ? nullptr : h->agent0_d, (const uint32_t *)d, nullptr, (const uint8_t *)dm, h->n, h->stream));
     return MGX_OK;
 }
 
@@ -1234,6 +1359,7 @@ extern "C" int mgx_reset(mgx_handle h, const uint64_t *seeds, const uint8_t *mas
     if (h->cfg.level_kind == MGX_LEVEL_NONE)
         return mgx_fail(MGX_ERR_NO_LEVELGEN, "mgx_reset: this handle has no built-in level generator; use mgx_set_state");
     const size_t n = (size_t)h->n, cells = (size_t)h->cells;
+    if ((rc = lg_drain(h))) return rc;
     if (seeds && h->sched_K) { // explicit seeds define the episode start themselves: the schedule ends (include/mgx.h)
         h->sched_K = 0; h->needs_full_reset = false;
         if (h->has_seed_d) HIP_TRY(hipMemsetAsync(h->has_seed_d, 0, (size_t)h->n_pad, h->stream));
@@ -1269,7 +1395,9 @@ extern "C" int mgx_reset(mgx_handle h, const uint64_t *seeds, const uint8_t *mas
         ConsumeParams c = consume_params(h, (const uint8_t *)dm);
         if (h->stream_mode) { // the next level is waiting in the buffer: make it current, refill behind it
             c.flag_regen = 1;
+            if (h->lg_ring) { c.regen = nullptr; c.bank = h->bank_d; c.bank_envs = h->n_pad; } // (the buffer the env's ring position names)
             HIP_TRY(mgx_launch_consume(c, h->stream));
+            if (h->lg_ring) HIP_TRY(mgx_launch_ring_consumed(h->bank_d, h->regen_d, (const uint8_t *)dm, h->n, h->lg_ring, h->stream));
             if ((rc = launch_levelgen(h))) return rc;
         } else {
             if (h->dynobs) { // the obstacle walks' place in the stream back into (block, stream position)
@@ -1315,6 +1443,7 @@ extern "C" int mgx_reset(mgx_handle h, const uint64_t *seeds, const uint8_t *mas
         c.flag_regen = h->stream_mode ? 1 : 0;
         HIP_TRY(mgx_launch_consume(c, h->stream));
         if (h->stream_mode && (rc = launch_levelgen(h))) return rc;
+        if ((rc = lg_ring_init(h, (const uint8_t *)dm))) return rc;
         if (!mask) h->seeded = true; // every env's RNG stream exists from here on: reset() without seeds may continue it
         if (h->dynobs) { // obstacle order out of the generator's markers + snapshot of the RNG right after reset()
             DynObsParams dp = dynobs_params(h);

@@ -50,7 +50,10 @@ struct LevelGenParams {
     MgxCounters *ctr;
     int64_t n;
     int n_tiles, S;
+    int64_t bank_envs; // handles with a ring of next-level buffers: n_pad -- a work flag of b + 1 means buffer b, at env + b * bank_envs (else 0)
 };
+// layout of k_levelgen's lane slices and queues in LDS, sized per family by mgx_levelgen_layout (lanes: generating lanes per fast wave)
+struct FastLayout { int cmd_cap, river_cap, img_dw, slice_dw, n_fast_waves, span, lanes, queue_off; };
 struct DynObsParams;
 struct StepParams {
     uint8_t *cells;        // u8[n_pad][S]   internal cell codes, x-major
@@ -84,6 +87,8 @@ struct StepParams {
     uint8_t *bank;         // u8[n_pad]: list index of the env's CURRENT episode
     int n_banks;           // K
     int64_t bank_envs;     // n_pad (0 without a schedule)
+    int ring;              // R > 0 (a power of two): the banks are a RING of R next-level buffers (new_level_each_episode handles whose generator runs beside
+                           // the steps): bank[e] names the buffer the next reset consumes; the reset moves it on and raises regen[e] = buffer + 1
     int64_t n;
     int n_tiles;
     int W, H, S, LS, wave_lds, view;
@@ -150,7 +155,8 @@ struct DynObsParams {
     int W, H, S, n_obst;
     int n_tiles, LS, wave_lds; // k_dynobs: one wave per 64-env tile, cells + RNG windows staged in LDS
 };
-#define MGX_SEED_WIN 64 /* words of the first MT19937 block a virtual RNG state keeps (tools/draw_stats.cpp: what the families' levels draw) */
+#define MGX_SEED_WIN 64
+#define MGX_LG_RING_MAX 16 /* most next-level buffers per env where the level generator runs beside the steps (mgx_api.cpp: lg_ring) */ /* words of the first MT19937 block a virtual RNG state keeps (tools/draw_stats.cpp: what the families' levels draw) */
 #define MGX_DYN_TAPE_DW 56 /* two bit planes of 848 stream positions (624 of the block + 224 of the next), 28 dwords each */
 int mgx_dynobs_wave_lds(int LS);
 hipError_t mgx_launch_dynobs_init(const DynObsParams &p, hipStream_t st);
@@ -179,6 +185,11 @@ struct StepLaunchCfg { int tail_blocks, stagger_units, stagger_min; };
 hipError_t mgx_step_launch_cfg(int device, StepLaunchCfg *out);
 hipError_t mgx_launch_step(const StepParams &p, int mode, int waves_per_block, const StepLaunchCfg &lc, hipStream_t st);
 hipError_t mgx_launch_step_dyn(const StepParams &p, const DynObsParams &d, const StepLaunchCfg &lc, hipStream_t st); // (declared below: DynObsParams)
+// the step + the level generator's blocks for the buffers the LAST step consumed, in one launch (g.regen null: nothing pending, the step alone)
+// ring of next-level buffers, caller-side: regen[i] = bank[i] + 1 and bank[i] ^= 1 for the masked envs (a buffer was consumed) | bank[i] = 0 and
+// regen[i] = 2 (buffer 0 holds the next level, buffer 1 is to be made)
+hipError_t mgx_launch_ring_consumed(uint8_t *bank, uint8_t *regen, const uint8_t *mask, int64_t n, int ring, hipStream_t st);
+hipError_t mgx_launch_ring_init(uint8_t *bank, uint8_t *regen, const uint8_t *mask, int64_t n, int flag, hipStream_t st);
 const char *mgx_step_kernel_label(const StepParams &p, int mode); // the instantiation the selector picks, e.g. "k_step<8,8,0,7>"
 hipError_t mgx_launch_rollout(const StepParams &p, const uint8_t *actions, uint8_t *obs, float *reward, uint8_t *done, int64_t T, int full, hipStream_t st);
 hipError_t mgx_preload_step_kernels();

@@ -282,7 +282,8 @@ class VecMiniGrid:
     # ------------------------------------------------------------------ state injection / inspection
     def set_state(self, grid, agent, aux=None, carry=None, steps=None):
         """Reference-encoded state (host numpy arrays): grid (N,W,H,3) u8, agent (N,3) i32, aux (N,W,H) u8,
-        carry (N,3) u8, steps (N,) i32.  Also becomes the episode start used by auto-reset."""
+        carry (N,3) u8, steps (N,) i32.  Also becomes the episode start used by auto-reset -- except on a seeded
+        new_level_each_episode handle, where it replaces the current episode only and the next one is the env's next level."""
         n, W, H = self.num_envs, self.width, self.height
         g = np.ascontiguousarray(grid, np.uint8)
         assert g.shape == (n, W, H, 3), g.shape

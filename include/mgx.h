@@ -293,7 +293,10 @@ int mgx_set_seed_schedule(mgx_handle h, const uint64_t *seeds, int32_t K, int32_
 
 /* Inject / read back the full simulator state.  set_state also records the state as the
  * episode start used by auto_reset.  aux, carry, steps may be NULL (zeros / nothing / 0).
- * get_state: any pointer may be NULL. */
+ * get_state: any pointer may be NULL.
+ * new_level_each_episode handles (after a seeded reset of every env): the injected state replaces the CURRENT episode only, like
+ * assignments to env.grid / env.agent_pos in the reference, which draw nothing: the next episode is the level the env's RNG
+ * stream gives next, as if set_state had not been called.  The same holds for mgx_set_task and mgx_set_object_state there. */
 int mgx_set_state(mgx_handle h, const uint8_t *grid, const uint8_t *aux, const int32_t *agent,
                   const uint8_t *carry, const int32_t *steps);
 int mgx_get_state(mgx_handle h, uint8_t *grid, uint8_t *aux, int32_t *agent, uint8_t *carry, int32_t *steps);

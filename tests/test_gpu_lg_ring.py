@@ -1,0 +1,133 @@
+"""new_level_each_episode with the level generator running BESIDE the steps (a ring of four next-level buffers per env, k_levelgen on a stream
+of its own every second step) against the form with one buffer and k_levelgen behind every step (MGX_LG_RING=off), which
+tests/test_gpu_stream.py pins to the reference's traces and to host generator + oracle (and which the default form passes there too).  Both forms run side by side here: every observation, reward, done and state equal,
+through caller-side resets of all three kinds, injected states and captured rollouts of odd and even length."""
+import numpy as np
+import pytest
+
+import gym_minigrid_amd as mg
+from helpers import to_np
+
+pytestmark = pytest.mark.gpu
+
+FAMILIES = ["MiniGrid-LavaCrossingS9N1-v0", "MiniGrid-DoorKey-5x5-v0", "MiniGrid-LavaGapS7-v1", "MiniGrid-Empty-Random-6x6-v0",
+            "MiniGrid-SimpleCrossingS11N5-v0", "MiniGrid-DoorKey-8x8-v0", "MiniGrid-LavaCrossingS9N3-v0"]
+
+
+def pair(env_id, N, monkeypatch, auto_reset=True, seed=5):
+    envs = []
+    for f in ("on", "off"):
+        monkeypatch.setenv("MGX_LG_RING", f)
+        envs.append(mg.VecMiniGrid(env_id, num_envs=N, seeds=seed, auto_reset=auto_reset, new_level_each_episode=True, backend="torch"))
+    monkeypatch.delenv("MGX_LG_RING")
+    return envs
+
+
+def same_state(a, b):
+    sa, sb = a.get_state(), b.get_state()
+    return all(np.array_equal(sa[k], sb[k]) for k in ("grid", "agent", "steps", "carry"))
+
+
+@pytest.mark.parametrize("env_id", FAMILIES)
+def test_ring_generator_equals_split(env_id, monkeypatch):
+    N, T = 1500, 400
+    a, b = pair(env_id, N, monkeypatch)
+    assert np.array_equal(to_np(a.reset()), to_np(b.reset()))
+    acts = to_np(a.fill_actions(3, 0, T))
+    if "DoorKey" not in env_id:
+        acts = np.where(acts > 2, 2, acts).astype(np.uint8)       # mostly forward: episodes a few steps long, back-to-back dones
+    for t in range(T):
+        oa, ra, da, _ = a.step(acts[t])
+        ob, rb, db, _ = b.step(acts[t])
+        assert np.array_equal(to_np(da), to_np(db)), t
+        assert np.array_equal(to_np(oa), to_np(ob)), t
+        assert np.array_equal(to_np(ra), to_np(rb)), t
+        if t % 97 == 0:
+            assert same_state(a, b), t
+    assert same_state(a, b)
+    assert a.stats()["episodes"] == b.stats()["episodes"] and (a.stats()["episodes"] >= N or "S11N5" in env_id or "8x8" in env_id)
+    a.close(); b.close()
+
+
+def test_ring_generator_caller_side_boundaries(monkeypatch):
+    """Masked seeded resets, plain resets (the ring's consumer on the caller's side) and injected states in between steps."""
+    env_id, N, T = "MiniGrid-LavaCrossingS9N1-v0", 1100, 240
+    a, b = pair(env_id, N, monkeypatch)
+    assert np.array_equal(to_np(a.reset()), to_np(b.reset()))
+    acts = to_np(a.fill_actions(11, 0, T))
+    acts = np.where(acts > 2, 2, acts).astype(np.uint8)
+    rs = np.random.RandomState(2)
+    g0, a0 = mg.generate_levels(env_id, np.arange(N, dtype=np.uint64) + 900)
+    for t in range(T):
+        oa, ra, da, _ = a.step(acts[t])
+        ob, rb, db, _ = b.step(acts[t])
+        assert np.array_equal(to_np(da), to_np(db)) and np.array_equal(to_np(oa), to_np(ob)) and np.array_equal(to_np(ra), to_np(rb)), t
+        kind = t % 12
+        if kind in (3, 7, 10):
+            m = (rs.rand(N) < (0.3 if kind != 10 else 1.1)).astype(np.uint8)
+            mask = None if kind == 10 and t % 24 == 10 else m
+            reseed = kind == 7
+            assert np.array_equal(to_np(a.reset(mask, reseed=reseed)), to_np(b.reset(mask, reseed=reseed))), (t, kind)
+            assert same_state(a, b), t
+        elif kind == 5 and t < 100:
+            a.set_state(g0, a0); b.set_state(g0, a0)
+            assert np.array_equal(to_np(a.observe()), to_np(b.observe())), t
+    assert same_state(a, b)
+    assert a.stats()["episodes"] == b.stats()["episodes"]
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("T", [1, 2, 7, 32])
+def test_ring_generator_in_captured_rollouts(T, monkeypatch):
+    """mgx_rollout captures the per-step launches: the graph starts from "no flags waiting" and drains behind its last step, so replays,
+    single steps and resets may follow each other in any order."""
+    import torch
+    env_id, N = "MiniGrid-DoorKey-5x5-v0", 912
+    a, b = pair(env_id, N, monkeypatch)
+    a.reset(); b.reset()
+    for rnd in range(5):
+        acts = a.fill_actions(20 + rnd, 0, T)
+        acts = torch.where(acts > 2, torch.full_like(acts, 2), acts).contiguous()
+        ra = a.rollout(acts)
+        ob, rb, db = [], [], []
+        for t in range(T):
+            o, r, d, _ = b.step(acts[t])
+            ob.append(to_np(o).copy()); rb.append(to_np(r).copy()); db.append(to_np(d).copy())
+        assert np.array_equal(to_np(ra[0]), np.stack(ob)) and np.array_equal(to_np(ra[1]), np.stack(rb)) and np.array_equal(to_np(ra[2]), np.stack(db)), rnd
+        assert same_state(a, b), rnd
+        if rnd % 2:
+            o1 = a.step(acts[0]); o2 = b.step(acts[0])
+            assert np.array_equal(to_np(o1[0]), to_np(o2[0]))
+        if rnd == 2:
+            assert np.array_equal(to_np(a.reset(reseed=False)), to_np(b.reset(reseed=False)))
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("ring", ["on", "off"])
+@pytest.mark.parametrize("env_id", ["MiniGrid-LavaCrossingS9N1-v0", "MiniGrid-Fetch-6x6-N2-v0"])
+def test_injected_state_draws_nothing(env_id, ring, monkeypatch):
+    """set_state / set_task on a new_level_each_episode handle are attribute assignments in the reference (env.grid, env.agent_pos, ...): the
+    env's RNG stream is untouched, so the episode after the injected one is level 1 of the env's stream -- generate_level_stream(seed_i)[1]."""
+    monkeypatch.setenv("MGX_LG_RING", ring)
+    N, seed = 300, 40
+    env = mg.VecMiniGrid(env_id, num_envs=N, seeds=seed, auto_reset=True, new_level_each_episode=True, backend="numpy")
+    env.reset()
+    levels = [mg.generate_level_stream(env_id, seed + i, 3, with_task=True) for i in range(N)]
+    G = np.stack([lv[0] for lv in levels]); A = np.stack([lv[1] for lv in levels]); K = np.stack([lv[2] for lv in levels])
+    g_other, a_other = mg.generate_levels(env_id, np.arange(N, dtype=np.uint64) + 7000)
+    env.set_state(g_other, a_other, steps=np.full(N, env.cfg.max_steps - 1, np.int32))   # the injected episode ends with the next step
+    if env.cfg.task_kind:
+        env.set_task(np.full(N, 0x0205, np.uint32))
+    obs, rew, done, _ = env.step(np.zeros(N, np.uint8))
+    assert done.all()
+    st = env.get_state()
+    assert np.array_equal(st["grid"], G[:, 1]) and np.array_equal(st["agent"], A[:, 1])
+    if env.cfg.task_kind:
+        assert np.array_equal(env.get_task() & 0xFF, K[:, 1] & 0xFF)
+    env.step(np.zeros(N, np.uint8))
+    env.set_state(g_other, a_other, steps=np.full(N, env.cfg.max_steps - 1, np.int32))
+    obs, rew, done, _ = env.step(np.zeros(N, np.uint8))
+    assert done.all()
+    st = env.get_state()
+    assert np.array_equal(st["grid"], G[:, 2]) and np.array_equal(st["agent"], A[:, 2])
+    env.close()
