@@ -30,6 +30,13 @@ PY
   rm -rf $OUT/tmp_$name
   echo "stats $name ok"
 }
+plain() { # name, bench args...: the bench line WITHOUT a profiler attached, over the one the profiled run printed -- for the handles whose level
+  # generator runs on a stream of its own beside the steps: rocprofv3 stretches every event pair between the two streams (51.6 -> 74 us per step)
+  local name=$1; shift
+  timeout -k 10 300 $PY $R/bench.py --no-cpu-baseline "$@" > $OUT/$name.plain.log 2>&1 || { echo "plain $name failed"; return 0; }
+  grep "^{\"metric\"" $OUT/$name.plain.log | tail -n 1 > $OUT/${TAG}_bench_$name.json
+  echo "plain $name ok"
+}
 pmc() { # name, counter, bench args...: per-dispatch counter values of one pass
   local name=$1 c=$2; shift; shift
   rm -rf $OUT/tmp_pmc
@@ -52,7 +59,11 @@ if [ $PART = stats ] || [ $PART = all ]; then
   stats lavacrossing_4M --config lava4m --envs-per-gpu 4194304 --steps 256 --warmup 16
   stats lavacrossing_1M --config lava4m --envs-per-gpu 1048576 --steps 512 --warmup 32
   stats lavacrossing_1M_newlevel --config lava4m --envs-per-gpu 1048576 --new-level-each-episode --steps 256
+  plain lavacrossing_1M_newlevel --config lava4m --envs-per-gpu 1048576 --new-level-each-episode --steps 256
+  stats lavacrossing_512k_newlevel --config lava4m --new-level-each-episode --steps 256
+  plain lavacrossing_512k_newlevel --config lava4m --new-level-each-episode --steps 256
   stats doorkey8x8_1M_newlevel --config doorkey8 --new-level-each-episode --steps 1400 --warmup 64   # (episodes time out at 640 steps: two boundaries inside)
+  plain doorkey8x8_1M_newlevel --config doorkey8 --new-level-each-episode --steps 1400 --warmup 64
   stats keycorridor_s3r3_256k_newlevel --env MiniGrid-KeyCorridorS3R3-v0 --envs-per-gpu 262144 --new-level-each-episode --steps 600 --warmup 30
   stats dynobs8x8_1M --env MiniGrid-Dynamic-Obstacles-8x8-v0 --steps 512 --warmup 64
   stats dynobs16x16_1M --env MiniGrid-Dynamic-Obstacles-16x16-v0 --steps 256 --warmup 32
@@ -73,6 +84,11 @@ if [ $PART = dyn ]; then   # only the Dynamic-Obstacles runs (re-taken after a c
 fi
 if [ $PART = newlevel ]; then   # only the runs in which k_levelgen works (re-taken after a change to it)
   stats lavacrossing_1M_newlevel --config lava4m --envs-per-gpu 1048576 --new-level-each-episode --steps 256
+  plain lavacrossing_1M_newlevel --config lava4m --envs-per-gpu 1048576 --new-level-each-episode --steps 256
+  stats lavacrossing_512k_newlevel --config lava4m --new-level-each-episode --steps 256
+  plain lavacrossing_512k_newlevel --config lava4m --new-level-each-episode --steps 256
+  stats doorkey8x8_1M_newlevel --config doorkey8 --new-level-each-episode --steps 1400 --warmup 64
+  plain doorkey8x8_1M_newlevel --config doorkey8 --new-level-each-episode --steps 1400 --warmup 64
   stats multiroom_n6_256k_newlevel --env MiniGrid-MultiRoom-N6-v0 --envs-per-gpu 262144 --new-level-each-episode --steps 600 --warmup 30
   stats keycorridor_s3r3_256k_newlevel --env MiniGrid-KeyCorridorS3R3-v0 --envs-per-gpu 262144 --new-level-each-episode --steps 600 --warmup 30
 fi

@@ -3,7 +3,7 @@ import csv, json, os, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 P = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
 names = ["empty8x8_1M", "empty8x8_1M_k20", "doorkey8x8_1M", "lavacrossing_512k", "empty16x16_full_256k", "empty8x8_4M", "lavacrossing_4M", "lavacrossing_1M",
-         "lavacrossing_1M_newlevel", "doorkey8x8_1M_newlevel", "dynobs8x8_1M", "dynobs16x16_1M", "multiroom_n6_256k_newlevel", "keycorridor_s3r3_256k_newlevel", "fourrooms_full_128k", "fourrooms_full_512k", "multiroom_n6_full_128k", "multiroom_n6_256k",
+         "lavacrossing_1M_newlevel", "lavacrossing_512k_newlevel", "doorkey8x8_1M_newlevel", "dynobs8x8_1M", "dynobs16x16_1M", "multiroom_n6_256k_newlevel", "keycorridor_s3r3_256k_newlevel", "fourrooms_full_128k", "fourrooms_full_512k", "multiroom_n6_full_128k", "multiroom_n6_256k",
          "fourrooms_1M", "empty16x16_512k", "keycorridor_s6r3_512k", "obstructedmaze_2dlhb_256k", "empty8x8_1M_partial_onehot"]
 names = [n for n in names if os.path.exists(os.path.join(P, "%s_kernel_stats_%s.csv" % (tag, n)))]
 for n in names:
