@@ -348,6 +348,8 @@ int lg_ring_init(mgx_handle h, const uint8_t *mask_dev)
     return MGX_OK;
 }
 
+int resize_snapshots(mgx_handle h, int K);
+
 // Every entry point runs with the handle's device current and puts the caller's device back on the way out (a process
 // that drives several GPUs -- or torch with another current device -- must not find it changed behind its back).
 struct DeviceGuard {
@@ -655,35 +657,32 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
         CREATE_TRY(hipMalloc((void **)&h->sp0_d, (size_t)h->n_pad * sizeof(uint32_t)));
         CREATE_TRY(hipMemsetAsync(h->sp0_d, 0, (size_t)h->n_pad * sizeof(uint32_t), h->stream));
     }
-    {   // The generator beside the steps: new_level_each_episode handles of the families whose levels take a few dozen draws, on the staged
-        // kernels.  k_levelgen behind every step is compute (MT19937 draws, rejection loops: 17 us for the ~50 k levels a step of 1 Mi LavaCrossing
-        // envs ends) in front of a memory-bound step; beside the steps it fills the step's stalls.  Two things decide the form, both measured
+    {   // The generator beside the steps (new_level_each_episode, partial views).  k_levelgen behind every step is compute (MT19937 draws, rejection
+        // loops: 17 us for the ~50 k levels a step of 1 Mi LavaCrossing envs ends, 10 % of the chip's issue slots: one wave's dependent chain) in
+        // front of a memory-bound step; beside the steps it fills the step's stalls.  Two things decide the form, both measured
         // (profiles/README.md, round 4): a kernel with both kinds of block runs every step wave at the generator's 128 VGPRs (74 us against 62
         // for the two launches), and an event pair between two streams costs 10-20 us on this stack, so the coupling is loose: a fork every
         // R/2 steps, its join due R/2 steps later.  us per step at 1 Mi / 512 Ki / 64 Ki LavaCrossingS9N1 envs: one buffer 59.0 / 39.5 / 21.2,
-        // R = 4: 58.7 / 38.5 / 19.1, R = 8: 53.8 / 33.4 / 16.5, R = 16: 53.8 / 32.0 / 15.1 (replay 44.0 / 24 / 9); families whose episodes
-        // end rarely (DoorKey, Empty-Random, SimpleCrossing) are within 1 us either way.  (R * (S + 8) B per env: 1.7 KB at 9x9.)
+        // R = 4: 58.7 / 38.5 / 19.1, R = 8: 53.8 / 33.4 / 16.5, R = 16: 51.6 / 31.0 / 15.3 (replay 43.1 / 23.0 / 8.4).  Other families at R = 16
+        // (profiles/r04_levelgen_ring_families.txt): Unlock 62.6 -> 47.6, Fetch 71.9 -> 60.3, GoToDoor 97.4 -> 82.1, RedBlueDoors 66.4 -> 54.8,
+        // MemoryS13Random 47.4 -> 38.1, KeyCorridorS3R3 74.5 -> 66.7; those whose episodes end rarely (DoorKey, Empty-Random, SimpleCrossing,
+        // FourRooms, LockedRoom) within 1 us either way; MultiRoom-N6, whose 262,144 levels of one step are a 5.7 ms launch that any join
+        // waits for, 68.7 -> 74.0: it keeps one buffer.  (R * (S + 8) B per env, three planes with object_state: 1.7 KB at 9x9.)
         // MGX_LG_RING=off | 2 | 4 | 8 | 16: one buffer and k_levelgen behind every step on the caller's stream (tests, A/B), or another depth.
         const char *lf = getenv("MGX_LG_RING");
-        const int k = cfg->level_kind;
-        const bool cheap = k == MGX_LEVEL_EMPTY || k == MGX_LEVEL_DOORKEY || k == MGX_LEVEL_CROSSING || k == MGX_LEVEL_LAVAGAP;
-        const int R = lf ? atoi(lf) : 16; // ("off" -> 0)
-        if (h->stream_mode && cheap && h->kernel_mode == 0 && !cfg->object_state && cfg->obs_mode == MGX_OBS_PARTIAL && !h->mt2_d &&
+        const int R = (lf && strcmp(lf, "on")) ? atoi(lf) : 16; // ("off" -> 0)
+        // (every partial-view step kernel -- staged, gather, with or without hidden object state -- is step_body, which knows the ring; the
+        // FullyObs kernels do not)
+        if (h->stream_mode && h->partial && (h->kernel_mode == 0 || h->kernel_mode == 3) && cfg->level_kind != MGX_LEVEL_MULTIROOM &&
             (R == 2 || R == 4 || R == 8 || R == 16)) h->lg_ring = R;
+        // R next-level buffers (+ hidden planes) per env; a handle too large for them keeps one buffer and the generator behind every step
+        if (h->lg_ring && resize_snapshots(h, R) != MGX_OK) { h->lg_ring = 0; (void)hipGetLastError(); }
         if (h->lg_ring) {
             int prio_lo = 0, prio_hi = 0;
             CREATE_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
             CREATE_TRY(hipStreamCreateWithPriority(&h->lg_stream, hipStreamNonBlocking, prio_hi));
             CREATE_TRY(hipEventCreateWithFlags(&h->lg_fork, hipEventDisableTiming));
             for (int a = 0; a < 2; a++) CREATE_TRY(hipEventCreateWithFlags(&h->lg_join[a], hipEventDisableTiming));
-            const size_t cb = (size_t)R * h->n_pad * h->S, ab = (size_t)R * h->n_pad * sizeof(uint2);
-            (void)hipFree(h->cells0_d); (void)hipFree(h->agent0_d);
-            h->cells0_d = nullptr; h->agent0_d = nullptr;
-            CREATE_TRY(hipMalloc((void **)&h->cells0_d, cb));
-            CREATE_TRY(hipMalloc((void **)&h->agent0_d, ab));
-            CREATE_TRY(hipMemsetAsync(h->cells0_d, 0, cb, h->stream));
-            CREATE_TRY(hipMemsetAsync(h->agent0_d, 0, ab, h->stream));
-            h->snap_banks = R;
             CREATE_TRY(hipMalloc((void **)&h->bank_d, (size_t)h->n_pad));
             CREATE_TRY(hipMemsetAsync(h->bank_d, 0, (size_t)h->n_pad, h->stream));
             h->lg_flags[0] = h->regen_d;

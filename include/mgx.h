@@ -197,11 +197,12 @@ typedef struct {
                                    in HBM.  Needs a level_kind with a generator and W*H <= 4096.  Device memory per env: the
                                    MT19937 block, 2.5 KB; the draw-heavy families (everything but Empty / DoorKey / Crossing /
                                    LavaGap / DistShift) keep the following block ready as well, 5 KB in all -- dropped silently
-                                   (same results, slower level bursts) when that second allocation fails.  Empty-Random /
-                                   DoorKey / Crossing / LavaGap handles with the 7x7-or-other partial view on grids up to
-                                   11x11 keep 16 next levels per env ready (16 * (ceil4(W*H) + 8) bytes) and generate beside
-                                   the steps, on a stream of the handle's own that every entry point joins before it touches
-                                   levels or RNG state from the host side; results do not depend on it. */
+                                   (same results, slower level bursts) when that second allocation fails.  Partial-view
+                                   handles (every family but MultiRoom) keep 16 next levels per env ready -- 16 * (ceil4(W*H)
+                                   + 8) bytes, three times the cells with object_state; one level when that allocation
+                                   fails -- and generate beside the steps, on a stream of the handle's own that every entry
+                                   point joins before it touches levels or RNG state from the host side; results do not
+                                   depend on it. */
     int32_t agent_view_size;    /* 0 = 7 (minigrid.py:776).  ViewSizeWrapper (wrappers.py:579-608): 3, 5, 7, 9 or 11;
                                    obs is then uint8 [N][V][V][3].  Ignored by MGX_OBS_FULL. */
     int32_t extended_actions;   /* 1 = ExtendedActions (minigrid.py:747-764): 7 = strafe_left, 8 = strafe_right */
