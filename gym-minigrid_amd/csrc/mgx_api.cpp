@@ -969,6 +969,12 @@ static int run_step(mgx_handle h, bool do_step, const uint8_t *actions, uint8_t 
     if ((rc = dev_out(h, 2, done, (size_t)h->n, &o[2]))) return rc;
     p.obs = (uint8_t *)o[0].dev; p.reward = (float *)o[1].dev; p.done = (uint8_t *)o[2].dev;
     if (((h->oh_nc >= 0 && !h->oh_fused) || h->flat) && p.obs) p.obs = h->tri_d; // the simulator writes triples; the epilogue below expands them
+    if (do_step && h->lg_ring) {
+        // first step of a half of the ring: the generators forked a half ago refilled the buffers consumed a whole turn of the ring ago -- the first
+        // of which this step may need again -- and cleared this half's flag arrays (ahead of the profiling events: the wait is not the kernel)
+        const int a = h->lg_s, half = h->lg_ring / 2, grp = a / half;
+        if (a == grp * half && h->lg_unjoined[grp]) { HIP_TRY(hipStreamWaitEvent(h->stream, h->lg_join[grp], 0)); h->lg_unjoined[grp] = false; }
+    }
     // profiling: this launch alone between its own two events (not while a graph is being captured)
     const bool sample = do_step && h->profiling && !h->assume_device && h->prof_samples < MGX_PROF_MAX_SAMPLES &&
                         (h->prof_launches % h->prof_stride) == 0;
@@ -982,9 +988,6 @@ static int run_step(mgx_handle h, bool do_step, const uint8_t *actions, uint8_t 
     }
     if (do_step && h->lg_ring) {
         const int a = h->lg_s, half = h->lg_ring / 2, grp = a / half;
-        // (first step of a half: the generators forked a half ago refilled the buffers consumed a whole turn of the ring ago -- the first of which
-        // this step may need again -- and cleared this half's flag arrays)
-        if (a == grp * half && h->lg_unjoined[grp]) { HIP_TRY(hipStreamWaitEvent(h->stream, h->lg_join[grp], 0)); h->lg_unjoined[grp] = false; }
         p.regen = h->lg_flags[a];
         HIP_TRY(mgx_launch_step(p, h->kernel_mode, h->wpb, h->launch_cfg, h->stream));
         h->lg_dirty[a] = true;
