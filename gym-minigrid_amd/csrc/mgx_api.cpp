@@ -110,16 +110,17 @@ struct mgx_env_s {
     uint8_t *virt_d = nullptr;
     bool maybe_virtual = false;   // some env may still hold a virtual state (a plain reset() materializes the masked ones first)
     // new_level_each_episode with the generator running BESIDE the steps (cheap families on the staged kernels): a ring of R next-level buffers
-    // per env (snapshot banks; bank_d = the one the env's next reset consumes), the flags of step s in lg_flags[s % R], and every R/2 steps
+    // per env (snapshot banks; bank_d = the one the env's next reset consumes), the flags of step s in lg_flags[s % R], and every R/4 steps
     // k_levelgen for the flags of those steps -- in step order, the order of the env's RNG stream -- on a stream of its own: forked behind the
-    // last of them, joined R/2 steps later, before the first of its buffers can be needed again (an env finishes at most one episode per step)
+    // last of them, joined 3R/4 steps later, before the first of its buffers can be needed again (an env finishes at most one episode per step)
     int lg_ring = 0;                               // R buffers (a power of two, 0: one buffer, the generator behind every step)
     uint8_t *lg_flags[MGX_LG_RING_MAX] = {};       // ([0] = regen_d)
     int lg_s = 0;                                  // the flag array the NEXT step raises
     bool lg_dirty[MGX_LG_RING_MAX] = {};           // raised by a step, not handed to a generator yet
-    bool lg_unjoined[2] = {};                      // the generator launches for the first / second half of the arrays: not waited for by the caller's stream yet
+    int lg_groups = 4;                             // the arrays in lg_groups runs of lg_ring / lg_groups steps, one fork / join per run
+    bool lg_unjoined[4] = {};                      // the generator launches of a run: not waited for by the caller's stream yet
     hipStream_t lg_stream = nullptr;
-    hipEvent_t lg_fork = nullptr, lg_join[2] = {};
+    hipEvent_t lg_fork = nullptr, lg_join[4] = {};
     // object_state: hidden Goal/Box planes (+ episode-start snapshots) and the carried object's pair
     uint8_t *objaux_d = nullptr, *objaux0_d = nullptr, *objcont_d = nullptr, *objcont0_d = nullptr;
     uint16_t *objcarry_d = nullptr;
@@ -322,9 +323,9 @@ bool next_level_waiting(mgx_handle h) { return h->stream_mode && h->seeded && h-
 int lg_drain(mgx_handle h)
 {
     if (!h->lg_ring) return MGX_OK;
-    for (int pr = 0; pr < 2; pr++)
+    for (int pr = 0; pr < 4; pr++)
         if (h->lg_unjoined[pr]) { HIP_TRY(hipStreamWaitEvent(h->stream, h->lg_join[pr], 0)); h->lg_unjoined[pr] = false; }
-    for (int k = 0; k < h->lg_ring; k++) { // (the steps of a half whose generators have not been launched)
+    for (int k = 0; k < h->lg_ring; k++) { // (the steps of a run whose generators have not been launched)
         const int a = (h->lg_s + k) & (h->lg_ring - 1); // oldest first
         if (!h->lg_dirty[a]) continue;
         LevelGenParams g = levelgen_params(h);
@@ -662,7 +663,7 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
         // front of a memory-bound step; beside the steps it fills the step's stalls.  Two things decide the form, both measured
         // (profiles/README.md, round 4): a kernel with both kinds of block runs every step wave at the generator's 128 VGPRs (74 us against 62
         // for the two launches), and an event pair between two streams costs 10-20 us on this stack, so the coupling is loose: a fork every
-        // R/2 steps, its join due R/2 steps later.  us per step at 1 Mi / 512 Ki / 64 Ki LavaCrossingS9N1 envs: one buffer 59.0 / 39.5 / 21.2,
+        // R/4 steps, its join due 3R/4 steps later (R < 8: halves).  us per step at 1 Mi / 512 Ki / 64 Ki LavaCrossingS9N1 envs: one buffer 59.0 / 39.5 / 21.2,
         // R = 4: 58.7 / 38.5 / 19.1, R = 8: 53.8 / 33.4 / 16.5, R = 16: 51.6 / 31.0 / 15.3 (replay 43.1 / 23.0 / 8.4).  Other families at R = 16
         // (profiles/r04_levelgen_ring_families.txt): Unlock 62.6 -> 47.6, Fetch 71.9 -> 60.3, GoToDoor 97.4 -> 82.1, RedBlueDoors 66.4 -> 54.8,
         // MemoryS13Random 47.4 -> 38.1, KeyCorridorS3R3 74.5 -> 66.7; those whose episodes end rarely (DoorKey, Empty-Random, SimpleCrossing,
@@ -682,7 +683,9 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
             CREATE_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
             CREATE_TRY(hipStreamCreateWithPriority(&h->lg_stream, hipStreamNonBlocking, prio_hi));
             CREATE_TRY(hipEventCreateWithFlags(&h->lg_fork, hipEventDisableTiming));
-            for (int a = 0; a < 2; a++) CREATE_TRY(hipEventCreateWithFlags(&h->lg_join[a], hipEventDisableTiming));
+            for (int a = 0; a < 4; a++) CREATE_TRY(hipEventCreateWithFlags(&h->lg_join[a], hipEventDisableTiming));
+            h->lg_groups = R >= 8 ? 4 : 2; // (quarters: the join is due three quarters of a turn after the fork -- 50.9 / 31.2 us per step at 1 Mi / 512 Ki
+                                           // LavaCrossing envs against 51.3 / 31.9 with halves, whose generators end about when their join is due)
             CREATE_TRY(hipMalloc((void **)&h->bank_d, (size_t)h->n_pad));
             CREATE_TRY(hipMemsetAsync(h->bank_d, 0, (size_t)h->n_pad, h->stream));
             h->lg_flags[0] = h->regen_d;
@@ -734,7 +737,7 @@ extern "C" int mgx_destroy(mgx_handle h)
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     if (h->lg_stream) (void)hipStreamDestroy(h->lg_stream);
     if (h->lg_fork) (void)hipEventDestroy(h->lg_fork);
-    for (int a = 0; a < 2; a++) if (h->lg_join[a]) (void)hipEventDestroy(h->lg_join[a]);
+    for (int a = 0; a < 4; a++) if (h->lg_join[a]) (void)hipEventDestroy(h->lg_join[a]);
     for (int a = 1; a < MGX_LG_RING_MAX; a++) (void)hipFree(h->lg_flags[a]);
     (void)hipFree(h->obst_d); (void)hipFree(h->obst0_d); (void)hipFree(h->act_d); (void)hipFree(h->restart_d); (void)hipFree(h->mt0_d); (void)hipFree(h->pos0_d); (void)hipFree(h->tape_d); (void)hipFree(h->tape0_d);
     (void)hipFree(h->sp0_d); (void)hipFree(h->bank_d); (void)hipFree(h->win_d); (void)hipFree(h->virt_d);
@@ -970,9 +973,9 @@ static int run_step(mgx_handle h, bool do_step, const uint8_t *actions, uint8_t 
     p.obs = (uint8_t *)o[0].dev; p.reward = (float *)o[1].dev; p.done = (uint8_t *)o[2].dev;
     if (((h->oh_nc >= 0 && !h->oh_fused) || h->flat) && p.obs) p.obs = h->tri_d; // the simulator writes triples; the epilogue below expands them
     if (do_step && h->lg_ring) {
-        // first step of a half of the ring: the generators forked a half ago refilled the buffers consumed a whole turn of the ring ago -- the first
-        // of which this step may need again -- and cleared this half's flag arrays (ahead of the profiling events: the wait is not the kernel)
-        const int a = h->lg_s, half = h->lg_ring / 2, grp = a / half;
+        // first step of a run of the ring: the generators forked three runs ago refilled the buffers consumed a whole turn of the ring ago -- the first
+        // of which this step may need again -- and cleared this run's flag arrays (ahead of the profiling events: the wait is not the kernel)
+        const int a = h->lg_s, half = h->lg_ring / h->lg_groups, grp = a / half;
         if (a == grp * half && h->lg_unjoined[grp]) { HIP_TRY(hipStreamWaitEvent(h->stream, h->lg_join[grp], 0)); h->lg_unjoined[grp] = false; }
     }
     // profiling: this launch alone between its own two events (not while a graph is being captured)
@@ -987,11 +990,11 @@ static int run_step(mgx_handle h, bool do_step, const uint8_t *actions, uint8_t 
         HIP_TRY(hipEventRecord(h->prof_ev[2 * h->prof_samples], h->stream));
     }
     if (do_step && h->lg_ring) {
-        const int a = h->lg_s, half = h->lg_ring / 2, grp = a / half;
+        const int a = h->lg_s, half = h->lg_ring / h->lg_groups, grp = a / half;
         p.regen = h->lg_flags[a];
         HIP_TRY(mgx_launch_step(p, h->kernel_mode, h->wpb, h->launch_cfg, h->stream));
         h->lg_dirty[a] = true;
-        if (a == grp * half + half - 1) { // last step of a half: its flags, in step order (the env's RNG stream), beside the steps of the other half
+        if (a == grp * half + half - 1) { // last step of a run: its flags, in step order (the env's RNG stream), beside the steps of the other runs
             HIP_TRY(hipEventRecord(h->lg_fork, h->stream));
             HIP_TRY(hipStreamWaitEvent(h->lg_stream, h->lg_fork, 0));
             LevelGenParams g = levelgen_params(h);
