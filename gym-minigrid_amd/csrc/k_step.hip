@@ -39,13 +39,13 @@ namespace {
 
 // Task rules that env subclasses layer on MiniGridEnv.step (they run after the base step, time-out included).
 template <int CH, class CellAt>
-__device__ __forceinline__ void task_rule(const StepParams &p, Lane &L, uint32_t act, float &reward, bool &done, CellAt cell_at,
+__device__ __forceinline__ void task_rule(const StepParams &p, Lane &L, uint32_t act, double &reward, bool &done, CellAt cell_at,
                                           int fidx, uint32_t fc, uint32_t carry0, bool &fault)
 {
     if (p.task == MGX_TASK_FETCH) { // envs/fetch.py:74-86
         if (L.carry != MGX_CODE_EMPTY) {
             done = true;
-            reward = ((L.carry & 0x7Fu) == (L.task & 0x7Fu)) ? (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps)) : 0.f;
+            reward = ((L.carry & 0x7Fu) == (L.task & 0x7Fu)) ? (1.0 - 0.9 * ((double)L.steps / (double)p.max_steps)) : 0.0;
         }
     } else if (p.task == MGX_TASK_GOTODOOR) { // envs/gotodoor.py:71-93: `done` next to a door; the target door is the red one
         if (act == 6) {
@@ -57,7 +57,7 @@ __device__ __forceinline__ void task_rule(const StepParams &p, Lane &L, uint32_t
                 const uint32_t k = n4[i] & 15u;
                 const bool door = k == MGX_K_DOOR_OPEN || k == MGX_K_DOOR_CLOSED || k == MGX_K_DOOR_LOCKED;
                 if (door) done = true;
-                if (door && ((n4[i] >> 4) & 7u) == 0u) reward = (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps));
+                if (door && ((n4[i] >> 4) & 7u) == 0u) reward = (1.0 - 0.9 * ((double)L.steps / (double)p.max_steps));
             }
         }
     } else if (p.task == MGX_TASK_REDBLUEDOORS) { // envs/redbluedoors.py:44-66; cell_at() is the state AFTER the step
@@ -66,7 +66,7 @@ __device__ __forceinline__ void task_rule(const StepParams &p, Lane &L, uint32_t
         const bool red_after = (cell_at(ri) & 15u) == MGX_K_DOOR_OPEN, blue_after = (cell_at(bi) & 15u) == MGX_K_DOOR_OPEN;
         const bool red_before = ((ri == fidx ? fc : cell_at(ri)) & 15u) == MGX_K_DOOR_OPEN;
         const bool blue_before = ((bi == fidx ? fc : cell_at(bi)) & 15u) == MGX_K_DOOR_OPEN;
-        if (blue_after) { reward = red_before ? (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps)) : 0.f; done = true; }
+        if (blue_after) { reward = red_before ? (1.0 - 0.9 * ((double)L.steps / (double)p.max_steps)) : 0.f; done = true; }
         else if (red_after && blue_before) { reward = 0.f; done = true; }
     } else if (p.task == MGX_TASK_TWOGOALS) { // envs/twogoals.py:118-146 on top of the base transition; L.task = goal_count, fc = the
                                               // front cell BEFORE the step (a toggled goal is gone afterwards)
@@ -80,7 +80,7 @@ __device__ __forceinline__ void task_rule(const StepParams &p, Lane &L, uint32_t
         }
         if (act == 6) done = true;
         if (L.task >= 2u) { // reward += 1. - 0.9 * self.step_count/self.max_steps   (NOT _reward(): the product comes first)
-            reward = (float)((double)reward + (1.0 - (0.9 * (double)L.steps) / (double)p.max_steps));
+            reward = reward + (1.0 - (0.9 * (double)L.steps) / (double)p.max_steps);
             done = true;
         }
     } else if (p.task == MGX_TASK_PUTNEAR) { // envs/putnear.py:91-110; carry0 = preCarrying
@@ -90,25 +90,25 @@ __device__ __forceinline__ void task_rule(const StepParams &p, Lane &L, uint32_t
             if (L.carry == MGX_CODE_EMPTY) { // the drop happened: the object now lies in the front cell
                 const int ox = L.ax + (L.dir == 0) - (L.dir == 2), oy = L.ay + (L.dir == 1) - (L.dir == 3);
                 const int dx = ox - (int)((L.task >> 5) & 7u), dy = oy - (int)((L.task >> 8) & 7u);
-                if (dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1) reward = (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps));
+                if (dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1) reward = (1.0 - 0.9 * ((double)L.steps / (double)p.max_steps));
             }
             done = true;
         }
     } else if (p.task == MGX_TASK_UNLOCK) { // envs/unlock.py:33-41: the door is at (5, task)
         const int H = CH ? CH : p.H;
-        if (act == 5 && (cell_at(5 * H + (int)(L.task & 15u)) & 15u) == MGX_K_DOOR_OPEN) { reward = (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps)); done = true; }
+        if (act == 5 && (cell_at(5 * H + (int)(L.task & 15u)) & 15u) == MGX_K_DOOR_OPEN) { reward = (1.0 - 0.9 * ((double)L.steps / (double)p.max_steps)); done = true; }
     } else if (p.task == MGX_TASK_PICKUPBOX) { // envs/unlockpickup.py:35-43, keycorridor.py:51-59: `self.carrying == self.obj`
-        if (act == 3 && (L.carry & 0x7Fu) == (L.task & 0x7Fu)) { reward = (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps)); done = true; }
+        if (act == 3 && (L.carry & 0x7Fu) == (L.task & 0x7Fu)) { reward = (1.0 - 0.9 * ((double)L.steps / (double)p.max_steps)); done = true; }
     } else if (p.task == MGX_TASK_MEMORY) { // envs/memory.py:92-99 (the pickup -> toggle remap happens where the action is loaded)
         const int H = CH ? CH : p.H;
         const int tx = (int)(L.task & 15u), sy = ((L.task >> 4) & 1u) ? H / 2 - 1 : H / 2 + 1, fy = ((L.task >> 4) & 1u) ? H / 2 + 1 : H / 2 - 1;
-        if (L.ax == tx && L.ay == sy) { reward = (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps)); done = true; }
+        if (L.ax == tx && L.ay == sy) { reward = (1.0 - 0.9 * ((double)L.steps / (double)p.max_steps)); done = true; }
         if (L.ax == tx && L.ay == fy) { reward = 0.f; done = true; }
     } else if (p.task == MGX_TASK_GOTOOBJECT) { // envs/gotoobject.py:68-84
         if (act == 5) done = true;              // "Toggle/pickup action terminates the episode"
         if (act == 6) {
             const int dx = L.ax - (int)(L.task & 15u), dy = L.ay - (int)((L.task >> 4) & 15u);
-            if (dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1) reward = (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps));
+            if (dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1) reward = (1.0 - 0.9 * ((double)L.steps / (double)p.max_steps));
             done = true;
         }
     }
@@ -155,7 +155,7 @@ __device__ __forceinline__ bool box_overlappable(const ObjRef &o, int idx, uint3
 }
 
 template <int CH, class CellAt>
-__device__ __forceinline__ uint32_t transition_apply(const StepParams &p, Lane &L, uint32_t act, uint32_t fc, float &reward, bool &done,
+__device__ __forceinline__ uint32_t transition_apply(const StepParams &p, Lane &L, uint32_t act, uint32_t fc, double &reward, bool &done,
                                                      CellAt cell_at, bool &refbug, int tidx, const ObjRef &o)
 {
     const int dir = L.dir;
@@ -176,7 +176,7 @@ __device__ __forceinline__ uint32_t transition_apply(const StepParams &p, Lane &
                 if ((lc & 15u) == MGX_K_GOAL) ov = (lc & 0x80u) != 0;
                 else { ov = false; refbug = true; }
             }
-            if (ov) { done = true; reward = (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps)); }
+            if (ov) { done = true; reward = (1.0 - 0.9 * ((double)L.steps / (double)p.max_steps)); }
         }
         if (k == MGX_K_LAVA) done = true; // no 'v1' special case on the strafe path (minigrid.py:1304-1305,1313-1314)
         return fc;
@@ -200,7 +200,7 @@ __device__ __forceinline__ uint32_t transition_apply(const StepParams &p, Lane &
     if (fwd && k == MGX_K_GOAL && (fc & 0x80u)) { // goal.overlap (minigrid.py:1259-1261)
         done = true;
         // _reward(): 1 - 0.9*(step_count/max_steps) in Python doubles (minigrid.py:933-937), then f32
-        reward = (float)(1.0 - 0.9 * ((double)L.steps / (double)p.max_steps));
+        reward = (1.0 - 0.9 * ((double)L.steps / (double)p.max_steps));
     }
     const bool lava = fwd && k == MGX_K_LAVA; // minigrid.py:1262-1268 ('v1' classes: reward -1, no done)
     done = lava ? !p.lava_v1 : done;
@@ -331,6 +331,25 @@ __device__ __forceinline__ void restore_own(const StepParams &p, int64_t env, in
             }
         }
     }
+}
+
+// ActionBonus / StateBonus (wrappers.py:87-153): a visit count per env and key -- (agent_pos, agent_dir, action) / agent_pos, the state AFTER the
+// step and before any reset, kept across episodes -- and reward += 1 / math.sqrt(new_count), in the order the wrappers were stacked
+// (mgx_add_bonus), in doubles like the reference.  The lane owns its env: a plain read-modify-write.
+__device__ __forceinline__ double exploration_bonus(const StepParams &p, int64_t env, const Lane &L, uint32_t act, double reward)
+{
+    const int cell = (int)L.ax * p.H + (int)L.ay;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int kind = (p.bonus >> (4 * k)) & 15;
+        if (kind == 0) break;
+        uint32_t *c = kind == MGX_BONUS_ACTION ? p.bonus_action + env * (int64_t)(p.W * p.H * 4 * p.bonus_na) + ((cell * 4 + (int)L.dir) * p.bonus_na + (int)act)
+                                               : p.bonus_state + env * (int64_t)(p.W * p.H) + cell;
+        const uint32_t n = *c + 1u;
+        *c = n;
+        reward += 1.0 / sqrt((double)n);
+    }
+    return reward;
 }
 
 __device__ __forceinline__ void wave_stats(const StepParams &p, bool valid, bool done, float reward, bool bad_act, bool oob, int lane, int tile)
@@ -850,7 +869,7 @@ __device__ __forceinline__ void step_body(const StepParams &p, const DynObsParam
     Lane L = unpack_rec(rec, p.task);
     uint8_t *g = lds + lane * LS;                       // (staged modes) this env's cells in LDS
     const uint8_t *row = GATHER ? p.cells + env * S : g; // where cells are read from
-    float reward = 0.f;
+    double reward = 0.0; // (Python doubles in the reference: rounded to the f32 the caller gets once, at the store)
     bool done = false, bad_act = false, oob = false;
     int pidx = -1;
     uint32_t pcode = 0;
@@ -874,13 +893,16 @@ __device__ __forceinline__ void step_body(const StepParams &p, const DynObsParam
             // the one cell a transition can change; skipped when the env is about to be restored anyway
             if (nc != fc && !(p.auto_reset && done)) { p.cells[env * S + fidx] = (uint8_t)nc; pidx = fidx; pcode = nc; L.dirty = MGX_REC_DIRTY; }
         } else if (valid && L.steps >= p.max_steps) done = true;
-        if (crash) { reward = -1.f; done = true; } // envs/dynamicobstacles.py:83-86
+        if (crash) { reward = -1.0; done = true; } // envs/dynamicobstacles.py:83-86
+        if (p.bonus && valid && !bad_act) // (the wrapper's key holds the action the CALLER gave: MemoryEnv.step turns pickup into toggle on its own)
+            reward = exploration_bonus(p, env, L, p.task == MGX_TASK_MEMORY ? (uint32_t)p.actions[env] : act, reward);
 #ifdef MGX_TIMELINE
         tlv[6] = __builtin_amdgcn_s_memrealtime();
 #endif
-        if (p.reward && valid) __builtin_nontemporal_store(reward, &p.reward[env]);
+        const float reward_out = (float)reward;
+        if (p.reward && valid) __builtin_nontemporal_store(reward_out, &p.reward[env]);
         if (p.done && valid) __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), &p.done[env]);
-        wave_stats(p, valid, done, reward, bad_act, oob, lane, tile);
+        wave_stats(p, valid, done, reward_out, bad_act, oob, lane, tile);
         // the snapshot differs from the current cells only if a step changed one (dirty), if it holds the NEXT level (stream
         // mode) or if k_dynobs moved obstacles (both: p.regen)
         // (... or, under a seed schedule, the level of the NEXT seed of the env's list: ReseedWrapper.reset, wrappers.py:24-28)
@@ -1148,7 +1170,7 @@ __global__ __launch_bounds__(256, (RAGGED && CW == 19) ? 8 : 1) void k_step_full
         const bool crash = p.task == MGX_TASK_DYNOBS && (act & 0x80u);
         if (p.task == MGX_TASK_DYNOBS) act &= 0x7Fu;
         if (p.task == MGX_TASK_MEMORY && act == 3u) act = 5u;
-        float reward = 0.f;
+        double reward = 0.0;
         bool done = false, bad_act = false, oob = false, reset = false;
         uint32_t wr = 0, changed = 0, nb = 0;
         if (p.do_step) {
@@ -1169,10 +1191,13 @@ __global__ __launch_bounds__(256, (RAGGED && CW == 19) ? 8 : 1) void k_step_full
                     L.dirty = MGX_REC_DIRTY;
                 }
             } else if (valid && L.steps >= p.max_steps) done = true;
-            if (crash) { reward = -1.f; done = true; }
-            if (p.reward && valid) __builtin_nontemporal_store(reward, &p.reward[env]);
+            if (crash) { reward = -1.0; done = true; }
+            if (p.bonus && valid && !bad_act) // (the wrapper's key holds the action the CALLER gave: MemoryEnv.step turns pickup into toggle on its own)
+            reward = exploration_bonus(p, env, L, p.task == MGX_TASK_MEMORY ? (uint32_t)p.actions[env] : act, reward);
+            const float reward_out = (float)reward;
+            if (p.reward && valid) __builtin_nontemporal_store(reward_out, &p.reward[env]);
             if (p.done && valid) __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), &p.done[env]);
-            wave_stats(p, valid, done, reward, bad_act, oob, lane, tile);
+            wave_stats(p, valid, done, reward_out, bad_act, oob, lane, tile);
             if (p.auto_reset && valid && done) {
                 reset = L.dirty != 0u || p.regen != nullptr || p.bank != nullptr; // else the cells already equal the snapshot: nothing to copy back
                 if (p.bank) { // seed schedule: the level of the next seed of the env's list (ReseedWrapper.reset, wrappers.py:24-28)
@@ -1376,7 +1401,7 @@ __global__ __launch_bounds__(256) void k_rollout(const StepParams p, const Rollo
         uint32_t act = act_next;
         if (t + 1 < q.T && valid) act_next = q.actions[(t + 1) * p.n + env]; // in flight during this step
         if (p.task == MGX_TASK_MEMORY && act == 3u) act = 5u;
-        float reward = 0.f;
+        double reward = 0.0;
         bool done = false, bad_act = false, oob = false;
         const int fidx = transition_begin<CW, CH>(p, L, act, valid, bad_act, oob);
         uint32_t fc = 0, nc = 0;
@@ -1390,7 +1415,8 @@ __global__ __launch_bounds__(256) void k_rollout(const StepParams p, const Rollo
             if (p.task) task_rule<CH>(p, L, act, reward, done, [&](int i) -> uint32_t { return (uint32_t)g[i]; }, fidx, fc, carry0, oob);
             if (nc != fc && !(p.auto_reset && done)) { L.dirty = MGX_REC_DIRTY; wrote = true; }
         } else if (valid && L.steps >= p.max_steps) done = true;
-        if (q.reward && valid) __builtin_nontemporal_store(reward, &q.reward[t * p.n + env]);
+        const float reward_out = (float)reward;
+        if (q.reward && valid) __builtin_nontemporal_store(reward_out, &q.reward[t * p.n + env]);
         if (q.done && valid) __builtin_nontemporal_store((uint8_t)(done ? 1 : 0), &q.done[t * p.n + env]);
         wave_stats(p, valid, done, reward, bad_act, oob, lane, tile);
         if (p.auto_reset && valid && done) {

@@ -121,6 +121,9 @@ struct mgx_env_s {
     bool lg_unjoined[4] = {};                      // the generator launches of a run: not waited for by the caller's stream yet
     hipStream_t lg_stream = nullptr;
     hipEvent_t lg_fork = nullptr, lg_join[4] = {};
+    // ActionBonus / StateBonus (mgx_add_bonus): the stacking order (innermost in bits 3:0) and the wrappers' counts
+    int bonus = 0;
+    uint32_t *bonus_action_d = nullptr, *bonus_state_d = nullptr;
     // object_state: hidden Goal/Box planes (+ episode-start snapshots) and the carried object's pair
     uint8_t *objaux_d = nullptr, *objaux0_d = nullptr, *objcont_d = nullptr, *objcont0_d = nullptr;
     uint16_t *objcarry_d = nullptr;
@@ -242,6 +245,8 @@ StepParams base_params(mgx_handle h)
     p.onehot = h->oh_fused ? 1 : 0;
     p.bank = h->sched_K ? h->bank_d : nullptr; p.n_banks = h->sched_K ? h->sched_K : 1; p.bank_envs = h->sched_K ? h->n_pad : 0;
     if (h->lg_ring) { p.bank = h->bank_d; p.n_banks = h->lg_ring; p.bank_envs = h->n_pad; p.ring = h->lg_ring; }
+    p.bonus = h->bonus; p.bonus_na = h->cfg.extended_actions ? 9 : MGX_NUM_ACTIONS;
+    p.bonus_action = h->bonus_action_d; p.bonus_state = h->bonus_state_d;
     return p;
 }
 
@@ -740,6 +745,7 @@ extern "C" int mgx_destroy(mgx_handle h)
     for (int a = 0; a < 4; a++) if (h->lg_join[a]) (void)hipEventDestroy(h->lg_join[a]);
     for (int a = 1; a < MGX_LG_RING_MAX; a++) (void)hipFree(h->lg_flags[a]);
     (void)hipFree(h->obst_d); (void)hipFree(h->obst0_d); (void)hipFree(h->act_d); (void)hipFree(h->restart_d); (void)hipFree(h->mt0_d); (void)hipFree(h->pos0_d); (void)hipFree(h->tape_d); (void)hipFree(h->tape0_d);
+    (void)hipFree(h->bonus_action_d); (void)hipFree(h->bonus_state_d);
     (void)hipFree(h->sp0_d); (void)hipFree(h->bank_d); (void)hipFree(h->win_d); (void)hipFree(h->virt_d);
     for (auto &s : h->st_in) if (s.dev) (void)hipFree(s.dev);
     for (auto &s : h->st_out) if (s.dev) (void)hipFree(s.dev);
@@ -894,6 +900,51 @@ static int set_state_impl(mgx_handle h, const uint8_t *grid, const uint8_t *aux,
     if (after.invalid_state != before.invalid_state)
         return mgx_fail(MGX_ERR_INVALID_STATE, "mgx_set_state: input holds a cell/agent/carry value the reference cannot produce "
                                                "(type 1..9, color 0..6, state 0 or door 0..2, agent inside the grid, dir 0..3, carry key/ball/box)");
+    return MGX_OK;
+}
+
+// ActionBonus / StateBonus (wrappers.py:87-153) as a property of the handle: the step kernels count and add (exploration_bonus, k_step.hip)
+extern "C" int mgx_add_bonus(mgx_handle h, int32_t kind)
+{
+    DeviceGuard dev_guard;
+    int rc = dev_guard.enter(h, "mgx_add_bonus");
+    if (rc) return rc;
+    if (kind != 0 && kind != MGX_BONUS_ACTION && kind != MGX_BONUS_STATE)
+        return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_add_bonus: kind %d is not 0, MGX_BONUS_ACTION or MGX_BONUS_STATE", kind);
+    HIP_TRY(hipStreamSynchronize(h->stream)); // (steps in flight still count into the arrays)
+    if (h->roll_exec) { (void)hipGraphExecDestroy(h->roll_exec); h->roll_exec = nullptr; } // (a captured rollout holds the old parameters)
+    if (kind == 0) {
+        (void)hipFree(h->bonus_action_d); (void)hipFree(h->bonus_state_d);
+        h->bonus_action_d = nullptr; h->bonus_state_d = nullptr; h->bonus = 0;
+        return MGX_OK;
+    }
+    if ((h->bonus & 15) == kind || ((h->bonus >> 4) & 15) == kind)
+        return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_add_bonus: this handle already carries that wrapper");
+    if (h->bonus >> 4) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_add_bonus: two wrappers are stacked already");
+    uint32_t **arr = kind == MGX_BONUS_ACTION ? &h->bonus_action_d : &h->bonus_state_d;
+    const size_t per_env = (size_t)h->W * h->H * (kind == MGX_BONUS_ACTION ? 4u * (h->cfg.extended_actions ? 9u : (unsigned)MGX_NUM_ACTIONS) : 1u);
+    const hipError_t e = hipMalloc((void **)arr, (size_t)h->n_pad * per_env * sizeof(uint32_t));
+    if (e != hipSuccess) {
+        *arr = nullptr; (void)hipGetLastError();
+        return mgx_fail(MGX_ERR_HIP, "mgx_add_bonus: %zu bytes of counts: %s", (size_t)h->n_pad * per_env * sizeof(uint32_t), hipGetErrorString(e));
+    }
+    h->bonus = h->bonus ? (h->bonus | (kind << 4)) : kind;
+    // "every call zeroes the counts": the wrapper objects are new
+    if (h->bonus_action_d) HIP_TRY(hipMemsetAsync(h->bonus_action_d, 0, (size_t)h->n_pad * h->W * h->H * 4u * (h->cfg.extended_actions ? 9u : (unsigned)MGX_NUM_ACTIONS) * sizeof(uint32_t), h->stream));
+    if (h->bonus_state_d) HIP_TRY(hipMemsetAsync(h->bonus_state_d, 0, (size_t)h->n_pad * h->W * h->H * sizeof(uint32_t), h->stream));
+    return MGX_OK;
+}
+
+extern "C" int mgx_get_bonus_counts(mgx_handle h, int32_t kind, uint32_t *counts)
+{
+    DeviceGuard dev_guard;
+    int rc = dev_guard.enter(h, "mgx_get_bonus_counts");
+    if (rc) return rc;
+    const uint32_t *src = kind == MGX_BONUS_ACTION ? h->bonus_action_d : (kind == MGX_BONUS_STATE ? h->bonus_state_d : nullptr);
+    if (!src || !counts) return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_get_bonus_counts: the handle does not carry that wrapper (or counts is NULL)");
+    const size_t bytes = (size_t)h->n * h->W * h->H * (kind == MGX_BONUS_ACTION ? 4u * (h->cfg.extended_actions ? 9u : (unsigned)MGX_NUM_ACTIONS) : 1u) * sizeof(uint32_t);
+    HIP_TRY(hipMemcpyAsync(counts, src, bytes, hipMemcpyDefault, h->stream));
+    if (!is_device_ptr(counts)) HIP_TRY(hipStreamSynchronize(h->stream));
     return MGX_OK;
 }
 
@@ -1079,7 +1130,7 @@ extern "C" int mgx_rollout(mgx_handle h, int64_t T, const uint8_t *actions, uint
     // 151 -> 138; at 16x16 the 19.7 KB of LDS per wave leave six waves per CU and the direct form wins, 44 against 51 at 262,144 envs)
     const bool fused_ok = (h->partial ? (h->kernel_mode == 0 || (h->kernel_mode == 3 && h->S <= 256)) : h->S <= 192) &&
                           !h->cfg.alt_visibility && !h->objaux_d && !h->stream_mode &&
-                          !h->dynobs && h->oh_nc < 0 && !h->flat && !h->sched_K && !(rf && !strcmp(rf, "graph"));
+                          !h->dynobs && h->oh_nc < 0 && !h->flat && !h->sched_K && !h->bonus && !(rf && !strcmp(rf, "graph"));
     if (fused_ok) {
         StepParams p = base_params(h);
         p.do_step = 1;

@@ -87,6 +87,10 @@ struct StepParams {
     uint8_t *bank;         // u8[n_pad]: list index of the env's CURRENT episode
     int n_banks;           // K
     int64_t bank_envs;     // n_pad (0 without a schedule)
+    // exploration bonuses (mgx_add_bonus): up to two stacked wrappers, innermost in bits 3:0 of `bonus` (MGX_BONUS_*), the next in bits 7:4
+    int bonus, bonus_na;   // bonus_na: actions per (cell, dir) in the ActionBonus counts (7, or 9 with extended_actions)
+    uint32_t *bonus_action; // u32[n_pad][W*H*4*bonus_na]
+    uint32_t *bonus_state;  // u32[n_pad][W*H]
     int ring;              // R > 0 (a power of two): the banks are a RING of R next-level buffers (new_level_each_episode handles whose generator runs beside
                            // the steps): bank[e] names the buffer the next reset consumes; the reset moves it on and raises regen[e] = buffer + 1
     int64_t n;

@@ -116,6 +116,37 @@ class ReseedWrapper:
         return getattr(self.env, name)
 
 
+class _BonusWrapper:
+    kind = None
+
+    def __init__(self, env):
+        self.env = env
+        base = env
+        while not isinstance(base, SingleEnv):   # (through ReseedWrapper / another bonus wrapper)
+            base = base.env
+        base._vec.add_bonus(self.kind)
+
+    def reset(self):
+        return self.env.reset()
+
+    def step(self, action):
+        return self.env.step(action)
+
+    def __getattr__(self, name):
+        return getattr(self.env, name)
+
+
+class ActionBonus(_BonusWrapper):
+    """The reference's ActionBonus (wrappers.py:87-119): reward += 1 / sqrt(visits to (agent_pos, agent_dir, action)), counted on the GPU
+    inside the step kernel (VecMiniGrid.add_bonus("action"))."""
+    kind = "action"
+
+
+class StateBonus(_BonusWrapper):
+    """The reference's StateBonus (wrappers.py:121-153): reward += 1 / sqrt(visits to agent_pos)."""
+    kind = "state"
+
+
 def make(env_id, **kwargs):
     """gym.make(env_id) for the built-in ids (gym_minigrid_amd.env_ids())."""
     return SingleEnv(env_id, **kwargs)

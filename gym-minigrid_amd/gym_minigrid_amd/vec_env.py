@@ -193,6 +193,26 @@ class VecMiniGrid:
             raise ValueError("seeds must have shape (%d, K)" % self.num_envs)
         _lib.check(_lib.lib().mgx_set_seed_schedule(self._h, _ptr(s), int(s.shape[1]), int(seed_idx)))
 
+    BONUS_KINDS = {"action": 1, "state": 2}   # MGX_BONUS_ACTION / MGX_BONUS_STATE (include/mgx.h)
+
+    def add_bonus(self, kind):
+        """env = ActionBonus(env) ("action") / StateBonus(env) ("state") for every env (wrappers.py:87-153): each step adds
+        1 / sqrt(visits of this env to (agent_pos, agent_dir, action) / to agent_pos) to the reward; the counts persist across episodes.
+        Calls stack in call order, innermost first, one of each at most; kind=None removes both.  Every call zeroes the counts."""
+        if self._torch is not None:
+            self._bind_stream()
+        _lib.check(_lib.lib().mgx_add_bonus(self._h, 0 if kind is None else self.BONUS_KINDS[kind]))
+
+    def bonus_counts(self, kind):
+        """The wrapper's self.counts as a dense uint32 array: (N, W, H, 4, A) for "action" (A = 7, or 9 with extended actions), (N, W, H) for "state"."""
+        A = 9 if self.cfg.extended_actions else 7
+        shape = (self.num_envs, self.width, self.height) + ((4, A) if kind == "action" else ())
+        out = np.zeros(shape, np.uint32)
+        if self._torch is not None:
+            self._bind_stream()
+        _lib.check(_lib.lib().mgx_get_bonus_counts(self._h, self.BONUS_KINDS[kind], _ptr(out)))
+        return out
+
     def reset(self, mask=None, reseed=True):
         """reseed=True: seed(seed_i); reset() for every env (or those with mask[i] != 0) -- ReseedWrapper(seeds=[seed_i]) semantics.
         reseed=False: the reference's plain reset() (minigrid.py:831-858; `if done: env.reset()`, run_tests.py:64-66): the env's own RNG

@@ -296,6 +296,19 @@ int mgx_reset(mgx_handle h, const uint64_t *seeds, const uint8_t *mask, uint8_t 
  * alternatives of the reference: with or without the wrapper) and not for grids beyond 64x64 cells: MGX_ERR_UNSUPPORTED. */
 int mgx_set_seed_schedule(mgx_handle h, const uint64_t *seeds, int32_t K, int32_t idx0);
 
+/* env = ActionBonus(env) / env = StateBonus(env) (wrappers.py:87-153): every step adds 1 / math.sqrt(count) to the reward, count =
+ * the visits of this env to (agent_pos, agent_dir, action) / to agent_pos -- the state AFTER the step (before an auto-reset), this
+ * step included -- kept across episodes (the wrappers' reset() leaves self.counts alone).  The sum is formed in doubles like the
+ * reference's and rounded to the float the caller gets once.  Calls stack in call order, innermost first, at most one of each kind
+ * (StateBonus(ActionBonus(env)) = MGX_BONUS_ACTION, then MGX_BONUS_STATE); kind 0 removes both and frees the counts.  Every call
+ * zeroes the counts.  Device memory: uint32 [N][W][H][4][A] (A = 7 actions, 9 with extended_actions) for the action bonus,
+ * uint32 [N][W][H] for the state bonus.  Steps that hit the reference's `unknown action` assertion count nothing.
+ * mgx_rollout of such a handle is the captured graph of per-step launches. */
+typedef enum { MGX_BONUS_ACTION = 1, MGX_BONUS_STATE = 2 } mgx_bonus_kind;
+int mgx_add_bonus(mgx_handle h, int32_t kind);
+/* The counts of one of the wrappers (its self.counts as a dense array, layout above), device or host memory. */
+int mgx_get_bonus_counts(mgx_handle h, int32_t kind, uint32_t *counts);
+
 /* Inject / read back the full simulator state.  set_state also records the state as the
  * episode start used by auto_reset.  aux, carry, steps may be NULL (zeros / nothing / 0).
  * get_state: any pointer may be NULL.

@@ -51,7 +51,7 @@ import numpy as np  # noqa: E402
 import gym  # noqa: E402
 import gym_minigrid  # noqa: E402,F401
 from gym_minigrid import minigrid as M  # noqa: E402
-from gym_minigrid.wrappers import FullyObsWrapper, ReseedWrapper, ViewSizeWrapper  # noqa: E402
+from gym_minigrid.wrappers import ActionBonus, FullyObsWrapper, ReseedWrapper, StateBonus, ViewSizeWrapper  # noqa: E402
 
 OUT = os.path.join(REPO, "tests", "golden")
 
@@ -308,10 +308,12 @@ def doorkey_script(env):
 
 # --------------------------------------------------------------------------- recorder
 def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False, reseed=True, n_actions=7, objstate=False, gym_id=None,
-                seed_lists=None, seed_idx0=0):
+                seed_lists=None, seed_idx0=0, bonus=()):
     """seed_lists (round 4): trace k runs under the reference's own ReseedWrapper(env, seeds=seed_lists[k], seed_idx=seed_idx0)
     (wrappers.py:12-28): every reset() -- the first one included -- seeds with the next entry of the list, cyclically.  `seeds` is
-    then ignored; z['seed'][k] is the seed of the first episode and z['seed_list'] (K, L) the lists."""
+    then ignored; z['seed'][k] is the seed of the first episode and z['seed_list'] (K, L) the lists.
+    bonus (round 4): the reference's ActionBonus / StateBonus (wrappers.py:87-153) stacked around the env in the given order, innermost
+    first ("action", "state"); z['reward'] is then what the outermost wrapper's step() returns; meta['bonus'] keeps the order."""
     if seed_lists is not None:
         seeds = [sl[seed_idx0] for sl in seed_lists]
     K = len(seeds)
@@ -322,7 +324,7 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
                 see_through=bool(env0.see_through_walls), lava_v1=bool(v1), full_obs=bool(full_obs),
                 reseed=("list" if seed_lists is not None else bool(reseed)), seed_idx0=int(seed_idx0), extended=bool(n_actions > 7), alt_vis=not bool(env0.default_vis),
                 task=11 if type(env0).__name__.startswith("TwoGoals") else 10 if type(env0).__name__.startswith("PutNear") else 9 if type(env0).__name__ == "LockedRoom" else 7 if type(env0).__name__ == "Unlock" else 8 if type(env0).__name__ in ("UnlockPickup", "BlockedUnlockPickup") or type(env0).__name__.startswith(("KeyCorridor", "ObstructedMaze")) else 6 if type(env0).__name__.startswith("Memory") else 5 if type(env0).__name__.startswith("RedBlueDoor") else 4 if type(env0).__name__.startswith(("GoToObject", "GotoEnv")) else (1 if hasattr(env0, "targetType") else (2 if hasattr(env0, "target_pos") else 0)),
-                objstate=bool(objstate), dynobs=int(getattr(env0, "n_obstacles", 0)), gym_id=gym_id or "")
+                objstate=bool(objstate), dynobs=int(getattr(env0, "n_obstacles", 0)), gym_id=gym_id or "", bonus=list(bonus))
     z = dict(
         seed=np.zeros(K, np.int64), init_grid=np.zeros((K, W, H, 3), np.uint8),
         init_aux=np.zeros((K, W, H), np.uint8), init_agent=np.zeros((K, 3), np.int32),
@@ -352,6 +354,9 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
         else:
             env.seed(int(s))
             o = env.reset()
+        stepper = env
+        for b in bonus:
+            stepper = {"action": ActionBonus, "state": StateBonus}[b](stepper)
         z["seed"][k] = s
         z["init_grid"][k] = env.grid.encode()
         z["init_aux"][k] = aux_plane(env)
@@ -380,7 +385,7 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
             if type(env).__name__.startswith("TwoGoals"):   # its own step() raises on pickup / drop and on toggling an empty cell
                 if a in (3, 4) or (a == 5 and env.grid.get(*env.front_pos) is None):
                     a = 1
-            o, r, d, info = env.step(int(a))
+            o, r, d, info = stepper.step(int(a))
             assert info == {}
             z["actions"][k, t] = a
             z["obs"][k, t] = o["image"]
@@ -1017,6 +1022,18 @@ def main():
                 objstate=True, gym_id="MiniGrid-ObstructedMaze-1Dlhb-v0")
     record_case("DynObs-8x8-seedlist", mk("MiniGrid-Dynamic-Obstacles-8x8-v0"), None, 400, seed_lists=sl(10, 3, 600), seed_idx0=1, n_actions=4, gym_id="MiniGrid-Dynamic-Obstacles-8x8-v0")
     record_case("DynObs-16x16-seedlist", mk("MiniGrid-Dynamic-Obstacles-16x16-v0"), None, 300, seed_lists=sl(3, 2, 700), n_actions=4, gym_id="MiniGrid-Dynamic-Obstacles-16x16-v0")
+    # round 4: the exploration-bonus wrappers (wrappers.py:87-153) around the env; names start with "Bonus-" (tests/test_bonus.py, test_gpu_bonus.py)
+    record_case("Bonus-DoorKey-8x8-action", mk("MiniGrid-DoorKey-8x8-v0"), list(range(6)), 900, scripts=[doorkey_script] * 3 + [None] * 3,
+                bonus=("action",), gym_id="MiniGrid-DoorKey-8x8-v0")
+    record_case("Bonus-LavaCrossingS9N1-state", mk("MiniGrid-LavaCrossingS9N1-v0"), list(range(6)), 500, bonus=("state",), gym_id="MiniGrid-LavaCrossingS9N1-v0")
+    record_case("Bonus-DoorKey-5x5-state-action", mk("MiniGrid-DoorKey-5x5-v0"), list(range(6)), 600, scripts=[doorkey_script] * 4 + [None] * 2,
+                bonus=("state", "action"), gym_id="MiniGrid-DoorKey-5x5-v0")     # ActionBonus(StateBonus(env))
+    record_case("Bonus-Empty-Random-6x6-action-state-stream", mk("MiniGrid-Empty-Random-6x6-v0"), list(range(4)), 500, reseed=False,
+                bonus=("action", "state"), gym_id="MiniGrid-Empty-Random-6x6-v0")   # StateBonus(ActionBonus(env)), a new level per episode
+    record_case("Bonus-Soup-8x8-strafe-action", lambda: SoupEnv(8, 8, False, 96, 0.45, extended=True), list(range(4)), 300, n_actions=9, bonus=("action",))
+    record_case("Bonus-MemoryS13Random-action", mk("MiniGrid-MemoryS13Random-v0"), list(range(4)), 300, bonus=("action",), gym_id="MiniGrid-MemoryS13Random-v0")
+    record_case("Bonus-TwoGoals-8x8-state", mk("MiniGrid-TwoGoals-8x8-v0"), list(range(4)), 300, bonus=("state",), gym_id="MiniGrid-TwoGoals-8x8-v0")
+    record_case("Bonus-Empty-16x16-full-state", mk("MiniGrid-Empty-16x16-v0"), [0, 1], 1100, full_obs=True, bonus=("state",), gym_id="MiniGrid-Empty-16x16-v0")
     if only:
         return
     record_levels()

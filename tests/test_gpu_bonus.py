@@ -1,0 +1,193 @@
+"""ActionBonus / StateBonus (wrappers.py:87-153) inside the step kernels (mgx_add_bonus) against (1) traces recorded through the reference's
+own wrapper classes (tests/golden/Bonus-*.npz) and (2) the CPU oracle + the wrappers' restatement (oracle/bonus_oracle.py, pinned to the
+same traces by tests/test_oracle_golden.py) on seeded random batches.  Rewards: float32(the reference's double) == the returned float32,
+tolerance 0; the counts themselves are compared too."""
+import numpy as np
+import pytest
+
+import gym_minigrid_amd as mg
+from conftest import bonus_cases, load_case
+from helpers import make_oracle, random_states, to_np
+from oracle.bonus_oracle import BonusOracle
+from test_gpu_parity import cfg_from
+
+pytestmark = pytest.mark.gpu
+
+
+def open_case(name, N, auto_reset, backend):
+    meta, z = load_case(name)
+    K = z["actions"].shape[0]
+    sel = np.arange(N) % K
+    task = meta.get("task", 0)
+    env = mg.VecMiniGrid(config=cfg_from(meta["W"], meta["H"], meta["max_steps"], meta["see_through"], meta["lava_v1"], task), num_envs=N,
+                         obs_mode="full" if meta["full_obs"] else "partial", auto_reset=auto_reset, backend=backend, agent_view_size=meta.get("view", 7),
+                         extended_actions=meta.get("extended", False), default_vis=not meta.get("alt_vis", False))
+    env.set_state(z["init_grid"][sel], z["init_agent"][sel], aux=z["init_aux"][sel])
+    if task:
+        env.set_task(z["init_task"][sel])
+    for b in meta["bonus"]:
+        env.add_bonus(b)
+    return meta, z, sel, env
+
+
+def check_counts(env, meta, z, sel, T):
+    """the wrappers' self.counts, rebuilt from the recorded poses and actions"""
+    bo = BonusOracle(len(sel), meta["W"], meta["H"], meta["bonus"], 9 if meta.get("extended") else 7)
+    for t in range(T):
+        bo.step(np.zeros(len(sel)), z["agent"][sel, t], z["actions"][sel, t])
+    for b in meta["bonus"]:
+        assert np.array_equal(env.bonus_counts(b), (bo.action if b == "action" else bo.state).astype(np.uint32)), b
+
+
+@pytest.mark.parametrize("backend", ["numpy", "torch"])
+@pytest.mark.parametrize("name", bonus_cases())
+def test_bonus_trace_caller_reset(name, backend):
+    """The reference's loop: step through the wrapper(s), `if done: env.reset()` -- the recorded post-reset state is injected; the counts go on."""
+    N = 197 if backend == "numpy" else 70
+    meta, z, sel, env = open_case(name, N, False, backend)
+    T = z["actions"].shape[1]
+    task = meta.get("task", 0)
+    want_obs = z["full"] if meta["full_obs"] else z["obs"]
+    for t in range(T):
+        obs, rew, done, _ = env.step(z["actions"][sel, t])
+        obs, rew, done = to_np(obs), to_np(rew), to_np(done)
+        assert np.array_equal(obs, want_obs[sel, t]), (name, t)
+        assert np.array_equal(rew, z["reward"][sel, t].astype(np.float32)), (name, t)
+        assert np.array_equal(done, z["done"][sel, t]), (name, t)
+        if done.any():
+            st = env.get_state()
+            cur_task = env.get_task().copy() if task else None
+            d = done.astype(bool)
+            rmap = {int(k): r for r, (k, tt) in enumerate(zip(z["reset_k"], z["reset_t"])) if int(tt) == t}
+            for i in np.flatnonzero(d):
+                r = rmap[int(sel[i])]
+                st["grid"][i], st["aux"][i], st["agent"][i] = z["reset_grid"][r], z["reset_aux"][r], z["reset_agent"][r]
+                if task:
+                    cur_task[i] = z["reset_task"][r]
+            st["carry"][d] = (1, 0, 0)
+            st["steps"][d] = 0
+            env.set_state(st["grid"], st["agent"], aux=st["aux"], carry=st["carry"], steps=st["steps"])
+            if task:
+                env.set_task(cur_task)
+    check_counts(env, meta, z, sel, T)
+    try:
+        env.sync()
+    except (mg.InvalidAction, mg.OutOfBounds):
+        assert task == 11                    # TwoGoals: the recorder kept pickup / drop out, the reference's other exceptions not
+    env.close()
+
+
+@pytest.mark.parametrize("name", [n for n in bonus_cases() if "stream" not in n])
+def test_bonus_trace_autoreset(name):
+    """In-kernel reset: the bonus of the terminal step is counted on the terminal state, before the env is restored."""
+    meta, z, sel, env = open_case(name, 64 + 6, True, "torch")
+    T = z["actions"].shape[1]
+    for t in range(T):
+        obs, rew, done, _ = env.step(z["actions"][sel, t])
+        assert np.array_equal(to_np(rew), z["reward"][sel, t].astype(np.float32)), (name, t)
+        assert np.array_equal(to_np(done), z["done"][sel, t]), (name, t)
+    check_counts(env, meta, z, sel, T)
+    s = env.stats()
+    assert abs(s["reward_sum"] - float(z["reward"][sel].astype(np.float32).astype(np.float64).sum())) < 1e-6
+    env.close()
+
+
+@pytest.mark.parametrize("mode", ["partial", "full"])
+@pytest.mark.parametrize("W,H,kinds", [(8, 8, ("action",)), (9, 9, ("state",)), (19, 19, ("state", "action")), (25, 25, ("action", "state")),
+                                       (16, 16, ("action",)), (7, 11, ("state",)), (5, 5, ("action", "state"))])
+def test_bonus_random_batch_vs_oracle(W, H, kinds, mode):
+    """Seeded random states, uniform random actions, every kernel form, in-kernel resets."""
+    N, T, max_steps = (64 * 9 + 17 if W * H <= 400 else 64 * 2 + 3), 60, 23
+    grid, aux, agent, carry, steps = random_states(N, W, H, seed=W * 100 + H)
+    orc = make_oracle(W, H, max_steps, False, False, grid, aux, agent, carry, steps)
+    bo = BonusOracle(N, W, H, kinds)
+    env = mg.VecMiniGrid(config=cfg_from(W, H, max_steps, False), num_envs=N, obs_mode=mode, auto_reset=True, backend="torch")
+    env.set_state(grid, agent, aux=aux, carry=carry, steps=steps)
+    for k in kinds:
+        env.add_bonus(k)
+    rs = np.random.RandomState(3)
+    for t in range(T):
+        a = rs.randint(0, 7, size=N).astype(np.uint8)
+        obs, rew, done, _ = env.step(a)
+        oo, of, orew, odone = orc.step(a, full=True)
+        want = bo.step(orew, orc.agent, a)
+        orc.reset_where(odone)
+        assert np.array_equal(to_np(done), odone), t
+        assert np.array_equal(to_np(rew), want.astype(np.float32)), t
+    for k in kinds:
+        assert np.array_equal(env.bonus_counts(k), (bo.action if k == "action" else bo.state).astype(np.uint32))
+    env.close()
+
+
+def test_bonus_rollout_and_api():
+    """mgx_rollout of a handle with a bonus is the captured graph of per-step launches (the one-launch k_rollout does not count); wrappers
+    stack once each; every add zeroes the counts; None removes them."""
+    import torch
+    env_id, N, T = "MiniGrid-DoorKey-8x8-v0", 1008, 40
+    a = mg.VecMiniGrid(env_id, num_envs=N, seeds=3, backend="torch")
+    b = mg.VecMiniGrid(env_id, num_envs=N, seeds=3, backend="torch")
+    for e in (a, b):
+        e.reset()
+        e.add_bonus("state")
+        e.add_bonus("action")
+    with pytest.raises(mg.MgxError):
+        a.add_bonus("state")
+    acts = a.fill_actions(5, 0, T)
+    obs, rew, done = a.rollout(acts)
+    for t in range(T):
+        o, r, d, _ = b.step(acts[t])
+        assert torch.equal(rew[t], r) and torch.equal(done[t], d) and torch.equal(obs[t], o), t
+    assert np.array_equal(a.bonus_counts("action"), b.bonus_counts("action")) and np.array_equal(a.bonus_counts("state"), b.bonus_counts("state"))
+    assert a.bonus_counts("state").sum() == N * T
+    assert float(rew.min()) > 0.0                         # every step pays something
+    a.add_bonus(None)
+    with pytest.raises(mg.MgxError):
+        a.bonus_counts("state")
+    a.add_bonus("action")                                # new wrapper objects: counts from zero
+    assert a.bonus_counts("action").sum() == 0
+    o, r, d, _ = a.step(acts[0])
+    assert a.bonus_counts("action").sum() == N
+    bad = torch.full((N,), 7, dtype=torch.uint8, device=acts.device)   # the reference's `assert False, "unknown action"`: no wrapper sees the step
+    a.step(bad)
+    assert a.bonus_counts("action").sum() == N
+    a.clear_faults()
+    a.close(); b.close()
+
+
+def test_bonus_compat_wrappers():
+    """The single-env mirrors: StateBonus(ActionBonus(make(id))) steps like the reference's stack (first visits pay 1 + 1)."""
+    from gym_minigrid_amd import compat
+    env = compat.StateBonus(compat.ActionBonus(compat.make("MiniGrid-Empty-5x5-v0")))
+    env.reset()
+    _, r, _, _ = env.step(env.actions.left)
+    assert r == 2.0
+    _, r, _, _ = env.step(env.actions.right)
+    assert r == np.float32(1.0 + 1.0 / np.sqrt(2.0))      # a new (pos, dir, action) key; the second visit of the cell
+    env.close()
+
+
+@pytest.mark.parametrize("form", ["fused", "split"])
+def test_bonus_dynamic_obstacles(form, monkeypatch):
+    """Dynamic-Obstacles (obstacle walk + step in one kernel, or k_dynobs + k_step): the bonus sits on top of the crash / goal rule.  Actions
+    inside the env's Discrete(3) action space; beyond it the key holds the action the env acted on (it turns them into 0 itself)."""
+    from oracle.dynobs_oracle import DynObsOracle
+    if form == "split":
+        monkeypatch.setenv("MGX_DYNOBS", "split")
+    env_id, size, n_obst, N, T = "MiniGrid-Dynamic-Obstacles-6x6-v0", 6, 3, 64 * 2 + 9, 80
+    seeds = (np.arange(N, dtype=np.uint64) * 7919 + 5) % 100003
+    orc = DynObsOracle(size, n_obst, False, seeds)
+    bo = BonusOracle(N, size, size, ("action", "state"))
+    env = mg.VecMiniGrid(env_id, num_envs=N, seeds=seeds, auto_reset=True, backend="torch")
+    env.reset()
+    env.add_bonus("action"); env.add_bonus("state")
+    rs = np.random.RandomState(4)
+    for t in range(T):
+        a = rs.choice([0, 1, 2, 0, 1], size=N).astype(np.uint8)
+        obs, rew, done, _ = env.step(a)
+        oo, orew, odone = orc.step(a)
+        want = bo.step(orew, orc.base.agent, a)
+        orc.reset_where(odone)
+        assert np.array_equal(to_np(done), odone), t
+        assert np.array_equal(to_np(rew), want.astype(np.float32)), t
+    assert np.array_equal(env.bonus_counts("action"), bo.action.astype(np.uint32)) and np.array_equal(env.bonus_counts("state"), bo.state.astype(np.uint32))
+    env.close()

@@ -4,14 +4,17 @@ oracle and every output byte, reward, done flag and post-step state must match."
 import numpy as np
 import pytest
 
-from conftest import golden_cases, load_case
+from conftest import bonus_cases, golden_cases, load_case
+from oracle.bonus_oracle import BonusOracle
 from oracle.minigrid_oracle import OracleEnvs
 
 
-@pytest.mark.parametrize("name", golden_cases())
+@pytest.mark.parametrize("name", golden_cases() + bonus_cases())
 def test_oracle_replays_reference_trace(name):
+    """(`Bonus-*`: the same through the restatement of the ActionBonus / StateBonus wrappers, oracle/bonus_oracle.py, on top.)"""
     meta, z = load_case(name)
     K, T = z["actions"].shape
+    bonus = BonusOracle(K, meta["W"], meta["H"], meta["bonus"], 9 if meta.get("extended") else 7) if meta.get("bonus") else None
     full = meta["full_obs"]
     env = OracleEnvs(meta["W"], meta["H"], meta["max_steps"], meta["see_through"], meta["lava_v1"], view=meta.get("view", 7), extended=meta.get("extended", False), alt_vis=meta.get("alt_vis", False), task=meta.get("task", 0))
     env.set_state(z["init_grid"], z["init_agent"], aux=z["init_aux"])
@@ -37,6 +40,8 @@ def test_oracle_replays_reference_trace(name):
         else:
             obs, rew, done = out
         assert (env.err == 0).all()
+        if bonus:
+            rew = bonus.step(rew, env.agent, z["actions"][:, t])
         assert np.array_equal(obs, z["obs"][:, t]), (name, t)
         assert np.array_equal(rew, z["reward"][:, t]), (name, t)       # float64, exact
         assert np.array_equal(done, z["done"][:, t]), (name, t)
