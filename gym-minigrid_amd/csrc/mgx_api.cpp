@@ -903,6 +903,16 @@ static int set_state_impl(mgx_handle h, const uint8_t *grid, const uint8_t *aux,
     return MGX_OK;
 }
 
+// (the handle moves between the sized step kernel of its grid and the run-time-size instance, which carries the bonus code: what mgx_create
+// derived from the kernel function is derived again)
+static int bonus_kernel_changed(mgx_handle h)
+{
+    const StepParams sp = base_params(h);
+    if (h->wave_lds + 2 * h->lds_guard > 64 * 1024) HIP_TRY(mgx_raise_lds_limit(sp, h->kernel_mode, h->wave_lds + 2 * h->lds_guard));
+    HIP_TRY(mgx_step_round_blocks(sp, h->kernel_mode, h->wpb, &h->round_blocks));
+    return MGX_OK;
+}
+
 // ActionBonus / StateBonus (wrappers.py:87-153) as a property of the handle: the step kernels count and add (exploration_bonus, k_step.hip)
 extern "C" int mgx_add_bonus(mgx_handle h, int32_t kind)
 {
@@ -916,7 +926,7 @@ extern "C" int mgx_add_bonus(mgx_handle h, int32_t kind)
     if (kind == 0) {
         (void)hipFree(h->bonus_action_d); (void)hipFree(h->bonus_state_d);
         h->bonus_action_d = nullptr; h->bonus_state_d = nullptr; h->bonus = 0;
-        return MGX_OK;
+        return bonus_kernel_changed(h);
     }
     if ((h->bonus & 15) == kind || ((h->bonus >> 4) & 15) == kind)
         return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_add_bonus: this handle already carries that wrapper");
@@ -932,7 +942,7 @@ extern "C" int mgx_add_bonus(mgx_handle h, int32_t kind)
     // "every call zeroes the counts": the wrapper objects are new
     if (h->bonus_action_d) HIP_TRY(hipMemsetAsync(h->bonus_action_d, 0, (size_t)h->n_pad * h->W * h->H * 4u * (h->cfg.extended_actions ? 9u : (unsigned)MGX_NUM_ACTIONS) * sizeof(uint32_t), h->stream));
     if (h->bonus_state_d) HIP_TRY(hipMemsetAsync(h->bonus_state_d, 0, (size_t)h->n_pad * h->W * h->H * sizeof(uint32_t), h->stream));
-    return MGX_OK;
+    return bonus_kernel_changed(h);
 }
 
 extern "C" int mgx_get_bonus_counts(mgx_handle h, int32_t kind, uint32_t *counts)
@@ -1587,7 +1597,7 @@ extern "C" int mgx_step_kernel_name(mgx_handle h, char *out, int cap)
     char dyn_name[32];
     const char *name = mgx_step_kernel_label(base_params(h), h->kernel_mode); // (host-side table lookup: no device call)
     if (h->dyn_fused) { // walk + step in one launch (mgx_launch_step_dyn: sized instances for the registered Dynamic-Obstacles grids)
-        const bool sized = (h->W == h->H) && (h->W == 5 || h->W == 6 || h->W == 8 || h->W == 16);
+        const bool sized = (h->W == h->H) && (h->W == 5 || h->W == 6 || h->W == 8 || h->W == 16) && !h->bonus;
         snprintf(dyn_name, sizeof dyn_name, "k_step_dyn<%d,%d>", sized ? h->W : 0, sized ? h->H : 0);
         name = dyn_name;
     }
