@@ -68,6 +68,28 @@ __global__ __launch_bounds__(256) void k_onehot(const uint8_t *__restrict__ tri,
 
 } // namespace
 
+namespace {
+// DACWrapper.step's `return self.last_obs, ...` (wrappers.py:58-78; last_obs['image'] = obs['image'] * 0 + 1, :51): a wave looks at 64 envs'
+// records and fills the observation row of every absorbed one with ones, 64 bytes per instruction (rows are `row_bytes` apart, any alignment).
+__global__ __launch_bounds__(256) void k_dac_obs(const uint2 *__restrict__ agent, uint8_t *__restrict__ obs, int64_t n, int64_t row_bytes)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool mine = t < n && (agent[t].x & (1u << 22)); // MGX_REC_ABSORBED (mgx_device.h)
+    for (unsigned long long m = __ballot(mine); m; m &= m - 1) {
+        const int64_t e = t - lane + __builtin_ctzll(m);
+        uint8_t *row = obs + e * row_bytes;
+        for (int64_t i = lane; i < row_bytes; i += 64) row[i] = 1;
+    }
+}
+} // namespace
+
+hipError_t mgx_launch_dac_obs(const uint2 *agent, uint8_t *obs, int64_t n, int64_t row_bytes, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_dac_obs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, agent, obs, n, row_bytes);
+    return hipGetLastError();
+}
+
 hipError_t mgx_launch_onehot(const uint8_t *tri, uint8_t *out, int64_t n_cells, int nc, int ns, hipStream_t st)
 {
     const dim3 grid((unsigned)((n_cells + 1023) / 1024)), block(256);

@@ -879,10 +879,16 @@ __device__ __forceinline__ void step_body(const StepParams &p, const DynObsParam
     using RewardT = typename std::conditional<BONUS, double, float>::type;
     RewardT reward = 0;
     bool done = false, bad_act = false, oob = false;
+    // DACWrapper (wrappers.py:35-84; mgx_set_dac, the same instances): an env that is done before its time-out is not reset but absorbed --
+    // its steps only count on, reward 0, until step max_steps reports done
+    bool absorbed = false, absorb_now = false;
+    if constexpr (BONUS) {
+        if (p.dac) { absorbed = (rec.x & MGX_REC_ABSORBED) != 0u; L.dirty |= rec.x & MGX_REC_ABSORBED; }
+    }
     int pidx = -1;
     uint32_t pcode = 0;
     if (p.do_step) {
-        const int fidx = transition_begin<CW, CH>(p, L, act, valid, bad_act, oob);
+        const int fidx = transition_begin<CW, CH>(p, L, act, valid && !absorbed, bad_act, oob);
         uint32_t fc = 0, nc = 0; // forward cell before / after the transition
 #ifdef MGX_TIMELINE
         tlv[5] = __builtin_amdgcn_s_memrealtime();
@@ -898,9 +904,15 @@ __device__ __forceinline__ void step_body(const StepParams &p, const DynObsParam
             if constexpr (!GATHER) { if (nc != fc) g[fidx] = (uint8_t)nc; }
             if (valid && L.steps >= p.max_steps) done = true; // minigrid.py:1320-1321
             if (p.task) task_rule<CH>(p, L, act, reward, done, [&](int i) -> uint32_t { return (GATHER && i == fidx) ? nc : (uint32_t)row[i]; }, fidx, fc, carry0, oob);
+            if constexpr (BONUS) {
+                if (p.dac && done && L.steps < p.max_steps) { done = false; absorb_now = true; } // (`return obs, rew, False, info`, wrappers.py:69-78)
+            }
             // the one cell a transition can change; skipped when the env is about to be restored anyway
             if (nc != fc && !(p.auto_reset && done)) { p.cells[env * S + fidx] = (uint8_t)nc; pidx = fidx; pcode = nc; L.dirty = MGX_REC_DIRTY; }
         } else if (valid && L.steps >= p.max_steps) done = true;
+        if constexpr (BONUS) { // (the time-out step returns last_obs as well: `obs = self.last_obs; self.env_done = True`, wrappers.py:71-76)
+            if (p.dac && valid && (done || absorb_now)) L.dirty |= MGX_REC_ABSORBED;
+        }
         if (crash) { reward = (RewardT)-1; done = true; } // envs/dynamicobstacles.py:83-86
         if constexpr (BONUS) {
             if (p.bonus && valid && !bad_act) // (the wrapper's key holds the action the CALLER gave: MemoryEnv.step turns pickup into toggle on its own)
@@ -1184,9 +1196,13 @@ __global__ __launch_bounds__(256, (RAGGED && CW == 19) ? 8 : 1) void k_step_full
         using RewardT = typename std::conditional<BONUS, double, float>::type;
         RewardT reward = 0;
         bool done = false, bad_act = false, oob = false, reset = false;
+        bool absorbed = false, absorb_now = false; // DACWrapper (as step_body)
+        if constexpr (BONUS) {
+            if (p.dac) { const uint32_t rx = p.agent[env].x; absorbed = (rx & MGX_REC_ABSORBED) != 0u; L.dirty |= rx & MGX_REC_ABSORBED; }
+        }
         uint32_t wr = 0, changed = 0, nb = 0;
         if (p.do_step) {
-            const int fidx = transition_begin<CW, CH>(p, L, act, valid, bad_act, oob);
+            const int fidx = transition_begin<CW, CH>(p, L, act, valid && !absorbed, bad_act, oob);
             if (fidx >= 0) {
                 const uint32_t fc = p.cells[env * S + fidx], carry0 = L.carry;
                 // hidden object state rides only on the run-time-size kernels (mgx_launch_step routes there): pruned from the sized ones
@@ -1196,6 +1212,9 @@ __global__ __launch_bounds__(256, (RAGGED && CW == 19) ? 8 : 1) void k_step_full
                                                          [&](int i) -> uint32_t { return p.cells[env * S + i]; }, oob, fidx, obj);
                 if (valid && L.steps >= p.max_steps) done = true;
                 if (p.task) task_rule<CH>(p, L, act, reward, done, [&](int i) -> uint32_t { return (i == fidx) ? nc : (uint32_t)p.cells[env * S + i]; }, fidx, fc, carry0, oob);
+                if constexpr (BONUS) {
+                    if (p.dac && done && L.steps < p.max_steps) { done = false; absorb_now = true; }
+                }
                 if (nc != fc && !(p.auto_reset && done)) {
                     p.cells[env * S + fidx] = (uint8_t)nc;
                     wr = (uint32_t)fidx | (nc << 16);
@@ -1203,6 +1222,9 @@ __global__ __launch_bounds__(256, (RAGGED && CW == 19) ? 8 : 1) void k_step_full
                     L.dirty = MGX_REC_DIRTY;
                 }
             } else if (valid && L.steps >= p.max_steps) done = true;
+            if constexpr (BONUS) {
+                if (p.dac && valid && (done || absorb_now)) L.dirty |= MGX_REC_ABSORBED;
+            }
             if (crash) { reward = (RewardT)-1; done = true; }
             if constexpr (BONUS) {
                 if (p.bonus && valid && !bad_act) reward = exploration_bonus(p, env, L, p.task == MGX_TASK_MEMORY ? (uint32_t)p.actions[env] : act, reward);
@@ -1501,8 +1523,8 @@ StepChoice choose_sized(const StepParams &p, int mode)
     if (mode == 0) return {k_step<CW, CH, 0, 7>, false, n0};
     if (mode == 1) return {k_step<CW, CH, 1, 7>, false, n1};
     if (((CW && CH) ? CW * CH : p.W * p.H) % 4 == 0) return {k_step_fulldirect<CW, CH>, true, n2};
-    if (CW == 0 && !p.objaux && !p.bonus && p.W == 19 && p.H == 19) return {k_step_fulldirect<19, 19, true>, true, "k_step_fulldirect<19,19,ragged>"};
-    if (CW == 0 && !p.objaux && !p.bonus && p.W == 25 && p.H == 25) return {k_step_fulldirect<25, 25, true>, true, "k_step_fulldirect<25,25,ragged>"};
+    if (CW == 0 && !p.objaux && !(p.bonus | p.dac) && p.W == 19 && p.H == 19) return {k_step_fulldirect<19, 19, true>, true, "k_step_fulldirect<19,19,ragged>"};
+    if (CW == 0 && !p.objaux && !(p.bonus | p.dac) && p.W == 25 && p.H == 25) return {k_step_fulldirect<25, 25, true>, true, "k_step_fulldirect<25,25,ragged>"};
     return {k_step_fulldirect<CW, CH, true>, true, n3};
 }
 
@@ -1576,14 +1598,14 @@ static StepChoice choose_step_kernel(const StepParams &p, int mode)
         return none;
     }
     if (mode == 3) { // large grids: gather form (the default view and visibility by the size rule, anything else when the tile image cannot fit the LDS)
-        if (p.view == 7 && !p.alt_vis && !p.objaux && !p.bonus) { // the default view: 13x13 Memory, every 16x16 id, 17x17 Memory, FourRooms / LockedRoom / Playground 19x19, MultiRoom 25x25, any other size
+        if (p.view == 7 && !p.alt_vis && !p.objaux && !(p.bonus | p.dac)) { // the default view: 13x13 Memory, every 16x16 id, 17x17 Memory, FourRooms / LockedRoom / Playground 19x19, MultiRoom 25x25, any other size
 #define GCASE(w, h) if (p.W == w && p.H == h) return {k_step<w, h, 3, 7, false, false>, false, "k_step<" #w "," #h ",3,7>"};
             GCASE(13, 13) GCASE(16, 16) GCASE(17, 17) GCASE(19, 19) GCASE(25, 25)
 #undef GCASE
             return {k_step<0, 0, 3, 7, false, false>, false, "k_step<0,0,3,7>"};
         }
         if (p.view == 7 && !p.alt_vis) { // ... with the hidden Goal / Box planes (ObstructedMaze 2Dl / 2Dlh / 2Dlhb / 1Q / 2Q / Full are 16x16)
-            if (p.W == 16 && p.H == 16 && !p.bonus) return {k_step<16, 16, 3, 7, false, true>, false, "k_step<16,16,3,7,obj>"};
+            if (p.W == 16 && p.H == 16 && !(p.bonus | p.dac)) return {k_step<16, 16, 3, 7, false, true>, false, "k_step<16,16,3,7,obj>"};
             return {k_step<0, 0, 3, 7, false, true>, false, "k_step<0,0,3,7,obj>"};
         }
 #define VCASE(v) if (p.view == v) return p.alt_vis ? StepChoice{k_step<0, 0, 3, v, true>, false, "k_step<0,0,3," MGX_STR(v) ",alt>"} : StepChoice{k_step<0, 0, 3, v>, false, "k_step<0,0,3," MGX_STR(v) ",obj>"};
@@ -1603,11 +1625,11 @@ static StepChoice choose_step_kernel(const StepParams &p, int mode)
 #undef VCASE
         return none;
     }
-    if (p.objaux && mode == 0 && p.view == 7 && !p.bonus) { // ObstructedMaze's grids with their boxed keys: sized instances that keep the plane accesses
+    if (p.objaux && mode == 0 && p.view == 7 && !(p.bonus | p.dac)) { // ObstructedMaze's grids with their boxed keys: sized instances that keep the plane accesses
         if (p.W == 11 && p.H == 6) return {k_step<11, 6, 0, 7, false, true>, false, "k_step<11,6,0,7,obj>"};
         if (p.W == 16 && p.H == 16) return {k_step<16, 16, 0, 7, false, true>, false, "k_step<16,16,0,7,obj>"};
     }
-    if (p.objaux || p.bonus) return choose_sized<0, 0>(p, mode); // (hidden object state and exploration bonuses: the run-time-size instances)
+    if (p.objaux || p.bonus || p.dac) return choose_sized<0, 0>(p, mode); // (hidden object state and exploration bonuses: the run-time-size instances)
 #define CASE(w, h) if (p.W == w && p.H == h) return choose_sized<w, h>(p, mode);
     MGX_SIZED(CASE)
 #undef CASE
@@ -1697,7 +1719,7 @@ hipError_t mgx_launch_step_dyn(const StepParams &p0, const DynObsParams &d, cons
     p.tail_block0 = (tb > 0 && blocks > tb) ? blocks - tb : 0x7fffffff;
     p.stagger = 0; // (the walk's own loads come first and spread the waves by themselves)
     const size_t shmem = (size_t)wpb * p.wave_lds + 2 * (size_t)p.lds_guard;
-#define CASE(w, h) if (p.W == w && p.H == h && !p.bonus) { hipLaunchKernelGGL((k_step_dyn<w, h>), dim3(blocks), dim3(64 * wpb), shmem, st, p, d); return hipGetLastError(); }
+#define CASE(w, h) if (p.W == w && p.H == h && !(p.bonus | p.dac)) { hipLaunchKernelGGL((k_step_dyn<w, h>), dim3(blocks), dim3(64 * wpb), shmem, st, p, d); return hipGetLastError(); }
     CASE(5, 5) CASE(6, 6) CASE(8, 8) CASE(16, 16) // the registered Dynamic-Obstacles sizes (exploration bonuses: the run-time-size instance)
 #undef CASE
     hipLaunchKernelGGL((k_step_dyn<0, 0>), dim3(blocks), dim3(64 * wpb), shmem, st, p, d);

@@ -124,6 +124,7 @@ struct mgx_env_s {
     // ActionBonus / StateBonus (mgx_add_bonus): the stacking order (innermost in bits 3:0) and the wrappers' counts
     int bonus = 0;
     uint32_t *bonus_action_d = nullptr, *bonus_state_d = nullptr;
+    bool dac = false; // DACWrapper (mgx_set_dac)
     // object_state: hidden Goal/Box planes (+ episode-start snapshots) and the carried object's pair
     uint8_t *objaux_d = nullptr, *objaux0_d = nullptr, *objcont_d = nullptr, *objcont0_d = nullptr;
     uint16_t *objcarry_d = nullptr;
@@ -245,6 +246,7 @@ StepParams base_params(mgx_handle h)
     p.onehot = h->oh_fused ? 1 : 0;
     p.bank = h->sched_K ? h->bank_d : nullptr; p.n_banks = h->sched_K ? h->sched_K : 1; p.bank_envs = h->sched_K ? h->n_pad : 0;
     if (h->lg_ring) { p.bank = h->bank_d; p.n_banks = h->lg_ring; p.bank_envs = h->n_pad; p.ring = h->lg_ring; }
+    p.dac = h->dac ? 1 : 0;
     p.bonus = h->bonus; p.bonus_na = h->cfg.extended_actions ? 9 : MGX_NUM_ACTIONS;
     p.bonus_action = h->bonus_action_d; p.bonus_state = h->bonus_state_d;
     return p;
@@ -945,6 +947,21 @@ extern "C" int mgx_add_bonus(mgx_handle h, int32_t kind)
     return bonus_kernel_changed(h);
 }
 
+// DACWrapper(env) (wrappers.py:35-84) as a property of the handle
+extern "C" int mgx_set_dac(mgx_handle h, int32_t on)
+{
+    DeviceGuard dev_guard;
+    int rc = dev_guard.enter(h, "mgx_set_dac");
+    if (rc) return rc;
+    if (on && (h->oh_nc >= 0 || h->flat))
+        return mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_set_dac: the wrapper's last_obs is defined on the uint8 image (obs_mode MGX_OBS_PARTIAL or MGX_OBS_FULL)");
+    if (on && h->dynobs) return mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_set_dac: not for Dynamic-Obstacles handles");
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->roll_exec) { (void)hipGraphExecDestroy(h->roll_exec); h->roll_exec = nullptr; }
+    h->dac = on != 0;
+    return bonus_kernel_changed(h);
+}
+
 extern "C" int mgx_get_bonus_counts(mgx_handle h, int32_t kind, uint32_t *counts)
 {
     DeviceGuard dev_guard;
@@ -1081,6 +1098,7 @@ static int run_step(mgx_handle h, bool do_step, const uint8_t *actions, uint8_t 
         HIP_TRY(hipEventRecord(h->prof_ev[2 * h->prof_samples + 1], h->stream));
         h->prof_samples++;
     }
+    if (h->dac && o[0].dev) HIP_TRY(mgx_launch_dac_obs(h->agent_d, (uint8_t *)o[0].dev, h->n, h->obs_bytes, h->stream));
     if (h->oh_nc >= 0 && !h->oh_fused && o[0].dev)
         HIP_TRY(mgx_launch_onehot(h->tri_d, (uint8_t *)o[0].dev, h->n * (h->tri_bytes / 3), h->oh_nc, h->oh_ns, h->stream));
     if (h->flat && o[0].dev)
@@ -1140,7 +1158,7 @@ extern "C" int mgx_rollout(mgx_handle h, int64_t T, const uint8_t *actions, uint
     // 151 -> 138; at 16x16 the 19.7 KB of LDS per wave leave six waves per CU and the direct form wins, 44 against 51 at 262,144 envs)
     const bool fused_ok = (h->partial ? (h->kernel_mode == 0 || (h->kernel_mode == 3 && h->S <= 256)) : h->S <= 192) &&
                           !h->cfg.alt_visibility && !h->objaux_d && !h->stream_mode &&
-                          !h->dynobs && h->oh_nc < 0 && !h->flat && !h->sched_K && !h->bonus && !(rf && !strcmp(rf, "graph"));
+                          !h->dynobs && h->oh_nc < 0 && !h->flat && !h->sched_K && !h->bonus && !h->dac && !(rf && !strcmp(rf, "graph"));
     if (fused_ok) {
         StepParams p = base_params(h);
         p.do_step = 1;

@@ -137,6 +137,8 @@ struct Lane {
                     // nothing ever changes, so their resets (40 % of LavaCrossing's waves see one per step) move no cells.
 };
 #define MGX_REC_DIRTY (1u << 23)
+#define MGX_REC_ABSORBED (1u << 22) /* DACWrapper handles (mgx_set_dac): the env is done and waits for the wrapper's time-out; rides in Lane.dirty
+                                       through pack_rec (the run-time-size step kernels only: the others never see the bit set) */
 
 // record word 1 = step_count, or step_count | task << 16 for handles with a task rule (max_steps <= 65535 there)
 __device__ __forceinline__ Lane unpack_rec(uint2 r, int has_task = 0)

@@ -88,6 +88,7 @@ struct StepParams {
     int n_banks;           // K
     int64_t bank_envs;     // n_pad (0 without a schedule)
     // exploration bonuses (mgx_add_bonus): up to two stacked wrappers, innermost in bits 3:0 of `bonus` (MGX_BONUS_*), the next in bits 7:4
+    int dac;               // 1: DACWrapper (mgx_set_dac): envs done before their time-out are absorbed, not reset
     int bonus, bonus_na;   // bonus_na: actions per (cell, dir) in the ActionBonus counts (7, or 9 with extended_actions)
     uint32_t *bonus_action; // u32[n_pad][W*H*4*bonus_na]
     uint32_t *bonus_state;  // u32[n_pad][W*H]
@@ -192,6 +193,8 @@ hipError_t mgx_launch_step_dyn(const StepParams &p, const DynObsParams &d, const
 // the step + the level generator's blocks for the buffers the LAST step consumed, in one launch (g.regen null: nothing pending, the step alone)
 // ring of next-level buffers, caller-side: regen[i] = bank[i] + 1 and bank[i] ^= 1 for the masked envs (a buffer was consumed) | bank[i] = 0 and
 // regen[i] = 2 (buffer 0 holds the next level, buffer 1 is to be made)
+// DACWrapper's `last_obs`: the observation rows of absorbed envs (record bit MGX_REC_ABSORBED) become all ones (k_epilogue.hip)
+hipError_t mgx_launch_dac_obs(const uint2 *agent, uint8_t *obs, int64_t n, int64_t row_bytes, hipStream_t st);
 hipError_t mgx_launch_ring_consumed(uint8_t *bank, uint8_t *regen, const uint8_t *mask, int64_t n, int ring, hipStream_t st);
 hipError_t mgx_launch_ring_init(uint8_t *bank, uint8_t *regen, const uint8_t *mask, int64_t n, int flag, hipStream_t st);
 const char *mgx_step_kernel_label(const StepParams &p, int mode); // the instantiation the selector picks, e.g. "k_step<8,8,0,7>"

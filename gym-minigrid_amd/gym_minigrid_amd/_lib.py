@@ -72,6 +72,7 @@ SIGNATURES = {
     "mgx_reset": (_int, [_vp, _vp, _vp, _vp]),
     "mgx_set_seed_schedule": (_int, [_vp, _vp, ctypes.c_int32, ctypes.c_int32]),
     "mgx_add_bonus": (_int, [_vp, ctypes.c_int32]),
+    "mgx_set_dac": (_int, [_vp, ctypes.c_int32]),
     "mgx_get_bonus_counts": (_int, [_vp, ctypes.c_int32, _vp]),
     "mgx_set_state": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "mgx_get_state": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),

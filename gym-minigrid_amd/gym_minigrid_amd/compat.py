@@ -136,6 +136,34 @@ class _BonusWrapper:
         return getattr(self.env, name)
 
 
+class DACWrapper:
+    """The reference's DACWrapper for a SingleEnv (wrappers.py:35-84): once the env is done the observation is `last_obs` (the image all
+    ones, direction and mission of the episode's first observation), the reward 0, and done comes with the max_steps-th step.  The handle
+    does the counting and the image (VecMiniGrid.set_dac); this class keeps last_obs' other two entries."""
+
+    def __init__(self, env):
+        self.env = env
+        base = env
+        while not isinstance(base, SingleEnv):
+            base = base.env
+        base._vec.set_dac(True)
+        self.last_obs = None
+
+    def reset(self):
+        obs = self.env.reset()
+        self.last_obs = dict(obs, image=obs["image"] * 0 + 1)
+        return obs
+
+    def step(self, action):
+        obs, rew, done, info = self.env.step(action)
+        if (obs["image"] == 1).all():   # the absorbed env (no real view is all ones: an empty cell is (1, 0, 0), an unseen one (0, 0, 0))
+            obs = self.last_obs
+        return obs, rew, done, info
+
+    def __getattr__(self, name):
+        return getattr(self.env, name)
+
+
 class ActionBonus(_BonusWrapper):
     """The reference's ActionBonus (wrappers.py:87-119): reward += 1 / sqrt(visits to (agent_pos, agent_dir, action)), counted on the GPU
     inside the step kernel (VecMiniGrid.add_bonus("action"))."""

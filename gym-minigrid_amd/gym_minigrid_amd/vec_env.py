@@ -203,6 +203,13 @@ class VecMiniGrid:
             self._bind_stream()
         _lib.check(_lib.lib().mgx_add_bonus(self._h, 0 if kind is None else self.BONUS_KINDS[kind]))
 
+    def set_dac(self, on=True):
+        """env = DACWrapper(env) for every env (wrappers.py:35-84, the fork's absorbing-state wrapper): an env that is done before its
+        max_steps-th step is not reset; until that step its image is all ones, its reward 0, its actions ignored; that step reports done."""
+        if self._torch is not None:
+            self._bind_stream()
+        _lib.check(_lib.lib().mgx_set_dac(self._h, 1 if on else 0))
+
     def bonus_counts(self, kind):
         """The wrapper's self.counts as a dense uint32 array: (N, W, H, 4, A) for "action" (A = 7, or 9 with extended actions), (N, W, H) for "state"."""
         A = 9 if self.cfg.extended_actions else 7

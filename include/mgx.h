@@ -309,6 +309,16 @@ int mgx_add_bonus(mgx_handle h, int32_t kind);
 /* The counts of one of the wrappers (its self.counts as a dense array, layout above), device or host memory. */
 int mgx_get_bonus_counts(mgx_handle h, int32_t kind, uint32_t *counts);
 
+/* env = DACWrapper(env) (wrappers.py:35-84, the fork's absorbing-state wrapper): an env that is done before step max_steps of its
+ * episode is not reset; from that step on its observation is the wrapper's `last_obs` -- the image with every byte 1 --, its reward 0
+ * (the terminal step still reports the env's reward) and its actions are ignored, until the step that is the max_steps-th since the
+ * reset reports done = 1 (and, with auto_reset, starts the next episode in the same step).  Every episode is max_steps long.
+ * on = 0 removes the wrapper.  uint8 image observations only (MGX_OBS_PARTIAL / MGX_OBS_FULL); not for Dynamic-Obstacles handles.
+ * mgx_get_state of an absorbed env: the env's state after its last step, with `steps` = the wrapper's count; mgx_get_direction: the
+ * direction after that step (the reference's last_obs carries the direction of the episode's first observation).  With a bonus
+ * wrapper as well the handle is ActionBonus / StateBonus(DACWrapper(env)): absorbed steps count visits of the frozen pose. */
+int mgx_set_dac(mgx_handle h, int32_t on);
+
 /* Inject / read back the full simulator state.  set_state also records the state as the
  * episode start used by auto_reset.  aux, carry, steps may be NULL (zeros / nothing / 0).
  * get_state: any pointer may be NULL.

@@ -31,3 +31,33 @@ class BonusOracle:
                 c = self.state[idx, x, y]
             r[idx] = r[idx] + 1.0 / np.sqrt(c.astype(np.float64))   # bonus = 1 / math.sqrt(new_count); reward += bonus
         return r
+
+
+class DacOracle:
+    """The fork's DACWrapper (wrappers.py:35-84) over n envs: `env_done`, `count` and the all-ones `last_obs` image.  Used like the wrapper:
+    reset_where(mask) when the caller resets, then per step `stepping()` = the envs whose env.step() the wrapper still calls, and
+    step(obs, reward, done) on what those returned (rows of absorbed envs are ignored) -> what the wrapper returns."""
+
+    def __init__(self, n, max_steps):
+        self.env_done = np.zeros(n, bool)
+        self.count = np.zeros(n, np.int64)
+        self.max_steps = int(max_steps)
+
+    def reset_where(self, mask):
+        m = np.asarray(mask).astype(bool)
+        self.env_done[m] = False      # (wrappers.py:44-56)
+        self.count[m] = 0
+
+    def stepping(self):
+        return ~self.env_done         # `if self.env_done: ... return self.last_obs, 0, ...` never touches the env (wrappers.py:60-66)
+
+    def step(self, obs, reward, done):
+        self.count += 1
+        was = self.env_done.copy()
+        d = np.asarray(done).astype(bool) & ~was
+        out_obs = np.array(obs, copy=True)
+        out_rew = np.where(was, 0.0, np.asarray(reward, np.float64))
+        self.env_done = was | d
+        out_obs[self.env_done] = 1    # last_obs['image'] = obs['image'] * 0 + 1   (wrappers.py:51)
+        out_done = (self.env_done & (self.count >= self.max_steps)).astype(np.uint8)
+        return out_obs, out_rew, out_done

@@ -51,7 +51,7 @@ import numpy as np  # noqa: E402
 import gym  # noqa: E402
 import gym_minigrid  # noqa: E402,F401
 from gym_minigrid import minigrid as M  # noqa: E402
-from gym_minigrid.wrappers import ActionBonus, FullyObsWrapper, ReseedWrapper, StateBonus, ViewSizeWrapper  # noqa: E402
+from gym_minigrid.wrappers import ActionBonus, DACWrapper, FullyObsWrapper, ReseedWrapper, StateBonus, ViewSizeWrapper  # noqa: E402
 
 OUT = os.path.join(REPO, "tests", "golden")
 
@@ -355,8 +355,11 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
             env.seed(int(s))
             o = env.reset()
         stepper = env
-        for b in bonus:
-            stepper = {"action": ActionBonus, "state": StateBonus}[b](stepper)
+        for b in bonus:   # ("dac": the fork's DACWrapper, wrappers.py:35-84 -- obs / reward / done are then the wrapper's and resets go through it;
+            stepper = {"action": ActionBonus, "state": StateBonus, "dac": DACWrapper}[b](stepper)   # the recorded state arrays stay the ENV's)
+        if "dac" in bonus:
+            env.seed(int(s))
+            o = stepper.reset()   # (DACWrapper.reset sets last_obs and count; re-seeded: the env draws the same level again)
         z["seed"][k] = s
         z["init_grid"][k] = env.grid.encode()
         z["init_aux"][k] = aux_plane(env)
@@ -409,7 +412,7 @@ def record_case(name, make_env, seeds, T, scripts=None, full_obs=False, v1=False
                 else:
                     if reseed:
                         env.seed(int(s))
-                    o2 = env.reset()  # reseed=False: the env's own RNG stream continues -> a new level
+                    o2 = stepper.reset() if "dac" in bonus else env.reset()  # reseed=False: the env's own RNG stream continues -> a new level
                 rk.append(k)
                 rt.append(t)
                 rg.append(env.grid.encode())
@@ -1034,6 +1037,10 @@ def main():
     record_case("Bonus-MemoryS13Random-action", mk("MiniGrid-MemoryS13Random-v0"), list(range(4)), 300, bonus=("action",), gym_id="MiniGrid-MemoryS13Random-v0")
     record_case("Bonus-TwoGoals-8x8-state", mk("MiniGrid-TwoGoals-8x8-v0"), list(range(4)), 300, bonus=("state",), gym_id="MiniGrid-TwoGoals-8x8-v0")
     record_case("Bonus-Empty-16x16-full-state", mk("MiniGrid-Empty-16x16-v0"), [0, 1], 1100, full_obs=True, bonus=("state",), gym_id="MiniGrid-Empty-16x16-v0")
+    # the fork's DACWrapper (names start with "Dac-"; tests/test_oracle_golden.py, tests/test_gpu_bonus.py)
+    record_case("Dac-LavaCrossingS9N1", mk("MiniGrid-LavaCrossingS9N1-v0"), list(range(6)), 700, bonus=("dac",), gym_id="MiniGrid-LavaCrossingS9N1-v0")
+    record_case("Dac-Fetch-5x5-N2", mk("MiniGrid-Fetch-5x5-N2-v0"), list(range(6)), 300, bonus=("dac",), gym_id="MiniGrid-Fetch-5x5-N2-v0")
+    record_case("Dac-LavaGapS7-state", mk("MiniGrid-LavaGapS7-v0"), list(range(4)), 500, bonus=("dac", "state"), gym_id="MiniGrid-LavaGapS7-v0")   # StateBonus(DACWrapper(env))
     if only:
         return
     record_levels()

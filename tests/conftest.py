@@ -19,13 +19,18 @@ def pytest_configure(config):
 
 def golden_cases():
     """Trace cases whose state can be injected with set_state (DynObs-* carry an RNG stream: tests/test_dynobs.py)."""
-    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and not f.startswith(("DynObs-", "Bonus-"))
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and not f.startswith(("DynObs-", "Bonus-", "Dac-"))
                   and f not in ("levels.npz", "level_streams.npz", "onehot.npz", "flat.npz", "levels_obstructed.npz"))
 
 
 def bonus_cases():
     """Traces recorded through the reference's ActionBonus / StateBonus wrappers (meta['bonus'] = the stacking order, innermost first)."""
     return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.startswith("Bonus-") and f.endswith(".npz"))
+
+
+def dac_cases():
+    """Traces recorded through the fork's DACWrapper (meta['bonus'] = the wrapper stack, innermost first, "dac" among them)."""
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.startswith("Dac-") and f.endswith(".npz"))
 
 
 def load_case(name):

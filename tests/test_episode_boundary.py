@@ -19,7 +19,7 @@ import os
 def cases(kind):
     out = []
     for f in sorted(os.listdir(GOLDEN)):
-        if not f.endswith(".npz") or f.startswith("Bonus-") or f in ("levels.npz", "level_streams.npz", "onehot.npz", "flat.npz", "levels_obstructed.npz"):
+        if not f.endswith(".npz") or f.startswith(("Bonus-", "Dac-")) or f in ("levels.npz", "level_streams.npz", "onehot.npz", "flat.npz", "levels_obstructed.npz"):
             continue
         meta, _ = load_case(f[:-4])
         if meta.get("reseed", True) == kind:

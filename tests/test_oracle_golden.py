@@ -4,8 +4,8 @@ oracle and every output byte, reward, done flag and post-step state must match."
 import numpy as np
 import pytest
 
-from conftest import bonus_cases, golden_cases, load_case
-from oracle.bonus_oracle import BonusOracle
+from conftest import bonus_cases, dac_cases, golden_cases, load_case
+from oracle.bonus_oracle import BonusOracle, DacOracle
 from oracle.minigrid_oracle import OracleEnvs
 
 
@@ -82,3 +82,44 @@ def test_oracle_replays_reference_trace(name):
                 assert np.array_equal((o[0] if full else o)[k], z["reset_obs"][r])
                 if full:
                     assert np.array_equal(o[1][k], z["reset_full"][r])   # FullyObsWrapper image returned by the reference's reset()
+
+
+STATE = ("grid", "aux", "agent", "carry", "steps", "task")
+
+
+@pytest.mark.parametrize("name", dac_cases())
+def test_oracle_replays_dac_trace(name):
+    """The fork's DACWrapper (wrappers.py:35-84) around the env: the oracle steps only the envs the wrapper still steps (the others keep
+    their state), oracle/bonus_oracle.py's DacOracle turns what they return into the wrapper's obs / reward / done; every byte of the
+    recorded trace, resets through the wrapper included."""
+    meta, z = load_case(name)
+    K, T = z["actions"].shape
+    full = meta["full_obs"]
+    env = OracleEnvs(meta["W"], meta["H"], meta["max_steps"], meta["see_through"], meta["lava_v1"], task=meta.get("task", 0))
+    env.set_state(z["init_grid"], z["init_agent"], aux=z["init_aux"])
+    if meta.get("task", 0):
+        env.task = z["init_task"].copy()
+    dac = DacOracle(K, meta["max_steps"])
+    outer = [b for b in meta["bonus"][meta["bonus"].index("dac") + 1:]]
+    assert meta["bonus"][0] == "dac"
+    bonus = BonusOracle(K, meta["W"], meta["H"], outer) if outer else None
+    want_obs = z["full"] if full else z["obs"]
+    for t in range(T):
+        keep = ~dac.stepping()
+        state = [k for k in STATE if getattr(env, k) is not None]
+        saved = {k: getattr(env, k)[keep].copy() for k in state}
+        out = env.step(z["actions"][:, t], full=full)
+        for k in state:
+            getattr(env, k)[keep] = saved[k]
+        obs, rew, done = (out[1], out[2], out[3]) if full else out
+        obs, rew, done = dac.step(obs, rew, done)
+        if bonus:
+            rew = bonus.step(rew, env.agent, z["actions"][:, t])
+        assert np.array_equal(obs, want_obs[:, t]), (name, t)
+        assert np.array_equal(rew, z["reward"][:, t]), (name, t)
+        assert np.array_equal(done, z["done"][:, t]), (name, t)
+        assert np.array_equal(env.agent, z["agent"][:, t]) and np.array_equal(env.grid, z["grid"][:, t]) and np.array_equal(env.steps, z["steps"][:, t]), (name, t)
+        if done.any():   # the recorder's `env.seed(s); wrapper.reset()`: the episode start again
+            env.reset_where(done)
+            dac.reset_where(done)
+    assert z["done"].sum() >= 2 * K and (want_obs.reshape(K, T, -1) == 1).all(-1).sum() > K * 50
