@@ -923,6 +923,7 @@ extern "C" int mgx_add_bonus(mgx_handle h, int32_t kind)
     if (rc) return rc;
     if (kind != 0 && kind != MGX_BONUS_ACTION && kind != MGX_BONUS_STATE)
         return mgx_fail(MGX_ERR_INVALID_ARG, "mgx_add_bonus: kind %d is not 0, MGX_BONUS_ACTION or MGX_BONUS_STATE", kind);
+    if (kind != 0 && h->oh_fused) return mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_add_bonus: not with MGX_ONEHOT=fused (the two-kernel one-hot form carries it)");
     HIP_TRY(hipStreamSynchronize(h->stream)); // (steps in flight still count into the arrays)
     if (h->roll_exec) { (void)hipGraphExecDestroy(h->roll_exec); h->roll_exec = nullptr; } // (a captured rollout holds the old parameters)
     if (kind == 0) {
@@ -956,6 +957,7 @@ extern "C" int mgx_set_dac(mgx_handle h, int32_t on)
     if (on && (h->oh_nc >= 0 || h->flat))
         return mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_set_dac: the wrapper's last_obs is defined on the uint8 image (obs_mode MGX_OBS_PARTIAL or MGX_OBS_FULL)");
     if (on && h->dynobs) return mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_set_dac: not for Dynamic-Obstacles handles");
+    if (on && h->oh_fused) return mgx_fail(MGX_ERR_UNSUPPORTED, "mgx_set_dac: not with MGX_ONEHOT=fused");
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (h->roll_exec) { (void)hipGraphExecDestroy(h->roll_exec); h->roll_exec = nullptr; }
     h->dac = on != 0;
@@ -1615,8 +1617,9 @@ extern "C" int mgx_step_kernel_name(mgx_handle h, char *out, int cap)
     char dyn_name[32];
     const char *name = mgx_step_kernel_label(base_params(h), h->kernel_mode); // (host-side table lookup: no device call)
     if (h->dyn_fused) { // walk + step in one launch (mgx_launch_step_dyn: sized instances for the registered Dynamic-Obstacles grids)
-        const bool sized = (h->W == h->H) && (h->W == 5 || h->W == 6 || h->W == 8 || h->W == 16) && !h->bonus;
-        snprintf(dyn_name, sizeof dyn_name, "k_step_dyn<%d,%d>", sized ? h->W : 0, sized ? h->H : 0);
+        const bool sized = (h->W == h->H) && (h->W == 5 || h->W == 6 || h->W == 8 || h->W == 16);
+        if (h->bonus || h->dac) snprintf(dyn_name, sizeof dyn_name, "k_step_dyn_wrap");
+        else snprintf(dyn_name, sizeof dyn_name, "k_step_dyn<%d,%d>", sized ? h->W : 0, sized ? h->H : 0);
         name = dyn_name;
     }
     const int len = (int)strlen(name);

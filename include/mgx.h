@@ -303,7 +303,8 @@ int mgx_set_seed_schedule(mgx_handle h, const uint64_t *seeds, int32_t K, int32_
  * (StateBonus(ActionBonus(env)) = MGX_BONUS_ACTION, then MGX_BONUS_STATE); kind 0 removes both and frees the counts.  Every call
  * zeroes the counts.  Device memory: uint32 [N][W][H][4][A] (A = 7 actions, 9 with extended_actions) for the action bonus,
  * uint32 [N][W][H] for the state bonus.  Steps that hit the reference's `unknown action` assertion count nothing.
- * mgx_rollout of such a handle is the captured graph of per-step launches. */
+ * mgx_rollout of such a handle is the captured graph of per-step launches.  The step kernel is then a `k_step_wrap` / `k_step_dyn_wrap`
+ * / wrap-`k_step_fulldirect` instance (mgx_step_kernel_name): the only kernels that carry this code. */
 typedef enum { MGX_BONUS_ACTION = 1, MGX_BONUS_STATE = 2 } mgx_bonus_kind;
 int mgx_add_bonus(mgx_handle h, int32_t kind);
 /* The counts of one of the wrappers (its self.counts as a dense array, layout above), device or host memory. */
