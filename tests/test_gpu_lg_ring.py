@@ -168,3 +168,24 @@ def test_ring_is_the_default_form(monkeypatch):
     monkeypatch.setenv("MGX_LG_RING", "off")
     full_single = cost("MiniGrid-LavaCrossingS9N1-v0", obs_mode="full")
     assert abs(full - full_single) < 6 * per_level, (full, full_single)         # (allocator noise; a ring would be 15)
+
+
+def test_ring_generator_under_the_wrappers(monkeypatch):
+    """The bonus / DAC kernels (k_step_wrap) know the ring like every step_body instance: StateBonus(DACWrapper(env)) on a ring handle
+    equals the same on a one-buffer handle, through in-kernel resets at the wrapper's time-outs."""
+    env_id, N, T = "MiniGrid-LavaCrossingS9N1-v0", 1100, 700
+    a, b = pair(env_id, N, monkeypatch)
+    for e in (a, b):
+        e.reset()
+        e.set_dac(True)
+        e.add_bonus("state")
+    assert a.step_kernel_name() == "k_step_wrap<0,7>"
+    acts = to_np(a.fill_actions(13, 0, T))
+    acts = np.where(acts > 2, 2, acts).astype(np.uint8)
+    for t in range(T):
+        oa, ra, da, _ = a.step(acts[t])
+        ob, rb, db, _ = b.step(acts[t])
+        assert np.array_equal(to_np(da), to_np(db)) and np.array_equal(to_np(oa), to_np(ob)) and np.array_equal(to_np(ra), to_np(rb)), t
+    assert same_state(a, b) and np.array_equal(a.bonus_counts("state"), b.bonus_counts("state"))
+    assert a.stats()["episodes"] == 2 * N        # every episode is max_steps (324) long under the DAC wrapper
+    a.close(); b.close()
