@@ -14,9 +14,10 @@ namespace {
 #define MGX_LG_WAVES 4
 #endif
 // (the generator itself -- word sources, lane-per-level fast path, wave-per-level slow path -- is levelgen_device.h)
+template <bool MULTI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MGX_LG_WAVES, MGX_LG_WAVES))) void k_levelgen(const LevelGenParams p, const FastLayout fl)
 {
-    levelgen_block(p, fl, (int)blockIdx.x);
+    levelgen_block<MULTI>(p, fl, (int)blockIdx.x);
 }
 
 // reset(): the freshly generated next-level buffer becomes the current episode (for the masked envs) and is flagged
@@ -608,12 +609,14 @@ hipError_t mgx_launch_levelgen(const LevelGenParams &p, hipStream_t st)
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
         if (!raised[dev]) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_levelgen), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_levelgen<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_levelgen<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024);
             if (e != hipSuccess) return e;
             raised[dev] = true;
         }
     }
-    hipLaunchKernelGGL(k_levelgen, dim3(blocks), dim3(256), shmem, st, p, fl);
+    if (p.n_regen > 1) hipLaunchKernelGGL(k_levelgen<true>, dim3(blocks), dim3(256), shmem, st, p, fl);
+    else hipLaunchKernelGGL(k_levelgen<false>, dim3(blocks), dim3(256), shmem, st, p, fl);
     return hipGetLastError();
 }
 

@@ -352,6 +352,7 @@ __device__ __forceinline__ bool fast_level(const LevelGenParams &p, const FastLa
 #define MGX_LG_WAVES 4
 #endif
 // One block of the level generator: 256 threads, span `fl.span` of envs starting at block_id * fl.span (the body of k_levelgen).
+template <bool MULTI>
 __device__ __forceinline__ void levelgen_block(const LevelGenParams &p, const FastLayout &fl, int block_id)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_slices[]; // n_fast_waves x `lanes` slices; reused by the slow path (>= 4 workspaces)
@@ -361,28 +362,6 @@ __device__ __forceinline__ void levelgen_block(const LevelGenParams &p, const Fa
     __shared__ int s_count, s_nslow, s_head;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t env_base = (int64_t)block_id * fl.span;
-    if (tid == 0) { s_count = 0; s_nslow = 0; s_head = 0; }
-    __syncthreads();
-    if (tid < fl.span / 8) { // scan 8 flags per thread (the regen array is padded to whole tiles and the span is a multiple of 64)
-        const int64_t e0 = env_base + (int64_t)tid * 8;
-        if (e0 < p.n) {
-            uint2 *f2 = reinterpret_cast<uint2 *>(p.regen + e0);
-            const uint2 a = *f2;
-            if (a.x | a.y) {
-#pragma unroll
-                for (int i = 0; i < 8; i++)
-                    // (a ring of next-level buffers, LevelGenParams.bank_envs != 0: the flag is the buffer's index + 1, bits 14:11 of the queue entry; a span has at most 2048 envs)
-                    if ((((i < 4 ? a.x : a.y) >> (8 * (i & 3))) & 255u) && e0 + i < p.n) {
-                        const uint32_t v = ((i < 4 ? a.x : a.y) >> (8 * (i & 3))) & 255u;
-                        s_queue[atomicAdd(&s_count, 1)] = (uint16_t)((tid * 8 + i) | (p.bank_envs ? ((v - 1u) & 15u) << 11 : 0u));
-                    }
-                *f2 = make_uint2(0, 0);
-            }
-        }
-    }
-    __syncthreads();
-    const int count = s_count;
-    if (count == 0) return;
     const int W = p.cfg.width, H = p.cfg.height, cells = W * H;
     // the cheap form for the families whose levels take a bounded, small number of draws on small grids (measured: the
     // sliding form costs the crossing generator 10-20 %); the sliding window and the direct paint for everything else
@@ -390,41 +369,84 @@ __device__ __forceinline__ void levelgen_block(const LevelGenParams &p, const Fa
     const bool cheap = p.S <= MGX_LGF_MAXS_CHEAP && (kind == MGX_LEVEL_EMPTY || kind == MGX_LEVEL_DOORKEY || kind == MGX_LEVEL_CROSSING ||
                                                kind == MGX_LEVEL_LAVAGAP || kind == MGX_LEVEL_DISTSHIFT);
     const bool slide = !cheap || p.virt != nullptr; // (a virtual state is 64 words long: the cheap form's all-or-nothing window of 32 would send 1 % of DoorKey-8x8's levels to the slow path)
-    if (fl.n_fast_waves == 0) { // every level by a whole wave (levelgen_one)
-        for (int i = tid; i < count; i += 256) s_slow[i] = s_queue[i];
-        if (tid == 0) s_nslow = count;
-    }
-    if (wv < fl.n_fast_waves && lane < fl.lanes) {
-        uint32_t *slice = s_slices + ((size_t)wv * fl.lanes + lane) * fl.slice_dw;
-        const int stride = fl.lanes * fl.n_fast_waves;
-        // The queue goes round the waves level by level (entry lane * waves + wave of each chunk), not wave by wave: a steady flow of resets
-        // leaves a block a few dozen levels, and filled wave by wave they all sat in wave 0 -- one wave per block alone on its SIMD,
-        // running the union of 40 lanes' control flow with nothing to hide its latencies, three waves waiting at the barrier (PutNear,
-        // 262,144 envs: every launch 60-70 us for ~10 k cheap levels).
-        for (int i = lane * fl.n_fast_waves + wv; i < ((count + stride - 1) / stride) * stride; i += stride) {
-            if (i >= count) continue;
-            const int64_t env = env_base + (s_queue[i] & 0x7FF);
-            const int64_t senv = env + (int64_t)((s_queue[i] >> 11) & 15) * p.bank_envs;
-            bool crossed;
-            const bool ok = slide ? fast_level<true>(p, fl, env, senv, slice, W, H, cells, crossed) : fast_level<false>(p, fl, env, senv, slice, W, H, cells, crossed);
-            // (the second queue holds both kinds of whole-wave work: levels the lane path gave up on, and -- bit 15 -- envs whose level is
-            // done but ended in their second MT19937 block)
-            if (!ok) s_slow[atomicAdd(&s_nslow, 1)] = s_queue[i];
-            else if (crossed) s_slow[atomicAdd(&s_nslow, 1)] = (uint16_t)(s_queue[i] | 0x8000u);
+    // Several flag arrays (LevelGenParams.n_regen: the steps of one run of a ring, oldest first) in ONE launch: a pass takes, for every env, the
+    // flag of the OLDEST array that has one -- its levels are independent of each other and fill the waves together -- and leaves the env's later
+    // flags for the next pass: an env that finished twice within the run draws its two levels in step order, the order of its RNG stream.  One
+    // array: one pass, as ever.
+    // (MULTI is a template parameter: with the pass loop around it the one-array kernel spilled 83 registers instead of 46 and every launch of it
+    // took 10 us longer)
+    const int n_regen = MULTI ? (p.n_regen > 1 ? p.n_regen : 1) : 1;
+    for (int pass = 0; pass < n_regen; pass++) {
+        if (tid == 0) { s_count = 0; s_nslow = 0; s_head = 0; }
+        __syncthreads();
+        if (tid < fl.span / 8) { // scan 8 flags per thread and array (the regen arrays are padded to whole tiles and the span is a multiple of 64)
+            const int64_t e0 = env_base + (int64_t)tid * 8;
+            if (e0 < p.n) {
+                uint32_t taken = 0u; // envs of this thread that have their level of this pass
+                for (int a = 0; a < n_regen; a++) {
+                    uint2 *f2 = reinterpret_cast<uint2 *>((a == 0 ? p.regen : p.regen_more[a - 1]) + e0);
+                    uint2 f = *f2;
+                    if (!(f.x | f.y)) continue;
+                    bool wrote = false;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        // (a ring of next-level buffers, LevelGenParams.bank_envs != 0: the flag is the buffer's index + 1, bits 14:11 of the queue entry; a span has at most 2048 envs)
+                        const uint32_t v = ((i < 4 ? f.x : f.y) >> (8 * (i & 3))) & 255u;
+                        if (v && !((taken >> i) & 1u) && e0 + i < p.n) {
+                            s_queue[atomicAdd(&s_count, 1)] = (uint16_t)((tid * 8 + i) | (p.bank_envs ? ((v - 1u) & 15u) << 11 : 0u));
+                            taken |= 1u << i;
+                            if (i < 4) f.x &= ~(255u << (8 * i)); else f.y &= ~(255u << (8 * (i - 4)));
+                            wrote = true;
+                        } else if (v && e0 + i >= p.n) { // (padding never carries flags; cleared all the same)
+                            if (i < 4) f.x &= ~(255u << (8 * i)); else f.y &= ~(255u << (8 * (i - 4)));
+                            wrote = true;
+                        }
+                    }
+                    if (wrote) *f2 = f;
+                }
+            }
         }
-    }
-    __syncthreads();
-    const int nslow = s_nslow;
-    if (nslow == 0) return;
-    uint8_t *base = reinterpret_cast<uint8_t *>(s_slices) + (size_t)wv * MGX_LG_LDS_PER_WAVE;
-    for (;;) { // wave-uniform
-        int i = 0;
-        if (lane == 0) i = atomicAdd(&s_head, 1);
-        i = __builtin_amdgcn_readfirstlane(i);
-        if (i >= nslow) break;
-        const uint32_t job = s_slow[i];
-        if (job & 0x8000u) advance_env(p, env_base + (job & 0x7FFu), base, lane);
-        else levelgen_one(p, env_base + (job & 0x7FFu), base, lane, env_base + (job & 0x7FFu) + (int64_t)((job >> 11) & 15u) * p.bank_envs);
+        __syncthreads();
+        const int count = s_count;
+        if (count == 0) break; // (block-uniform)
+        if (fl.n_fast_waves == 0) { // every level by a whole wave (levelgen_one)
+            for (int i = tid; i < count; i += 256) s_slow[i] = s_queue[i];
+            if (tid == 0) s_nslow = count;
+        }
+        if (wv < fl.n_fast_waves && lane < fl.lanes) {
+            uint32_t *slice = s_slices + ((size_t)wv * fl.lanes + lane) * fl.slice_dw;
+            const int stride = fl.lanes * fl.n_fast_waves;
+            // The queue goes round the waves level by level (entry lane * waves + wave of each chunk), not wave by wave: a steady flow of resets
+            // leaves a block a few dozen levels, and filled wave by wave they all sat in wave 0 -- one wave per block alone on its SIMD,
+            // running the union of 40 lanes' control flow with nothing to hide its latencies, three waves waiting at the barrier (PutNear,
+            // 262,144 envs: every launch 60-70 us for ~10 k cheap levels).
+            for (int i = lane * fl.n_fast_waves + wv; i < ((count + stride - 1) / stride) * stride; i += stride) {
+                if (i >= count) continue;
+                const int64_t env = env_base + (s_queue[i] & 0x7FF);
+                const int64_t senv = env + (int64_t)((s_queue[i] >> 11) & 15) * p.bank_envs;
+                bool crossed;
+                const bool ok = slide ? fast_level<true>(p, fl, env, senv, slice, W, H, cells, crossed) : fast_level<false>(p, fl, env, senv, slice, W, H, cells, crossed);
+                // (the second queue holds both kinds of whole-wave work: levels the lane path gave up on, and -- bit 15 -- envs whose level is
+                // done but ended in their second MT19937 block)
+                if (!ok) s_slow[atomicAdd(&s_nslow, 1)] = s_queue[i];
+                else if (crossed) s_slow[atomicAdd(&s_nslow, 1)] = (uint16_t)(s_queue[i] | 0x8000u);
+            }
+        }
+        __syncthreads();
+        const int nslow = s_nslow;
+        if (nslow != 0) {
+            uint8_t *base = reinterpret_cast<uint8_t *>(s_slices) + (size_t)wv * MGX_LG_LDS_PER_WAVE;
+            for (;;) { // wave-uniform
+                int i = 0;
+                if (lane == 0) i = atomicAdd(&s_head, 1);
+                i = __builtin_amdgcn_readfirstlane(i);
+                if (i >= nslow) break;
+                const uint32_t job = s_slow[i];
+                if (job & 0x8000u) advance_env(p, env_base + (job & 0x7FFu), base, lane);
+                else levelgen_one(p, env_base + (job & 0x7FFu), base, lane, env_base + (job & 0x7FFu) + (int64_t)((job >> 11) & 15u) * p.bank_envs);
+            }
+        }
+        if (pass + 1 < n_regen) __syncthreads(); // (the next pass reuses the queues, the counters and the slices)
     }
 }
 

@@ -117,6 +117,7 @@ struct mgx_env_s {
     uint8_t *lg_flags[MGX_LG_RING_MAX] = {};       // ([0] = regen_d)
     int lg_s = 0;                                  // the flag array the NEXT step raises
     bool lg_dirty[MGX_LG_RING_MAX] = {};           // raised by a step, not handed to a generator yet
+    bool lg_merge = false;                         // one k_levelgen launch per run (its arrays together) instead of one per array
     int lg_groups = 4;                             // the arrays in lg_groups runs of lg_ring / lg_groups steps, one fork / join per run
     bool lg_unjoined[4] = {};                      // the generator launches of a run: not waited for by the caller's stream yet
     hipStream_t lg_stream = nullptr;
@@ -681,7 +682,14 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
         const int R = (lf && strcmp(lf, "on")) ? atoi(lf) : 16; // ("off" -> 0)
         // (every partial-view step kernel -- staged, gather, with or without hidden object state -- is step_body, which knows the ring; the
         // FullyObs kernels do not)
-        if (h->stream_mode && h->partial && (h->kernel_mode == 0 || h->kernel_mode == 3) && cfg->level_kind != MGX_LEVEL_MULTIROOM &&
+        // (the families it costs 1-4 % instead: their episodes end together, at the time-out, and a burst of N levels is as long beside the
+        // steps as behind one -- MultiRoom-N6 68.7 -> 74.0, FourRooms 36.4 -> 37.2, LockedRoom 20.5 -> 22.0, Playground 37.9 -> 38.5 -- or there are
+        // more levels per step than steps' worth of work: GoToObject, whose `done` action ends two episodes in seven, 251 -> 260.  They keep
+        // one buffer; MGX_LG_RING set to a depth overrides the rule)
+        const int lk = cfg->level_kind;
+        const bool ring_pays = lk != MGX_LEVEL_MULTIROOM && lk != MGX_LEVEL_FOURROOMS && lk != MGX_LEVEL_LOCKEDROOM && lk != MGX_LEVEL_PLAYGROUND &&
+                               lk != MGX_LEVEL_GOTOOBJECT;
+        if (h->stream_mode && h->partial && (h->kernel_mode == 0 || h->kernel_mode == 3) && (ring_pays || lf) &&
             (R == 2 || R == 4 || R == 8 || R == 16)) h->lg_ring = R;
         // R next-level buffers (+ hidden planes) per env; a handle too large for them keeps one buffer and the generator behind every step
         if (h->lg_ring && resize_snapshots(h, R) != MGX_OK) { h->lg_ring = 0; (void)hipGetLastError(); }
@@ -691,6 +699,14 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
             CREATE_TRY(hipStreamCreateWithPriority(&h->lg_stream, hipStreamNonBlocking, prio_hi));
             CREATE_TRY(hipEventCreateWithFlags(&h->lg_fork, hipEventDisableTiming));
             for (int a = 0; a < 4; a++) CREATE_TRY(hipEventCreateWithFlags(&h->lg_join[a], hipEventDisableTiming));
+            // One generator launch per run of the ring (its four steps' flag arrays together, k_levelgen<true>) where a step ends few episodes
+            // and every launch is as long as its slowest level -- us per step, a launch per array -> one per run: KeyCorridorS3R3 66.8 -> 41.7,
+            // GoToDoor 85.9 -> 56.6, Fetch 59.6 -> 52.3, PutNear 120.6 -> 98.2, ObstructedMaze-1Dlhb 22.2 -> 21.7; where a step ends many, the
+            // one launch is one wave's work four times over and its pass loop costs the kernel 37 more spilled registers: LavaCrossing 52.1 ->
+            // 56.1, Unlock 46.0 -> 49.4, RedBlueDoors 55.7 -> 59.1, MemoryS13 37.3 -> 42.9 (profiles/r04_levelgen_ring_families.txt).
+            // MGX_LG_MERGE=0|1 overrides the family rule.
+            h->lg_merge = lk == MGX_LEVEL_KEYCORRIDOR || lk == MGX_LEVEL_GOTODOOR || lk == MGX_LEVEL_FETCH || lk == MGX_LEVEL_PUTNEAR || lk == MGX_LEVEL_OBSTRUCTEDMAZE;
+            if (const char *e = getenv("MGX_LG_MERGE")) h->lg_merge = atoi(e) != 0;
             h->lg_groups = R >= 8 ? 4 : 2; // (quarters: the join is due three quarters of a turn after the fork -- 50.9 / 31.2 us per step at 1 Mi / 512 Ki
                                            // LavaCrossing envs against 51.3 / 31.9 with halves, whose generators end about when their join is due)
             CREATE_TRY(hipMalloc((void **)&h->bank_d, (size_t)h->n_pad));
@@ -1078,11 +1094,18 @@ static int run_step(mgx_handle h, bool do_step, const uint8_t *actions, uint8_t 
             HIP_TRY(hipEventRecord(h->lg_fork, h->stream));
             HIP_TRY(hipStreamWaitEvent(h->lg_stream, h->lg_fork, 0));
             LevelGenParams g = levelgen_params(h);
-            for (int b = grp * half; b <= a; b++) {
-                g.regen = h->lg_flags[b];
+            if (h->lg_merge) { // one launch for the run's arrays (half <= 4)
+                g.regen = h->lg_flags[grp * half];
+                g.n_regen = half;
+                for (int b = grp * half + 1; b <= a; b++) g.regen_more[b - grp * half - 1] = h->lg_flags[b];
                 HIP_TRY(mgx_launch_levelgen(g, h->lg_stream));
-                h->lg_dirty[b] = false;
+            } else {
+                for (int b = grp * half; b <= a; b++) {
+                    g.regen = h->lg_flags[b];
+                    HIP_TRY(mgx_launch_levelgen(g, h->lg_stream));
+                }
             }
+            for (int b = grp * half; b <= a; b++) h->lg_dirty[b] = false;
             HIP_TRY(hipEventRecord(h->lg_join[grp], h->lg_stream));
             h->lg_unjoined[grp] = true;
         }

@@ -43,6 +43,8 @@ struct LevelGenParams {
     const uint64_t *seed0;   // u64[n_pad] the seed behind a virtual state
     const uint32_t *mt_init; // init_genrand(19650218)'s 624 words
     uint8_t *regen;    // u8[n_pad]        work flags, cleared here
+    uint8_t *regen_more[3]; // ... and up to three more arrays of them, later steps of the same run of a ring (n_regen arrays in all, oldest first;
+    int n_regen;       //      0 / 1: just `regen`): one launch takes them together, an env's levels in array order
     uint8_t *cells0;   // next-level buffer (codes) and its agent record
     uint2 *agent0;
     uint8_t *objaux0, *objcont0; // object_state handles (else null): the next level's hidden-state planes -- aux all zero,

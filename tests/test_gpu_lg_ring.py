@@ -38,8 +38,12 @@ def same_state(a, b):
     return ok
 
 
+@pytest.mark.parametrize("merge", ["0", "1"])
 @pytest.mark.parametrize("env_id", FAMILIES)
-def test_ring_generator_equals_split(env_id, monkeypatch):
+def test_ring_generator_equals_split(env_id, merge, monkeypatch):
+    """merge: a generator launch per step's flag array, or one per run of four steps (k_levelgen<true>: an env that finished twice within the
+    run draws its levels in step order, pass by pass) -- the family rule picks one, both must agree with the one-buffer form."""
+    monkeypatch.setenv("MGX_LG_MERGE", merge)
     N, T = (1500, 400) if "Memory" not in env_id else (400, 300)
     T = {"MiniGrid-SimpleCrossingS11N5-v0": 520, "MiniGrid-DoorKey-8x8-v0": 700}.get(env_id, T)   # (time-outs at 484 / 640 steps)
     a, b = pair(env_id, N, monkeypatch)
@@ -146,7 +150,7 @@ def test_injected_state_draws_nothing(env_id, ring, monkeypatch):
 
 def test_ring_is_the_default_form(monkeypatch):
     """The ring is what a handle gets without MGX_LG_RING (and what the side-by-side tests above therefore compare): its 16 next-level buffers
-    per env show in the device's free memory; MultiRoom and FullyObs handles keep one buffer."""
+    per env show in the device's free memory; FullyObs handles (and the families of mgx_create's rule) keep one buffer."""
     import torch
     N = 262144
 
