@@ -1,7 +1,7 @@
 #!/bin/bash
 # Usage (GPU box, repo root): tools/ring_families.sh > gpurun_out/ring_families.txt
 # new_level_each_episode, us per step: replay | one next-level buffer, k_levelgen behind every step (MGX_LG_RING=off) | ring of 16, generator beside the steps,
-# a launch per step's flags (16) or one launch per run of four steps (16m)
+# a launch per step's flags (16) or one launch per run of four steps (16m); default = what mgx_create's family rules pick
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 us() { python3 -c "import json,sys; print('%.1f' % (1000 * json.loads(sys.stdin.readlines()[-1])['ms_per_step']))"; }
 run() { # env n [extra bench args]
@@ -11,6 +11,7 @@ run() { # env n [extra bench args]
   for f in off 16 16m; do
     line="$line | ring=$f $(MGX_LG_MERGE=$([ $f = 16m ] && echo 1 || echo 0) MGX_LG_RING=${f%m} timeout -k 10 120 python3 $R/bench.py --config lava4m --env $e --envs-per-gpu $n --new-level-each-episode --steps 600 --warmup 64 --no-cpu-baseline "$@" 2>/dev/null | us)"
   done
+  line="$line | default $(timeout -k 10 120 python3 $R/bench.py --config lava4m --env $e --envs-per-gpu $n --new-level-each-episode --steps 600 --warmup 64 --no-cpu-baseline "$@" 2>/dev/null | us)"
   echo "$line"
 }
 run MiniGrid-Fetch-8x8-N3-v0 1048576
