@@ -303,3 +303,37 @@ def test_dac_api():
         assert d == (t == env.max_steps - 1)
     assert seen_absorbed
     env.close()
+
+
+@pytest.mark.parametrize("env_id,kw", [("MiniGrid-DoorKey-8x8-v0", dict(obs_mode="partial_onehot")), ("MiniGrid-DoorKey-8x8-v0", dict(obs_mode="flat")),
+                                       ("MiniGrid-LavaCrossingS9N1-v0", dict(agent_view_size=3)), ("MiniGrid-LavaCrossingS9N1-v0", dict(agent_view_size=9, default_vis=False)),
+                                       ("MiniGrid-ObstructedMaze-1Dlhb-v0", dict()), ("MiniGrid-FourRooms-v0", dict(obs_mode="full_onehot")),
+                                       ("MiniGrid-MultiRoom-N6-v0", dict()), ("MiniGrid-KeyCorridorS6R3-v0", dict(extended_actions=True))])
+def test_bonus_on_every_kind_of_handle(env_id, kw):
+    """The wrap kernels behind the other handle kinds -- epilogues, other views, the alternative visibility, hidden object state, the gather
+    form, strafing: a handle with both bonuses steps like the same handle without, and its rewards are the other's plus the restated bonuses
+    (compared where the env's own reward is exactly representable: 0 on all but a few terminal steps)."""
+    N, T = 300, 120
+    a = mg.VecMiniGrid(env_id, num_envs=N, seeds=9, auto_reset=False, backend="torch", **kw)
+    b = mg.VecMiniGrid(env_id, num_envs=N, seeds=9, auto_reset=False, backend="torch", **kw)
+    a.reset(); b.reset()
+    a.add_bonus("action"); a.add_bonus("state")
+    T = min(T, a.max_steps - 10)
+    assert "wrap" in a.step_kernel_name() and "wrap" not in b.step_kernel_name()
+    A = 9 if kw.get("extended_actions") else 7
+    bo = BonusOracle(N, a.width, a.height, ("action", "state"), A)
+    rs = np.random.RandomState(8)
+    alive = np.ones(N, bool)
+    for t in range(T):
+        acts = rs.randint(0, A, size=N).astype(np.uint8)
+        oa, ra, da, _ = a.step(acts)
+        ob, rb, db, _ = b.step(acts)
+        ra, rb, da = to_np(ra), to_np(rb), to_np(da)
+        assert np.array_equal(to_np(oa), to_np(ob)) and np.array_equal(da, to_np(db)), t
+        want = bo.step(rb.astype(np.float64), to_np(b.pose()), acts)
+        ok = alive & (rb == 0)
+        assert np.array_equal(ra[ok], want.astype(np.float32)[ok]), t
+        alive &= ~da.astype(bool)          # (a finished env is stepped on by neither loop of the reference; here it just stops being compared)
+    assert alive.sum() > N // 4
+    a.clear_faults(); b.clear_faults()
+    a.close(); b.close()
