@@ -1,6 +1,6 @@
 #!/bin/bash
 # Same-box A/B of libmgx.so variants on Dynamic-Obstacles (k_dynobs + k_step per step): us per step, whole step.
-#   tools/r03_dyn_ab.sh <rounds> <name> <name> ...   (variants from tools/build_variant.sh; MGX_EXP_DYN bits are timing-only)
+#   tools/archive_r03/r03_dyn_ab.sh <rounds> <name> <name> ...   (variants from tools/build_variant.sh; MGX_EXP_DYN bits are timing-only)
 rounds=${1:-2}; shift
 mkdir -p gpurun_out
 for env in MiniGrid-Dynamic-Obstacles-8x8-v0 MiniGrid-Dynamic-Obstacles-16x16-v0; do

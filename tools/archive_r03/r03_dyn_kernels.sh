@@ -1,6 +1,6 @@
 #!/bin/bash
 # Per-kernel durations (rocprofv3 --kernel-trace --stats) of the Dynamic-Obstacles step for builds of libmgx.so under ab/:
-#   tools/r03_dyn_kernels.sh <env id> <envs> <name> <name> ...     (MGX_LIB is read by gym_minigrid_amd/_lib.py)
+#   tools/archive_r03/r03_dyn_kernels.sh <env id> <envs> <name> <name> ...     (MGX_LIB is read by gym_minigrid_amd/_lib.py)
 env_id=$1; envs=$2; shift 2
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 PY=$(readlink -f "$(command -v python3)")

@@ -1,5 +1,5 @@
 #!/bin/bash
-# FETCH_SIZE / WRITE_SIZE of k_dynobs (one counter per pass, --kernel-trace only):  tools/r03_dyn_traffic.sh <env id> <envs> [variant]
+# FETCH_SIZE / WRITE_SIZE of k_dynobs (one counter per pass, --kernel-trace only):  tools/archive_r03/r03_dyn_traffic.sh <env id> <envs> [variant]
 env_id=$1; envs=$2; v=$3
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 PY=$(readlink -f "$(command -v python3)")

@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counters of the ONE k_levelgen launch that makes a level for every env (the burst at step max_steps of a lock-step family):
-#   tools/r03_lg_burst_pmc.sh <env id> <envs> <steps>     (steps > max_steps; the longest launch is picked; LG_PICK=median: the median one)
+#   tools/archive_r03/r03_lg_burst_pmc.sh <env id> <envs> <steps>     (steps > max_steps; the longest launch is picked; LG_PICK=median: the median one)
 env_id=$1; envs=$2; steps=$3
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 PY=$(readlink -f "$(command -v python3)")

@@ -1,5 +1,5 @@
 #!/bin/bash
-# per-launch durations of k_levelgen over a run with a new level per episode:  tools/r03_lg_trace.sh <env id> <envs> <steps>
+# per-launch durations of k_levelgen over a run with a new level per episode:  tools/archive_r03/r03_lg_trace.sh <env id> <envs> <steps>
 env_id=$1; envs=$2; steps=$3
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 PY=$(readlink -f "$(command -v python3)")

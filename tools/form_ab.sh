@@ -2,7 +2,7 @@
 # Same-box A/B of a FORM-SELECTION knob (read in every build: MGX_PARTIAL_KERNEL staged|gather, MGX_FULL_KERNEL lds|direct, MGX_GATHER_CACHE on|off,
 # MGX_DYNOBS fused|split, MGX_ONEHOT split|fused, MGX_SEED_FORM window|full, MGX_ROLLOUT graph): bench.py per workload under each value.
 #   [BENCH_EXTRA="--obs-mode full"] tools/form_ab.sh <tag> <KNOB> <value,value,...> env[:n_envs] ...      (value `rule` = knob unset)
-# (one script for what round 3 kept as tools/r03_ab_16.sh, r03_ab_small.sh, r03_ab_gather*.sh, r03_ab_full.sh)
+# (one script for what round 3 kept as tools/archive_r03/r03_ab_16.sh, r03_ab_small.sh, r03_ab_gather*.sh, r03_ab_full.sh)
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O; cd $R
 TAG=$1; KNOB=$2; VALUES=${3//,/ }; shift 3
 EXTRA=${BENCH_EXTRA:-}   # extra bench.py arguments for every run, e.g. BENCH_EXTRA="--obs-mode full"

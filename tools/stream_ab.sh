@@ -2,7 +2,7 @@
 # new_level_each_episode, us per step and env-steps/s, for a list of workloads -- optionally across builds (ab/<name>.so from
 # tools/build_variant.sh / build_lg_variant.sh) and across settings of the level generator's tuning knobs (tuning builds only).
 #   tools/stream_ab.sh <tag> [-l name,name,...] [-k "MGX_LG_LANES=16 MGX_LG_LANES=32 ..."] env[:n_envs] ...
-# (one script for what round 3 kept as tools/r03_stream7.sh ... r03_stream20.sh; their tables are in profiles/r03_levelgen_paths.txt)
+# (one script for what round 3 kept as tools/archive_r03/r03_stream7.sh ... r03_stream20.sh; their tables are in profiles/r03_levelgen_paths.txt)
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O; cd $R
 TAG=$1; shift
 LIBS="-"; KNOBS="-"
