@@ -688,7 +688,8 @@ extern "C" int mgx_create(const mgx_config *cfg, int64_t n_envs, int device, mgx
         // one buffer; MGX_LG_RING set to a depth overrides the rule)
         const int lk = cfg->level_kind;
         const bool ring_pays = lk != MGX_LEVEL_MULTIROOM && lk != MGX_LEVEL_FOURROOMS && lk != MGX_LEVEL_LOCKEDROOM && lk != MGX_LEVEL_PLAYGROUND &&
-                               lk != MGX_LEVEL_GOTOOBJECT;
+                               lk != MGX_LEVEL_GOTOOBJECT &&
+                               !((lk == MGX_LEVEL_DOORKEY || lk == MGX_LEVEL_EMPTY) && h->kernel_mode == 3); // (DoorKey-16x16: 33.0 -> 34.2, time-outs only)
         if (h->stream_mode && h->partial && (h->kernel_mode == 0 || h->kernel_mode == 3) && (ring_pays || lf) &&
             (R == 2 || R == 4 || R == 8 || R == 16)) h->lg_ring = R;
         // R next-level buffers (+ hidden planes) per env; a handle too large for them keeps one buffer and the generator behind every step

@@ -198,7 +198,8 @@ typedef struct {
                                    MT19937 block, 2.5 KB; the draw-heavy families (everything but Empty / DoorKey / Crossing /
                                    LavaGap / DistShift) keep the following block ready as well, 5 KB in all -- dropped silently
                                    (same results, slower level bursts) when that second allocation fails.  Partial-view
-                                   handles (every family but MultiRoom, FourRooms, LockedRoom, Playground, GoToObject) keep 16
+                                   handles (every family but MultiRoom, FourRooms, LockedRoom, Playground, GoToObject and DoorKey / Empty
+                                   on grids from 13x13 up) keep 16
                                    next levels per env ready -- 16 * (ceil4(W*H)
                                    + 8) bytes, three times the cells with object_state; one level when that allocation
                                    fails -- and generate beside the steps, on a stream of the handle's own that every entry
